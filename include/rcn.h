@@ -1,0 +1,164 @@
+/*
+ * rcn.h -- C ABI of the MI355X (gfx950) matching + bundle-adjustment core.
+ *
+ * Drop-in boundary for ONE hot path of smileyenot983/reconstructor:
+ *   - all-pairs descriptor matching  (replaces FlannMatcher::matchFeatures' call into
+ *     cv::DescriptorMatcher::knnMatch, FeatureMatcher.cpp:32-65, and the pair loop of
+ *     SequentialReconstructor::matchFeatures, SequentialReconstructor.cpp:199-279)
+ *   - bundle adjustment              (replaces BundleAdjuster::adjust's call into
+ *     ceres::Solve, BundleAdjuster.cpp:72-146)
+ *
+ * Plain pointers and sizes only; no C++ or torch types; never throws.  Every entry point
+ * returns an int status (RCN_OK == 0, negative = error; rcn_last_error() has the text).
+ * Host arrays are borrowed for the duration of the call; device buffers belong to the ctx.
+ * One ctx per GPU.  A ctx is safe to call from several host threads (internal mutex): the
+ * reference calls its matcher from 4 OpenMP threads (SequentialReconstructor.cpp:202).
+ *
+ * There is NO CPU fallback behind this ABI: without a usable HIP device rcn_create fails.
+ */
+#ifndef RCN_H
+#define RCN_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RCN_OK               0
+#define RCN_ERR_ARG         -1   /* bad argument (null pointer, negative size, mismatched D, ...) */
+#define RCN_ERR_HIP         -2   /* HIP runtime error; text in rcn_last_error */
+#define RCN_ERR_NO_DEVICE   -3   /* no gfx950 device visible */
+#define RCN_ERR_UNSUPPORTED -4   /* shape outside what the kernels cover */
+#define RCN_ERR_NOT_FOUND   -5   /* image id not resident */
+#define RCN_ERR_NUMERIC     -6   /* BA: non-finite cost / Cholesky breakdown that LM could not recover */
+
+typedef struct rcn_ctx rcn_ctx;
+
+/* ---- context ------------------------------------------------------------------------- */
+int         rcn_create(int device_id, rcn_ctx **out);
+void        rcn_destroy(rcn_ctx *ctx);
+const char *rcn_last_error(const rcn_ctx *ctx);      /* never NULL */
+const char *rcn_version(void);
+/* Run all work of this ctx on an existing HIP stream (e.g. torch's current stream, passed as
+ * the raw hipStream_t).  NULL = the ctx's own stream.  */
+int         rcn_set_stream(rcn_ctx *ctx, void *hip_stream);
+int         rcn_synchronize(rcn_ctx *ctx);
+
+/* ---- descriptors -----------------------------------------------------------------------
+ * One dense row-major K x D fp32 matrix per image: exactly what featDescToCV builds per call
+ * (FeatureMatcher.cpp:11-25), built once per image here instead of once per pair.
+ * All resident images must share D.  Re-uploading an id replaces it.  K may be 0. */
+int rcn_desc_upload(rcn_ctx *ctx, int32_t img_id, const float *desc_host, int32_t K, int32_t D);
+/* Same, from a DEVICE pointer (e.g. the landing buffer of an RCCL all-gather); copied. */
+int rcn_desc_upload_device(rcn_ctx *ctx, int32_t img_id, const float *desc_dev, int32_t K, int32_t D);
+int rcn_desc_clear(rcn_ctx *ctx);
+int rcn_desc_count(const rcn_ctx *ctx);
+
+/* ---- matching --------------------------------------------------------------------------
+ * Result of one (query image, train image) pair: out[i] = train row matched to query row i,
+ * or -1.  This is the std::map<int,int> FlannMatcher::matchFeatures fills
+ * (FeatureMatcher.cpp:53-64) in dense form: exact 2-NN under L2, ratio test
+ * dist0 < ratio * dist1 in fp32, then the lowest query index keeps a contested train row.
+ * K2 < 2 yields no matches (the reference reads knn[i][1] unconditionally there).          */
+
+/* One pair straight from host rows (the per-call shape of FeatureMatcher::matchFeatures). */
+int rcn_match_pair(rcn_ctx *ctx, const float *q_host, int32_t K1,
+                   const float *t_host, int32_t K2, int32_t D, float ratio,
+                   int32_t *out_train_for_query /* K1 */, int32_t *out_count);
+
+/* Pair grid over resident images (SequentialReconstructor.cpp:199-279).  pairs = n_pairs x
+ * (query image id, train image id) on the HOST.  out = n_pairs rows of out_stride int32 on
+ * the HOST (out_stride >= K of every query image; tail of each row is set to -1),
+ * counts[p] = matches of pair p.                                                          */
+int rcn_match_grid(rcn_ctx *ctx, const int32_t *pairs_host, int32_t n_pairs, float ratio,
+                   int32_t *out_host, int64_t out_stride, int32_t *counts_host);
+
+/* Same, results left in HBM: out_dev / counts_dev are DEVICE pointers; asynchronous on the
+ * ctx stream (no host synchronisation inside once the workspace has reached its size).     */
+int rcn_match_grid_device(rcn_ctx *ctx, const int32_t *pairs_host, int32_t n_pairs, float ratio,
+                          int32_t *out_dev, int64_t out_stride, int32_t *counts_dev);
+
+/* Statistics of the last grid call (diagnostics; rows_total = sum of K1 over pairs). */
+typedef struct {
+    int64_t rows_total;
+    int64_t rows_exact_fallback;  /* query rows the coarse pass could not certify */
+    int64_t pair_distances;       /* sum of K1*K2 */
+    double  err_bound_d2;         /* largest certified bound on |coarse - exact| squared distance */
+    int32_t used_mfma_path;       /* 1 = fp16 MFMA coarse pass + exact re-rank, 0 = exact kernel only */
+    int32_t reserved;
+} rcn_match_stats;
+int rcn_match_last_stats(const rcn_ctx *ctx, rcn_match_stats *out);
+
+/* ---- bundle adjustment -----------------------------------------------------------------
+ * Flat form of what BundleAdjuster::adjust packs (BundleAdjuster.cpp:17-97):
+ *   poses      n_cams x 6   angle-axis * angle, translation   (world -> camera, :46-59)
+ *   intrinsics n_cams x 6   fx fy cx cy k1 k2                 (:37-42)
+ *   points     n_points x 3                                   (:65-70)
+ *   observations landmark-major (:74-97): obs_pt non-decreasing.
+ * Camera index = position in imgIdxOrder.  All three parameter arrays are updated in place. */
+typedef struct {
+    int32_t        n_cams, n_points, n_obs, reserved;
+    double        *poses;
+    double        *intrinsics;
+    double        *points;
+    const double  *obs_uv;    /* n_obs x 2 (integer pixel coordinates cast to double, :83-84) */
+    const int32_t *obs_cam;   /* n_obs */
+    const int32_t *obs_pt;    /* n_obs, non-decreasing */
+} rcn_ba_problem;
+
+typedef struct {
+    int32_t max_iterations;        /* 150 if n_cams < 10 else 50           (BundleAdjuster.cpp:135-142) */
+    int32_t intrinsics_mode;       /* 0: all intrinsics constant (n_cams<10, :112-115);
+                                      1: cx,cy constant, fx,fy upper-bounded (:117-121) */
+    int32_t fix_cam0_pose;         /* 1                                     (:100-101) */
+    int32_t fix_cam1_translation;  /* 1                                     (:104-105) */
+    double  focal_upper_bound;     /* 1000                                  (:120-121) */
+    /* Ceres 2.x trust-region defaults (solver.h), none overridden by the reference */
+    double  initial_trust_region_radius;   /* 1e4  */
+    double  max_trust_region_radius;       /* 1e16 */
+    double  min_trust_region_radius;       /* 1e-32 */
+    double  min_relative_decrease;         /* 1e-3 */
+    double  min_lm_diagonal;               /* 1e-6 */
+    double  max_lm_diagonal;               /* 1e32 */
+    double  function_tolerance;            /* 1e-6 */
+    double  gradient_tolerance;            /* 1e-10 */
+    double  parameter_tolerance;           /* 1e-8 */
+    int32_t max_consecutive_invalid_steps; /* 5 */
+    int32_t jacobi_scaling;                /* 1 */
+} rcn_ba_options;
+
+/* Fills the options exactly as BundleAdjuster::adjust + Ceres defaults would for n_cams. */
+void rcn_ba_default_options(int32_t n_cams, rcn_ba_options *out);
+
+#define RCN_BA_CONVERGENCE_FUNCTION   1
+#define RCN_BA_CONVERGENCE_GRADIENT   2
+#define RCN_BA_CONVERGENCE_PARAMETER  3
+#define RCN_BA_CONVERGENCE_RADIUS     4
+#define RCN_BA_NO_CONVERGENCE         5   /* max_iterations reached */
+#define RCN_BA_FAILURE                6   /* too many consecutive invalid steps */
+
+typedef struct {
+    double  initial_cost;       /* 1/2 sum r^2 at the input */
+    double  final_cost;
+    double  initial_rms_px;     /* sqrt(sum r^2 / n_obs) */
+    double  final_rms_px;
+    int32_t iterations;         /* LM iterations attempted (successful + unsuccessful) */
+    int32_t successful_steps;
+    int32_t unsuccessful_steps;
+    int32_t invalid_steps;
+    int32_t termination;        /* RCN_BA_* */
+    int32_t line_search_backtracks;
+    int32_t bound_projections;
+    int32_t reduced_dim;        /* rows of the reduced camera system */
+    double  solve_seconds;      /* wall time of the LM loop, inputs resident */
+    double  cost_trace[160];    /* cost after each iteration, [0] = initial */
+} rcn_ba_summary;
+
+int rcn_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *problem, const rcn_ba_options *options,
+                 rcn_ba_summary *summary);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RCN_H */

@@ -1,0 +1,150 @@
+"""ctypes binding of librcn.so (the C ABI declared in include/rcn.h).
+
+The HIP library IS the product: if it is missing or cannot be loaded this module raises --
+there is no CPU fallback anywhere in reconstructor_amd.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "librcn.so")
+
+RCN_OK = 0
+ERRORS = {-1: "RCN_ERR_ARG", -2: "RCN_ERR_HIP", -3: "RCN_ERR_NO_DEVICE",
+          -4: "RCN_ERR_UNSUPPORTED", -5: "RCN_ERR_NOT_FOUND", -6: "RCN_ERR_NUMERIC"}
+
+# every symbol include/rcn.h declares (tests check the library exports exactly these)
+SYMBOLS = [
+    "rcn_create", "rcn_destroy", "rcn_last_error", "rcn_version", "rcn_set_stream",
+    "rcn_synchronize", "rcn_desc_upload", "rcn_desc_upload_device", "rcn_desc_clear",
+    "rcn_desc_count", "rcn_match_pair", "rcn_match_grid", "rcn_match_grid_device",
+    "rcn_match_last_stats", "rcn_ba_default_options", "rcn_ba_solve",
+]
+
+
+class RcnError(RuntimeError):
+    def __init__(self, code, text=""):
+        self.code = code
+        super().__init__("%s (%d)%s" % (ERRORS.get(code, "RCN_ERR"), code, ": " + text if text else ""))
+
+
+class MatchStats(C.Structure):
+    _fields_ = [("rows_total", C.c_int64), ("rows_exact_fallback", C.c_int64),
+                ("pair_distances", C.c_int64), ("err_bound_d2", C.c_double),
+                ("used_mfma_path", C.c_int32), ("reserved", C.c_int32)]
+
+
+class BaProblem(C.Structure):
+    _fields_ = [("n_cams", C.c_int32), ("n_points", C.c_int32), ("n_obs", C.c_int32),
+                ("reserved", C.c_int32),
+                ("poses", C.c_void_p), ("intrinsics", C.c_void_p), ("points", C.c_void_p),
+                ("obs_uv", C.c_void_p), ("obs_cam", C.c_void_p), ("obs_pt", C.c_void_p)]
+
+
+class BaOptions(C.Structure):
+    _fields_ = [("max_iterations", C.c_int32), ("intrinsics_mode", C.c_int32),
+                ("fix_cam0_pose", C.c_int32), ("fix_cam1_translation", C.c_int32),
+                ("focal_upper_bound", C.c_double),
+                ("initial_trust_region_radius", C.c_double),
+                ("max_trust_region_radius", C.c_double),
+                ("min_trust_region_radius", C.c_double),
+                ("min_relative_decrease", C.c_double),
+                ("min_lm_diagonal", C.c_double), ("max_lm_diagonal", C.c_double),
+                ("function_tolerance", C.c_double), ("gradient_tolerance", C.c_double),
+                ("parameter_tolerance", C.c_double),
+                ("max_consecutive_invalid_steps", C.c_int32), ("jacobi_scaling", C.c_int32)]
+
+
+class BaSummary(C.Structure):
+    _fields_ = [("initial_cost", C.c_double), ("final_cost", C.c_double),
+                ("initial_rms_px", C.c_double), ("final_rms_px", C.c_double),
+                ("iterations", C.c_int32), ("successful_steps", C.c_int32),
+                ("unsuccessful_steps", C.c_int32), ("invalid_steps", C.c_int32),
+                ("termination", C.c_int32), ("line_search_backtracks", C.c_int32),
+                ("bound_projections", C.c_int32), ("reduced_dim", C.c_int32),
+                ("solve_seconds", C.c_double), ("cost_trace", C.c_double * 160)]
+
+
+_LIB = None
+
+
+def load():
+    """Load librcn.so.  torch (when used in the same process) must be imported first so that
+    both share one HIP runtime (same SONAME libamdhip64.so.7); callers in this package do so."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(SO_PATH):
+        raise ImportError(
+            "reconstructor_amd/librcn.so is missing: run `python -c 'import __graft_entry__ as g; "
+            "g.build()'` (hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+    L = C.CDLL(SO_PATH, mode=C.RTLD_GLOBAL)
+    vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+    L.rcn_create.restype = C.c_int
+    L.rcn_create.argtypes = [C.c_int, C.POINTER(vp)]
+    L.rcn_destroy.restype = None
+    L.rcn_destroy.argtypes = [vp]
+    L.rcn_last_error.restype = C.c_char_p
+    L.rcn_last_error.argtypes = [vp]
+    L.rcn_version.restype = C.c_char_p
+    L.rcn_version.argtypes = []
+    L.rcn_set_stream.restype = C.c_int
+    L.rcn_set_stream.argtypes = [vp, vp]
+    L.rcn_synchronize.restype = C.c_int
+    L.rcn_synchronize.argtypes = [vp]
+    L.rcn_desc_upload.restype = C.c_int
+    L.rcn_desc_upload.argtypes = [vp, i32, vp, i32, i32]
+    L.rcn_desc_upload_device.restype = C.c_int
+    L.rcn_desc_upload_device.argtypes = [vp, i32, vp, i32, i32]
+    L.rcn_desc_clear.restype = C.c_int
+    L.rcn_desc_clear.argtypes = [vp]
+    L.rcn_desc_count.restype = C.c_int
+    L.rcn_desc_count.argtypes = [vp]
+    L.rcn_match_pair.restype = C.c_int
+    L.rcn_match_pair.argtypes = [vp, vp, i32, vp, i32, i32, f32, vp, C.POINTER(i32)]
+    L.rcn_match_grid.restype = C.c_int
+    L.rcn_match_grid.argtypes = [vp, vp, i32, f32, vp, i64, vp]
+    L.rcn_match_grid_device.restype = C.c_int
+    L.rcn_match_grid_device.argtypes = [vp, vp, i32, f32, vp, i64, vp]
+    L.rcn_match_last_stats.restype = C.c_int
+    L.rcn_match_last_stats.argtypes = [vp, C.POINTER(MatchStats)]
+    L.rcn_ba_default_options.restype = None
+    L.rcn_ba_default_options.argtypes = [i32, C.POINTER(BaOptions)]
+    L.rcn_ba_solve.restype = C.c_int
+    L.rcn_ba_solve.argtypes = [vp, C.POINTER(BaProblem), C.POINTER(BaOptions), C.POINTER(BaSummary)]
+    _LIB = L
+    return L
+
+
+class Context:
+    """One rcn_ctx (one GPU)."""
+
+    def __init__(self, device=0):
+        self.lib = load()
+        h = C.c_void_p()
+        rc = self.lib.rcn_create(int(device), C.byref(h))
+        if rc != RCN_OK:
+            raise RcnError(rc, "rcn_create(device=%d): no usable gfx950 device" % device)
+        self.h = h
+        self.device = device
+
+    def check(self, rc):
+        if rc != RCN_OK:
+            raise RcnError(rc, self.lib.rcn_last_error(self.h).decode())
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.rcn_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()

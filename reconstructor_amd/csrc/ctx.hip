@@ -1,0 +1,75 @@
+// ctx.hip -- context lifetime of the C ABI (include/rcn.h).
+#include "rcn_internal.h"
+
+#include <cstdlib>
+
+extern "C" {
+
+const char *rcn_version(void) { return "reconstructor_amd 0.1 (gfx950)"; }
+
+int rcn_create(int device_id, rcn_ctx **out)
+{
+    if (!out) return RCN_ERR_ARG;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device_id < 0 || device_id >= n)
+        return RCN_ERR_NO_DEVICE;
+    rcn_ctx *ctx = new rcn_ctx();
+    ctx->device = device_id;
+    if (hipSetDevice(device_id) != hipSuccess ||
+        hipGetDeviceProperties(&ctx->prop, device_id) != hipSuccess) {
+        delete ctx;
+        return RCN_ERR_NO_DEVICE;
+    }
+    // the code object holds gfx950 ISA only: fail loudly on anything else
+    if (std::string(ctx->prop.gcnArchName).rfind("gfx950", 0) != 0) {
+        delete ctx;
+        return RCN_ERR_NO_DEVICE;
+    }
+    if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) {
+        delete ctx;
+        return RCN_ERR_HIP;
+    }
+    ctx->stream = ctx->own_stream;
+    const char *fe = std::getenv("RCN_FORCE_EXACT");
+    ctx->force_exact = fe && fe[0] == '1';
+    memset(&ctx->last_stats, 0, sizeof(ctx->last_stats));
+    *out = ctx;
+    return RCN_OK;
+}
+
+void rcn_destroy(rcn_ctx *ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    rcn_match_release(ctx);
+    DevBuf *bufs[] = {&ctx->img_table, &ctx->pairs_dev, &ctx->cand, &ctx->best, &ctx->owner,
+                      &ctx->fb_list, &ctx->counters, &ctx->stats_dev, &ctx->out_tmp, &ctx->cnt_tmp};
+    for (DevBuf *b : bufs) b->release();
+    for (DevBuf &b : ctx->ba_ws) b.release();
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+}
+
+const char *rcn_last_error(const rcn_ctx *ctx) { return ctx ? ctx->err.c_str() : "null ctx"; }
+
+int rcn_set_stream(rcn_ctx *ctx, void *hip_stream)
+{
+    if (!ctx) return RCN_ERR_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    RCN_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : ctx->own_stream;
+    return RCN_OK;
+}
+
+int rcn_synchronize(rcn_ctx *ctx)
+{
+    if (!ctx) return RCN_ERR_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    RCN_HIP(hipSetDevice(ctx->device));
+    RCN_HIP(hipStreamSynchronize(ctx->stream));
+    return RCN_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,804 @@
+// match.hip -- all-pairs descriptor matching on MI355X (gfx950): kernels + C ABI.
+//
+// Replaces, behind include/rcn.h:
+//   FlannMatcher::matchFeatures          FeatureMatcher.cpp:32-65   (per pair)
+//   cv::DescriptorMatcher::knnMatch(k=2) call site FeatureMatcher.cpp:49
+//   SequentialReconstructor::matchFeatures pair loop, SequentialReconstructor.cpp:199-279
+//
+// Pipeline per grid call:
+//   K1 k_coarse_top2   fp16 MFMA (v_mfma_f32_32x32x16_f16) distance tiles, running top-2 per
+//                      query with the train index packed into the low mantissa bits
+//   K2 k_rerank        exact fp64 re-computation of the two candidates in the canonical
+//                      order, certified against a rigorous bound on the coarse error;
+//                      rows that cannot be certified go to the fallback list
+//   K2b k_exact_rows   exact brute force of the listed rows (also the generic path)
+//   K3 k_unique_claim / k_unique_emit   lowest query index keeps a contested train row
+// The result is bit-identical to the canonical exact matcher whatever the coarse pass does:
+// the coarse pass only ever *proposes*.
+#include "rcn_internal.h"
+
+#include <algorithm>
+#include <cmath>
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define RCN_QT 256          // query rows per workgroup (4 waves x 64)
+#define RCN_BT 64           // train rows per LDS tile
+#define RCN_PAD_HN 1.0e30f  // half-norm of padded train rows: never a candidate
+
+// ---------------------------------------------------------------------------------------
+// 16-byte-chunk swizzle of the fp16 image.  A row of DP halfs has DP/8 chunks; rows that a
+// ds_read_b128 lane group reads together (16 different rows, same logical chunk) must land
+// on 16 different 16-B slots of the 256-B LDS bank row.
+template <int DP> __host__ __device__ __forceinline__ int swz(int row)
+{
+    if (DP >= 128) return row & 15;
+    if (DP == 64) return (row >> 1) & 7;
+    return (row >> 2) & 3;  // DP == 32
+}
+
+// ---------------------------------------------------------------------------------------
+// Row statistics at upload: |x|^2 in fp64 (ascending k, fma chain) and the running maxima
+// that fix the global power-of-two scale.
+__global__ void k_rowstats(const float *__restrict__ x, int K, int D, double *__restrict__ nrm2,
+                           unsigned *__restrict__ g_maxabs_bits,
+                           unsigned long long *__restrict__ g_maxnrm2_bits)
+{
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    float ma = 0.f;
+    double acc = 0.0;
+    if (j < K) {
+        const float *row = x + (size_t)j * D;
+        for (int k = 0; k < D; ++k) {
+            float v = row[k];
+            ma = fmaxf(ma, fabsf(v));
+            acc = fma((double)v, (double)v, acc);
+        }
+        nrm2[j] = acc;
+    }
+    // non-negative floats / doubles order like their bit patterns
+    for (int o = 32; o; o >>= 1) {
+        ma = fmaxf(ma, __shfl_xor(ma, o));
+        acc = fmax(acc, __shfl_xor(acc, o));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicMax(g_maxabs_bits, __float_as_uint(ma));
+        atomicMax(g_maxnrm2_bits, (unsigned long long)__double_as_longlong(acc));
+    }
+}
+
+// fp32 rows -> scaled fp16 rows (chunk-swizzled) + biased half-norms.
+template <int DP>
+__global__ void k_prepare(const float *__restrict__ x, const double *__restrict__ nrm2, int K,
+                          int Kp, int D, float scale, double half_s2, double bias,
+                          _Float16 *__restrict__ f16, float *__restrict__ hn)
+{
+    constexpr int CPR = DP / 8;
+    int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    int row = gid / CPR, c = gid % CPR;
+    if (row >= Kp) return;
+    half8 v;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        int k = c * 8 + e;
+        float f = (row < K && k < D) ? x[(size_t)row * D + k] * scale : 0.f;
+        v[e] = (_Float16)f;  // round to nearest even
+    }
+    *reinterpret_cast<half8 *>(f16 + (size_t)row * DP + ((c ^ swz<DP>(row)) * 8)) = v;
+    if (c == 0) hn[row] = row < K ? (float)(half_s2 * nrm2[row] + bias) : RCN_PAD_HN;
+}
+
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned umed3(unsigned a, unsigned b, unsigned c)
+{
+    unsigned r;
+    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
+struct CoarseArgs {
+    const ImgDev *imgs;
+    const int32_t *pairs;   // n_pairs x (query slot, train slot)
+    uint2 *cand;            // [n_pairs][kq_stride] packed (best, second)
+    int32_t n_pairs, tiles_per_pair, items_per_xcd, kq_stride;
+    uint32_t idx_mask;      // low bits that carry the train row
+};
+
+// K1: one workgroup = 256 query rows of one pair against every train row of the pair.
+//   MFMA orientation: A = train tile (rows -> accumulator registers), B = -query (columns ->
+//   lanes), C initialised with the train rows' biased half-norms, so each accumulator
+//   element is  s^2 * (|t|^2/2 - q.t) + BIAS  > 0  and orders like the squared distance for a
+//   fixed query.  Positive floats order like unsigned integers, so the running top-2 per
+//   (lane, column block) is v_and_or + v_med3_u32 + v_min_u32 per element.
+template <int DP>
+__global__ __launch_bounds__(256, 2) void k_coarse_top2(CoarseArgs a)
+{
+    constexpr int KS = DP / 16;
+    constexpr int ROWB = DP * 2;
+    constexpr int TILEB = RCN_BT * ROWB;
+    constexpr int NINST = TILEB / 4 / 1024;  // 1-KiB LDS-DMA pieces per wave per tile
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int b = blockIdx.x;
+    const int item = (b & 7) * a.items_per_xcd + (b >> 3);  // XCD x walks a contiguous item range
+    if (item >= a.n_pairs * a.tiles_per_pair) return;
+    const int pair = item / a.tiles_per_pair, qt = item - pair * a.tiles_per_pair;
+    const ImgDev qi = a.imgs[a.pairs[2 * pair]];
+    const ImgDev ti = a.imgs[a.pairs[2 * pair + 1]];
+    if (qt * RCN_QT >= qi.K || ti.K < 2) return;
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 31, h = lane >> 5;
+
+    // query fragments, negated, resident for the whole train sweep
+    half8 bq[2][KS];
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+        const int qrow = qt * RCN_QT + w * 64 + cb * 32 + r;  // < Kp (Kp is a multiple of 256)
+        const char *base = reinterpret_cast<const char *>(qi.f16) + (size_t)qrow * ROWB;
+        const int sw = swz<DP>(qrow);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            uint4 v = *reinterpret_cast<const uint4 *>(base + (((ks * 2 + h) ^ sw) << 4));
+            v.x ^= 0x80008000u; v.y ^= 0x80008000u; v.z ^= 0x80008000u; v.w ^= 0x80008000u;
+            bq[cb][ks] = __builtin_bit_cast(half8, v);
+        }
+    }
+
+    unsigned m1[2] = {0xFFFFFFFFu, 0xFFFFFFFFu}, m2[2] = {0xFFFFFFFFu, 0xFFFFFFFFu};
+    const unsigned hmask = ~a.idx_mask;
+    const int nT = (ti.K + RCN_BT - 1) / RCN_BT;
+    const char *timg = reinterpret_cast<const char *>(ti.f16);
+
+    auto stage = [&](int t, int buf) {
+#pragma unroll
+        for (int i = 0; i < NINST; ++i) {
+            const int off = w * (TILEB / 4) + i * 1024;
+            const char *src = timg + (size_t)t * TILEB + off + lane * 16;
+            char *dst = smem + buf * TILEB + off;  // + lane*16 applied by the hardware
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void *)src,
+                (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+        }
+    };
+
+    stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    int buf = 0;
+    for (int t = 0; t < nT; ++t) {
+        if (t + 1 < nT) stage(t + 1, buf ^ 1);
+        const char *tile = smem + buf * TILEB;
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) {
+            f32x16 acc0, acc1;
+            const float4 *hp = reinterpret_cast<const float4 *>(ti.hn + t * RCN_BT + rb * 32 + 4 * h);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float4 v = hp[2 * g];  // rows 8g + 4h + 0..3
+                acc0[4 * g + 0] = v.x; acc0[4 * g + 1] = v.y; acc0[4 * g + 2] = v.z; acc0[4 * g + 3] = v.w;
+            }
+            acc1 = acc0;
+            const int lrow = rb * 32 + r;
+            const char *arow = tile + lrow * ROWB;
+            const int sw = swz<DP>(lrow);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                half8 av = *reinterpret_cast<const half8 *>(arow + (((ks * 2 + h) ^ sw) << 4));
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bq[0][ks], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bq[1][ks], acc1, 0, 0, 0);
+            }
+            const unsigned rowbase = (unsigned)(t * RCN_BT + rb * 32);
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const unsigned idx = rowbase + (reg & 3) + 8 * (reg >> 2);  // + 4h added at the end
+                unsigned u0 = (__float_as_uint(acc0[reg]) & hmask) | idx;
+                unsigned u1 = (__float_as_uint(acc1[reg]) & hmask) | idx;
+                m2[0] = umed3(m1[0], m2[0], u0); m1[0] = min(m1[0], u0);
+                m2[1] = umed3(m1[1], m2[1], u1); m1[1] = min(m1[1], u1);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        buf ^= 1;
+    }
+
+    // lane l and l^32 hold the same query, disjoint train rows: merge, then lanes 0..31 store
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+        unsigned a1 = m1[cb] | (unsigned)(4 * h), a2 = m2[cb] | (unsigned)(4 * h);
+        if (m1[cb] == 0xFFFFFFFFu) a1 = 0xFFFFFFFFu;
+        if (m2[cb] == 0xFFFFFFFFu) a2 = 0xFFFFFFFFu;
+        unsigned b1 = __shfl_xor(a1, 32), b2 = __shfl_xor(a2, 32);
+        unsigned r1 = min(a1, b1);
+        unsigned r2 = min(max(a1, b1), min(a2, b2));
+        const int qrow = qt * RCN_QT + w * 64 + cb * 32 + r;
+        if (h == 0 && qrow < qi.K) a.cand[(size_t)pair * a.kq_stride + qrow] = make_uint2(r1, r2);
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// canonical squared distance: fp64 fma chain in ascending k
+template <bool VEC4>
+__device__ __forceinline__ double exact_d2(const float *__restrict__ q, const float *__restrict__ t, int D)
+{
+    double acc = 0.0;
+    if (VEC4) {
+        const float4 *q4 = reinterpret_cast<const float4 *>(q);
+        const float4 *t4 = reinterpret_cast<const float4 *>(t);
+        for (int k = 0; k < D / 4; ++k) {
+            float4 a = q4[k], b = t4[k];
+            double d;
+            d = (double)a.x - (double)b.x; acc = fma(d, d, acc);
+            d = (double)a.y - (double)b.y; acc = fma(d, d, acc);
+            d = (double)a.z - (double)b.z; acc = fma(d, d, acc);
+            d = (double)a.w - (double)b.w; acc = fma(d, d, acc);
+        }
+    } else {
+        for (int k = 0; k < D; ++k) {
+            double d = (double)q[k] - (double)t[k];
+            acc = fma(d, d, acc);
+        }
+    }
+    return acc;
+}
+
+// Lowe ratio test exactly as FeatureMatcher.cpp:55 on float distances (sqrt of squared L2).
+__device__ __forceinline__ bool ratio_pass(double d2_best, double d2_second, float ratio)
+{
+    float dist0 = sqrtf((float)d2_best);
+    float dist1 = sqrtf((float)d2_second);
+    return dist0 < ratio * dist1;
+}
+
+struct RerankArgs {
+    const ImgDev *imgs;
+    const int32_t *pairs;
+    const uint2 *cand;
+    int32_t *out;                 // [n_pairs][out_stride]: >=0 train row, -1 none (before uniqueness)
+    int64_t out_stride;
+    unsigned long long *fb_list;  // (pair << 32 | query) rows needing the exact kernel
+    unsigned *fb_count;
+    int32_t n_pairs, kq_stride, D, qblocks;
+    uint32_t idx_mask;
+    float ratio;
+    // error model of the coarse pass, in accumulator units unless stated
+    double s2;          // s^2
+    double bias;        // BIAS
+    double c_in;        // (2u+u^2) s^2            x |q| Nmax
+    double c_sub;       // 2^-14 sqrt(DP) s        x (|q| + Nmax)
+    double c_acc;       // (DP+8) 2^-23
+    double hn_max;      // s^2 Nmax^2 / 2 + BIAS
+    double n_max;       // Nmax
+    double rel_slack;   // relative slack for the fp64 evaluation of the bound itself
+    int32_t all_to_fallback;
+};
+
+// K2: one thread per (pair, query row).
+template <bool VEC4> __global__ void k_rerank(RerankArgs a)
+{
+    const int pair = blockIdx.x / a.qblocks;
+    const int q = (blockIdx.x - pair * a.qblocks) * blockDim.x + threadIdx.x;
+    const ImgDev qi = a.imgs[a.pairs[2 * pair]];
+    const ImgDev ti = a.imgs[a.pairs[2 * pair + 1]];
+    if (q >= qi.K) return;
+    int32_t *o = a.out + (size_t)pair * a.out_stride + q;
+    if (ti.K < 2) { *o = -1; return; }
+    if (a.all_to_fallback) {
+        unsigned slot = atomicAdd(a.fb_count, 1u);
+        a.fb_list[slot] = ((unsigned long long)pair << 32) | (unsigned)q;
+        *o = -1;
+        return;
+    }
+    const uint2 c = a.cand[(size_t)pair * a.kq_stride + q];
+    int ia = (int)(c.x & a.idx_mask), ib = (int)(c.y & a.idx_mask);
+    const float *qrow = qi.f32 + (size_t)q * a.D;
+    double ea = exact_d2<VEC4>(qrow, ti.f32 + (size_t)ia * a.D, a.D);
+    double eb = exact_d2<VEC4>(qrow, ti.f32 + (size_t)ib * a.D, a.D);
+    if (eb < ea || (eb == ea && ib < ia)) { double te = ea; ea = eb; eb = te; int tq = ia; ia = ib; ib = tq; }
+
+    // every train row that is not a candidate has accumulator >= lbacc
+    double lbnc = INFINITY;
+    if (ti.K > 2) {
+        const double nq2 = qi.nrm2[q];
+        const double nq = sqrt(nq2) * (1.0 + 1e-12);
+        const double mag = a.s2 * nq * a.n_max;
+        const double eps = a.c_in * nq * a.n_max + a.c_sub * (nq + a.n_max) + 1e-9 +
+                           a.c_acc * (a.hn_max + mag) + 6.0e-8 * a.hn_max;
+        const double lbacc = (double)__uint_as_float(c.y & ~a.idx_mask);
+        lbnc = nq2 + (2.0 / a.s2) * (lbacc - eps - a.bias);
+        lbnc -= a.rel_slack * (nq2 + a.n_max * a.n_max);
+    }
+    const bool nn_certain = ea < lbnc;
+    double lb1 = fmin(eb, lbnc), lb0 = fmin(ea, lbnc);
+    if (lb1 < 0.0) lb1 = 0.0;
+    if (lb0 < 0.0) lb0 = 0.0;
+    if (nn_certain && ratio_pass(ea, lb1, a.ratio)) { *o = ia; return; }
+    if (!ratio_pass(lb0, eb, a.ratio)) { *o = -1; return; }
+    unsigned slot = atomicAdd(a.fb_count, 1u);
+    a.fb_list[slot] = ((unsigned long long)pair << 32) | (unsigned)q;
+    *o = -1;
+}
+
+// K2b: exact brute force of listed rows, one wave per row, grid-stride over the list.
+template <bool VEC4>
+__global__ __launch_bounds__(256) void k_exact_rows(const ImgDev *__restrict__ imgs,
+                                                     const int32_t *__restrict__ pairs,
+                                                     const unsigned long long *__restrict__ list,
+                                                     const unsigned *__restrict__ count, int D,
+                                                     float ratio, int32_t *__restrict__ out,
+                                                     int64_t out_stride)
+{
+    const int lane = threadIdx.x & 63;
+    const unsigned wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const unsigned nwaves = (gridDim.x * blockDim.x) >> 6;
+    const unsigned n = *count;
+    for (unsigned it = wave; it < n; it += nwaves) {
+        const unsigned long long e = list[it];
+        const int pair = (int)(e >> 32), q = (int)(e & 0xFFFFFFFFu);
+        const ImgDev qi = imgs[pairs[2 * pair]];
+        const ImgDev ti = imgs[pairs[2 * pair + 1]];
+        const float *qrow = qi.f32 + (size_t)q * D;
+        double b0 = INFINITY, b1 = INFINITY;
+        int i0 = 0x7FFFFFFF, i1 = 0x7FFFFFFF;
+        for (int j = lane; j < ti.K; j += 64) {
+            double d = exact_d2<VEC4>(qrow, ti.f32 + (size_t)j * D, D);
+            if (d < b0) { b1 = b0; i1 = i0; b0 = d; i0 = j; }          // ascending j: strict <
+            else if (d < b1) { b1 = d; i1 = j; }
+        }
+        // merge (value, index)-ordered pairs across the wave
+        for (int o = 32; o; o >>= 1) {
+            double c0 = __shfl_xor(b0, o), c1 = __shfl_xor(b1, o);
+            int j0 = __shfl_xor(i0, o), j1 = __shfl_xor(i1, o);
+            // first = lexicographic min of (b0,i0),(c0,j0)
+            bool mine = (b0 < c0) || (b0 == c0 && i0 < j0);
+            double f0 = mine ? b0 : c0; int fi0 = mine ? i0 : j0;
+            double l0 = mine ? c0 : b0; int li0 = mine ? j0 : i0;   // the loser of the firsts
+            double s0 = mine ? b1 : c1; int si0 = mine ? i1 : j1;   // winner's own second
+            bool pick = (l0 < s0) || (l0 == s0 && li0 < si0);
+            b0 = f0; i0 = fi0;
+            b1 = pick ? l0 : s0; i1 = pick ? li0 : si0;
+        }
+        if (lane == 0) out[(size_t)pair * out_stride + q] = ratio_pass(b0, b1, ratio) ? i0 : -1;
+    }
+}
+
+// K3: uniqueness (FeatureMatcher.cpp:58-62): ascending query order, first claim wins
+//     == the smallest claiming query index per train row.
+__global__ void k_unique_claim(const ImgDev *__restrict__ imgs, const int32_t *__restrict__ pairs,
+                               const int32_t *__restrict__ out, int64_t out_stride,
+                               int32_t *__restrict__ owner, int owner_stride, int qblocks)
+{
+    const int pair = blockIdx.x / qblocks;
+    const int q = (blockIdx.x - pair * qblocks) * blockDim.x + threadIdx.x;
+    if (q >= imgs[pairs[2 * pair]].K) return;
+    const int t = out[(size_t)pair * out_stride + q];
+    if (t >= 0) atomicMin(owner + (size_t)pair * owner_stride + t, q);
+}
+
+__global__ void k_unique_emit(const ImgDev *__restrict__ imgs, const int32_t *__restrict__ pairs,
+                              int32_t *__restrict__ out, int64_t out_stride,
+                              const int32_t *__restrict__ owner, int owner_stride,
+                              int32_t *__restrict__ counts, int qblocks)
+{
+    const int pair = blockIdx.x / qblocks;
+    const int q = (blockIdx.x - pair * qblocks) * blockDim.x + threadIdx.x;
+    if (q >= out_stride) return;
+    int32_t *o = out + (size_t)pair * out_stride + q;
+    bool keep = false;
+    if (q < imgs[pairs[2 * pair]].K) {
+        const int t = *o;
+        keep = t >= 0 && owner[(size_t)pair * owner_stride + t] == q;
+    }
+    if (!keep) *o = -1;
+    const unsigned long long m = __ballot(keep);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(counts + pair, (int)__popcll(m));
+}
+
+// =========================================================================================
+// host side
+// =========================================================================================
+static int pad_dim(int D)
+{
+    if (D <= 32) return 32;
+    if (D <= 64) return 64;
+    if (D <= 128) return 128;
+    if (D <= 256) return 256;
+    return 0;  // no MFMA path
+}
+
+int rcn_match_release(rcn_ctx *ctx)
+{
+    for (auto &kv : ctx->images) {
+        ImgHost &im = kv.second;
+        if (im.f32) (void)hipFree(im.f32);
+        if (im.f16) (void)hipFree(im.f16);
+        if (im.hn) (void)hipFree(im.hn);
+        if (im.nrm2) (void)hipFree(im.nrm2);
+    }
+    ctx->images.clear();
+    ctx->prepared = false;
+    ctx->D = ctx->DP = 0;
+    return RCN_OK;
+}
+
+static int ensure_counters(rcn_ctx *ctx)
+{
+    if (!ctx->counters.p) {
+        RCN_HIP(ctx->counters.reserve(64));
+        RCN_HIP(hipMemsetAsync(ctx->counters.p, 0, 64, ctx->stream));
+    }
+    return RCN_OK;
+}
+// counters layout: [0] u32 maxabs bits, [2..3] u64 max nrm2 bits, [4] u32 fallback count
+
+static int upload_common(rcn_ctx *ctx, int32_t img_id, const float *src, bool src_is_device,
+                         int32_t K, int32_t D)
+{
+    if (!ctx || K < 0 || D <= 0 || (K > 0 && !src)) {
+        if (ctx) ctx->set_error("rcn_desc_upload: bad argument");
+        return RCN_ERR_ARG;
+    }
+    if (!ctx->images.empty() && ctx->D != D) {
+        ctx->set_error("rcn_desc_upload: all resident images must share D");
+        return RCN_ERR_ARG;
+    }
+    RCN_HIP(hipSetDevice(ctx->device));
+    int rc = ensure_counters(ctx);
+    if (rc) return rc;
+    ctx->D = D;
+    ctx->DP = pad_dim(D);
+    auto it = ctx->images.find(img_id);
+    if (it != ctx->images.end()) {
+        ImgHost &o = it->second;
+        RCN_HIP(hipStreamSynchronize(ctx->stream));
+        if (o.f32) (void)hipFree(o.f32);
+        if (o.f16) (void)hipFree(o.f16);
+        if (o.hn) (void)hipFree(o.hn);
+        if (o.nrm2) (void)hipFree(o.nrm2);
+        ctx->images.erase(it);
+    }
+    ImgHost im;
+    im.K = K;
+    im.Kp = (K + RCN_QT - 1) / RCN_QT * RCN_QT;
+    if (im.Kp == 0) im.Kp = RCN_QT;
+    const int DPa = ctx->DP ? ctx->DP : 32;
+    RCN_HIP(hipMalloc(&im.f32, std::max<size_t>(16, (size_t)K * D * sizeof(float))));
+    RCN_HIP(hipMalloc(&im.f16, (size_t)im.Kp * DPa * sizeof(_Float16)));
+    RCN_HIP(hipMalloc(&im.hn, (size_t)im.Kp * sizeof(float)));
+    RCN_HIP(hipMalloc(&im.nrm2, std::max<size_t>(8, (size_t)K * sizeof(double))));
+    if (K > 0) {
+        RCN_HIP(hipMemcpyAsync(im.f32, src, (size_t)K * D * sizeof(float),
+                               src_is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
+                               ctx->stream));
+        unsigned *cnt = ctx->counters.as<unsigned>();
+        k_rowstats<<<(K + 255) / 256, 256, 0, ctx->stream>>>(
+            im.f32, K, D, im.nrm2, cnt, reinterpret_cast<unsigned long long *>(cnt + 2));
+        RCN_HIP(hipGetLastError());
+        if (!src_is_device) RCN_HIP(hipStreamSynchronize(ctx->stream));  // host rows are borrowed
+    }
+    ctx->images[img_id] = im;
+    ctx->prepared = false;
+    return RCN_OK;
+}
+
+template <int DP> static void launch_prepare(rcn_ctx *ctx, const ImgHost &im, float s, double hs2, double bias)
+{
+    const int n = im.Kp * (DP / 8);
+    k_prepare<DP><<<(n + 255) / 256, 256, 0, ctx->stream>>>(im.f32, im.nrm2, im.K, im.Kp, ctx->D, s,
+                                                            hs2, bias, im.f16, im.hn);
+}
+
+// Fix the global scale / bias, (re)build every image's fp16 copy and the device image table.
+static int prepare_all(rcn_ctx *ctx)
+{
+    if (ctx->prepared) return RCN_OK;
+    unsigned hc[4] = {0, 0, 0, 0};
+    RCN_HIP(hipMemcpyAsync(hc, ctx->counters.p, 16, hipMemcpyDeviceToHost, ctx->stream));
+    RCN_HIP(hipStreamSynchronize(ctx->stream));
+    float maxabs;
+    double maxn2;
+    memcpy(&maxabs, &hc[0], 4);
+    memcpy(&maxn2, &hc[2], 8);
+    if (!(maxabs > 0.f) || !std::isfinite(maxabs)) maxabs = 1.f;
+    if (!(maxn2 > 0.0) || !std::isfinite(maxn2)) maxn2 = 1.0;
+    // s = 2^e with s*maxabs in (2^13, 2^14]  (fp16 max is 65504; the query side is negated only)
+    int ex;
+    (void)std::frexp((double)maxabs, &ex);  // maxabs = m * 2^ex, m in [0.5,1)
+    const double s = std::ldexp(1.0, 14 - ex);
+    ctx->scale = s;
+    ctx->max_norm = std::sqrt(maxn2) * (1.0 + 1e-12);
+    ctx->bias = 0.5625 * s * s * maxn2 + 1.0;  // accumulator >= s^2 Nmax^2/16 > 0 for every (q,t)
+    const double hs2 = 0.5 * s * s;
+
+    std::vector<ImgDev> table;
+    table.reserve(ctx->images.size());
+    int slot = 0;
+    for (auto &kv : ctx->images) {
+        ImgHost &im = kv.second;
+        im.slot = slot++;
+        if (ctx->DP) {
+            switch (ctx->DP) {
+            case 32: launch_prepare<32>(ctx, im, (float)s, hs2, ctx->bias); break;
+            case 64: launch_prepare<64>(ctx, im, (float)s, hs2, ctx->bias); break;
+            case 128: launch_prepare<128>(ctx, im, (float)s, hs2, ctx->bias); break;
+            default: launch_prepare<256>(ctx, im, (float)s, hs2, ctx->bias); break;
+            }
+            RCN_HIP(hipGetLastError());
+        }
+        table.push_back(ImgDev{im.f32, im.f16, im.hn, im.nrm2, im.K, im.Kp});
+    }
+    RCN_HIP(ctx->img_table.reserve(std::max<size_t>(1, table.size()) * sizeof(ImgDev)));
+    if (!table.empty())
+        RCN_HIP(hipMemcpyAsync(ctx->img_table.p, table.data(), table.size() * sizeof(ImgDev),
+                               hipMemcpyHostToDevice, ctx->stream));
+    RCN_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->prepared = true;
+    return RCN_OK;
+}
+
+template <int DP> static hipError_t launch_coarse(rcn_ctx *ctx, const CoarseArgs &ca, int blocks)
+{
+    const size_t lds = 2 * RCN_BT * DP * 2;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_coarse_top2<DP>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    k_coarse_top2<DP><<<blocks, 256, lds, ctx->stream>>>(ca);
+    return hipGetLastError();
+}
+
+static int match_grid_impl(rcn_ctx *ctx, const int32_t *pairs_host, int32_t n_pairs, float ratio,
+                           int32_t *out_dev, int64_t out_stride, int32_t *counts_dev)
+{
+    if (n_pairs < 0 || (n_pairs > 0 && (!pairs_host || !out_dev || !counts_dev))) {
+        ctx->set_error("rcn_match_grid: bad argument");
+        return RCN_ERR_ARG;
+    }
+    memset(&ctx->last_stats, 0, sizeof(ctx->last_stats));
+    if (n_pairs == 0) return RCN_OK;
+    RCN_HIP(hipSetDevice(ctx->device));
+    int rc = prepare_all(ctx);
+    if (rc) return rc;
+
+    // image ids -> table slots; shape bookkeeping
+    std::vector<int32_t> slots(2 * (size_t)n_pairs);
+    int kq_max = 0, kt_max = 0, ktp_max = 0;
+    int64_t rows = 0, pd = 0;
+    for (int p = 0; p < n_pairs; ++p) {
+        auto a = ctx->images.find(pairs_host[2 * p]), b = ctx->images.find(pairs_host[2 * p + 1]);
+        if (a == ctx->images.end() || b == ctx->images.end()) {
+            ctx->set_error("rcn_match_grid: image id not resident");
+            return RCN_ERR_NOT_FOUND;
+        }
+        slots[2 * p] = a->second.slot;
+        slots[2 * p + 1] = b->second.slot;
+        kq_max = std::max(kq_max, a->second.K);
+        kt_max = std::max(kt_max, b->second.K);
+        ktp_max = std::max(ktp_max, b->second.Kp);
+        rows += a->second.K;
+        pd += (int64_t)a->second.K * b->second.K;
+    }
+    if (out_stride < kq_max) {
+        ctx->set_error("rcn_match_grid: out_stride smaller than a query image's K");
+        return RCN_ERR_ARG;
+    }
+    const int tiles = std::max(1, (kq_max + RCN_QT - 1) / RCN_QT);
+    const int kq_stride = tiles * RCN_QT;
+    int idx_bits = 1;
+    while ((1 << idx_bits) < ktp_max) ++idx_bits;
+    const bool mfma = ctx->DP != 0 && idx_bits <= 13 && !ctx->force_exact && kq_max > 0 && kt_max >= 2;
+    const uint32_t idx_mask = (1u << idx_bits) - 1u;
+    const int owner_stride = std::max(1, kt_max);
+
+    RCN_HIP(ctx->pairs_dev.reserve(slots.size() * sizeof(int32_t)));
+    RCN_HIP(ctx->cand.reserve((size_t)n_pairs * kq_stride * sizeof(uint2)));
+    RCN_HIP(ctx->owner.reserve((size_t)n_pairs * owner_stride * sizeof(int32_t)));
+    RCN_HIP(ctx->fb_list.reserve(std::max<int64_t>(1, rows) * sizeof(unsigned long long)));
+    RCN_HIP(hipMemcpyAsync(ctx->pairs_dev.p, slots.data(), slots.size() * sizeof(int32_t),
+                           hipMemcpyHostToDevice, ctx->stream));
+    unsigned *fb_count = ctx->counters.as<unsigned>() + 4;
+    RCN_HIP(hipMemsetAsync(fb_count, 0, 16, ctx->stream));
+    RCN_HIP(hipMemsetAsync(ctx->owner.p, 0x7f, (size_t)n_pairs * owner_stride * sizeof(int32_t), ctx->stream));
+    RCN_HIP(hipMemsetAsync(counts_dev, 0, (size_t)n_pairs * sizeof(int32_t), ctx->stream));
+
+    const ImgDev *imgs = ctx->img_table.as<ImgDev>();
+    const int32_t *pairs = ctx->pairs_dev.as<int32_t>();
+    const bool vec4 = (ctx->D % 4) == 0;
+
+    if (mfma) {
+        CoarseArgs ca;
+        ca.imgs = imgs; ca.pairs = pairs; ca.cand = ctx->cand.as<uint2>();
+        ca.n_pairs = n_pairs; ca.tiles_per_pair = tiles; ca.kq_stride = kq_stride;
+        const int64_t items = (int64_t)n_pairs * tiles;
+        ca.items_per_xcd = (int)((items + 7) / 8);
+        ca.idx_mask = idx_mask;
+        const int blocks = ca.items_per_xcd * 8;
+        hipError_t e;
+        switch (ctx->DP) {
+        case 32: e = launch_coarse<32>(ctx, ca, blocks); break;
+        case 64: e = launch_coarse<64>(ctx, ca, blocks); break;
+        case 128: e = launch_coarse<128>(ctx, ca, blocks); break;
+        default: e = launch_coarse<256>(ctx, ca, blocks); break;
+        }
+        RCN_HIP(e);
+    }
+
+    RerankArgs ra;
+    memset(&ra, 0, sizeof(ra));
+    ra.imgs = imgs; ra.pairs = pairs; ra.cand = ctx->cand.as<uint2>();
+    ra.out = out_dev; ra.out_stride = out_stride;
+    ra.fb_list = ctx->fb_list.as<unsigned long long>(); ra.fb_count = fb_count;
+    ra.n_pairs = n_pairs; ra.kq_stride = kq_stride; ra.D = ctx->D; ra.idx_mask = idx_mask;
+    ra.ratio = ratio;
+    const double s = ctx->scale, u = std::ldexp(1.0, -11);
+    const int DPa = ctx->DP ? ctx->DP : 32;
+    ra.s2 = s * s; ra.bias = ctx->bias;
+    ra.c_in = (2 * u + u * u) * s * s;
+    ra.c_sub = std::ldexp(1.0, -14) * std::sqrt((double)DPa) * s;
+    ra.c_acc = (DPa + 8) * std::ldexp(1.0, -23);
+    ra.n_max = ctx->max_norm;
+    ra.hn_max = 0.5 * s * s * ctx->max_norm * ctx->max_norm + ctx->bias;
+    ra.rel_slack = 1e-9;
+    ra.all_to_fallback = mfma ? 0 : 1;
+    if (kq_max > 0) {
+        const int qblocks = (kq_max + 255) / 256;
+        ra.qblocks = qblocks;
+        dim3 g((unsigned)qblocks * (unsigned)n_pairs);
+        if (vec4) k_rerank<true><<<g, 256, 0, ctx->stream>>>(ra);
+        else k_rerank<false><<<g, 256, 0, ctx->stream>>>(ra);
+        RCN_HIP(hipGetLastError());
+        const int fb_blocks = ctx->prop.multiProcessorCount * 4;
+        if (vec4) k_exact_rows<true><<<fb_blocks, 256, 0, ctx->stream>>>(imgs, pairs, ra.fb_list, fb_count, ctx->D, ratio, out_dev, out_stride);
+        else k_exact_rows<false><<<fb_blocks, 256, 0, ctx->stream>>>(imgs, pairs, ra.fb_list, fb_count, ctx->D, ratio, out_dev, out_stride);
+        RCN_HIP(hipGetLastError());
+        k_unique_claim<<<g, 256, 0, ctx->stream>>>(imgs, pairs, out_dev, out_stride, ctx->owner.as<int32_t>(), owner_stride, qblocks);
+        RCN_HIP(hipGetLastError());
+    }
+    {
+        const int eblocks = (int)((out_stride + 255) / 256);
+        dim3 g((unsigned)eblocks * (unsigned)n_pairs);
+        k_unique_emit<<<g, 256, 0, ctx->stream>>>(imgs, pairs, out_dev, out_stride, ctx->owner.as<int32_t>(), owner_stride, counts_dev, eblocks);
+        RCN_HIP(hipGetLastError());
+    }
+    // stats: the fallback count is read back lazily in rcn_match_last_stats
+    ctx->last_stats.rows_total = rows;
+    ctx->last_stats.pair_distances = pd;
+    ctx->last_stats.used_mfma_path = mfma ? 1 : 0;
+    ctx->last_stats.rows_exact_fallback = -1;
+    {
+        const double nq = ctx->max_norm;
+        const double eps = ra.c_in * nq * nq + ra.c_sub * 2 * nq + ra.c_acc * (ra.hn_max + ra.s2 * nq * nq) + 6.0e-8 * ra.hn_max;
+        ctx->last_stats.err_bound_d2 = 2.0 * eps / ra.s2;
+    }
+    return RCN_OK;
+}
+
+// =========================================================================================
+extern "C" {
+
+int rcn_desc_upload(rcn_ctx *ctx, int32_t img_id, const float *desc_host, int32_t K, int32_t D)
+{
+    if (!ctx) return RCN_ERR_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    return upload_common(ctx, img_id, desc_host, false, K, D);
+}
+
+int rcn_desc_upload_device(rcn_ctx *ctx, int32_t img_id, const float *desc_dev, int32_t K, int32_t D)
+{
+    if (!ctx) return RCN_ERR_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    return upload_common(ctx, img_id, desc_dev, true, K, D);
+}
+
+int rcn_desc_clear(rcn_ctx *ctx)
+{
+    if (!ctx) return RCN_ERR_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    RCN_HIP(hipSetDevice(ctx->device));
+    RCN_HIP(hipStreamSynchronize(ctx->stream));
+    rcn_match_release(ctx);
+    if (ctx->counters.p) RCN_HIP(hipMemsetAsync(ctx->counters.p, 0, 64, ctx->stream));
+    return RCN_OK;
+}
+
+int rcn_desc_count(const rcn_ctx *ctx) { return ctx ? (int)ctx->images.size() : 0; }
+
+int rcn_match_grid_device(rcn_ctx *ctx, const int32_t *pairs_host, int32_t n_pairs, float ratio,
+                          int32_t *out_dev, int64_t out_stride, int32_t *counts_dev)
+{
+    if (!ctx) return RCN_ERR_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    return match_grid_impl(ctx, pairs_host, n_pairs, ratio, out_dev, out_stride, counts_dev);
+}
+
+int rcn_match_grid(rcn_ctx *ctx, const int32_t *pairs_host, int32_t n_pairs, float ratio,
+                   int32_t *out_host, int64_t out_stride, int32_t *counts_host)
+{
+    if (!ctx) return RCN_ERR_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    if (n_pairs < 0 || (n_pairs > 0 && (!pairs_host || !out_host || !counts_host)) || out_stride < 0) {
+        ctx->set_error("rcn_match_grid: bad argument");
+        return RCN_ERR_ARG;
+    }
+    if (n_pairs == 0) return RCN_OK;
+    const int64_t stride = std::max<int64_t>(out_stride, 1);
+    RCN_HIP(ctx->out_tmp.reserve((size_t)n_pairs * stride * sizeof(int32_t)));
+    RCN_HIP(ctx->cnt_tmp.reserve((size_t)n_pairs * sizeof(int32_t)));
+    int rc = match_grid_impl(ctx, pairs_host, n_pairs, ratio, ctx->out_tmp.as<int32_t>(), stride,
+                             ctx->cnt_tmp.as<int32_t>());
+    if (rc) return rc;
+    RCN_HIP(hipMemcpyAsync(out_host, ctx->out_tmp.p, (size_t)n_pairs * stride * sizeof(int32_t),
+                           hipMemcpyDeviceToHost, ctx->stream));
+    RCN_HIP(hipMemcpyAsync(counts_host, ctx->cnt_tmp.p, (size_t)n_pairs * sizeof(int32_t),
+                           hipMemcpyDeviceToHost, ctx->stream));
+    RCN_HIP(hipStreamSynchronize(ctx->stream));
+    return RCN_OK;
+}
+
+int rcn_match_pair(rcn_ctx *ctx, const float *q_host, int32_t K1, const float *t_host, int32_t K2,
+                   int32_t D, float ratio, int32_t *out_train_for_query, int32_t *out_count)
+{
+    if (!ctx) return RCN_ERR_ARG;
+    if (K1 < 0 || K2 < 0 || D <= 0 || (K1 > 0 && (!q_host || !out_train_for_query)) || (K2 > 0 && !t_host)) {
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        ctx->set_error("rcn_match_pair: bad argument");
+        return RCN_ERR_ARG;
+    }
+    // a private two-image context state would serialise callers anyway; reuse a scratch ctx
+    // slot pair under the lock (ids INT32_MIN, INT32_MIN+1 are reserved for this call)
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    if (!ctx->images.empty() && ctx->D != D) {
+        ctx->set_error("rcn_match_pair: D differs from the resident images' D");
+        return RCN_ERR_ARG;
+    }
+    const int32_t ida = INT32_MIN, idb = INT32_MIN + 1;
+    int rc = upload_common(ctx, ida, q_host, false, K1, D);
+    if (rc) return rc;
+    rc = upload_common(ctx, idb, t_host, false, K2, D);
+    if (rc) return rc;
+    int32_t pr[2] = {ida, idb};
+    int32_t cnt = 0;
+    const int64_t stride = std::max(K1, 1);
+    RCN_HIP(ctx->out_tmp.reserve((size_t)stride * sizeof(int32_t)));
+    RCN_HIP(ctx->cnt_tmp.reserve(sizeof(int32_t)));
+    rc = match_grid_impl(ctx, pr, 1, ratio, ctx->out_tmp.as<int32_t>(), stride, ctx->cnt_tmp.as<int32_t>());
+    if (rc == RCN_OK) {
+        if (K1 > 0)
+            RCN_HIP(hipMemcpyAsync(out_train_for_query, ctx->out_tmp.p, (size_t)K1 * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+        RCN_HIP(hipMemcpyAsync(&cnt, ctx->cnt_tmp.p, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+        RCN_HIP(hipStreamSynchronize(ctx->stream));
+        if (out_count) *out_count = cnt;
+    }
+    // drop the scratch images again
+    for (int32_t id : {ida, idb}) {
+        auto it = ctx->images.find(id);
+        if (it != ctx->images.end()) {
+            ImgHost &o = it->second;
+            if (o.f32) (void)hipFree(o.f32);
+            if (o.f16) (void)hipFree(o.f16);
+            if (o.hn) (void)hipFree(o.hn);
+            if (o.nrm2) (void)hipFree(o.nrm2);
+            ctx->images.erase(it);
+        }
+    }
+    ctx->prepared = false;
+    return rc;
+}
+
+int rcn_match_last_stats(const rcn_ctx *cctx, rcn_match_stats *out)
+{
+    rcn_ctx *ctx = const_cast<rcn_ctx *>(cctx);
+    if (!ctx || !out) return RCN_ERR_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    if (ctx->last_stats.rows_exact_fallback < 0 && ctx->counters.p) {
+        unsigned n = 0;
+        RCN_HIP(hipMemcpyAsync(&n, ctx->counters.as<unsigned>() + 4, 4, hipMemcpyDeviceToHost, ctx->stream));
+        RCN_HIP(hipStreamSynchronize(ctx->stream));
+        ctx->last_stats.rows_exact_fallback = n;
+    }
+    *out = ctx->last_stats;
+    return RCN_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,84 @@
+// rcn_internal.h -- shared host-side state of the C ABI (include/rcn.h).  gfx950 only.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/rcn.h"
+
+#define RCN_HIP(call)                                                                    \
+    do {                                                                                 \
+        hipError_t e_ = (call);                                                          \
+        if (e_ != hipSuccess) {                                                          \
+            ctx->set_error(std::string(#call) + ": " + hipGetErrorString(e_));           \
+            return RCN_ERR_HIP;                                                          \
+        }                                                                                \
+    } while (0)
+
+// One growable device buffer; never shrinks; no allocation once large enough.
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    hipError_t reserve(size_t bytes)
+    {
+        if (bytes <= cap) return hipSuccess;
+        if (p) { hipError_t e = hipFree(p); p = nullptr; cap = 0; if (e != hipSuccess) return e; }
+        size_t want = bytes + bytes / 8 + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    template <class T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+// Per-image device record (mirrored in a device table for the kernels).
+struct ImgDev {
+    const float *f32;      // [K][D]      original rows (exact re-rank reads these)
+    const _Float16 *f16;   // [Kp][DP]    scaled by the global power of two, 16-B chunks XOR-swizzled
+    const float *hn;       // [Kp]        0.5*s^2*|t|^2 + BIAS ; padded rows = huge
+    const double *nrm2;    // [K]         |x|^2 in fp64
+    int32_t K, Kp;
+};
+
+struct ImgHost {
+    float *f32 = nullptr;
+    _Float16 *f16 = nullptr;
+    float *hn = nullptr;
+    double *nrm2 = nullptr;
+    int32_t K = 0, Kp = 0;
+    int32_t slot = -1;  // row in the device image table
+};
+
+struct rcn_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    std::mutex mu;
+    std::string err = "";
+    hipDeviceProp_t prop;
+
+    // ---- matcher state
+    int32_t D = 0, DP = 0;
+    std::map<int32_t, ImgHost> images;
+    bool prepared = false;
+    double scale = 1.0;      // s, power of two
+    double bias = 0.0;       // BIAS in accumulator units
+    double max_norm = 0.0;   // max |x| over resident rows
+    DevBuf img_table, pairs_dev, cand, best, owner, fb_list, counters, stats_dev, out_tmp, cnt_tmp;
+    rcn_match_stats last_stats;
+    bool force_exact = false;  // RCN_FORCE_EXACT=1: skip the MFMA coarse pass (diagnostics)
+
+    // ---- BA state (ba.hip)
+    DevBuf ba_ws[24];
+
+    void set_error(const std::string &s) { err = s; }
+};
+
+int rcn_match_release(rcn_ctx *ctx);
