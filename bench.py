@@ -1,0 +1,184 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark: descriptor pair-distances/s of the all-pairs matcher.
+
+Workload (BASELINE.json configs[1]): synthetic 100 images x 2048 SuperPoint-like 256-d
+keypoints, exact brute-force L2 2-NN + ratio + uniqueness over all 4950 image pairs.
+One "step" = one pass of the hot path over the whole pair grid, descriptors resident in HBM,
+match tables left in HBM.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+N > 1 (weak scaling): the image count grows as 100*sqrt(N) so every rank keeps ~4950 pairs.
+Each rank owns n/N images ("detected locally"), one RCCL all-gather over xGMI replicates
+the descriptors, then the pair list is dealt round-robin to ranks; no other exchange.  The
+all-gather and the per-image ingest are INSIDE the timed step for N > 1.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+K_PER_IMAGE = 2048
+D = 256
+N_IMAGES_1GPU = 100
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
+MFMA_F16_PEAK_TFLOPS = 2500.0  # dense bf16/f16 MFMA peak (same guide)
+
+
+def cpu_baseline(images, n_threads):
+    """Oracle (CPU restatement, kind "port") on a bounded sample of the same workload."""
+    from oracle import orc
+    n_sample = max(n_threads, 6 * n_threads)
+    allp = orc.all_pairs(len(images))
+    rng = np.random.default_rng(0)
+    pick = allp[rng.choice(len(allp), size=min(n_sample, len(allp)), replace=False)]
+    orc.match_grid(images, pick[:n_threads], threads=n_threads)  # warm (page-in, transposes)
+    t0 = time.perf_counter()
+    orc.match_grid(images, pick, threads=n_threads)
+    dt = time.perf_counter() - t0
+    pd = sum(images[a].shape[0] * images[b].shape[0] for a, b in pick)
+    return {"value": pd / dt, "unit": "pair-distances/s", "cores": n_threads, "kind": "port",
+            "sample": "%d of %d image pairs (2048x2048x256 each), oracle/match_oracle.c, OpenMP over pairs, %.1f s"
+                      % (len(pick), len(allp), dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--images", type=int, default=0, help="override image count (debug)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--ba", action="store_true", help="also time BA (cfg 4) and report it in the line")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus must equal WORLD_SIZE")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from reconstructor_amd import synth
+    from reconstructor_amd.matcher import HipL2Matcher, all_pairs
+    from reconstructor_amd import pairgrid
+
+    n_img = args.images or int(round(N_IMAGES_1GPU * math.sqrt(world)))
+    n_img = (n_img + world - 1) // world * world if world > 1 else n_img
+    matcher = HipL2Matcher(device=local_rank)
+    stream = torch.cuda.current_stream(dev)
+    matcher.ctx.check(matcher.ctx.lib.rcn_set_stream(matcher.ctx.h, stream.cuda_stream))
+
+    # ---- inputs: every rank generates only the images it "detected"
+    lo, hi = pairgrid.owned_images(n_img, world, rank)
+    pool = synth.world_pool("superpoint", 4 * K_PER_IMAGE, seed=1234)
+    local = np.stack([synth.image_descriptors("superpoint", i, K_PER_IMAGE, pool, seed=1234)
+                      for i in range(lo, hi)])
+    local_dev = torch.from_numpy(local).to(dev)
+    pairs = all_pairs(n_img)
+    my_pairs = pairgrid.shard_pairs(pairs, world, rank)
+    out = torch.empty((len(my_pairs), K_PER_IMAGE), dtype=torch.int32, device=dev)
+    counts = torch.empty((len(my_pairs),), dtype=torch.int32, device=dev)
+    gathered = torch.empty((n_img, K_PER_IMAGE, D), dtype=torch.float32, device=dev) if world > 1 else None
+
+    def ingest():
+        """RCCL all-gather of the per-image descriptor blocks + per-image ingest (N > 1)."""
+        dist.all_gather_into_tensor(gathered.view(-1), local_dev.view(-1))
+        matcher.upload_batch_device(0, n_img, gathered.data_ptr(), K_PER_IMAGE, D)
+
+    if world == 1:
+        matcher.upload_batch_device(0, n_img, local_dev.data_ptr(), K_PER_IMAGE, D)
+
+    def step():
+        if world > 1:
+            ingest()
+        matcher.match_grid_device(my_pairs, out.data_ptr(), K_PER_IMAGE, counts.data_ptr())
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    matcher.stats()                 # clears counters
+    matcher.profile(True)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    st = matcher.stats()
+    matcher.profile(False)
+
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+        tot = torch.tensor([float(st["pair_distances"]), float(counts.sum().item())], dtype=torch.float64, device=dev)
+        dist.all_reduce(tot)
+        pd_step, n_matches = float(tot[0].item()), int(tot[1].item())
+    else:
+        pd_step, n_matches = float(st["pair_distances"]), int(counts.sum().item())
+
+    if rank == 0:
+        ms_step = dt / args.steps * 1e3
+        value = pd_step * args.steps / dt
+        calls = max(1, st["profiled_calls"])
+        coarse_ms = st["coarse_ms"] / calls
+        my_pd = float(st["pair_distances"])
+        flops = 2.0 * D * my_pd                      # 2*D flop per pair-distance
+        achieved = flops / (coarse_ms * 1e-3) / 1e12 if coarse_ms > 0 else 0.0
+        line = {
+            "metric": "descriptor pair-distances/s (256-d L2, exact 2-NN + ratio + uniqueness, all image pairs)",
+            "value": value, "unit": "pair-distances/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f16 MFMA coarse + f64 exact re-rank",
+            "data": "synthetic",
+            "config": {"workload": "cfg2: %d images x %d keypoints x %d-d, %d image pairs%s"
+                                   % (n_img, K_PER_IMAGE, D, len(pairs),
+                                      "" if world == 1 else " (weak scaling of cfg2: ~4950 pairs per rank, RCCL all-gather + ingest inside the step)"),
+                       "pairs_per_rank": int(len(my_pairs)), "pair_matches_per_s": len(pairs) * args.steps / dt,
+                       "matches_found": n_matches,
+                       "rows_exact_fallback": int(st["rows_exact_fallback"]), "rows_total": int(st["rows_total"])},
+            "roofline": {"bound": "mfma", "kernel": "k_coarse_top2<256>", "achieved": achieved,
+                         "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / MFMA_F16_PEAK_TFLOPS, "traffic": None,
+                         "launch_ms": coarse_ms, "rerank_ms": st["rerank_ms"] / calls,
+                         "unique_ms": st["unique_ms"] / calls},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            images = [local[i] for i in range(local.shape[0])]
+            line["cpu_baseline"] = cpu_baseline(images, len(os.sched_getaffinity(0)))
+        elif world == 1:
+            line["cpu_baseline"] = None
+        if args.ba and world == 1:
+            from reconstructor_amd import ba_bench
+            line["ba"] = ba_bench.run(matcher.ctx)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -52,6 +52,13 @@ int         rcn_synchronize(rcn_ctx *ctx);
 int rcn_desc_upload(rcn_ctx *ctx, int32_t img_id, const float *desc_host, int32_t K, int32_t D);
 /* Same, from a DEVICE pointer (e.g. the landing buffer of an RCCL all-gather); copied. */
 int rcn_desc_upload_device(rcn_ctx *ctx, int32_t img_id, const float *desc_dev, int32_t K, int32_t D);
+/* n_images equally shaped images [n][K][D] in one DEVICE buffer, ids first_img_id.. ; the
+ * buffer is BORROWED (zero copy) until rcn_desc_clear / re-upload of those ids: the caller
+ * keeps it alive and unchanged.  One stats launch + one conversion launch for the whole
+ * batch; calling it again with the same shape reuses every allocation (per-step ingest of
+ * an all-gather landing buffer). */
+int rcn_desc_upload_batch_device(rcn_ctx *ctx, int32_t first_img_id, int32_t n_images,
+                                 const float *desc_dev, int32_t K, int32_t D);
 int rcn_desc_clear(rcn_ctx *ctx);
 int rcn_desc_count(const rcn_ctx *ctx);
 
@@ -86,9 +93,15 @@ typedef struct {
     int64_t pair_distances;       /* sum of K1*K2 */
     double  err_bound_d2;         /* largest certified bound on |coarse - exact| squared distance */
     int32_t used_mfma_path;       /* 1 = fp16 MFMA coarse pass + exact re-rank, 0 = exact kernel only */
-    int32_t reserved;
+    int32_t profiled_calls;       /* grid calls summed into the *_ms fields (rcn_match_profile) */
+    double  coarse_ms;            /* HIP-event time of k_coarse_top2 launches, summed */
+    double  rerank_ms;            /* k_rerank + k_exact_rows */
+    double  unique_ms;            /* k_unique_claim + k_unique_emit */
 } rcn_match_stats;
 int rcn_match_last_stats(const rcn_ctx *ctx, rcn_match_stats *out);
+/* enable != 0: bracket the kernels of every following grid call with HIP events on the ctx
+ * stream (up to 64 calls are kept); rcn_match_last_stats sums and clears them. */
+int rcn_match_profile(rcn_ctx *ctx, int enable);
 
 /* ---- bundle adjustment -----------------------------------------------------------------
  * Flat form of what BundleAdjuster::adjust packs (BundleAdjuster.cpp:17-97):

@@ -16,9 +16,9 @@ ERRORS = {-1: "RCN_ERR_ARG", -2: "RCN_ERR_HIP", -3: "RCN_ERR_NO_DEVICE",
 # every symbol include/rcn.h declares (tests check the library exports exactly these)
 SYMBOLS = [
     "rcn_create", "rcn_destroy", "rcn_last_error", "rcn_version", "rcn_set_stream",
-    "rcn_synchronize", "rcn_desc_upload", "rcn_desc_upload_device", "rcn_desc_clear",
+    "rcn_synchronize", "rcn_desc_upload", "rcn_desc_upload_device", "rcn_desc_upload_batch_device", "rcn_desc_clear",
     "rcn_desc_count", "rcn_match_pair", "rcn_match_grid", "rcn_match_grid_device",
-    "rcn_match_last_stats", "rcn_ba_default_options", "rcn_ba_solve",
+    "rcn_match_last_stats", "rcn_match_profile", "rcn_ba_default_options", "rcn_ba_solve",
 ]
 
 
@@ -31,7 +31,8 @@ class RcnError(RuntimeError):
 class MatchStats(C.Structure):
     _fields_ = [("rows_total", C.c_int64), ("rows_exact_fallback", C.c_int64),
                 ("pair_distances", C.c_int64), ("err_bound_d2", C.c_double),
-                ("used_mfma_path", C.c_int32), ("reserved", C.c_int32)]
+                ("used_mfma_path", C.c_int32), ("profiled_calls", C.c_int32),
+                ("coarse_ms", C.c_double), ("rerank_ms", C.c_double), ("unique_ms", C.c_double)]
 
 
 class BaProblem(C.Structure):
@@ -96,6 +97,8 @@ def load():
     L.rcn_desc_upload.argtypes = [vp, i32, vp, i32, i32]
     L.rcn_desc_upload_device.restype = C.c_int
     L.rcn_desc_upload_device.argtypes = [vp, i32, vp, i32, i32]
+    L.rcn_desc_upload_batch_device.restype = C.c_int
+    L.rcn_desc_upload_batch_device.argtypes = [vp, i32, i32, vp, i32, i32]
     L.rcn_desc_clear.restype = C.c_int
     L.rcn_desc_clear.argtypes = [vp]
     L.rcn_desc_count.restype = C.c_int
@@ -108,6 +111,8 @@ def load():
     L.rcn_match_grid_device.argtypes = [vp, vp, i32, f32, vp, i64, vp]
     L.rcn_match_last_stats.restype = C.c_int
     L.rcn_match_last_stats.argtypes = [vp, C.POINTER(MatchStats)]
+    L.rcn_match_profile.restype = C.c_int
+    L.rcn_match_profile.argtypes = [vp, C.c_int]
     L.rcn_ba_default_options.restype = None
     L.rcn_ba_default_options.argtypes = [i32, C.POINTER(BaOptions)]
     L.rcn_ba_solve.restype = C.c_int

@@ -48,6 +48,9 @@ void rcn_destroy(rcn_ctx *ctx)
                       &ctx->fb_list, &ctx->counters, &ctx->stats_dev, &ctx->out_tmp, &ctx->cnt_tmp};
     for (DevBuf *b : bufs) b->release();
     for (DevBuf &b : ctx->ba_ws) b.release();
+    if (ctx->ev_made)
+        for (auto &row : ctx->ev)
+            for (auto &e : row) (void)hipEventDestroy(e);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }

@@ -89,6 +89,30 @@ __global__ void k_prepare(const float *__restrict__ x, const double *__restrict_
     if (c == 0) hn[row] = row < K ? (float)(half_s2 * nrm2[row] + bias) : RCN_PAD_HN;
 }
 
+// Same for a batch of n equally shaped images ([n][K][D] fp32 -> [n][Kp][DP] fp16).
+template <int DP>
+__global__ void k_prepare_batch(const float *__restrict__ x, const double *__restrict__ nrm2,
+                                int n, int K, int Kp, int D, float scale, double half_s2,
+                                double bias, _Float16 *__restrict__ f16, float *__restrict__ hn)
+{
+    constexpr int CPR = DP / 8;
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long grow = gid / CPR;
+    const int c = (int)(gid % CPR);
+    if (grow >= (long)n * Kp) return;
+    const int img = (int)(grow / Kp), row = (int)(grow % Kp);
+    const float *xi = x + (size_t)img * K * D;
+    half8 v;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        int k = c * 8 + e;
+        float f = (row < K && k < D) ? xi[(size_t)row * D + k] * scale : 0.f;
+        v[e] = (_Float16)f;
+    }
+    *reinterpret_cast<half8 *>(f16 + (size_t)grow * DP + ((c ^ swz<DP>(row)) * 8)) = v;
+    if (c == 0) hn[grow] = row < K ? (float)(half_s2 * nrm2[(size_t)img * K + row] + bias) : RCN_PAD_HN;
+}
+
 // ---------------------------------------------------------------------------------------
 __device__ __forceinline__ unsigned umed3(unsigned a, unsigned b, unsigned c)
 {
@@ -408,16 +432,30 @@ static int pad_dim(int D)
     return 0;  // no MFMA path
 }
 
+static void free_image(ImgHost &im)
+{
+    if (im.slab >= 0) return;  // views into a slab
+    if (im.f32) (void)hipFree(im.f32);
+    if (im.f16) (void)hipFree(im.f16);
+    if (im.hn) (void)hipFree(im.hn);
+    if (im.nrm2) (void)hipFree(im.nrm2);
+    im.f32 = nullptr; im.f16 = nullptr; im.hn = nullptr; im.nrm2 = nullptr;
+}
+
+static void free_slab(Slab &sl)
+{
+    if (sl.f16) (void)hipFree(sl.f16);
+    if (sl.hn) (void)hipFree(sl.hn);
+    if (sl.nrm2) (void)hipFree(sl.nrm2);
+    sl = Slab();
+}
+
 int rcn_match_release(rcn_ctx *ctx)
 {
-    for (auto &kv : ctx->images) {
-        ImgHost &im = kv.second;
-        if (im.f32) (void)hipFree(im.f32);
-        if (im.f16) (void)hipFree(im.f16);
-        if (im.hn) (void)hipFree(im.hn);
-        if (im.nrm2) (void)hipFree(im.nrm2);
-    }
+    for (auto &kv : ctx->images) free_image(kv.second);
     ctx->images.clear();
+    for (Slab &sl : ctx->slabs) free_slab(sl);
+    ctx->slabs.clear();
     ctx->prepared = false;
     ctx->D = ctx->DP = 0;
     return RCN_OK;
@@ -451,12 +489,8 @@ static int upload_common(rcn_ctx *ctx, int32_t img_id, const float *src, bool sr
     ctx->DP = pad_dim(D);
     auto it = ctx->images.find(img_id);
     if (it != ctx->images.end()) {
-        ImgHost &o = it->second;
         RCN_HIP(hipStreamSynchronize(ctx->stream));
-        if (o.f32) (void)hipFree(o.f32);
-        if (o.f16) (void)hipFree(o.f16);
-        if (o.hn) (void)hipFree(o.hn);
-        if (o.nrm2) (void)hipFree(o.nrm2);
+        free_image(it->second);
         ctx->images.erase(it);
     }
     ImgHost im;
@@ -481,6 +515,73 @@ static int upload_common(rcn_ctx *ctx, int32_t img_id, const float *src, bool sr
     ctx->images[img_id] = im;
     ctx->prepared = false;
     return RCN_OK;
+}
+
+static int upload_batch(rcn_ctx *ctx, int32_t first_id, int32_t n, const float *src, int32_t K, int32_t D)
+{
+    if (n < 0 || K <= 0 || D <= 0 || (n > 0 && !src) || (int64_t)n * K > 0x7fffffffLL) {
+        ctx->set_error("rcn_desc_upload_batch_device: bad argument");
+        return RCN_ERR_ARG;
+    }
+    if (n == 0) return RCN_OK;
+    if (!ctx->images.empty() && ctx->D != D) {
+        ctx->set_error("rcn_desc_upload_batch_device: all resident images must share D");
+        return RCN_ERR_ARG;
+    }
+    RCN_HIP(hipSetDevice(ctx->device));
+    int rc = ensure_counters(ctx);
+    if (rc) return rc;
+    ctx->D = D;
+    ctx->DP = pad_dim(D);
+    const int DPa = ctx->DP ? ctx->DP : 32;
+    const int Kp = (K + RCN_QT - 1) / RCN_QT * RCN_QT;
+    int si = -1;
+    for (size_t i = 0; i < ctx->slabs.size(); ++i) {
+        const Slab &sl = ctx->slabs[i];
+        if (sl.live && sl.first_id == first_id && sl.n == n && sl.K == K && sl.D == D) si = (int)i;
+    }
+    if (si < 0) {
+        // new shape: drop whatever these ids held, then allocate once
+        RCN_HIP(hipStreamSynchronize(ctx->stream));
+        for (int i = 0; i < n; ++i) {
+            auto it = ctx->images.find(first_id + i);
+            if (it != ctx->images.end()) { free_image(it->second); ctx->images.erase(it); }
+        }
+        Slab sl;
+        sl.first_id = first_id; sl.n = n; sl.K = K; sl.Kp = Kp; sl.D = D; sl.live = true;
+        RCN_HIP(hipMalloc(&sl.f16, (size_t)n * Kp * DPa * sizeof(_Float16)));
+        RCN_HIP(hipMalloc(&sl.hn, (size_t)n * Kp * sizeof(float)));
+        RCN_HIP(hipMalloc(&sl.nrm2, (size_t)n * K * sizeof(double)));
+        ctx->slabs.push_back(sl);
+        si = (int)ctx->slabs.size() - 1;
+    }
+    Slab &sl = ctx->slabs[si];
+    sl.f32 = src;
+    for (int i = 0; i < n; ++i) {
+        ImgHost im;
+        im.K = K; im.Kp = Kp; im.slab = si;
+        im.f32 = const_cast<float *>(src) + (size_t)i * K * D;
+        im.f16 = sl.f16 + (size_t)i * Kp * DPa;
+        im.hn = sl.hn + (size_t)i * Kp;
+        im.nrm2 = sl.nrm2 + (size_t)i * K;
+        auto it = ctx->images.find(first_id + i);
+        if (it != ctx->images.end()) im.slot = it->second.slot;
+        ctx->images[first_id + i] = im;
+    }
+    unsigned *cnt = ctx->counters.as<unsigned>();
+    const int rows = n * K;
+    k_rowstats<<<(rows + 255) / 256, 256, 0, ctx->stream>>>(src, rows, D, sl.nrm2, cnt,
+                                                            reinterpret_cast<unsigned long long *>(cnt + 2));
+    RCN_HIP(hipGetLastError());
+    ctx->prepared = false;
+    return RCN_OK;
+}
+
+template <int DP> static void launch_prepare_batch(rcn_ctx *ctx, const Slab &sl, float s, double hs2, double bias)
+{
+    const long nthr = (long)sl.n * sl.Kp * (DP / 8);
+    k_prepare_batch<DP><<<(unsigned)((nthr + 255) / 256), 256, 0, ctx->stream>>>(
+        sl.f32, sl.nrm2, sl.n, sl.K, sl.Kp, sl.D, s, hs2, bias, sl.f16, sl.hn);
 }
 
 template <int DP> static void launch_prepare(rcn_ctx *ctx, const ImgHost &im, float s, double hs2, double bias)
@@ -518,7 +619,7 @@ static int prepare_all(rcn_ctx *ctx)
     for (auto &kv : ctx->images) {
         ImgHost &im = kv.second;
         im.slot = slot++;
-        if (ctx->DP) {
+        if (ctx->DP && im.slab < 0) {
             switch (ctx->DP) {
             case 32: launch_prepare<32>(ctx, im, (float)s, hs2, ctx->bias); break;
             case 64: launch_prepare<64>(ctx, im, (float)s, hs2, ctx->bias); break;
@@ -529,6 +630,17 @@ static int prepare_all(rcn_ctx *ctx)
         }
         table.push_back(ImgDev{im.f32, im.f16, im.hn, im.nrm2, im.K, im.Kp});
     }
+    if (ctx->DP)
+        for (const Slab &sl : ctx->slabs) {
+            if (!sl.live) continue;
+            switch (ctx->DP) {
+            case 32: launch_prepare_batch<32>(ctx, sl, (float)s, hs2, ctx->bias); break;
+            case 64: launch_prepare_batch<64>(ctx, sl, (float)s, hs2, ctx->bias); break;
+            case 128: launch_prepare_batch<128>(ctx, sl, (float)s, hs2, ctx->bias); break;
+            default: launch_prepare_batch<256>(ctx, sl, (float)s, hs2, ctx->bias); break;
+            }
+            RCN_HIP(hipGetLastError());
+        }
     RCN_HIP(ctx->img_table.reserve(std::max<size_t>(1, table.size()) * sizeof(ImgDev)));
     if (!table.empty())
         RCN_HIP(hipMemcpyAsync(ctx->img_table.p, table.data(), table.size() * sizeof(ImgDev),
@@ -606,6 +718,9 @@ static int match_grid_impl(rcn_ctx *ctx, const int32_t *pairs_host, int32_t n_pa
     const int32_t *pairs = ctx->pairs_dev.as<int32_t>();
     const bool vec4 = (ctx->D % 4) == 0;
 
+    const int evi = ctx->ev_n % 64;
+    const bool prof = ctx->profile && ctx->ev_made;
+    if (prof) RCN_HIP(hipEventRecord(ctx->ev[evi][0], ctx->stream));
     if (mfma) {
         CoarseArgs ca;
         ca.imgs = imgs; ca.pairs = pairs; ca.cand = ctx->cand.as<uint2>();
@@ -624,6 +739,7 @@ static int match_grid_impl(rcn_ctx *ctx, const int32_t *pairs_host, int32_t n_pa
         RCN_HIP(e);
     }
 
+    if (prof) RCN_HIP(hipEventRecord(ctx->ev[evi][1], ctx->stream));
     RerankArgs ra;
     memset(&ra, 0, sizeof(ra));
     ra.imgs = imgs; ra.pairs = pairs; ra.cand = ctx->cand.as<uint2>();
@@ -652,6 +768,7 @@ static int match_grid_impl(rcn_ctx *ctx, const int32_t *pairs_host, int32_t n_pa
         if (vec4) k_exact_rows<true><<<fb_blocks, 256, 0, ctx->stream>>>(imgs, pairs, ra.fb_list, fb_count, ctx->D, ratio, out_dev, out_stride);
         else k_exact_rows<false><<<fb_blocks, 256, 0, ctx->stream>>>(imgs, pairs, ra.fb_list, fb_count, ctx->D, ratio, out_dev, out_stride);
         RCN_HIP(hipGetLastError());
+        if (prof) RCN_HIP(hipEventRecord(ctx->ev[evi][2], ctx->stream));
         k_unique_claim<<<g, 256, 0, ctx->stream>>>(imgs, pairs, out_dev, out_stride, ctx->owner.as<int32_t>(), owner_stride, qblocks);
         RCN_HIP(hipGetLastError());
     }
@@ -660,6 +777,10 @@ static int match_grid_impl(rcn_ctx *ctx, const int32_t *pairs_host, int32_t n_pa
         dim3 g((unsigned)eblocks * (unsigned)n_pairs);
         k_unique_emit<<<g, 256, 0, ctx->stream>>>(imgs, pairs, out_dev, out_stride, ctx->owner.as<int32_t>(), owner_stride, counts_dev, eblocks);
         RCN_HIP(hipGetLastError());
+    }
+    if (prof && kq_max > 0) {
+        RCN_HIP(hipEventRecord(ctx->ev[evi][3], ctx->stream));
+        ctx->ev_n++;
     }
     // stats: the fallback count is read back lazily in rcn_match_last_stats
     ctx->last_stats.rows_total = rows;
@@ -689,6 +810,14 @@ int rcn_desc_upload_device(rcn_ctx *ctx, int32_t img_id, const float *desc_dev, 
     if (!ctx) return RCN_ERR_ARG;
     std::lock_guard<std::mutex> lk(ctx->mu);
     return upload_common(ctx, img_id, desc_dev, true, K, D);
+}
+
+int rcn_desc_upload_batch_device(rcn_ctx *ctx, int32_t first_img_id, int32_t n_images,
+                                 const float *desc_dev, int32_t K, int32_t D)
+{
+    if (!ctx) return RCN_ERR_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    return upload_batch(ctx, first_img_id, n_images, desc_dev, K, D);
 }
 
 int rcn_desc_clear(rcn_ctx *ctx)
@@ -774,11 +903,7 @@ int rcn_match_pair(rcn_ctx *ctx, const float *q_host, int32_t K1, const float *t
     for (int32_t id : {ida, idb}) {
         auto it = ctx->images.find(id);
         if (it != ctx->images.end()) {
-            ImgHost &o = it->second;
-            if (o.f32) (void)hipFree(o.f32);
-            if (o.f16) (void)hipFree(o.f16);
-            if (o.hn) (void)hipFree(o.hn);
-            if (o.nrm2) (void)hipFree(o.nrm2);
+            free_image(it->second);
             ctx->images.erase(it);
         }
     }
@@ -797,7 +922,36 @@ int rcn_match_last_stats(const rcn_ctx *cctx, rcn_match_stats *out)
         RCN_HIP(hipStreamSynchronize(ctx->stream));
         ctx->last_stats.rows_exact_fallback = n;
     }
+    if (ctx->ev_n > 0 && ctx->ev_made) {
+        RCN_HIP(hipStreamSynchronize(ctx->stream));
+        const int n = ctx->ev_n < 64 ? ctx->ev_n : 64;
+        double c = 0, r = 0, u = 0;
+        for (int i = 0; i < n; ++i) {
+            float ms = 0.f;
+            RCN_HIP(hipEventElapsedTime(&ms, ctx->ev[i][0], ctx->ev[i][1])); c += ms;
+            RCN_HIP(hipEventElapsedTime(&ms, ctx->ev[i][1], ctx->ev[i][2])); r += ms;
+            RCN_HIP(hipEventElapsedTime(&ms, ctx->ev[i][2], ctx->ev[i][3])); u += ms;
+        }
+        ctx->last_stats.profiled_calls = n;
+        ctx->last_stats.coarse_ms = c; ctx->last_stats.rerank_ms = r; ctx->last_stats.unique_ms = u;
+        ctx->ev_n = 0;
+    }
     *out = ctx->last_stats;
+    return RCN_OK;
+}
+
+int rcn_match_profile(rcn_ctx *ctx, int enable)
+{
+    if (!ctx) return RCN_ERR_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    RCN_HIP(hipSetDevice(ctx->device));
+    if (enable && !ctx->ev_made) {
+        for (auto &row : ctx->ev)
+            for (auto &e : row) RCN_HIP(hipEventCreate(&e));
+        ctx->ev_made = true;
+    }
+    ctx->profile = enable != 0;
+    ctx->ev_n = 0;
     return RCN_OK;
 }
 

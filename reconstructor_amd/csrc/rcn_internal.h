@@ -54,6 +54,17 @@ struct ImgHost {
     double *nrm2 = nullptr;
     int32_t K = 0, Kp = 0;
     int32_t slot = -1;  // row in the device image table
+    int32_t slab = -1;  // >= 0: buffers are views into ctx->slabs[slab] (batch upload)
+};
+
+// One batch of equally shaped images (rcn_desc_upload_batch_device): one allocation per array.
+struct Slab {
+    int32_t first_id = 0, n = 0, K = 0, Kp = 0, D = 0;
+    const float *f32 = nullptr;   // borrowed from the caller
+    _Float16 *f16 = nullptr;
+    float *hn = nullptr;
+    double *nrm2 = nullptr;
+    bool live = false;
 };
 
 struct rcn_ctx {
@@ -67,12 +78,17 @@ struct rcn_ctx {
     // ---- matcher state
     int32_t D = 0, DP = 0;
     std::map<int32_t, ImgHost> images;
+    std::vector<Slab> slabs;
     bool prepared = false;
     double scale = 1.0;      // s, power of two
     double bias = 0.0;       // BIAS in accumulator units
     double max_norm = 0.0;   // max |x| over resident rows
     DevBuf img_table, pairs_dev, cand, best, owner, fb_list, counters, stats_dev, out_tmp, cnt_tmp;
     rcn_match_stats last_stats;
+    bool profile = false;
+    hipEvent_t ev[64][4];
+    bool ev_made = false;
+    int ev_n = 0;          // recorded calls since the last stats read (<= 64)
     bool force_exact = false;  // RCN_FORCE_EXACT=1: skip the MFMA coarse pass (diagnostics)
 
     // ---- BA state (ba.hip)

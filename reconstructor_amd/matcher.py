@@ -89,6 +89,12 @@ class HipL2Matcher(FeatureMatcher):
         self.ctx.check(self.ctx.lib.rcn_desc_upload_device(self.ctx.h, int(img_id),
                                                            C.c_void_p(dev_ptr), K, D))
 
+    def upload_batch_device(self, first_id, n_images, dev_ptr, K, D):
+        """[n][K][D] fp32 in HBM, borrowed (zero copy); one stats + one conversion launch."""
+        self._D = D
+        self.ctx.check(self.ctx.lib.rcn_desc_upload_batch_device(
+            self.ctx.h, int(first_id), int(n_images), C.c_void_p(dev_ptr), K, D))
+
     def clear(self):
         self.ctx.check(self.ctx.lib.rcn_desc_clear(self.ctx.h))
 
@@ -108,6 +114,9 @@ class HipL2Matcher(FeatureMatcher):
         self.ctx.check(self.ctx.lib.rcn_match_grid_device(
             self.ctx.h, pairs.ctypes.data, pairs.shape[0], self.ratio,
             C.c_void_p(out_dev_ptr), out_stride, C.c_void_p(counts_dev_ptr)))
+
+    def profile(self, enable=True):
+        self.ctx.check(self.ctx.lib.rcn_match_profile(self.ctx.h, 1 if enable else 0))
 
     def stats(self):
         s = _lib.MatchStats()

@@ -1,0 +1,132 @@
+"""GPU parity suite for the matcher: HIP path (through the C ABI) vs the CPU oracle,
+bit-exact on indices.  Run on the MI355X box with -m gpu."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import orc
+from reconstructor_amd import synth
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def matcher(gpu_ctx):
+    from reconstructor_amd.matcher import HipL2Matcher
+    return HipL2Matcher(ctx=gpu_ctx)
+
+
+def _cases(npz):
+    z = np.load(os.path.join(G, npz))
+    names = sorted({k.split("/")[0] for k in z.files})
+    return [(n, z[n + "/q"], z[n + "/t"], z[n + "/expect"]) for n in names]
+
+
+@pytest.mark.parametrize("name,q,t,expect", _cases("match_kat.npz"), ids=lambda v: v if isinstance(v, str) else "")
+def test_kat(matcher, name, q, t, expect):
+    assert np.array_equal(matcher.match_pair(q, t), expect)
+
+
+@pytest.mark.parametrize("name,q,t,expect", _cases("match_seeded.npz"), ids=lambda v: v if isinstance(v, str) else "")
+def test_seeded(matcher, name, q, t, expect):
+    assert np.array_equal(matcher.match_pair(q, t), expect)
+
+
+def test_plugin_signature_fills_map(matcher):
+    """FeatureMatcher::matchFeatures(features1, features2, matches, shape1, shape2)."""
+    z = np.load(os.path.join(G, "match_seeded.npz"))
+    q, t, exp = z["sift/q"], z["sift/t"], z["sift/expect"]
+    matches = {}
+    matcher.match_features(q, t, matches, (336, 512), (336, 512))
+    assert matches == {int(i): int(exp[i]) for i in np.nonzero(exp >= 0)[0]}
+
+
+def test_grid8_golden(matcher):
+    z = np.load(os.path.join(G, "match_grid8.npz"))
+    ks = list(z["ks"])
+    ims = synth.descriptor_set("superpoint", 8, ks, n_world=int(z["n_world"]), seed=int(z["seed"]))
+    matcher.clear()
+    for i, im in enumerate(ims):
+        matcher.upload(i, im)
+    out, counts = matcher.match_grid(z["pairs"], max(ks))
+    assert np.array_equal(out, z["expect"])
+    assert np.array_equal(counts, z["counts"])
+    matcher.clear()
+
+
+@pytest.mark.parametrize("kind,K1,K2", [("superpoint", 700, 1000), ("superpoint", 2048, 2048),
+                                        ("sift", 900, 640), ("orb", 500, 777)])
+def test_pair_vs_oracle(matcher, kind, K1, K2):
+    ims = synth.descriptor_set(kind, 2, [K1, K2], n_world=3000, seed=21)
+    exp, n = orc.match_pair(ims[0], ims[1])
+    got = matcher.match_pair(ims[0], ims[1])
+    assert np.array_equal(got, exp)
+    st = matcher.stats()
+    assert st["used_mfma_path"] == 1
+    assert st["pair_distances"] == K1 * K2
+    print(kind, K1, K2, "matches", n, "fallback rows", st["rows_exact_fallback"], "eps_d2", st["err_bound_d2"])
+
+
+def test_ragged_grid_vs_oracle(matcher):
+    ks = [300, 0, 257, 1, 512, 2, 640]
+    ims = synth.descriptor_set("superpoint", len(ks), ks, n_world=900, seed=5)
+    matcher.clear()
+    for i, im in enumerate(ims):
+        matcher.upload(i, im)
+    pairs = orc.all_pairs(len(ks))
+    # both orientations: the grid API takes any (query, train) list
+    pairs = np.concatenate([pairs, pairs[:, ::-1]]).astype(np.int32)
+    exp, ec = orc.match_grid(ims, pairs, threads=4)
+    out, counts = matcher.match_grid(pairs, max(ks))
+    assert np.array_equal(out, exp)
+    assert np.array_equal(counts, ec)
+    matcher.clear()
+
+
+def test_adversarial_near_duplicates(matcher):
+    """Many train rows within the coarse error bound of each other: the certified re-rank
+    must hand these rows to the exact kernel and still be bit-exact."""
+    rng = np.random.default_rng(8)
+    base = rng.standard_normal((40, 256)).astype(np.float32)
+    base /= np.linalg.norm(base, axis=1, keepdims=True)
+    t = np.repeat(base, 16, axis=0) + (rng.standard_normal((640, 256)) * 1e-5).astype(np.float32)
+    q = base + (rng.standard_normal((40, 256)) * 1e-5).astype(np.float32)
+    exp, _ = orc.match_pair(q, t)
+    assert np.array_equal(matcher.match_pair(q, t), exp)
+    assert matcher.stats()["rows_exact_fallback"] >= 0
+
+
+def test_unsupported_dim_takes_exact_kernel(matcher):
+    rng = np.random.default_rng(9)
+    q = rng.standard_normal((130, 300)).astype(np.float32)   # D > 256: no MFMA path
+    t = np.concatenate([q[:50] + 0.01, rng.standard_normal((100, 300)).astype(np.float32)]).astype(np.float32)
+    exp, _ = orc.match_pair(q, t)
+    assert np.array_equal(matcher.match_pair(q, t), exp)
+    assert matcher.stats()["used_mfma_path"] == 0
+    q = rng.standard_normal((65, 7)).astype(np.float32)       # D not a multiple of 4
+    t = rng.standard_normal((90, 7)).astype(np.float32)
+    exp, _ = orc.match_pair(q, t)
+    assert np.array_equal(matcher.match_pair(q, t), exp)
+
+
+def test_full_size_properties(matcher):
+    """BASELINE cfg-2 shapes (2048 x 2048 x 256): size-independent properties."""
+    ims = synth.descriptor_set("superpoint", 3, 2048, seed=1234)
+    matcher.clear()
+    for i, im in enumerate(ims):
+        matcher.upload(i, im)
+    pairs = np.array([[0, 0], [0, 1], [1, 0], [1, 2]], np.int32)
+    out, counts = matcher.match_grid(pairs, 2048)
+    # self pair: every row's nearest neighbour is itself at distance 0 -> identity map
+    assert np.array_equal(out[0], np.arange(2048))
+    for p in range(4):
+        m = out[p][out[p] >= 0]
+        assert len(m) == counts[p] and len(np.unique(m)) == len(m)      # uniqueness
+    # a sample of rows against the oracle's exact 2-NN
+    idx, d2 = orc.knn2(ims[0][:64], ims[1])
+    for i in range(64):
+        passes = np.sqrt(np.float32(d2[i, 0])) < np.float32(0.7) * np.sqrt(np.float32(d2[i, 1]))
+        assert out[1][i] in ((idx[i, 0], -1) if passes else (-1,))
+    matcher.clear()
