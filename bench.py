@@ -159,7 +159,7 @@ def main():
                                       "" if world == 1 else " (weak scaling of cfg2: ~4950 pairs per rank, RCCL all-gather + ingest inside the step)"),
                        "pairs_per_rank": int(len(my_pairs)), "pair_matches_per_s": len(pairs) * args.steps / dt,
                        "matches_found": n_matches,
-                       "rows_exact_fallback": int(st["rows_exact_fallback"]), "rows_total": int(st["rows_total"])},
+                       "rows_reranked": int(st["rows_reranked"]), "rows_exact_fallback": int(st["rows_exact_fallback"]), "rows_total": int(st["rows_total"])},
             "roofline": {"bound": "mfma", "kernel": "k_coarse_top2<256>", "achieved": achieved,
                          "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / MFMA_F16_PEAK_TFLOPS, "traffic": None,

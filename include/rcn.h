@@ -89,7 +89,8 @@ int rcn_match_grid_device(rcn_ctx *ctx, const int32_t *pairs_host, int32_t n_pai
 /* Statistics of the last grid call (diagnostics; rows_total = sum of K1 over pairs). */
 typedef struct {
     int64_t rows_total;
-    int64_t rows_exact_fallback;  /* query rows the coarse pass could not certify */
+    int64_t rows_reranked;        /* query rows whose two candidates were re-computed exactly (fp64) */
+    int64_t rows_exact_fallback;  /* query rows the coarse pass could not certify: exact brute force */
     int64_t pair_distances;       /* sum of K1*K2 */
     double  err_bound_d2;         /* largest certified bound on |coarse - exact| squared distance */
     int32_t used_mfma_path;       /* 1 = fp16 MFMA coarse pass + exact re-rank, 0 = exact kernel only */

@@ -29,7 +29,7 @@ class RcnError(RuntimeError):
 
 
 class MatchStats(C.Structure):
-    _fields_ = [("rows_total", C.c_int64), ("rows_exact_fallback", C.c_int64),
+    _fields_ = [("rows_total", C.c_int64), ("rows_reranked", C.c_int64), ("rows_exact_fallback", C.c_int64),
                 ("pair_distances", C.c_int64), ("err_bound_d2", C.c_double),
                 ("used_mfma_path", C.c_int32), ("profiled_calls", C.c_int32),
                 ("coarse_ms", C.c_double), ("rerank_ms", C.c_double), ("unique_ms", C.c_double)]

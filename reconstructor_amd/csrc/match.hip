@@ -284,6 +284,8 @@ struct RerankArgs {
     int64_t out_stride;
     unsigned long long *fb_list;  // (pair << 32 | query) rows needing the exact kernel
     unsigned *fb_count;
+    unsigned long long *sv_list;  // rows that survive the coarse filter: exact re-rank
+    unsigned *sv_count;
     int32_t n_pairs, kq_stride, D, qblocks;
     uint32_t idx_mask;
     float ratio;
@@ -299,50 +301,187 @@ struct RerankArgs {
     int32_t all_to_fallback;
 };
 
-// K2: one thread per (pair, query row).
-template <bool VEC4> __global__ void k_rerank(RerankArgs a)
+// ---- certified decision from exact candidate distances --------------
+// ea<=eb exact (fp64 chain) distances of the two candidates (ia, ib), ordered by (value, idx);
+// lbnc = lower bound on the exact distance of every non-candidate row.
+// returns  >=0 : certified match index,  -1 : certified "no match",  -2 : cannot certify.
+__device__ __forceinline__ int certify(double ea, int ia, double eb, double lbnc, float ratio)
+{
+    const bool nn_certain = ea < lbnc;
+    double lb1 = fmin(eb, lbnc), lb0 = fmin(ea, lbnc);
+    if (lb1 < 0.0) lb1 = 0.0;
+    if (lb0 < 0.0) lb0 = 0.0;
+    if (nn_certain && ratio_pass(ea, lb1, ratio)) return ia;
+    if (!ratio_pass(lb0, eb, ratio)) return -1;
+    return -2;
+}
+
+// coarse-error bound for one query, accumulator units
+__device__ __forceinline__ double coarse_eps(const RerankArgs &a, double nq2)
+{
+    const double nq = sqrt(nq2) * (1.0 + 1e-12);
+    const double mag = a.s2 * nq * a.n_max;
+    return a.c_in * nq * a.n_max + a.c_sub * (nq + a.n_max) + 1e-9 + a.c_acc * (a.hn_max + mag) +
+           6.0e-8 * a.hn_max;
+}
+// accumulator value -> squared distance (both real-valued), minus/plus the evaluation slack
+__device__ __forceinline__ double acc_to_d2(const RerankArgs &a, double nq2, double acc)
+{
+    return nq2 + (2.0 / a.s2) * (acc - a.bias);
+}
+
+__device__ __forceinline__ void list_append(unsigned long long *list, unsigned *count, bool want,
+                                            unsigned long long entry)
+{
+    const unsigned long long m = __ballot(want);
+    if (!m) return;
+    const int lane = threadIdx.x & 63;
+    const int leader = __ffsll((long long)m) - 1;
+    unsigned base = 0;
+    if (lane == leader) base = atomicAdd(count, (unsigned)__popcll(m));
+    base = __shfl(base, leader);
+    if (want) list[base + __popcll(m & ((1ull << lane) - 1ull))] = entry;
+}
+
+// K2a: one thread per (pair, query row): decide from the coarse values alone whenever the
+// ratio test fails for every distance pair compatible with the error bound (the common case:
+// queries without a true counterpart have dist0 ~ dist1); the rest go to the survivor list.
+__global__ void k_filter(RerankArgs a)
 {
     const int pair = blockIdx.x / a.qblocks;
     const int q = (blockIdx.x - pair * a.qblocks) * blockDim.x + threadIdx.x;
     const ImgDev qi = a.imgs[a.pairs[2 * pair]];
     const ImgDev ti = a.imgs[a.pairs[2 * pair + 1]];
-    if (q >= qi.K) return;
-    int32_t *o = a.out + (size_t)pair * a.out_stride + q;
-    if (ti.K < 2) { *o = -1; return; }
-    if (a.all_to_fallback) {
-        unsigned slot = atomicAdd(a.fb_count, 1u);
-        a.fb_list[slot] = ((unsigned long long)pair << 32) | (unsigned)q;
+    bool surv = false, fb = false;
+    if (q < qi.K) {
+        int32_t *o = a.out + (size_t)pair * a.out_stride + q;
         *o = -1;
-        return;
+        if (ti.K >= 2) {
+            if (a.all_to_fallback) fb = true;
+            else {
+                const uint2 c = a.cand[(size_t)pair * a.kq_stride + q];
+                const double nq2 = qi.nrm2[q];
+                const double eps = coarse_eps(a, nq2);
+                const double slack = a.rel_slack * (nq2 + a.n_max * a.n_max);
+                // every row has acc >= trunc(best); both candidates have acc < trunc(second)+quantum
+                const double lo = (double)__uint_as_float(c.x & ~a.idx_mask);
+                const double hi = (double)__uint_as_float((c.y & ~a.idx_mask) + a.idx_mask + 1u);
+                double lb0 = acc_to_d2(a, nq2, lo - eps) - slack;
+                const double ub1 = acc_to_d2(a, nq2, hi + eps) + slack;
+                if (lb0 < 0.0) lb0 = 0.0;
+                surv = ratio_pass(lb0, ub1, a.ratio);
+            }
+        }
     }
-    const uint2 c = a.cand[(size_t)pair * a.kq_stride + q];
-    int ia = (int)(c.x & a.idx_mask), ib = (int)(c.y & a.idx_mask);
-    const float *qrow = qi.f32 + (size_t)q * a.D;
-    double ea = exact_d2<VEC4>(qrow, ti.f32 + (size_t)ia * a.D, a.D);
-    double eb = exact_d2<VEC4>(qrow, ti.f32 + (size_t)ib * a.D, a.D);
-    if (eb < ea || (eb == ea && ib < ia)) { double te = ea; ea = eb; eb = te; int tq = ia; ia = ib; ib = tq; }
+    const unsigned long long entry = ((unsigned long long)pair << 32) | (unsigned)q;
+    list_append(a.sv_list, a.sv_count, surv, entry);
+    list_append(a.fb_list, a.fb_count, fb, entry);
+}
 
-    // every train row that is not a candidate has accumulator >= lbacc
-    double lbnc = INFINITY;
-    if (ti.K > 2) {
-        const double nq2 = qi.nrm2[q];
-        const double nq = sqrt(nq2) * (1.0 + 1e-12);
-        const double mag = a.s2 * nq * a.n_max;
-        const double eps = a.c_in * nq * a.n_max + a.c_sub * (nq + a.n_max) + 1e-9 +
-                           a.c_acc * (a.hn_max + mag) + 6.0e-8 * a.hn_max;
-        const double lbacc = (double)__uint_as_float(c.y & ~a.idx_mask);
-        lbnc = nq2 + (2.0 / a.s2) * (lbacc - eps - a.bias);
-        lbnc -= a.rel_slack * (nq2 + a.n_max * a.n_max);
+// K2: exact fp64 re-rank of the survivors.  One wave = 32 survivors = 64 chains (2 candidates
+// each).  Rows are staged through LDS in 32-float chunks so that global reads are whole
+// 128-B segments (8 lanes per row) instead of 64 lanes striding 1-KiB rows; each lane then
+// walks its own (query,candidate) chain in ascending k out of LDS.
+#define RR_ROWS 96
+#define RR_LD 36  // floats per LDS row: 32 + 4 pad (conflict-free ds_read_b128 by row)
+__global__ __launch_bounds__(64) void k_rerank_lds(RerankArgs a)
+{
+    __shared__ __attribute__((aligned(16))) float tile[RR_ROWS * RR_LD];
+    __shared__ const float *rowptr[RR_ROWS];
+    const int lane = threadIdx.x;
+    const unsigned n = *a.sv_count;
+    const int D = a.D;
+    const int nchunk = (D + 31) / 32;
+    for (unsigned g = blockIdx.x; g * 32u < n; g += gridDim.x) {
+        const unsigned sidx = g * 32u + (lane >> 1);
+        const bool live = sidx < n;
+        const unsigned long long e = a.sv_list[live ? sidx : g * 32u];
+        const int pair = (int)(e >> 32), q = (int)(e & 0xFFFFFFFFu);
+        const ImgDev qi = a.imgs[a.pairs[2 * pair]];
+        const ImgDev ti = a.imgs[a.pairs[2 * pair + 1]];
+        const uint2 c = a.cand[(size_t)pair * a.kq_stride + q];
+        const int myidx = (int)(((lane & 1) ? c.y : c.x) & a.idx_mask);
+        __syncthreads();  // previous group's reads of rowptr/tile are done
+        if ((lane & 1) == 0) rowptr[lane >> 1] = qi.f32 + (size_t)q * D;
+        rowptr[32 + lane] = ti.f32 + (size_t)myidx * D;
+        __syncthreads();
+        double acc = 0.0;
+        const float *qrow = tile + (lane >> 1) * RR_LD;
+        const float *trow = tile + (32 + lane) * RR_LD;
+        for (int ch = 0; ch < nchunk; ++ch) {
+            const int col = ch * 32 + (lane & 7) * 4;
+#pragma unroll
+            for (int i = 0; i < RR_ROWS / 8; ++i) {
+                const int r = i * 8 + (lane >> 3);
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (col < D) v = *reinterpret_cast<const float4 *>(rowptr[r] + col);
+                *reinterpret_cast<float4 *>(tile + r * RR_LD + (lane & 7) * 4) = v;
+            }
+            __syncthreads();
+            const int kmax = min(32, D - ch * 32);
+            for (int k4 = 0; k4 < kmax; k4 += 4) {
+                const float4 x = *reinterpret_cast<const float4 *>(qrow + k4);
+                const float4 y = *reinterpret_cast<const float4 *>(trow + k4);
+                double d;
+                d = (double)x.x - (double)y.x; acc = fma(d, d, acc);
+                d = (double)x.y - (double)y.y; acc = fma(d, d, acc);
+                d = (double)x.z - (double)y.z; acc = fma(d, d, acc);
+                d = (double)x.w - (double)y.w; acc = fma(d, d, acc);
+            }
+            __syncthreads();
+        }
+        // even lane = candidate from c.x, odd lane = candidate from c.y
+        const double other = __shfl_xor(acc, 1);
+        const int oidx = __shfl_xor(myidx, 1);
+        int res = -1;
+        bool fb = false;
+        if (live && (lane & 1) == 0) {
+            double ea = acc, eb = other;
+            int ia = myidx, ib = oidx;
+            if (eb < ea || (eb == ea && ib < ia)) { double te = ea; ea = eb; eb = te; ia = ib; }
+            double lbnc = INFINITY;
+            if (ti.K > 2) {
+                const double nq2 = qi.nrm2[q];
+                const double lbacc = (double)__uint_as_float(c.y & ~a.idx_mask);
+                lbnc = acc_to_d2(a, nq2, lbacc - coarse_eps(a, nq2)) - a.rel_slack * (nq2 + a.n_max * a.n_max);
+            }
+            res = certify(ea, ia, eb, lbnc, a.ratio);
+            if (res == -2) { fb = true; res = -1; }
+            a.out[(size_t)pair * a.out_stride + q] = res;
+        }
+        list_append(a.fb_list, a.fb_count, fb, e);
     }
-    const bool nn_certain = ea < lbnc;
-    double lb1 = fmin(eb, lbnc), lb0 = fmin(ea, lbnc);
-    if (lb1 < 0.0) lb1 = 0.0;
-    if (lb0 < 0.0) lb0 = 0.0;
-    if (nn_certain && ratio_pass(ea, lb1, a.ratio)) { *o = ia; return; }
-    if (!ratio_pass(lb0, eb, a.ratio)) { *o = -1; return; }
-    unsigned slot = atomicAdd(a.fb_count, 1u);
-    a.fb_list[slot] = ((unsigned long long)pair << 32) | (unsigned)q;
-    *o = -1;
+}
+
+// generic survivor re-rank (D not a multiple of 4): one thread per survivor
+__global__ void k_rerank_generic(RerankArgs a)
+{
+    const unsigned n = *a.sv_count;
+    for (unsigned s = blockIdx.x * blockDim.x + threadIdx.x; s < n; s += gridDim.x * blockDim.x) {
+        const unsigned long long e = a.sv_list[s];
+        const int pair = (int)(e >> 32), q = (int)(e & 0xFFFFFFFFu);
+        const ImgDev qi = a.imgs[a.pairs[2 * pair]];
+        const ImgDev ti = a.imgs[a.pairs[2 * pair + 1]];
+        const uint2 c = a.cand[(size_t)pair * a.kq_stride + q];
+        int ia = (int)(c.x & a.idx_mask), ib = (int)(c.y & a.idx_mask);
+        const float *qrow = qi.f32 + (size_t)q * a.D;
+        double ea = exact_d2<false>(qrow, ti.f32 + (size_t)ia * a.D, a.D);
+        double eb = exact_d2<false>(qrow, ti.f32 + (size_t)ib * a.D, a.D);
+        if (eb < ea || (eb == ea && ib < ia)) { double te = ea; ea = eb; eb = te; ia = ib; }
+        double lbnc = INFINITY;
+        if (ti.K > 2) {
+            const double nq2 = qi.nrm2[q];
+            const double lbacc = (double)__uint_as_float(c.y & ~a.idx_mask);
+            lbnc = acc_to_d2(a, nq2, lbacc - coarse_eps(a, nq2)) - a.rel_slack * (nq2 + a.n_max * a.n_max);
+        }
+        int res = certify(ea, ia, eb, lbnc, a.ratio);
+        if (res == -2) {
+            unsigned slot = atomicAdd(a.fb_count, 1u);
+            a.fb_list[slot] = e;
+            res = -1;
+        }
+        a.out[(size_t)pair * a.out_stride + q] = res;
+    }
 }
 
 // K2b: exact brute force of listed rows, one wave per row, grid-stride over the list.
@@ -707,6 +846,7 @@ static int match_grid_impl(rcn_ctx *ctx, const int32_t *pairs_host, int32_t n_pa
     RCN_HIP(ctx->cand.reserve((size_t)n_pairs * kq_stride * sizeof(uint2)));
     RCN_HIP(ctx->owner.reserve((size_t)n_pairs * owner_stride * sizeof(int32_t)));
     RCN_HIP(ctx->fb_list.reserve(std::max<int64_t>(1, rows) * sizeof(unsigned long long)));
+    RCN_HIP(ctx->sv_list.reserve(std::max<int64_t>(1, rows) * sizeof(unsigned long long)));
     RCN_HIP(hipMemcpyAsync(ctx->pairs_dev.p, slots.data(), slots.size() * sizeof(int32_t),
                            hipMemcpyHostToDevice, ctx->stream));
     unsigned *fb_count = ctx->counters.as<unsigned>() + 4;
@@ -745,6 +885,7 @@ static int match_grid_impl(rcn_ctx *ctx, const int32_t *pairs_host, int32_t n_pa
     ra.imgs = imgs; ra.pairs = pairs; ra.cand = ctx->cand.as<uint2>();
     ra.out = out_dev; ra.out_stride = out_stride;
     ra.fb_list = ctx->fb_list.as<unsigned long long>(); ra.fb_count = fb_count;
+    ra.sv_list = ctx->sv_list.as<unsigned long long>(); ra.sv_count = fb_count + 1;
     ra.n_pairs = n_pairs; ra.kq_stride = kq_stride; ra.D = ctx->D; ra.idx_mask = idx_mask;
     ra.ratio = ratio;
     const double s = ctx->scale, u = std::ldexp(1.0, -11);
@@ -761,9 +902,13 @@ static int match_grid_impl(rcn_ctx *ctx, const int32_t *pairs_host, int32_t n_pa
         const int qblocks = (kq_max + 255) / 256;
         ra.qblocks = qblocks;
         dim3 g((unsigned)qblocks * (unsigned)n_pairs);
-        if (vec4) k_rerank<true><<<g, 256, 0, ctx->stream>>>(ra);
-        else k_rerank<false><<<g, 256, 0, ctx->stream>>>(ra);
+        k_filter<<<g, 256, 0, ctx->stream>>>(ra);
         RCN_HIP(hipGetLastError());
+        if (mfma) {
+            if (vec4) k_rerank_lds<<<ctx->prop.multiProcessorCount * 16, 64, 0, ctx->stream>>>(ra);
+            else k_rerank_generic<<<ctx->prop.multiProcessorCount * 8, 256, 0, ctx->stream>>>(ra);
+            RCN_HIP(hipGetLastError());
+        }
         const int fb_blocks = ctx->prop.multiProcessorCount * 4;
         if (vec4) k_exact_rows<true><<<fb_blocks, 256, 0, ctx->stream>>>(imgs, pairs, ra.fb_list, fb_count, ctx->D, ratio, out_dev, out_stride);
         else k_exact_rows<false><<<fb_blocks, 256, 0, ctx->stream>>>(imgs, pairs, ra.fb_list, fb_count, ctx->D, ratio, out_dev, out_stride);
@@ -917,10 +1062,11 @@ int rcn_match_last_stats(const rcn_ctx *cctx, rcn_match_stats *out)
     if (!ctx || !out) return RCN_ERR_ARG;
     std::lock_guard<std::mutex> lk(ctx->mu);
     if (ctx->last_stats.rows_exact_fallback < 0 && ctx->counters.p) {
-        unsigned n = 0;
-        RCN_HIP(hipMemcpyAsync(&n, ctx->counters.as<unsigned>() + 4, 4, hipMemcpyDeviceToHost, ctx->stream));
+        unsigned n[2] = {0, 0};
+        RCN_HIP(hipMemcpyAsync(n, ctx->counters.as<unsigned>() + 4, 8, hipMemcpyDeviceToHost, ctx->stream));
         RCN_HIP(hipStreamSynchronize(ctx->stream));
-        ctx->last_stats.rows_exact_fallback = n;
+        ctx->last_stats.rows_exact_fallback = n[0];
+        ctx->last_stats.rows_reranked = n[1];
     }
     if (ctx->ev_n > 0 && ctx->ev_made) {
         RCN_HIP(hipStreamSynchronize(ctx->stream));
