@@ -33,6 +33,8 @@ int rcn_create(int device_id, rcn_ctx **out)
     ctx->stream = ctx->own_stream;
     const char *fe = std::getenv("RCN_FORCE_EXACT");
     ctx->force_exact = fe && fe[0] == '1';
+    const char *ab = std::getenv("RCN_COARSE_ABL");
+    ctx->ablate = ab ? std::atoi(ab) : 0;
     memset(&ctx->last_stats, 0, sizeof(ctx->last_stats));
     *out = ctx;
     return RCN_OK;

@@ -135,13 +135,17 @@ struct CoarseArgs {
 //   element is  s^2 * (|t|^2/2 - q.t) + BIAS  > 0  and orders like the squared distance for a
 //   fixed query.  Positive floats order like unsigned integers, so the running top-2 per
 //   (lane, column block) is v_and_or + v_med3_u32 + v_min_u32 per element.
-template <int DP>
+// ABL (ablation bits, diagnostics only -- results are wrong unless ABL == 0):
+//   1 skip the top-2 epilogue, 2 skip the half-norm init, 4 read the A fragment once per row
+//   block, 8 stage only the first tile.
+template <int DP, int ABL>
 __global__ __launch_bounds__(256, 2) void k_coarse_top2(CoarseArgs a)
 {
     constexpr int KS = DP / 16;
     constexpr int ROWB = DP * 2;
     constexpr int TILEB = RCN_BT * ROWB;
     constexpr int NINST = TILEB / 4 / 1024;  // 1-KiB LDS-DMA pieces per wave per tile
+    constexpr int BUFB = TILEB + 4 * 256;    // tile + one private copy of its 64 half-norms per wave
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int b = blockIdx.x;
@@ -152,7 +156,8 @@ __global__ __launch_bounds__(256, 2) void k_coarse_top2(CoarseArgs a)
     const ImgDev ti = a.imgs[a.pairs[2 * pair + 1]];
     if (qt * RCN_QT >= qi.K || ti.K < 2) return;
 
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 31, h = lane >> 5;
+    const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
 
     // query fragments, negated, resident for the whole train sweep
     half8 bq[2][KS];
@@ -170,62 +175,99 @@ __global__ __launch_bounds__(256, 2) void k_coarse_top2(CoarseArgs a)
     }
 
     unsigned m1[2] = {0xFFFFFFFFu, 0xFFFFFFFFu}, m2[2] = {0xFFFFFFFFu, 0xFFFFFFFFu};
-    const unsigned hmask = ~a.idx_mask;
+    // the mask lives in a VGPR so that (acc & mask) | idx is ONE v_and_or_b32 with idx in an SGPR
+    unsigned hmask;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(hmask) : "s"(~a.idx_mask));
     const int nT = (ti.K + RCN_BT - 1) / RCN_BT;
     const char *timg = reinterpret_cast<const char *>(ti.f16);
 
     auto stage = [&](int t, int buf) {
+        char *bbase = smem + buf * BUFB;
 #pragma unroll
         for (int i = 0; i < NINST; ++i) {
             const int off = w * (TILEB / 4) + i * 1024;
             const char *src = timg + (size_t)t * TILEB + off + lane * 16;
-            char *dst = smem + buf * TILEB + off;  // + lane*16 applied by the hardware
             __builtin_amdgcn_global_load_lds(
                 (const __attribute__((address_space(1))) void *)src,
-                (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+                (__attribute__((address_space(3))) void *)(bbase + off), 16, 0, 0);
         }
+        if (!(ABL & 2))
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void *)(ti.hn + t * RCN_BT + lane),
+                (__attribute__((address_space(3))) void *)(bbase + TILEB + w * 256), 4, 0, 0);
     };
 
     stage(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
+    // Software pipeline inside each wave: the MFMAs of row block n (32 train rows x 64 queries,
+    // 32 instructions) carry the top-2 epilogue of row block n-1 in their issue gaps: per
+    // k-step 2 MFMAs + 2 accumulator elements x (v_and_or, v_med3_u32, v_min_u32).
+    f32x16 pX0, pX1, pY0, pY1;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { pY0[i] = 3.0e38f; pY1[i] = 3.0e38f; }
+
+    auto top2 = [&](int cb, unsigned u) {
+        // med3(m1,m2,u) spelled so that isel forms v_med3_u32 (scheduler sees a plain VALU op)
+        const unsigned lo = min(m1[cb], m2[cb]), hi = max(m1[cb], m2[cb]);
+        m2[cb] = max(lo, min(hi, u));
+        m1[cb] = min(m1[cb], u);
+    };
+    // cur <- hn + A.B for row block (tile, rb); prev (row block before it) is folded into top-2
+    auto step = [&](f32x16 &c0, f32x16 &c1, const f32x16 &p0, const f32x16 &p1, const char *tile,
+                    const float *hnl, int rb, unsigned prev_rowbase) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float4 v = *reinterpret_cast<const float4 *>(hnl + rb * 32 + 8 * g + 4 * h);
+            c0[4 * g + 0] = v.x; c0[4 * g + 1] = v.y; c0[4 * g + 2] = v.z; c0[4 * g + 3] = v.w;
+        }
+        c1 = c0;
+        const int lrow = rb * 32 + r;
+        const char *arow = tile + lrow * ROWB;
+        const int sw = swz<DP>(lrow);
+        half8 av = *reinterpret_cast<const half8 *>(arow + ((h ^ sw) << 4));
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            half8 an = av;   // fragment of k-step ks+1 is in flight while ks computes
+            if (ks + 1 < KS) an = *reinterpret_cast<const half8 *>(arow + ((((ks + 1) * 2 + h) ^ sw) << 4));
+            c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bq[0][ks], c0, 0, 0, 0);
+            if (!(ABL & 1)) {
+#pragma unroll
+                for (int reg = ks * 16 / KS; reg < (ks + 1) * 16 / KS; ++reg)
+                    top2(0, (__float_as_uint(p0[reg]) & hmask) | (prev_rowbase + (reg & 3) + 8 * (reg >> 2)));
+            }
+            c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bq[1][ks], c1, 0, 0, 0);
+            if (!(ABL & 1)) {
+#pragma unroll
+                for (int reg = ks * 16 / KS; reg < (ks + 1) * 16 / KS; ++reg)
+                    top2(1, (__float_as_uint(p1[reg]) & hmask) | (prev_rowbase + (reg & 3) + 8 * (reg >> 2)));
+            }
+            av = an;
+        }
+    };
+
     int buf = 0;
     for (int t = 0; t < nT; ++t) {
-        if (t + 1 < nT) stage(t + 1, buf ^ 1);
-        const char *tile = smem + buf * TILEB;
-#pragma unroll
-        for (int rb = 0; rb < 2; ++rb) {
-            f32x16 acc0, acc1;
-            const float4 *hp = reinterpret_cast<const float4 *>(ti.hn + t * RCN_BT + rb * 32 + 4 * h);
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                float4 v = hp[2 * g];  // rows 8g + 4h + 0..3
-                acc0[4 * g + 0] = v.x; acc0[4 * g + 1] = v.y; acc0[4 * g + 2] = v.z; acc0[4 * g + 3] = v.w;
-            }
-            acc1 = acc0;
-            const int lrow = rb * 32 + r;
-            const char *arow = tile + lrow * ROWB;
-            const int sw = swz<DP>(lrow);
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                half8 av = *reinterpret_cast<const half8 *>(arow + (((ks * 2 + h) ^ sw) << 4));
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bq[0][ks], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bq[1][ks], acc1, 0, 0, 0);
-            }
-            const unsigned rowbase = (unsigned)(t * RCN_BT + rb * 32);
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                const unsigned idx = rowbase + (reg & 3) + 8 * (reg >> 2);  // + 4h added at the end
-                unsigned u0 = (__float_as_uint(acc0[reg]) & hmask) | idx;
-                unsigned u1 = (__float_as_uint(acc1[reg]) & hmask) | idx;
-                m2[0] = umed3(m1[0], m2[0], u0); m1[0] = min(m1[0], u0);
-                m2[1] = umed3(m1[1], m2[1], u1); m1[1] = min(m1[1], u1);
-            }
-        }
+        if (t + 1 < nT && !((ABL & 8) && t > 0)) stage(t + 1, buf ^ 1);
+        const char *tile = smem + buf * BUFB;
+        const float *hnl = reinterpret_cast<const float *>(tile + TILEB + w * 256);
+        const unsigned base = (unsigned)(t * RCN_BT);
+        step(pX0, pX1, pY0, pY1, tile, hnl, 0, base - 32u);   // epilogue of (t-1, rb 1)
+        step(pY0, pY1, pX0, pX1, tile, hnl, 1, base);         // epilogue of (t, rb 0)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         buf ^= 1;
+    }
+    if (ABL & 1) asm volatile("" ::"v"(pY0), "v"(pY1), "v"(pX0), "v"(pX1));
+    {   // drain: epilogue of the last row block
+        const unsigned rowbase = (unsigned)((nT - 1) * RCN_BT + 32);
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const unsigned idx = rowbase + (reg & 3) + 8 * (reg >> 2);
+            top2(0, (__float_as_uint(pY0[reg]) & hmask) | idx);
+            top2(1, (__float_as_uint(pY1[reg]) & hmask) | idx);
+        }
     }
 
     // lane l and l^32 hold the same query, disjoint train rows: merge, then lanes 0..31 store
@@ -789,13 +831,13 @@ static int prepare_all(rcn_ctx *ctx)
     return RCN_OK;
 }
 
-template <int DP> static hipError_t launch_coarse(rcn_ctx *ctx, const CoarseArgs &ca, int blocks)
+template <int DP, int ABL = 0> static hipError_t launch_coarse(rcn_ctx *ctx, const CoarseArgs &ca, int blocks)
 {
-    const size_t lds = 2 * RCN_BT * DP * 2;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_coarse_top2<DP>),
+    const size_t lds = 2 * (RCN_BT * DP * 2 + 1024);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_coarse_top2<DP, ABL>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    k_coarse_top2<DP><<<blocks, 256, lds, ctx->stream>>>(ca);
+    k_coarse_top2<DP, ABL><<<blocks, 256, lds, ctx->stream>>>(ca);
     return hipGetLastError();
 }
 
@@ -874,7 +916,15 @@ static int match_grid_impl(rcn_ctx *ctx, const int32_t *pairs_host, int32_t n_pa
         case 32: e = launch_coarse<32>(ctx, ca, blocks); break;
         case 64: e = launch_coarse<64>(ctx, ca, blocks); break;
         case 128: e = launch_coarse<128>(ctx, ca, blocks); break;
-        default: e = launch_coarse<256>(ctx, ca, blocks); break;
+        default:
+            switch (ctx->ablate) {   // RCN_COARSE_ABL: timing experiments only
+            case 1: e = launch_coarse<256, 1>(ctx, ca, blocks); break;
+            case 3: e = launch_coarse<256, 3>(ctx, ca, blocks); break;
+            case 7: e = launch_coarse<256, 7>(ctx, ca, blocks); break;
+            case 15: e = launch_coarse<256, 15>(ctx, ca, blocks); break;
+            default: e = launch_coarse<256>(ctx, ca, blocks); break;
+            }
+            break;
         }
         RCN_HIP(e);
     }

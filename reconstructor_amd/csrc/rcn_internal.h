@@ -89,6 +89,7 @@ struct rcn_ctx {
     hipEvent_t ev[64][4];
     bool ev_made = false;
     int ev_n = 0;          // recorded calls since the last stats read (<= 64)
+    int ablate = 0;            // RCN_COARSE_ABL (diagnostics)
     bool force_exact = false;  // RCN_FORCE_EXACT=1: skip the MFMA coarse pass (diagnostics)
 
     // ---- BA state (ba.hip)
