@@ -1,0 +1,638 @@
+/*
+ * ba_oracle.c -- CPU restatement of the reference's bundle adjustment (BundleAdjuster::adjust).
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing in the product path (reconstructor_amd/) may link,
+ * import or call this file.  Checker for tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg.
+ *
+ * PARITY UNPINNED: the reference holds no BA tests or fixtures, and the solver is an
+ * un-vendored third-party dependency (Ceres Solver, `find_package(Ceres REQUIRED)`,
+ * Mapper/CMakeLists.txt:46; >= 2.1 because BundleAdjuster.cpp:105,119 use
+ * Problem::SetManifold / SubsetManifold) that is absent from the build container.  This
+ * file restates Ceres' published trust-region algorithm for exactly the problem the
+ * reference builds:
+ *
+ *   BundleAdjuster.h:27-58    ReprojectionError: angle-axis rotate + translate, z-divide,
+ *                             ADDITIVE radial term k1 r + k2 r^2 (r = x^2+y^2) on both x and
+ *                             y, fx/fy/cx/cy                          -> residual()
+ *   BundleAdjuster.cpp:74-97  one residual block per (landmark, observation), landmark-major,
+ *                             no robust loss (nullptr)
+ *   :100-105                  camera 0 pose constant; camera 1 translation constant
+ *                             (SubsetManifold{3,4,5})
+ *   :108-129                  < 10 cameras: intrinsics constant; else cx,cy constant
+ *                             (SubsetManifold{2,3}) and fx,fy <= 1000
+ *   :131-142                  DENSE_SCHUR, max_num_iterations 150 (<10 cams) / 50,
+ *                             everything else Ceres defaults
+ *
+ * Ceres behaviour restated (solver.h defaults, trust_region_minimizer.cc,
+ * levenberg_marquardt_strategy.cc, schur_eliminator, parameter_block.h):
+ *   - Jacobi scaling 1/(1+||J_col||) fixed at the initial point
+ *   - LM: D^2 = clamp(diag(J'J), 1e-6, 1e32) / radius (diag re-used after a rejected step),
+ *     solve (J'J + D^2) y = J'r via point Schur complement + dense Cholesky, step = -y
+ *   - model_cost_change = -m.(r + m/2), m = J step; <= 0 => invalid step
+ *   - Plus = add on the tangent coordinates, then clamp to the box (ParameterBlock::Plus)
+ *   - bounds present => projected Armijo line search along the step before evaluation
+ *     (TrustRegionMinimizer::DoLineSearch).  DEVIATION: Ceres interpolates with a cubic through
+ *     values and gradients; here a backtrack uses the quadratic through f(0), f'(0), f(a).
+ *     summary.line_search_backtracks counts how often that code ran (0 on every committed case).
+ *   - parameter tolerance, function tolerance (both before the accept test), rho =
+ *     cost_change / model_cost_change, accept if rho > 1e-3:
+ *     radius /= max(1/3, 1-(2 rho-1)^3), decrease factor reset to 2; reject: radius /= factor,
+ *     factor *= 2; gradient tolerance on the (projected) max-norm after every accepted step
+ * The analytic Jacobian replaces Ceres' AutoDiff Jets (same derivative, checked against
+ * central differences in tests/).
+ */
+#include <float.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#include "../include/rcn.h" /* option / summary struct layouts only */
+
+/* ---------------------------------------------------------------------------------------- */
+/* p = R(w) X (ceres::AngleAxisRotatePoint), R, and d(R X)/dw = -R [X]x Jr(w)                */
+static void rotate(const double w[3], const double X[3], double p[3], double R[9], double dpdw[9])
+{
+    const double th2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
+    if (th2 > DBL_EPSILON) {
+        const double th = sqrt(th2), c = cos(th), s = sin(th);
+        const double n[3] = {w[0] / th, w[1] / th, w[2] / th};
+        const double cr[3] = {n[1] * X[2] - n[2] * X[1], n[2] * X[0] - n[0] * X[2], n[0] * X[1] - n[1] * X[0]};
+        const double tmp = (n[0] * X[0] + n[1] * X[1] + n[2] * X[2]) * (1.0 - c);
+        for (int i = 0; i < 3; ++i) p[i] = X[i] * c + cr[i] * s + n[i] * tmp;
+        const double hs = sin(0.5 * th), omc = 2.0 * hs * hs; /* 1 - cos, no cancellation */
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) R[3 * i + j] = omc * n[i] * n[j] + (i == j ? c : 0.0);
+        R[1] -= s * n[2]; R[2] += s * n[1];
+        R[3] += s * n[2]; R[5] -= s * n[0];
+        R[6] -= s * n[1]; R[7] += s * n[0];
+        double a, b; /* Jr = I - a [w]x + b [w]x^2 */
+        if (th < 1e-2) {
+            a = 0.5 - th2 / 24.0 + th2 * th2 / 720.0;
+            b = 1.0 / 6.0 - th2 / 120.0 + th2 * th2 / 5040.0;
+        } else {
+            a = omc / th2;
+            b = (th - s) / (th2 * th);
+        }
+        const double K[9] = {0, -w[2], w[1], w[2], 0, -w[0], -w[1], w[0], 0};
+        double K2[9], Jr[9];
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j)
+                K2[3 * i + j] = K[3 * i] * K[j] + K[3 * i + 1] * K[3 + j] + K[3 * i + 2] * K[6 + j];
+        for (int i = 0; i < 9; ++i) Jr[i] = -a * K[i] + b * K2[i];
+        Jr[0] += 1; Jr[4] += 1; Jr[8] += 1;
+        /* M = -R [X]x ; dpdw = M Jr */
+        const double Xx[9] = {0, -X[2], X[1], X[2], 0, -X[0], -X[1], X[0], 0};
+        double M[9];
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j)
+                M[3 * i + j] = -(R[3 * i] * Xx[j] + R[3 * i + 1] * Xx[3 + j] + R[3 * i + 2] * Xx[6 + j]);
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j)
+                dpdw[3 * i + j] = M[3 * i] * Jr[j] + M[3 * i + 1] * Jr[3 + j] + M[3 * i + 2] * Jr[6 + j];
+    } else { /* first-order branch: p = X + w x X */
+        p[0] = X[0] + w[1] * X[2] - w[2] * X[1];
+        p[1] = X[1] + w[2] * X[0] - w[0] * X[2];
+        p[2] = X[2] + w[0] * X[1] - w[1] * X[0];
+        const double Rm[9] = {1, -w[2], w[1], w[2], 1, -w[0], -w[1], w[0], 1};
+        memcpy(R, Rm, sizeof(Rm));
+        const double D[9] = {0, X[2], -X[1], -X[2], 0, X[0], X[1], -X[0], 0};
+        memcpy(dpdw, D, sizeof(D));
+    }
+}
+
+/* residual (2) and, if J != NULL, its 2 x 15 Jacobian [pose 6 | intrinsics 6 | point 3] */
+void orc_ba_residual_jacobian(const double *pose, const double *intr, const double *X,
+                              const double *uv, double *res, double *J)
+{
+    double p[3], R[9], dpdw[9];
+    rotate(pose, X, p, R, dpdw);
+    p[0] += pose[3]; p[1] += pose[4]; p[2] += pose[5];
+    const double iz = 1.0 / p[2];
+    const double x = p[0] * iz, y = p[1] * iz;
+    const double r = x * x + y * y;
+    const double dist = intr[4] * r + intr[5] * r * r;
+    const double xd = x + dist, yd = y + dist;
+    res[0] = intr[0] * xd + intr[2] - uv[0];
+    res[1] = intr[1] * yd + intr[3] - uv[1];
+    if (!J) return;
+    const double g = intr[4] + 2.0 * intr[5] * r;
+    /* d(xd,yd)/d(x,y) */
+    const double a00 = 1.0 + 2.0 * g * x, a01 = 2.0 * g * y, a10 = 2.0 * g * x, a11 = 1.0 + 2.0 * g * y;
+    /* d(x,y)/dp */
+    const double b00 = iz, b02 = -x * iz, b11 = iz, b12 = -y * iz;
+    double Jp[6]; /* d(u,v)/dp, 2x3 */
+    Jp[0] = intr[0] * (a00 * b00);
+    Jp[1] = intr[0] * (a01 * b11);
+    Jp[2] = intr[0] * (a00 * b02 + a01 * b12);
+    Jp[3] = intr[1] * (a10 * b00);
+    Jp[4] = intr[1] * (a11 * b11);
+    Jp[5] = intr[1] * (a10 * b02 + a11 * b12);
+    for (int i = 0; i < 2; ++i) {
+        double *Ji = J + 15 * i;
+        const double *q = Jp + 3 * i;
+        for (int j = 0; j < 3; ++j) {
+            Ji[j] = q[0] * dpdw[j] + q[1] * dpdw[3 + j] + q[2] * dpdw[6 + j]; /* rotation */
+            Ji[3 + j] = q[j];                                                 /* translation */
+            Ji[12 + j] = q[0] * R[j] + q[1] * R[3 + j] + q[2] * R[6 + j];     /* point */
+        }
+    }
+    J[6] = xd; J[7] = 0; J[8] = 1; J[9] = 0; J[10] = intr[0] * r; J[11] = intr[0] * r * r;
+    J[15 + 6] = 0; J[15 + 7] = yd; J[15 + 8] = 0; J[15 + 9] = 1; J[15 + 10] = intr[1] * r; J[15 + 11] = intr[1] * r * r;
+}
+
+/* ---------------------------------------------------------------------------------------- */
+typedef struct {
+    int nc, np, no, n; /* n = reduced (camera) dimension */
+    const double *uv;
+    const int32_t *ocam, *opt;
+    int *pt_off;            /* np+1: observations of point j = [pt_off[j], pt_off[j+1]) */
+    int *cam_off, *cam_dim; /* reduced offset / tangent size per camera */
+    int (*cols)[10];        /* ambient column (0..11 of [pose|intr]) of each tangent coordinate */
+    int *cam_obs_off, *cam_obs; /* observations by camera */
+    double ub;              /* fx, fy upper bound (mode 1) */
+    int mode;
+} Prob;
+
+static double now_s(void)
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec + 1e-9 * ts.tv_nsec;
+}
+
+/* cost = 1/2 sum r^2; optionally r, tangent Jacobians Jc (2 x 10 per obs), Jp (2 x 3) */
+static double evaluate(const Prob *P, const double *poses, const double *intr, const double *pts,
+                       double *r, double *Jc, double *Jp)
+{
+    double cost = 0.0;
+#pragma omp parallel for reduction(+ : cost) schedule(static)
+    for (int o = 0; o < P->no; ++o) {
+        const int c = P->ocam[o], j = P->opt[o];
+        double res[2], J[30];
+        orc_ba_residual_jacobian(poses + 6 * c, intr + 6 * c, pts + 3 * j, P->uv + 2 * o, res, Jc ? J : NULL);
+        cost += res[0] * res[0] + res[1] * res[1];
+        if (r) { r[2 * o] = res[0]; r[2 * o + 1] = res[1]; }
+        if (Jc) {
+            const int dc = P->cam_dim[c];
+            for (int i = 0; i < 2; ++i) {
+                for (int k = 0; k < dc; ++k) Jc[20 * o + 10 * i + k] = J[15 * i + P->cols[c][k]];
+                for (int k = dc; k < 10; ++k) Jc[20 * o + 10 * i + k] = 0.0;
+                for (int k = 0; k < 3; ++k) Jp[6 * o + 3 * i + k] = J[15 * i + 12 + k];
+            }
+        }
+    }
+    return 0.5 * cost;
+}
+
+/* Plus: x + delta on tangent coordinates, then the box (ParameterBlock::Plus). */
+static int plus(const Prob *P, const double *poses, const double *intr, const double *pts,
+                const double *dc, const double *dp, double *poses2, double *intr2, double *pts2)
+{
+    int clamped = 0;
+    memcpy(poses2, poses, sizeof(double) * 6 * P->nc);
+    memcpy(intr2, intr, sizeof(double) * 6 * P->nc);
+    for (int c = 0; c < P->nc; ++c)
+        for (int k = 0; k < P->cam_dim[c]; ++k) {
+            const int col = P->cols[c][k];
+            const double d = dc[P->cam_off[c] + k];
+            if (col < 6) poses2[6 * c + col] += d;
+            else {
+                double *v = intr2 + 6 * c + (col - 6);
+                *v += d;
+                if (P->mode == 1 && col - 6 < 2 && *v > P->ub) { *v = P->ub; ++clamped; }
+            }
+        }
+    for (int i = 0; i < 3 * P->np; ++i) pts2[i] = pts[i] + dp[i];
+    return clamped;
+}
+
+/* in-place lower Cholesky, blocked right-looking; returns 0 ok, -1 not positive definite */
+static int cholesky(double *A, int n)
+{
+    const int B = 64;
+    for (int k0 = 0; k0 < n; k0 += B) {
+        const int kb = n - k0 < B ? n - k0 : B;
+        for (int j = k0; j < k0 + kb; ++j) { /* diagonal block, unblocked */
+            double d = A[(size_t)j * n + j];
+            for (int k = k0; k < j; ++k) d -= A[(size_t)j * n + k] * A[(size_t)j * n + k];
+            if (!(d > 0.0) || !isfinite(d)) return -1;
+            d = sqrt(d);
+            A[(size_t)j * n + j] = d;
+            for (int i = j + 1; i < k0 + kb; ++i) {
+                double s = A[(size_t)i * n + j];
+                for (int k = k0; k < j; ++k) s -= A[(size_t)i * n + k] * A[(size_t)j * n + k];
+                A[(size_t)i * n + j] = s / d;
+            }
+        }
+        const int r0 = k0 + kb;
+#pragma omp parallel for schedule(static)
+        for (int i = r0; i < n; ++i) { /* panel: A21 <- A21 L11^-T */
+            double *ai = A + (size_t)i * n;
+            for (int j = k0; j < k0 + kb; ++j) {
+                double s = ai[j];
+                const double *lj = A + (size_t)j * n;
+                for (int k = k0; k < j; ++k) s -= ai[k] * lj[k];
+                ai[j] = s / lj[j];
+            }
+        }
+#pragma omp parallel for schedule(dynamic, 8)
+        for (int i = r0; i < n; ++i) { /* trailing update, lower triangle */
+            double *ai = A + (size_t)i * n;
+            for (int j = r0; j <= i; ++j) {
+                const double *aj = A + (size_t)j * n;
+                double s = 0.0;
+                for (int k = k0; k < k0 + kb; ++k) s += ai[k] * aj[k];
+                ai[j] -= s;
+            }
+        }
+    }
+    return 0;
+}
+
+static void chol_solve(const double *L, int n, double *b)
+{
+    for (int i = 0; i < n; ++i) {
+        double s = b[i];
+        const double *li = L + (size_t)i * n;
+        for (int k = 0; k < i; ++k) s -= li[k] * b[k];
+        b[i] = s / li[i];
+    }
+    for (int i = n - 1; i >= 0; --i) {
+        double s = b[i];
+        for (int k = i + 1; k < n; ++k) s -= L[(size_t)k * n + i] * b[k];
+        b[i] = s / L[(size_t)i * n + i];
+    }
+}
+
+static int inv3_spd(const double *V, double *Vi)
+{
+    const double a = V[0], b = V[1], c = V[2], d = V[4], e = V[5], f = V[8];
+    const double A = d * f - e * e, Bc = c * e - b * f, Cc = b * e - c * d;
+    const double det = a * A + b * Bc + c * Cc;
+    if (!(det > 0.0) || !isfinite(det)) return -1;
+    const double id = 1.0 / det;
+    Vi[0] = A * id; Vi[1] = Bc * id; Vi[2] = Cc * id;
+    Vi[3] = Vi[1]; Vi[4] = (a * f - c * c) * id; Vi[5] = (b * c - a * e) * id;
+    Vi[6] = Vi[2]; Vi[7] = Vi[5]; Vi[8] = (a * d - b * b) * id;
+    return 0;
+}
+
+/* ---------------------------------------------------------------------------------------- */
+int orc_ba_solve(int n_cams, int n_points, int n_obs, double *poses, double *intr, double *pts,
+                 const double *obs_uv, const int32_t *obs_cam, const int32_t *obs_pt,
+                 const rcn_ba_options *opt, rcn_ba_summary *sum, int threads)
+{
+#ifdef _OPENMP
+    if (threads > 0) omp_set_num_threads(threads);
+#else
+    (void)threads;
+#endif
+    memset(sum, 0, sizeof(*sum));
+    Prob P;
+    memset(&P, 0, sizeof(P));
+    P.nc = n_cams; P.np = n_points; P.no = n_obs;
+    P.uv = obs_uv; P.ocam = obs_cam; P.opt = obs_pt;
+    P.mode = opt->intrinsics_mode; P.ub = opt->focal_upper_bound;
+    P.pt_off = (int *)calloc(n_points + 1, sizeof(int));
+    for (int o = 0; o < n_obs; ++o) {
+        if (o && obs_pt[o] < obs_pt[o - 1]) return RCN_ERR_ARG;
+        if (obs_pt[o] < 0 || obs_pt[o] >= n_points || obs_cam[o] < 0 || obs_cam[o] >= n_cams) return RCN_ERR_ARG;
+        P.pt_off[obs_pt[o] + 1]++;
+    }
+    for (int j = 0; j < n_points; ++j) P.pt_off[j + 1] += P.pt_off[j];
+    P.cam_off = (int *)calloc(n_cams + 1, sizeof(int));
+    P.cam_dim = (int *)calloc(n_cams, sizeof(int));
+    P.cols = (int(*)[10])calloc(n_cams, sizeof(int[10]));
+    int n = 0;
+    for (int c = 0; c < n_cams; ++c) {
+        int d = 0;
+        if (!(c == 0 && opt->fix_cam0_pose)) {
+            const int npose = (c == 1 && opt->fix_cam1_translation) ? 3 : 6;
+            for (int k = 0; k < npose; ++k) P.cols[c][d++] = k;
+        }
+        if (opt->intrinsics_mode == 1) { P.cols[c][d++] = 6; P.cols[c][d++] = 7; P.cols[c][d++] = 10; P.cols[c][d++] = 11; }
+        P.cam_off[c] = n; P.cam_dim[c] = d; n += d;
+    }
+    P.cam_off[n_cams] = n; P.n = n;
+    P.cam_obs_off = (int *)calloc(n_cams + 1, sizeof(int));
+    P.cam_obs = (int *)malloc(sizeof(int) * (n_obs > 0 ? n_obs : 1));
+    for (int o = 0; o < n_obs; ++o) P.cam_obs_off[obs_cam[o] + 1]++;
+    for (int c = 0; c < n_cams; ++c) P.cam_obs_off[c + 1] += P.cam_obs_off[c];
+    {
+        int *fill = (int *)calloc(n_cams, sizeof(int));
+        for (int o = 0; o < n_obs; ++o) { int c = obs_cam[o]; P.cam_obs[P.cam_obs_off[c] + fill[c]++] = o; }
+        free(fill);
+    }
+    sum->reduced_dim = n;
+
+    const size_t NO = n_obs > 0 ? n_obs : 1, NP3 = 3 * (size_t)(n_points > 0 ? n_points : 1), NN = n > 0 ? n : 1;
+    double *r = (double *)malloc(sizeof(double) * 2 * NO), *Jc = (double *)malloc(sizeof(double) * 20 * NO);
+    double *Jp = (double *)malloc(sizeof(double) * 6 * NO);
+    double *W = (double *)malloc(sizeof(double) * 30 * NO), *Y = (double *)malloc(sizeof(double) * 30 * NO);
+    double *Vinv = (double *)malloc(sizeof(double) * 3 * NP3), *gp = (double *)malloc(sizeof(double) * NP3);
+    double *sc = (double *)malloc(sizeof(double) * NN), *sp = (double *)malloc(sizeof(double) * NP3);
+    double *dgc = (double *)malloc(sizeof(double) * NN), *dgp = (double *)malloc(sizeof(double) * NP3); /* clamped diag(J'J) */
+    double *gc = (double *)malloc(sizeof(double) * NN);
+    double *S = (double *)malloc(sizeof(double) * NN * NN), *yc = (double *)malloc(sizeof(double) * NN);
+    double *stc = (double *)malloc(sizeof(double) * NN), *stp = (double *)malloc(sizeof(double) * NP3); /* scaled step */
+    double *dlc = (double *)malloc(sizeof(double) * NN), *dlp = (double *)malloc(sizeof(double) * NP3); /* delta */
+    double *poses2 = (double *)malloc(sizeof(double) * 6 * n_cams), *intr2 = (double *)malloc(sizeof(double) * 6 * n_cams);
+    double *pts2 = (double *)malloc(sizeof(double) * NP3);
+    double *ugc = (double *)malloc(sizeof(double) * NN), *ugp = (double *)malloc(sizeof(double) * NP3); /* unscaled gradient */
+
+    const double t_start = now_s();
+    double cost = evaluate(&P, poses, intr, pts, r, Jc, Jp);
+    sum->initial_cost = cost;
+    sum->initial_rms_px = sqrt(2.0 * cost / (n_obs > 0 ? n_obs : 1));
+    sum->cost_trace[0] = cost;
+
+    /* Jacobi scaling from the initial Jacobian */
+    for (int i = 0; i < n; ++i) sc[i] = 0.0;
+    for (size_t i = 0; i < NP3; ++i) sp[i] = 0.0;
+    for (int o = 0; o < n_obs; ++o) {
+        const int c = obs_cam[o], j = obs_pt[o];
+        for (int i = 0; i < 2; ++i) {
+            for (int k = 0; k < P.cam_dim[c]; ++k) { double v = Jc[20 * o + 10 * i + k]; sc[P.cam_off[c] + k] += v * v; }
+            for (int k = 0; k < 3; ++k) { double v = Jp[6 * o + 3 * i + k]; sp[3 * j + k] += v * v; }
+        }
+    }
+    for (int i = 0; i < n; ++i) sc[i] = opt->jacobi_scaling ? 1.0 / (1.0 + sqrt(sc[i])) : 1.0;
+    for (int i = 0; i < 3 * n_points; ++i) sp[i] = opt->jacobi_scaling ? 1.0 / (1.0 + sqrt(sp[i])) : 1.0;
+
+    double radius = opt->initial_trust_region_radius, decrease = 2.0;
+    int reuse_diag = 0, invalid_run = 0, termination = 0;
+    int need_gradient = 1;
+    int iter = 0;
+    for (;;) {
+        if (need_gradient) {
+            /* unscaled gradient J'r (tangent), projected max-norm test */
+            for (int i = 0; i < n; ++i) ugc[i] = 0.0;
+            for (int i = 0; i < 3 * n_points; ++i) ugp[i] = 0.0;
+            for (int o = 0; o < n_obs; ++o) {
+                const int c = obs_cam[o], j = obs_pt[o];
+                for (int i = 0; i < 2; ++i) {
+                    const double ri = r[2 * o + i];
+                    for (int k = 0; k < P.cam_dim[c]; ++k) ugc[P.cam_off[c] + k] += Jc[20 * o + 10 * i + k] * ri;
+                    for (int k = 0; k < 3; ++k) ugp[3 * j + k] += Jp[6 * o + 3 * i + k] * ri;
+                }
+            }
+            double gmax = 0.0;
+            for (int c = 0; c < n_cams; ++c)
+                for (int k = 0; k < P.cam_dim[c]; ++k) {
+                    double g = ugc[P.cam_off[c] + k];
+                    const int col = P.cols[c][k];
+                    if (P.mode == 1 && (col == 6 || col == 7)) { /* x - clamp(x - g) */
+                        const double x = intr[6 * c + col - 6];
+                        double xn = x - g;
+                        if (xn > P.ub) xn = P.ub;
+                        g = x - xn;
+                    }
+                    if (fabs(g) > gmax) gmax = fabs(g);
+                }
+            for (int i = 0; i < 3 * n_points; ++i)
+                if (fabs(ugp[i]) > gmax) gmax = fabs(ugp[i]);
+            need_gradient = 0;
+            if (gmax <= opt->gradient_tolerance) { termination = RCN_BA_CONVERGENCE_GRADIENT; break; }
+        }
+        if (iter >= opt->max_iterations) { termination = RCN_BA_NO_CONVERGENCE; break; }
+        if (radius <= opt->min_trust_region_radius) { termination = RCN_BA_CONVERGENCE_RADIUS; break; }
+        ++iter;
+
+        /* ---- LM step: (Js'Js + D^2) y = Js' r on the scaled Jacobian Js = J diag(scale) */
+        if (!reuse_diag) {
+            for (int i = 0; i < n; ++i) dgc[i] = 0.0;
+            for (int i = 0; i < 3 * n_points; ++i) dgp[i] = 0.0;
+            for (int o = 0; o < n_obs; ++o) {
+                const int c = obs_cam[o], j = obs_pt[o];
+                for (int i = 0; i < 2; ++i) {
+                    for (int k = 0; k < P.cam_dim[c]; ++k) { double v = Jc[20 * o + 10 * i + k] * sc[P.cam_off[c] + k]; dgc[P.cam_off[c] + k] += v * v; }
+                    for (int k = 0; k < 3; ++k) { double v = Jp[6 * o + 3 * i + k] * sp[3 * j + k]; dgp[3 * j + k] += v * v; }
+                }
+            }
+            for (int i = 0; i < n; ++i) dgc[i] = fmin(fmax(dgc[i], opt->min_lm_diagonal), opt->max_lm_diagonal);
+            for (int i = 0; i < 3 * n_points; ++i) dgp[i] = fmin(fmax(dgp[i], opt->min_lm_diagonal), opt->max_lm_diagonal);
+        }
+        int solve_ok = 1;
+        /* point blocks: V, V^-1, g_p ; W = Jc'Jp, Y = W V^-1 per observation */
+#pragma omp parallel for schedule(static)
+        for (int j = 0; j < n_points; ++j) {
+            double V[9] = {0}, g[3] = {0};
+            for (int o = P.pt_off[j]; o < P.pt_off[j + 1]; ++o)
+                for (int i = 0; i < 2; ++i) {
+                    double q[3];
+                    for (int k = 0; k < 3; ++k) q[k] = Jp[6 * o + 3 * i + k] * sp[3 * j + k];
+                    for (int a = 0; a < 3; ++a) {
+                        g[a] += q[a] * r[2 * o + i];
+                        for (int b = 0; b < 3; ++b) V[3 * a + b] += q[a] * q[b];
+                    }
+                }
+            for (int a = 0; a < 3; ++a) V[4 * a] += dgp[3 * j + a] / radius;
+            double Vi[9];
+            if (inv3_spd(V, Vi)) {
+#pragma omp atomic write
+                solve_ok = 0;
+                memset(Vi, 0, sizeof(Vi));
+            }
+            memcpy(Vinv + 9 * j, Vi, sizeof(Vi));
+            memcpy(gp + 3 * j, g, sizeof(g));
+            for (int o = P.pt_off[j]; o < P.pt_off[j + 1]; ++o) {
+                const int c = obs_cam[o], dcm = P.cam_dim[c];
+                double *Wo = W + 30 * o, *Yo = Y + 30 * o;
+                for (int a = 0; a < dcm; ++a) {
+                    for (int b = 0; b < 3; ++b) {
+                        double s = 0.0;
+                        for (int i = 0; i < 2; ++i)
+                            s += Jc[20 * o + 10 * i + a] * sc[P.cam_off[c] + a] * Jp[6 * o + 3 * i + b] * sp[3 * j + b];
+                        Wo[3 * a + b] = s;
+                    }
+                    for (int b = 0; b < 3; ++b)
+                        Yo[3 * a + b] = Wo[3 * a] * Vi[b] + Wo[3 * a + 1] * Vi[3 + b] + Wo[3 * a + 2] * Vi[6 + b];
+                }
+            }
+        }
+        /* reduced system, row block by row block (deterministic order) */
+        memset(S, 0, sizeof(double) * NN * NN);
+#pragma omp parallel for schedule(dynamic, 1)
+        for (int c = 0; c < n_cams; ++c) {
+            const int dcm = P.cam_dim[c], off = P.cam_off[c];
+            if (!dcm) continue;
+            double U[100] = {0}, g[10] = {0};
+            for (int e = P.cam_obs_off[c]; e < P.cam_obs_off[c + 1]; ++e) {
+                const int o = P.cam_obs[e], j = obs_pt[o];
+                double q[2][10];
+                for (int i = 0; i < 2; ++i)
+                    for (int k = 0; k < dcm; ++k) q[i][k] = Jc[20 * o + 10 * i + k] * sc[off + k];
+                for (int a = 0; a < dcm; ++a) {
+                    g[a] += q[0][a] * r[2 * o] + q[1][a] * r[2 * o + 1];
+                    for (int b = 0; b < dcm; ++b) U[10 * a + b] += q[0][a] * q[0][b] + q[1][a] * q[1][b];
+                }
+                const double *Yo = Y + 30 * o;
+                for (int a = 0; a < dcm; ++a)
+                    g[a] -= Yo[3 * a] * gp[3 * j] + Yo[3 * a + 1] * gp[3 * j + 1] + Yo[3 * a + 2] * gp[3 * j + 2];
+                for (int o2 = P.pt_off[j]; o2 < P.pt_off[j + 1]; ++o2) {
+                    const int c2 = obs_cam[o2], d2 = P.cam_dim[c2], off2 = P.cam_off[c2];
+                    const double *W2 = W + 30 * o2;
+                    for (int a = 0; a < dcm; ++a)
+                        for (int b = 0; b < d2; ++b)
+                            S[(size_t)(off + a) * n + off2 + b] -=
+                                Yo[3 * a] * W2[3 * b] + Yo[3 * a + 1] * W2[3 * b + 1] + Yo[3 * a + 2] * W2[3 * b + 2];
+                }
+            }
+            for (int a = 0; a < dcm; ++a) {
+                U[11 * a] += dgc[off + a] / radius;
+                for (int b = 0; b < dcm; ++b) S[(size_t)(off + a) * n + off + b] += U[10 * a + b];
+                gc[off + a] = g[a];
+            }
+        }
+        if (solve_ok && n > 0 && cholesky(S, n)) solve_ok = 0;
+        if (solve_ok) {
+            memcpy(yc, gc, sizeof(double) * n);
+            if (n > 0) chol_solve(S, n, yc);
+#pragma omp parallel for schedule(static)
+            for (int j = 0; j < n_points; ++j) {
+                double t[3] = {gp[3 * j], gp[3 * j + 1], gp[3 * j + 2]};
+                for (int o = P.pt_off[j]; o < P.pt_off[j + 1]; ++o) {
+                    const int c = obs_cam[o];
+                    const double *Wo = W + 30 * o;
+                    for (int a = 0; a < P.cam_dim[c]; ++a) {
+                        const double y = yc[P.cam_off[c] + a];
+                        t[0] -= Wo[3 * a] * y; t[1] -= Wo[3 * a + 1] * y; t[2] -= Wo[3 * a + 2] * y;
+                    }
+                }
+                const double *Vi = Vinv + 9 * j;
+                for (int a = 0; a < 3; ++a) stp[3 * j + a] = -(Vi[3 * a] * t[0] + Vi[3 * a + 1] * t[1] + Vi[3 * a + 2] * t[2]);
+            }
+            for (int i = 0; i < n; ++i) stc[i] = -yc[i];
+            for (int i = 0; i < n && solve_ok; ++i) if (!isfinite(stc[i])) solve_ok = 0;
+            for (int i = 0; i < 3 * n_points && solve_ok; ++i) if (!isfinite(stp[i])) solve_ok = 0;
+        }
+        reuse_diag = 1; /* LevenbergMarquardtStrategy::ComputeStep */
+        double model_change = 0.0;
+        if (solve_ok) {
+            double acc = 0.0;
+#pragma omp parallel for reduction(+ : acc) schedule(static)
+            for (int o = 0; o < n_obs; ++o) {
+                const int c = obs_cam[o], j = obs_pt[o];
+                for (int i = 0; i < 2; ++i) {
+                    double m = 0.0;
+                    for (int k = 0; k < P.cam_dim[c]; ++k) m += Jc[20 * o + 10 * i + k] * sc[P.cam_off[c] + k] * stc[P.cam_off[c] + k];
+                    for (int k = 0; k < 3; ++k) m += Jp[6 * o + 3 * i + k] * sp[3 * j + k] * stp[3 * j + k];
+                    acc += m * (r[2 * o + i] + 0.5 * m);
+                }
+            }
+            model_change = -acc;
+        }
+        if (!solve_ok || !(model_change > 0.0)) { /* HandleInvalidStep */
+            sum->invalid_steps++;
+            if (++invalid_run > opt->max_consecutive_invalid_steps) { termination = RCN_BA_FAILURE; break; }
+            radius /= decrease; decrease *= 2.0; reuse_diag = 0;
+            if (iter < 160) sum->cost_trace[iter] = cost;
+            continue;
+        }
+        invalid_run = 0;
+        for (int i = 0; i < n; ++i) dlc[i] = stc[i] * sc[i];
+        for (int i = 0; i < 3 * n_points; ++i) dlp[i] = stp[i] * sp[i];
+
+        double cand_cost;
+        if (P.mode == 1) { /* bounds present: projected Armijo search along delta from step 1 */
+            double g0 = 0.0;
+            for (int i = 0; i < n; ++i) g0 += ugc[i] * dlc[i];
+            for (int i = 0; i < 3 * n_points; ++i) g0 += ugp[i] * dlp[i];
+            double a = 1.0;
+            for (int ls = 0;; ++ls) {
+                for (int i = 0; i < n; ++i) stc[i] = a * dlc[i];
+                for (int i = 0; i < 3 * n_points; ++i) stp[i] = a * dlp[i];
+                sum->bound_projections += plus(&P, poses, intr, pts, stc, stp, poses2, intr2, pts2);
+                cand_cost = evaluate(&P, poses2, intr2, pts2, NULL, NULL, NULL);
+                if (isfinite(cand_cost) && cand_cost <= cost + 1e-4 * a * g0) break;
+                if (ls >= 20) { a = 1.0; break; }
+                double an = -g0 * a * a / (2.0 * (cand_cost - cost - g0 * a)); /* quadratic fit */
+                if (!isfinite(an)) an = 0.5 * a;
+                an = fmin(fmax(an, 1e-3 * a), 0.6 * a);
+                a = an;
+                sum->line_search_backtracks++;
+            }
+            if (a != 1.0) {
+                for (int i = 0; i < n; ++i) dlc[i] *= a;
+                for (int i = 0; i < 3 * n_points; ++i) dlp[i] *= a;
+            }
+        }
+        sum->bound_projections += plus(&P, poses, intr, pts, dlc, dlp, poses2, intr2, pts2);
+        cand_cost = evaluate(&P, poses2, intr2, pts2, NULL, NULL, NULL);
+        if (!isfinite(cand_cost)) cand_cost = DBL_MAX;
+
+        /* parameter tolerance (on x - candidate) and function tolerance, before the accept test */
+        double dn = 0.0, xn = 0.0;
+        for (int c = 0; c < n_cams; ++c)
+            for (int k = 0; k < 6; ++k) {
+                double d = poses2[6 * c + k] - poses[6 * c + k]; dn += d * d; xn += poses[6 * c + k] * poses[6 * c + k];
+                d = intr2[6 * c + k] - intr[6 * c + k]; dn += d * d; xn += intr[6 * c + k] * intr[6 * c + k];
+            }
+        for (int i = 0; i < 3 * n_points; ++i) { double d = pts2[i] - pts[i]; dn += d * d; xn += pts[i] * pts[i]; }
+        if (sqrt(dn) <= opt->parameter_tolerance * (sqrt(xn) + opt->parameter_tolerance)) {
+            termination = RCN_BA_CONVERGENCE_PARAMETER;
+            if (iter < 160) sum->cost_trace[iter] = cost;
+            break;
+        }
+        const double cost_change = cost - cand_cost;
+        if (fabs(cost_change) <= opt->function_tolerance * cost) {
+            termination = RCN_BA_CONVERGENCE_FUNCTION;
+            if (iter < 160) sum->cost_trace[iter] = cost;
+            break;
+        }
+        const double rho = cost_change / model_change;
+        if (rho > opt->min_relative_decrease) { /* HandleSuccessfulStep */
+            memcpy(poses, poses2, sizeof(double) * 6 * n_cams);
+            memcpy(intr, intr2, sizeof(double) * 6 * n_cams);
+            memcpy(pts, pts2, sizeof(double) * 3 * n_points);
+            cost = evaluate(&P, poses, intr, pts, r, Jc, Jp);
+            need_gradient = 1;
+            sum->successful_steps++;
+            const double t = 2.0 * rho - 1.0;
+            radius = radius / fmax(1.0 / 3.0, 1.0 - t * t * t);
+            radius = fmin(opt->max_trust_region_radius, radius);
+            decrease = 2.0; reuse_diag = 0;
+        } else {
+            sum->unsuccessful_steps++;
+            radius /= decrease; decrease *= 2.0; reuse_diag = 1;
+        }
+        if (iter < 160) sum->cost_trace[iter] = cost;
+    }
+    sum->iterations = iter;
+    sum->termination = termination;
+    sum->final_cost = cost;
+    sum->final_rms_px = sqrt(2.0 * cost / (n_obs > 0 ? n_obs : 1));
+    sum->solve_seconds = now_s() - t_start;
+
+    free(r); free(Jc); free(Jp); free(W); free(Y); free(Vinv); free(gp); free(sc); free(sp);
+    free(dgc); free(dgp); free(gc); free(S); free(yc); free(stc); free(stp); free(dlc); free(dlp);
+    free(poses2); free(intr2); free(pts2); free(ugc); free(ugp);
+    free(P.pt_off); free(P.cam_off); free(P.cam_dim); free(P.cols); free(P.cam_obs_off); free(P.cam_obs);
+    return RCN_OK;
+}
+
+void orc_ba_default_options(int n_cams, rcn_ba_options *o)
+{
+    o->max_iterations = n_cams < 10 ? 150 : 50;
+    o->intrinsics_mode = n_cams < 10 ? 0 : 1;
+    o->fix_cam0_pose = 1;
+    o->fix_cam1_translation = 1;
+    o->focal_upper_bound = 1000.0;
+    o->initial_trust_region_radius = 1e4;
+    o->max_trust_region_radius = 1e16;
+    o->min_trust_region_radius = 1e-32;
+    o->min_relative_decrease = 1e-3;
+    o->min_lm_diagonal = 1e-6;
+    o->max_lm_diagonal = 1e32;
+    o->function_tolerance = 1e-6;
+    o->gradient_tolerance = 1e-10;
+    o->parameter_tolerance = 1e-8;
+    o->max_consecutive_invalid_steps = 5;
+    o->jacobi_scaling = 1;
+}

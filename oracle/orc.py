@@ -48,12 +48,7 @@ def _sig():
     L.orc_match_grid.restype = None
     L.orc_match_grid.argtypes = [_f32p, _i64p, C.c_int, C.c_int, _i32p, C.c_int, C.c_float,
                                  _i32p, C.c_int64, _i32p, C.c_int]
-    if hasattr(L, "orc_ba_solve"):
-        _sig_ba(L)
-
-
-def _sig_ba(L):
-    from . import orc_ba  # noqa: F401  (registers signatures)
+    from . import orc_ba
     orc_ba.register(L)
 
 

@@ -1,0 +1,63 @@
+"""ctypes binding of the BA oracle (oracle/ba_oracle.c).  TEST INFRASTRUCTURE ONLY."""
+import ctypes as C
+
+import numpy as np
+
+from reconstructor_amd._lib import BaOptions, BaSummary  # struct layouts of include/rcn.h
+
+_f64p = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
+_i32p = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
+
+
+def register(L):
+    L.orc_ba_residual_jacobian.restype = None
+    L.orc_ba_residual_jacobian.argtypes = [_f64p, _f64p, _f64p, _f64p, _f64p, C.c_void_p]
+    L.orc_ba_solve.restype = C.c_int
+    L.orc_ba_solve.argtypes = [C.c_int, C.c_int, C.c_int, _f64p, _f64p, _f64p, _f64p, _i32p, _i32p,
+                               C.POINTER(BaOptions), C.POINTER(BaSummary), C.c_int]
+    L.orc_ba_default_options.restype = None
+    L.orc_ba_default_options.argtypes = [C.c_int, C.POINTER(BaOptions)]
+
+
+def _lib():
+    from . import orc
+    return orc.lib()
+
+
+def residual_jacobian(pose, intr, X, uv, jac=True):
+    res = np.zeros(2)
+    J = np.zeros((2, 15))
+    _lib().orc_ba_residual_jacobian(np.ascontiguousarray(pose, np.float64), np.ascontiguousarray(intr, np.float64),
+                                    np.ascontiguousarray(X, np.float64), np.ascontiguousarray(uv, np.float64),
+                                    res, J.ctypes.data if jac else None)
+    return res, J
+
+
+def default_options(n_cams):
+    o = BaOptions()
+    _lib().orc_ba_default_options(int(n_cams), C.byref(o))
+    return o
+
+
+def summary_dict(s):
+    d = {k: getattr(s, k) for k, _ in s._fields_ if k != "cost_trace"}
+    d["cost_trace"] = np.array(s.cost_trace[:min(160, s.iterations + 1)])
+    return d
+
+
+def solve(scene, options=None, threads=0):
+    """scene: dict with poses, intrinsics, points, obs_uv, obs_cam, obs_pt (reconstructor_amd.synth_ba).
+    Returns (poses, intrinsics, points, summary dict); inputs are not modified."""
+    poses = np.array(scene["poses"], np.float64, order="C")
+    intr = np.array(scene["intrinsics"], np.float64, order="C")
+    pts = np.array(scene["points"], np.float64, order="C")
+    uv = np.ascontiguousarray(scene["obs_uv"], np.float64)
+    cam = np.ascontiguousarray(scene["obs_cam"], np.int32)
+    pt = np.ascontiguousarray(scene["obs_pt"], np.int32)
+    o = options if options is not None else default_options(poses.shape[0])
+    s = BaSummary()
+    rc = _lib().orc_ba_solve(poses.shape[0], pts.shape[0], cam.shape[0], poses.reshape(-1), intr.reshape(-1),
+                             pts.reshape(-1), uv.reshape(-1), cam, pt, C.byref(o), C.byref(s), threads)
+    if rc != 0:
+        raise RuntimeError("orc_ba_solve rc=%d" % rc)
+    return poses, intr, pts, summary_dict(s)

@@ -1,0 +1,130 @@
+"""Host-side mirror (Python) of the reference's BundleAdjuster over the C ABI.
+
+  BundleAdjuster::adjust(features, landmarks, imgIdx2camPose, imgIdx2camIntrinsics, imgIdxOrder)
+      BundleAdjuster.h:80-84 / BundleAdjuster.cpp:11-188
+`solve_flat` is the flat form (what adjust packs, :17-97); `BundleAdjuster.adjust` packs and
+unpacks exactly as the reference does, including its quirks (axis/(angle+1e-6) on unpack,
+:161-170; integer feature coordinates, :83-84).  The C++ form of the same adapter is
+reconstructor_amd/host/HipBundleAdjuster.h.  All arithmetic of the solve runs in librcn.so.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+TERMINATION = {1: "CONVERGENCE (function tolerance)", 2: "CONVERGENCE (gradient tolerance)",
+               3: "CONVERGENCE (parameter tolerance)", 4: "CONVERGENCE (trust region radius)",
+               5: "NO_CONVERGENCE (max iterations)", 6: "FAILURE"}
+
+
+def default_options(ctx, n_cams):
+    o = _lib.BaOptions()
+    ctx.lib.rcn_ba_default_options(int(n_cams), C.byref(o))
+    return o
+
+
+def summary_dict(s):
+    d = {k: getattr(s, k) for k, _ in s._fields_ if k != "cost_trace"}
+    d["cost_trace"] = np.array(s.cost_trace[:min(160, s.iterations + 1)])
+    return d
+
+
+def solve_flat(ctx, poses, intrinsics, points, obs_uv, obs_cam, obs_pt, options=None):
+    """Returns (poses, intrinsics, points, summary); inputs are copied, not modified."""
+    poses = np.array(poses, np.float64, order="C")
+    intr = np.array(intrinsics, np.float64, order="C")
+    pts = np.array(points, np.float64, order="C").reshape(-1, 3)
+    uv = np.ascontiguousarray(obs_uv, np.float64)
+    cam = np.ascontiguousarray(obs_cam, np.int32)
+    pt = np.ascontiguousarray(obs_pt, np.int32)
+    pb = _lib.BaProblem(poses.shape[0], pts.shape[0], cam.shape[0], 0,
+                        poses.ctypes.data, intr.ctypes.data, pts.ctypes.data if pts.size else None,
+                        uv.ctypes.data if uv.size else None, cam.ctypes.data if cam.size else None,
+                        pt.ctypes.data if pt.size else None)
+    o = options if options is not None else default_options(ctx, poses.shape[0])
+    s = _lib.BaSummary()
+    ctx.check(ctx.lib.rcn_ba_solve(ctx.h, C.byref(pb), C.byref(o), C.byref(s)))
+    return poses, intr, pts, summary_dict(s)
+
+
+def solve_scene(ctx, scene, options=None):
+    return solve_flat(ctx, scene["poses"], scene["intrinsics"], scene["points"], scene["obs_uv"],
+                      scene["obs_cam"], scene["obs_pt"], options)
+
+
+def _rot_to_angle_axis(R):
+    c = (np.trace(R) - 1.0) / 2.0
+    th = np.arccos(np.clip(c, -1.0, 1.0))
+    if th < 1e-12:
+        return np.zeros(3)
+    ax = np.array([R[2, 1] - R[1, 2], R[0, 2] - R[2, 0], R[1, 0] - R[0, 1]]) / (2.0 * np.sin(th))
+    return ax * th
+
+
+def _angle_axis_to_rot(angle, axis):
+    """Eigen::AngleAxisd(angle, axis).toRotationMatrix() for a possibly non-unit axis."""
+    c, s = np.cos(angle), np.sin(angle)
+    x, y, z = axis
+    t = 1 - c
+    return np.array([[t * x * x + c, t * x * y - s * z, t * x * z + s * y],
+                     [t * x * y + s * z, t * y * y + c, t * y * z - s * x],
+                     [t * x * z - s * y, t * y * z + s * x, t * z * z + c]])
+
+
+class BundleAdjuster:
+    """Same call shape as the reference class (BundleAdjuster.h:76-85)."""
+
+    def __init__(self, ctx=None, device=0):
+        self.ctx = ctx if ctx is not None else _lib.Context(device)
+        self.last_summary = None
+
+    def adjust(self, features, landmarks, img_idx2cam_pose, img_idx2cam_intrinsics, img_idx_order):
+        """features[img][feat] -> (x, y) integer pixel coords (or objects with .featCoord.x/.y);
+        landmarks: list of dicts/objects with x, y, z and triangulatedFeatures = [(imgIdx, featIdx)];
+        img_idx2cam_pose: {img: 4x4 world->camera}; img_idx2cam_intrinsics: {img: [fx,fy,cx,cy,k1,k2]}.
+        Updates landmarks, poses and intrinsics in place; returns {global img idx: local idx}."""
+        order = list(img_idx_order)
+        g2l = {g: l for l, g in enumerate(order)}                       # BundleAdjuster.cpp:34-63
+        nc = len(order)
+        poses = np.zeros((nc, 6)); intr = np.zeros((nc, 6))
+        for l, g in enumerate(order):
+            intr[l] = np.asarray(img_idx2cam_intrinsics[g], np.float64)[:6]
+            T = np.asarray(img_idx2cam_pose[g], np.float64)
+            poses[l, :3] = _rot_to_angle_axis(T[:3, :3])
+            poses[l, 3:] = T[:3, 3]
+        get = (lambda lm, k: lm[k]) if isinstance(landmarks[0], dict) else getattr
+        pts = np.array([[get(lm, "x"), get(lm, "y"), get(lm, "z")] for lm in landmarks], np.float64)
+        uv, cam, pt = [], [], []
+        for j, lm in enumerate(landmarks):                              # :74-97, landmark-major
+            for (img, feat) in get(lm, "triangulatedFeatures"):
+                f = features[img][feat]
+                xy = (f.featCoord.x, f.featCoord.y) if hasattr(f, "featCoord") else (f[0], f[1])
+                uv.append((float(xy[0]), float(xy[1]))); cam.append(g2l[img]); pt.append(j)
+        P, I, X, s = solve_flat(self.ctx, poses, intr, pts, np.array(uv).reshape(-1, 2),
+                                np.array(cam, np.int32), np.array(pt, np.int32))
+        self.last_summary = s
+        for j, lm in enumerate(landmarks):                              # :150-155
+            if isinstance(lm, dict):
+                lm["x"], lm["y"], lm["z"] = X[j]
+            else:
+                lm.x, lm.y, lm.z = X[j]
+        for l, g in enumerate(order):                                   # :157-185
+            ang = float(np.sqrt((P[l, :3] ** 2).sum()))
+            axis = P[l, :3] / (ang + 1e-6)                               # the reference's non-unit axis
+            T = np.eye(4)
+            T[:3, :3] = _angle_axis_to_rot(ang, axis)
+            T[:3, 3] = P[l, 3:]
+            img_idx2cam_pose[g] = T
+            img_idx2cam_intrinsics[g] = I[l].copy()
+        return g2l
+
+
+def smoke(ctx):
+    """Small solve on the GPU checked against nothing but itself converging (used by
+    __graft_entry__.smoke together with the oracle comparison there)."""
+    from . import synth_ba
+    sc = synth_ba.make_scene(12, 300, seed=5)
+    P, I, X, s = solve_scene(ctx, sc)
+    assert s["final_rms_px"] < 1.0 < s["initial_rms_px"], s
+    return sc, (P, I, X, s)

@@ -1,0 +1,76 @@
+"""GPU parity suite for bundle adjustment: HIP path (through the C ABI) vs the CPU oracle.
+Tolerance from BASELINE.json north_star: final reprojection RMS within 1e-5 px of the CPU path."""
+import numpy as np
+import pytest
+
+from oracle import orc_ba
+from reconstructor_amd import synth_ba
+
+pytestmark = pytest.mark.gpu
+RMS_TOL_PX = 1e-5
+
+
+@pytest.mark.parametrize("nc,npts,k", [(3, 20, 3), (9, 150, 6), (12, 300, 10), (40, 3000, 10)])
+def test_small_scenes_match_oracle(gpu_ctx, nc, npts, k):
+    from reconstructor_amd import ba
+    sc = synth_ba.make_scene(nc, npts, obs_per_point=k, seed=5)
+    P0, I0, X0, s0 = orc_ba.solve(sc, threads=4)
+    P1, I1, X1, s1 = ba.solve_scene(gpu_ctx, sc)
+    print(nc, npts, "oracle", s0["iterations"], s0["final_rms_px"], "gpu", s1["iterations"], s1["final_rms_px"])
+    assert abs(s1["initial_cost"] - s0["initial_cost"]) <= 1e-9 * s0["initial_cost"]
+    assert abs(s1["final_rms_px"] - s0["final_rms_px"]) <= RMS_TOL_PX
+    assert s1["iterations"] == s0["iterations"] and s1["termination"] == s0["termination"]
+    n = min(len(s0["cost_trace"]), len(s1["cost_trace"]))
+    assert np.allclose(s1["cost_trace"][:n], s0["cost_trace"][:n], rtol=1e-7)
+    assert np.allclose(P1, P0, atol=1e-6) and np.allclose(X1, X0, atol=1e-5) and np.allclose(I1, I0, rtol=1e-6, atol=1e-6)
+    assert s1["line_search_backtracks"] == 0 == s0["line_search_backtracks"]
+
+
+def test_cfg4_parity(gpu_ctx):
+    """BASELINE cfg 4: 200 cams / 20k points / 200k observations."""
+    from reconstructor_amd import ba
+    sc = synth_ba.make_scene(200, 20000, obs_per_point=10, seed=2024)
+    P0, I0, X0, s0 = orc_ba.solve(sc, threads=0)
+    P1, I1, X1, s1 = ba.solve_scene(gpu_ctx, sc)
+    print("cfg4 oracle", s0["iterations"], s0["final_rms_px"], "%.2fs" % s0["solve_seconds"],
+          "gpu", s1["iterations"], s1["final_rms_px"], "%.3fs" % s1["solve_seconds"], "n", s1["reduced_dim"])
+    assert s1["reduced_dim"] == 6 * 199 - 3 + 4 * 200
+    assert abs(s1["final_rms_px"] - s0["final_rms_px"]) <= RMS_TOL_PX
+    assert s1["final_rms_px"] < 0.8 and s1["iterations"] == s0["iterations"]
+
+
+def test_noise_free_scene_converges_to_zero(gpu_ctx):
+    from reconstructor_amd import ba
+    sc = synth_ba.make_scene(15, 400, seed=9, noise_px=0.0, integer_obs=False)
+    P, I, X, s = ba.solve_scene(gpu_ctx, sc)
+    assert s["final_rms_px"] < 1e-6, s
+
+
+def test_adjust_signature(gpu_ctx):
+    """BundleAdjuster::adjust call shape: maps keyed by image index, landmarks with
+    triangulatedFeatures, in-place update, returns global->local camera map."""
+    from reconstructor_amd import ba
+    sc = synth_ba.make_scene(5, 60, obs_per_point=4, seed=3)
+    order = [7, 3, 11, 5, 2]                       # imgIdxOrder: local index = position
+    feats = {g: [] for g in order}
+    landmarks = []
+    for j in range(60):
+        tf = []
+        for o in np.nonzero(sc["obs_pt"] == j)[0]:
+            g = order[sc["obs_cam"][o]]
+            feats[g].append((int(sc["obs_uv"][o, 0]), int(sc["obs_uv"][o, 1])))
+            tf.append((g, len(feats[g]) - 1))
+        landmarks.append({"x": sc["points"][j, 0], "y": sc["points"][j, 1], "z": sc["points"][j, 2],
+                          "triangulatedFeatures": tf})
+    poses = {}
+    for l, g in enumerate(order):
+        T = np.eye(4); T[:3, :3] = synth_ba.rodrigues(sc["poses"][l, :3]); T[:3, 3] = sc["poses"][l, 3:]
+        poses[g] = T
+    intr = {g: sc["intrinsics"][l].copy() for l, g in enumerate(order)}
+    adj = ba.BundleAdjuster(ctx=gpu_ctx)
+    g2l = adj.adjust(feats, landmarks, poses, intr, order)
+    assert g2l == {g: l for l, g in enumerate(order)}
+    P0, I0, X0, s0 = orc_ba.solve(sc, threads=2)
+    assert abs(adj.last_summary["final_rms_px"] - s0["final_rms_px"]) <= RMS_TOL_PX
+    assert np.allclose([[lm["x"], lm["y"], lm["z"]] for lm in landmarks], X0, atol=1e-5)
+    assert np.allclose(poses[order[0]], np.vstack([np.c_[synth_ba.rodrigues(sc["poses"][0, :3]), sc["poses"][0, 3:]], [0, 0, 0, 1]]), atol=1e-5)
