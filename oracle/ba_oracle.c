@@ -30,7 +30,8 @@
  *   - LM: D^2 = clamp(diag(J'J), 1e-6, 1e32) / radius (diag re-used after a rejected step),
  *     solve (J'J + D^2) y = J'r via point Schur complement + dense Cholesky, step = -y
  *   - model_cost_change = -m.(r + m/2), m = J step; <= 0 => invalid step
- *   - Plus = add on the tangent coordinates, then clamp to the box (ParameterBlock::Plus)
+ *   - Plus = add on the tangent coordinates, then clamp to the box (ParameterBlock::Plus);
+ *     a bounds-constrained problem starts from the projection of x onto the box (IterationZero)
  *   - bounds present => projected Armijo line search along the step before evaluation
  *     (TrustRegionMinimizer::DoLineSearch).  DEVIATION: Ceres interpolates with a cubic through
  *     values and gradients; here a backtrack uses the quadratic through f(0), f'(0), f(a).
@@ -347,6 +348,12 @@ int orc_ba_solve(int n_cams, int n_points, int n_obs, double *poses, double *int
     double *ugc = (double *)malloc(sizeof(double) * NN), *ugp = (double *)malloc(sizeof(double) * NP3); /* unscaled gradient */
 
     const double t_start = now_s();
+    /* TrustRegionMinimizer::IterationZero: a bounds-constrained problem starts from the
+     * projection of x onto the box (Plus with a zero step) */
+    if (P.mode == 1)
+        for (int c = 0; c < n_cams; ++c)
+            for (int k = 0; k < 2; ++k)
+                if (intr[6 * c + k] > P.ub) { intr[6 * c + k] = P.ub; sum->bound_projections++; }
     double cost = evaluate(&P, poses, intr, pts, r, Jc, Jp);
     sum->initial_cost = cost;
     sum->initial_rms_px = sqrt(2.0 * cost / (n_obs > 0 ? n_obs : 1));

@@ -349,50 +349,110 @@ __global__ __launch_bounds__(64) void k_ba_cam_rhs(BaDev d)
 
 // ---------------------------------------------------------------------------------------
 // K7: dense Cholesky of the padded reduced system (npad multiple of 128), lower triangle.
-// Diagonal block: factor in LDS, then invert the factor (triangular), one workgroup.
+// Diagonal block (one workgroup, block resident in LDS):
+//   1. blocked factorization, 32-wide sub-panels: unblocked 32x32, row-wise triangular solve of
+//      the rows below, rank-32 update of the trailing square with 16x16 thread tiles;
+//   2. in-place inverse of the factor (dtrti2 order, two threads per row).
+// Writes L into S and L^-1 into Linv[kb] (used by the panel GEMM and the triangular solves).
+#define DL 129   // LDS row stride of the diagonal block (doubles): row walks are conflict-free
 __global__ __launch_bounds__(256) void k_chol_diag(double *S, int ld, int kb, double *Linv, int *flag)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    double *L = reinterpret_cast<double *>(smem_raw);  // [128][129]
+    double *L = reinterpret_cast<double *>(smem_raw);  // [128][DL]
+    __shared__ double xcol[NB + 2];   // + the breakdown flag; 16-byte multiple keeps the dynamic base aligned
+    double &bad = xcol[NB];
     const int t = threadIdx.x;
     double *A = S + ((size_t)kb * NB) * ld + (size_t)kb * NB;
+    if (t == 0) bad = 0.0;
     for (int i = t; i < NB * NB; i += 256) {
         const int r = i / NB, c = i % NB;
-        L[r * 129 + c] = c <= r ? A[(size_t)r * ld + c] : 0.0;
+        L[r * DL + c] = c <= r ? A[(size_t)r * ld + c] : 0.0;
     }
     __syncthreads();
-    for (int j = 0; j < NB; ++j) {
-        const double djj = L[j * 129 + j];
-        if (!(djj > 0.0) || !isfinite(djj)) { if (t == 0) *flag = 1; return; }  // uniform: read from LDS
-        const double dj = sqrt(djj);
+    for (int c0 = 0; c0 < NB; c0 += 32) {
+        // 1a. unblocked Cholesky of the 32x32 diagonal sub-block
+        for (int j = c0; j < c0 + 32; ++j) {
+            const double djj = L[j * DL + j];
+            if (!(djj > 0.0) || !isfinite(djj)) bad = 1.0;   // same value in every thread
+            __syncthreads();
+            if (bad != 0.0) { if (t == 0) *flag = 1; return; }
+            const double dj = sqrt(djj);
+            if (t == 0) L[j * DL + j] = dj;
+            if (t > 0 && j + t < c0 + 32) L[(j + t) * DL + j] /= dj;
+            __syncthreads();
+            const int m = c0 + 32 - j - 1;
+            for (int e = t; e < m * m; e += 256) {
+                const int i = j + 1 + e / m, c = j + 1 + e % m;
+                if (c <= i) L[i * DL + c] -= L[i * DL + j] * L[c * DL + j];
+            }
+            __syncthreads();
+        }
+        const int r0 = c0 + 32;
+        if (r0 >= NB) break;
+        // 1b. rows below: L[i, c0:c0+32] <- L[i, c0:c0+32] D^-T, one thread per row
+        if (t < NB - r0) {
+            double *row = L + (r0 + t) * DL + c0;
+            for (int c = 0; c < 32; ++c) {
+                const double *dc = L + (c0 + c) * DL + c0;
+                double v = row[c];
+                for (int m = 0; m < c; ++m) v -= row[m] * dc[m];
+                row[c] = v / dc[c];
+            }
+        }
         __syncthreads();
-        if (t == 0) L[j * 129 + j] = dj;
-        for (int i = j + 1 + t; i < NB; i += 256) L[i * 129 + j] /= dj;
-        __syncthreads();
-        // trailing update of the lower triangle: columns j+1.. ; element (i,c) -= L[i][j]*L[c][j]
-        const int m = NB - j - 1;
-        for (int e = t; e < m * m; e += 256) {
-            const int i = j + 1 + e / m, c = j + 1 + e % m;
-            if (c <= i) L[i * 129 + c] -= L[i * 129 + j] * L[c * 129 + j];
+        // 1c. trailing square -= panel panel^T ; thread (ty,tx) owns rows ty+16u, cols tx+16v
+        {
+            const int T = NB - r0, nt = T / 16;   // 6, 4, 2
+            const int ty = t >> 4, tx = t & 15;
+            double acc[6][6];
+            for (int u = 0; u < 6; ++u)
+                for (int v = 0; v < 6; ++v) acc[u][v] = 0.0;
+            for (int m = 0; m < 32; ++m) {
+                double a[6], b[6];
+                for (int u = 0; u < 6; ++u) {
+                    a[u] = u < nt ? L[(r0 + ty + 16 * u) * DL + c0 + m] : 0.0;
+                    b[u] = u < nt ? L[(r0 + tx + 16 * u) * DL + c0 + m] : 0.0;
+                }
+                for (int u = 0; u < 6; ++u)
+                    for (int v = 0; v < 6; ++v) acc[u][v] += a[u] * b[v];
+            }
+            for (int u = 0; u < nt; ++u)
+                for (int v = 0; v < nt; ++v) {
+                    const int i = r0 + ty + 16 * u, c = r0 + tx + 16 * v;
+                    if (c <= i) L[i * DL + c] -= acc[u][v];
+                }
         }
         __syncthreads();
     }
     for (int i = t; i < NB * NB; i += 256) {
         const int r = i / NB, c = i % NB;
-        if (c <= r) A[(size_t)r * ld + c] = L[r * 129 + c];
+        if (c <= r) A[(size_t)r * ld + c] = L[r * DL + c];
     }
-    // inverse of the lower-triangular factor: column c by forward substitution (thread per column)
-    if (t < NB) {
-        const int c = t;
-        double *out = Linv + (size_t)kb * NB * NB;
-        for (int r = 0; r < NB; ++r) {
-            double s = r == c ? 1.0 : 0.0;
-            if (r > c) {
-                for (int m = c; m < r; ++m) s -= L[r * 129 + m] * out[(size_t)m * NB + c];
-            }
-            const double v = r >= c ? s / L[r * 129 + r] : 0.0;
-            out[(size_t)r * NB + c] = v;
+    __syncthreads();
+    // 2. in-place inverse of the lower-triangular factor, column by column from the right:
+    //    new L[j+1:, j] = -(1/Ljj) * T * L[j+1:, j] with T the already inverted trailing block
+    for (int j = NB - 1; j >= 0; --j) {
+        const double ajj = 1.0 / L[j * DL + j];
+        if (t > j && t < NB) xcol[t] = L[t * DL + j];
+        __syncthreads();
+        const int i = j + 1 + (t >> 1);           // two threads per row split the dot product
+        double v = 0.0;
+        if (i < NB) {
+            const int len = i - j, half = (len + 1) >> 1;
+            const int m0 = j + 1 + ((t & 1) ? half : 0), m1 = (t & 1) ? i + 1 : j + 1 + half;
+            const double *Ti = L + i * DL;
+            for (int m = m0; m < m1; ++m) v += Ti[m] * xcol[m];
         }
+        v += __shfl_xor(v, 1);
+        __syncthreads();                           // every read of column j / T rows is done
+        if (i < NB && (t & 1) == 0) L[i * DL + j] = -ajj * v;
+        if (t == 0) L[j * DL + j] = ajj;
+        __syncthreads();
+    }
+    double *out = Linv + (size_t)kb * NB * NB;
+    for (int i = t; i < NB * NB; i += 256) {
+        const int r = i / NB, c = i % NB;
+        out[i] = c <= r ? L[r * DL + c] : 0.0;
     }
 }
 
@@ -750,7 +810,13 @@ int rcn_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_options *o
 
     auto H2D = [&](void *dst, const void *src, size_t bytes) { return bytes ? hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st) : hipSuccess; };
     RCN_HIP(H2D(d.poses, pb->poses, sizeof(double) * 6 * nc));
-    RCN_HIP(H2D(d.intr, pb->intrinsics, sizeof(double) * 6 * nc));
+    // TrustRegionMinimizer::IterationZero: start from the projection onto the box
+    std::vector<double> intr0(pb->intrinsics, pb->intrinsics + 6 * (size_t)nc);
+    if (opt->intrinsics_mode == 1)
+        for (int c = 0; c < nc; ++c)
+            for (int k = 0; k < 2; ++k)
+                if (intr0[6 * c + k] > opt->focal_upper_bound) { intr0[6 * c + k] = opt->focal_upper_bound; sum->bound_projections++; }
+    RCN_HIP(H2D(d.intr, intr0.data(), sizeof(double) * 6 * nc));
     RCN_HIP(H2D(d.pts, pb->points, sizeof(double) * 3 * np));
     RCN_HIP(H2D(uv, pb->obs_uv, sizeof(double) * 2 * no));
     RCN_HIP(H2D(p_ocam, pb->obs_cam, sizeof(int) * no));
@@ -762,7 +828,7 @@ int rcn_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_options *o
     RCN_HIP(H2D(p_camdim, cam_dim.data(), sizeof(int) * nc));
     RCN_HIP(H2D(p_cols, cols.data(), sizeof(int) * 10 * nc));
     RCN_HIP(hipMemsetAsync(vecs, 0, sizeof(double) * 12 * nvec, st));
-    RCN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_chol_diag), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 129 * 8));
+    RCN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_chol_diag), hipFuncAttributeMaxDynamicSharedMemorySize, NB * DL * 8));
     RCN_HIP(hipStreamSynchronize(st));   // host vectors go out of use; timing starts with inputs resident
 
     double hs[32];
@@ -827,7 +893,7 @@ int rcn_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_options *o
         RCN_HIP(hipGetLastError());
         // dense Cholesky, right-looking, 128-wide panels
         for (int kb = 0; kb < nblk; ++kb) {
-            k_chol_diag<<<1, 256, 128 * 129 * 8, st>>>(d.S, npad, kb, d.Linv, d.flag);
+            k_chol_diag<<<1, 256, NB * DL * 8, st>>>(d.S, npad, kb, d.Linv, d.flag);
             const int m = nblk - kb - 1;
             if (m > 0) {
                 k_gemm_nt<0><<<m, 256, 0, st>>>(d.S, npad, kb, nblk, d.Linv);

@@ -74,3 +74,33 @@ def test_adjust_signature(gpu_ctx):
     assert abs(adj.last_summary["final_rms_px"] - s0["final_rms_px"]) <= RMS_TOL_PX
     assert np.allclose([[lm["x"], lm["y"], lm["z"]] for lm in landmarks], X0, atol=1e-5)
     assert np.allclose(poses[order[0]], np.vstack([np.c_[synth_ba.rodrigues(sc["poses"][0, :3]), sc["poses"][0, 3:]], [0, 0, 0, 1]]), atol=1e-5)
+
+
+def test_bounds_active_matches_oracle(gpu_ctx):
+    """fx, fy start above the 1000 bound (BundleAdjuster.cpp:120-121): initial projection and
+    clamped Plus must follow the oracle step for step."""
+    from reconstructor_amd import ba
+    sc = synth_ba.make_scene(10, 150, obs_per_point=6, seed=4, focal_factor=2.2)
+    P0, I0, X0, s0 = orc_ba.solve(sc, threads=2)
+    P1, I1, X1, s1 = ba.solve_scene(gpu_ctx, sc)
+    assert (I1[:, :2] <= 1000.0 + 1e-12).all()
+    assert s1["iterations"] == s0["iterations"] and s1["termination"] == s0["termination"]
+    assert s1["line_search_backtracks"] == s0["line_search_backtracks"]
+    assert abs(s1["final_rms_px"] - s0["final_rms_px"]) <= 1e-5
+
+
+def test_cfg5_properties(gpu_ctx):
+    """BASELINE cfg 5 (1000 cams / 100k points / 1M observations): too big for the CPU oracle
+    inside the suite, so size-independent properties: monotone cost trace, gauge untouched,
+    reduced dimension 9991, converged RMS at the noise level, bit-reproducible first step."""
+    from reconstructor_amd import ba
+    sc = synth_ba.make_scene(1000, 100000, obs_per_point=10, seed=2024)
+    P, I, X, s = ba.solve_scene(gpu_ctx, sc)
+    print("cfg5", s["iterations"], s["initial_rms_px"], s["final_rms_px"], "%.3fs" % s["solve_seconds"], s["termination"])
+    assert s["reduced_dim"] == 9991
+    tr = s["cost_trace"]
+    assert (np.diff(tr) <= 1e-9 * tr[:-1]).all()
+    assert s["final_rms_px"] < 0.8 < s["initial_rms_px"]
+    assert np.array_equal(P[0], sc["poses"][0]) and np.array_equal(P[1, 3:], sc["poses"][1, 3:])
+    assert np.array_equal(I[:, 2:4], sc["intrinsics"][:, 2:4])
+    assert np.abs(X - sc["points_gt"]).mean() < 0.05

@@ -1,0 +1,65 @@
+"""CPU suite: the BA oracle against the committed golden vectors (no GPU)."""
+import os
+
+import numpy as np
+
+from oracle import orc_ba
+from reconstructor_amd import synth_ba
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def test_residual_jacobian_spots():
+    z = np.load(os.path.join(G, "ba_spots.npz"))
+    for i in range(len(z["pose"])):
+        res, J = orc_ba.residual_jacobian(z["pose"][i], z["intr"][i], z["X"][i], z["uv"][i])
+        assert np.allclose(res, z["res"][i], rtol=1e-13, atol=1e-12)
+        assert np.allclose(J, z["J"][i], rtol=1e-12, atol=1e-12)
+        # additive distortion (BundleAdjuster.h:43-47): the SAME scalar is added to x and y
+        pu, _ = synth_ba.project(z["pose"][i], z["intr"][i], z["X"][i])
+        assert np.allclose(res, pu - z["uv"][i], atol=1e-9)
+
+
+def test_scene_traces_match_golden_and_scipy_minimum():
+    z = np.load(os.path.join(G, "ba_scenes.npz"))
+    for name in ("cams3", "cams12"):
+        nc, npts, k, seed = z[name + "/args"]
+        sc = synth_ba.make_scene(int(nc), int(npts), obs_per_point=int(k), seed=int(seed))
+        P, I, X, s = orc_ba.solve(sc, threads=2)
+        assert s["iterations"] == int(z[name + "/iterations"]) and s["termination"] == int(z[name + "/termination"])
+        assert np.allclose(s["cost_trace"], z[name + "/cost_trace"], rtol=1e-9)
+        assert abs(s["final_rms_px"] - float(z[name + "/final_rms_px"])) < 1e-9
+        assert np.allclose(P, z[name + "/poses"], atol=1e-9) and np.allclose(X, z[name + "/points"], atol=1e-8)
+        cmin = float(z[name + "/scipy_min_cost"])
+        assert cmin <= s["final_cost"] * (1 + 1e-9) and s["final_cost"] - cmin <= 5e-6 * cmin
+
+
+def test_gauge_and_intrinsics_branches():
+    # < 10 cameras: intrinsics constant (BundleAdjuster.cpp:112-115); camera 0 pose and camera 1
+    # translation never move (:100-105)
+    sc = synth_ba.make_scene(6, 80, obs_per_point=5, seed=1)
+    P, I, X, s = orc_ba.solve(sc)
+    assert np.array_equal(I, sc["intrinsics"])
+    assert np.array_equal(P[0], sc["poses"][0]) and np.array_equal(P[1, 3:], sc["poses"][1, 3:])
+    assert not np.array_equal(P[1, :3], sc["poses"][1, :3])
+    assert s["reduced_dim"] == 3 + 6 * 4
+    # >= 10 cameras: fx, fy, k1, k2 free; cx, cy constant (:117-121)
+    sc = synth_ba.make_scene(10, 200, obs_per_point=6, seed=2)
+    P, I, X, s = orc_ba.solve(sc)
+    assert np.array_equal(I[:, 2:4], sc["intrinsics"][:, 2:4]) and not np.array_equal(I[:, 0], sc["intrinsics"][:, 0])
+    assert s["reduced_dim"] == 3 + 6 * 8 + 4 * 10
+    assert (I[:, :2] <= 1000.0).all()
+
+
+def test_upper_bound_is_a_projection():
+    # focal lengths that start above the 1000 bound are clamped by the first Plus (:120-121)
+    sc = synth_ba.make_scene(10, 150, obs_per_point=6, seed=4, focal_factor=2.2)   # f = 1126 > 1000
+    P, I, X, s = orc_ba.solve(sc)
+    assert (I[:, :2] <= 1000.0 + 1e-12).all() and s["bound_projections"] > 0
+
+
+def test_noise_free_converges_to_zero():
+    sc = synth_ba.make_scene(12, 200, seed=8, noise_px=0.0, integer_obs=False)
+    P, I, X, s = orc_ba.solve(sc)
+    assert s["final_rms_px"] < 1e-6
+    assert np.allclose(X, sc["points_gt"], atol=1e-5)

@@ -1,0 +1,67 @@
+"""CPU suite: sharding of the pair grid (pure functions + a world_size-2 gloo run)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+from reconstructor_amd import pairgrid
+from reconstructor_amd.matcher import all_pairs
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_shards_partition_the_grid():
+    for n in (2, 5, 100, 141):
+        pairs = all_pairs(n)
+        assert len(pairs) == n * (n - 1) // 2 and (pairs[:, 0] < pairs[:, 1]).all()
+        for world in (1, 2, 4, 8):
+            shards = [pairgrid.shard_pairs(pairs, world, r) for r in range(world)]
+            sizes = [len(s) for s in shards]
+            assert max(sizes) - min(sizes) <= 1
+            merged = pairgrid.merge_shards(shards, world)
+            assert np.array_equal(merged, pairs)
+            owned = [pairgrid.owned_images(n, world, r) for r in range(world)]
+            assert owned[0][0] == 0 and owned[-1][1] == n
+            assert all(owned[i][1] == owned[i + 1][0] for i in range(world - 1))
+
+
+WORKER = r'''
+import os, sys
+sys.path.insert(0, %r)
+import numpy as np, torch, torch.distributed as dist
+from reconstructor_amd import pairgrid, synth
+from reconstructor_amd.matcher import all_pairs
+from oracle import orc
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo")
+n, K, D = 6, 48, 32
+lo, hi = pairgrid.owned_images(n, world, rank)
+pool = synth.world_pool("orb", 96, seed=7)
+local = np.stack([synth.image_descriptors("orb", i, K, pool, seed=7) for i in range(lo, hi)])
+gathered = torch.empty((n, K, D), dtype=torch.float32)
+dist.all_gather_into_tensor(gathered.view(-1), torch.from_numpy(local).view(-1))      # the one collective
+ims = [gathered[i].numpy() for i in range(n)]
+mine = pairgrid.shard_pairs(all_pairs(n), world, rank)
+out, counts = orc.match_grid(ims, mine, threads=1)          # stand-in for the per-rank GPU grid call
+rows = [None] * world
+dist.all_gather_object(rows, out)
+if rank == 0:
+    merged = pairgrid.merge_shards(rows, world)
+    full = [synth.image_descriptors("orb", i, K, pool, seed=7) for i in range(n)]
+    exp, _ = orc.match_grid(full, all_pairs(n), threads=1)
+    assert np.array_equal(merged, exp)
+    print("OK", merged.shape, int((merged >= 0).sum()))
+dist.destroy_process_group()
+'''
+
+
+def test_two_ranks_gloo(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER % ROOT)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29533", str(script)],
+                       capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "OK" in r.stdout
