@@ -280,48 +280,72 @@ __device__ __forceinline__ void load_W(const BaDev &d, int o, int c, int j, doub
     }
 }
 
-// reduced system diagonal blocks: S[c,c] = scaled U + dgc/radius ; padded diagonal = 1
-__global__ void k_ba_S_diag(BaDev d, double inv_radius)
-{
-    const int c = blockIdx.x, t = threadIdx.x;
-    if (c < d.nc) {
-        const int dc = d.cam_dim[c], off = d.cam_off[c];
-        const int a = t / 10, b = t % 10;
-        if (t < 100 && a < dc && b < dc) {
-            double v = d.Uraw[100 * (size_t)c + t] * d.sc[off + a] * d.sc[off + b];
-            if (a == b) v += d.dgc[off + a] * inv_radius;
-            d.S[(size_t)(off + a) * d.npad + off + b] = v;
-        }
-    } else {
-        const int i = d.n + (c - d.nc) * 128 + t;
-        if (i < d.npad) d.S[(size_t)i * d.npad + i] = 1.0;
-    }
-}
-
-// K6: S[c,c'] -= Y_o W_o'^T for every ordered observation pair (o,o') of a point with
-// reduced offset(c') <= offset(c); Y_o = W_o V^-1.  One thread per (o, o') pair.
-__global__ __launch_bounds__(256) void k_ba_schur(BaDev d, const int *pair_off)
+// K6: Schur complement.  Contributions are accumulated in a camera-block-major buffer
+// Sb[c][c2][10][10] (c2 <= c): one wave owns one observation pair (o,o2) of a point at a time and
+// adds its 10x10 block -Y_o W_o2^T with two wave-wide f64 atomic instructions over 800
+// contiguous bytes (full-rate shape: MI355X_MICROARCH.md, global float atomics).
+__global__ __launch_bounds__(256) void k_ba_schur(BaDev d, double *Sb)
 {
     const int j = blockIdx.x;                      // point
     const int o0 = d.pt_off[j], k = d.pt_off[j + 1] - o0;
-    for (int pr = threadIdx.x; pr < k * k; pr += blockDim.x) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const double *Vi = d.Vinv + 9 * (size_t)j;
+    const double sp0 = d.sp[3 * (size_t)j], sp1 = d.sp[3 * (size_t)j + 1], sp2 = d.sp[3 * (size_t)j + 2];
+    for (int pr = w; pr < k * k; pr += nw) {
         const int o = o0 + pr / k, o2 = o0 + pr % k;
         const int c = d.ocam[o], c2 = d.ocam[o2];
-        const int off = d.cam_off[c], off2 = d.cam_off[c2], dc = d.cam_dim[c], dc2 = d.cam_dim[c2];
-        if (off2 > off || dc == 0 || dc2 == 0) continue;
-        double W[30], W2[30], Y[30];
-        load_W(d, o, c, j, W);
-        load_W(d, o2, c2, j, W2);
-        const double *Vi = d.Vinv + 9 * (size_t)j;
-        for (int a = 0; a < dc; ++a)
-            for (int b = 0; b < 3; ++b) Y[3 * a + b] = W[3 * a] * Vi[b] + W[3 * a + 1] * Vi[3 + b] + W[3 * a + 2] * Vi[6 + b];
-        for (int a = 0; a < dc; ++a)
-            for (int b = 0; b < dc2; ++b) {
-                const double v = Y[3 * a] * W2[3 * b] + Y[3 * a + 1] * W2[3 * b + 1] + Y[3 * a + 2] * W2[3 * b + 2];
-                unsafeAtomicAdd(d.S + (size_t)(off + a) * d.npad + off2 + b, -v);
-            }
+        if (c2 > c) continue;
+        const int dc = d.cam_dim[c], dc2 = d.cam_dim[c2];
+        if (dc == 0 || dc2 == 0) continue;
+        const int off = d.cam_off[c], off2 = d.cam_off[c2];
+        const double *jc = d.Jc + 20 * (size_t)o, *jp = d.Jp + 6 * (size_t)o;
+        const double *jc2 = d.Jc + 20 * (size_t)o2, *jp2 = d.Jp + 6 * (size_t)o2;
+        double *blk = Sb + ((size_t)c * d.nc + c2) * 100;
+#pragma unroll
+        for (int rep = 0; rep < 2; ++rep) {
+            const int e = lane + 64 * rep;
+            if (e >= 100) break;
+            const int a = e / 10, b = e % 10;
+            if (a >= dc || b >= dc2) continue;
+            const double sa = d.sc[off + a], sb = d.sc[off2 + b];
+            const double ja0 = jc[a] * sa, ja1 = jc[10 + a] * sa, jb0 = jc2[b] * sb, jb1 = jc2[10 + b] * sb;
+            // W[a][m] (this row of W_o), W2[b][m]
+            const double wa0 = (ja0 * jp[0] + ja1 * jp[3]) * sp0, wa1 = (ja0 * jp[1] + ja1 * jp[4]) * sp1,
+                         wa2 = (ja0 * jp[2] + ja1 * jp[5]) * sp2;
+            const double wb0 = (jb0 * jp2[0] + jb1 * jp2[3]) * sp0, wb1 = (jb0 * jp2[1] + jb1 * jp2[4]) * sp1,
+                         wb2 = (jb0 * jp2[2] + jb1 * jp2[5]) * sp2;
+            const double y0 = wa0 * Vi[0] + wa1 * Vi[3] + wa2 * Vi[6];
+            const double y1 = wa0 * Vi[1] + wa1 * Vi[4] + wa2 * Vi[7];
+            const double y2 = wa0 * Vi[2] + wa1 * Vi[5] + wa2 * Vi[8];
+            unsafeAtomicAdd(blk + e, -(y0 * wb0 + y1 * wb1 + y2 * wb2));
+        }
     }
-    (void)pair_off;
+}
+
+// dense padded reduced system from the block buffer: lower blocks (c2 <= c) of
+// S = blockdiag(scaled U + dgc/radius) + Sb ; padded diagonal = 1.  One workgroup per camera row.
+__global__ __launch_bounds__(256) void k_ba_S_assemble(BaDev d, const double *Sb, double inv_radius)
+{
+    const int c = blockIdx.x, t = threadIdx.x;
+    if (c >= d.nc) {   // padded rows: identity
+        for (int i = d.n + t; i < d.npad; i += 256)
+            if (c == d.nc) d.S[(size_t)i * d.npad + i] = 1.0;
+        return;
+    }
+    const int dc = d.cam_dim[c], off = d.cam_off[c];
+    if (dc == 0) return;
+    for (int idx = t; idx < (c + 1) * 100; idx += 256) {
+        const int c2 = idx / 100, e = idx % 100, a = e / 10, b = e % 10;
+        const int dc2 = d.cam_dim[c2];
+        if (a >= dc || b >= dc2) continue;
+        const int off2 = d.cam_off[c2];
+        double v = Sb[((size_t)c * d.nc + c2) * 100 + e];
+        if (c2 == c) {
+            v += d.Uraw[100 * (size_t)c + e] * d.sc[off + a] * d.sc[off + b];
+            if (a == b) v += d.dgc[off + a] * inv_radius;
+        }
+        d.S[(size_t)(off + a) * d.npad + off2 + b] = v;
+    }
 }
 
 // reduced rhs per camera: scaled gc - sum_o Y_o gp_j(o)   (deterministic order)
@@ -801,6 +825,7 @@ int rcn_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_options *o
     d.Vinv = ws.get<double>(9 * (size_t)np);
     d.S = ws.get<double>((size_t)npad * npad);
     d.Linv = ws.get<double>((size_t)nblk * NB * NB);
+    double *Sb = ws.get<double>(100 * (size_t)nc * nc);
     const int eb = (no + 255) / 256, pbk = (std::max(nc, np) + 255) / 256;
     d.partial = ws.get<double>(4 * (size_t)std::max(std::max(eb, pbk), 1) + 16);
     d.scal = ws.get<double>(32);
@@ -828,6 +853,7 @@ int rcn_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_options *o
     RCN_HIP(H2D(p_camdim, cam_dim.data(), sizeof(int) * nc));
     RCN_HIP(H2D(p_cols, cols.data(), sizeof(int) * 10 * nc));
     RCN_HIP(hipMemsetAsync(vecs, 0, sizeof(double) * 12 * nvec, st));
+    RCN_HIP(hipMemsetAsync(d.S, 0, sizeof(double) * (size_t)npad * npad, st));   // upper part / padding never rewritten
     RCN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_chol_diag), hipFuncAttributeMaxDynamicSharedMemorySize, NB * DL * 8));
     RCN_HIP(hipStreamSynchronize(st));   // host vectors go out of use; timing starts with inputs resident
 
@@ -884,11 +910,12 @@ int rcn_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_options *o
         }
         const double ir = 1.0 / radius;
         RCN_HIP(hipMemsetAsync(d.flag, 0, sizeof(int), st));
-        RCN_HIP(hipMemsetAsync(d.S, 0, sizeof(double) * (size_t)npad * npad, st));
+        RCN_HIP(hipMemsetAsync(Sb, 0, sizeof(double) * 100 * (size_t)nc * nc, st));
+        if (npad > n) RCN_HIP(hipMemsetAsync(d.S + (size_t)n * npad, 0, sizeof(double) * (size_t)(npad - n) * npad, st));
         RCN_HIP(hipMemsetAsync(d.rhs, 0, sizeof(double) * npad, st));
         if (np > 0) k_ba_point_solve<<<(np + 127) / 128, 128, 0, st>>>(d, ir);
-        k_ba_S_diag<<<nc + (npad - n + 127) / 128, 128, 0, st>>>(d, ir);
-        if (np > 0) k_ba_schur<<<np, std::min(256, std::max(64, (kmax * kmax + 63) / 64 * 64)), 0, st>>>(d, nullptr);
+        if (np > 0) k_ba_schur<<<np, std::min(256, std::max(64, 64 * ((kmax * kmax + 7) / 8))), 0, st>>>(d, Sb);
+        k_ba_S_assemble<<<nc + 1, 256, 0, st>>>(d, Sb, ir);
         k_ba_cam_rhs<<<nc, 64, 0, st>>>(d);
         RCN_HIP(hipGetLastError());
         // dense Cholesky, right-looking, 128-wide panels
