@@ -34,6 +34,12 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 MFMA_F16_PEAK_TFLOPS = 2500.0  # dense bf16/f16 MFMA peak (same guide)
 
 
+def host_threads():
+    """Threads for the CPU baselines: the GPU box's CPU share for one GPU is 16 cores even though
+    the affinity mask lists every core of the host."""
+    return max(1, min(16, len(os.sched_getaffinity(0))))
+
+
 def cpu_baseline(images, n_threads):
     """Oracle (CPU restatement, kind "port") on a bounded sample of the same workload."""
     from oracle import orc
@@ -51,6 +57,24 @@ def cpu_baseline(images, n_threads):
                       % (len(pick), len(allp), dt)}
 
 
+def ba_leg(ctx, with_cpu):
+    """BA LM-iterations/s on cfg 4 / cfg 5 (single GPU: BA does not shard, "replicas only"),
+    with the oracle's cfg-4 solve as the CPU baseline."""
+    from reconstructor_amd import ba_bench
+    sc4, out = ba_bench.run(ctx)
+    if with_cpu:
+        from oracle import orc_ba
+        threads = host_threads()
+        t0 = time.perf_counter()
+        P, I, X, s = orc_ba.solve(sc4, threads=threads)
+        out["cpu_baseline"] = {"value": s["iterations"] / s["solve_seconds"], "unit": "LM-iterations/s",
+                               "cores": threads, "kind": "port",
+                               "sample": "cfg4 full solve (%d iterations, %.2f s), oracle/ba_oracle.c" % (s["iterations"], time.perf_counter() - t0),
+                               "final_rms_px": s["final_rms_px"]}
+        out["cfg4"]["rms_diff_vs_cpu_px"] = abs(out["cfg4"]["final_rms_px"] - s["final_rms_px"])
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -58,7 +82,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--images", type=int, default=0, help="override image count (debug)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--ba", action="store_true", help="also time BA (cfg 4) and report it in the line")
+    ap.add_argument("--no-ba", action="store_true", help="skip the BA leg (cfg 4 + cfg 5 LM iterations/s)")
     args = ap.parse_args()
 
     import torch
@@ -168,12 +192,11 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:
             images = [local[i] for i in range(local.shape[0])]
-            line["cpu_baseline"] = cpu_baseline(images, len(os.sched_getaffinity(0)))
+            line["cpu_baseline"] = cpu_baseline(images, host_threads())
         elif world == 1:
             line["cpu_baseline"] = None
-        if args.ba and world == 1:
-            from reconstructor_amd import ba_bench
-            line["ba"] = ba_bench.run(matcher.ctx)
+        if not args.no_ba and world == 1:
+            line["ba"] = ba_leg(matcher.ctx, not args.no_cpu_baseline)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

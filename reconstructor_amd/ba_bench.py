@@ -1,9 +1,6 @@
 """BA leg of bench.py: LM iterations/s on the BASELINE.json BA configs (single GPU; BA does not
 shard -- "replicas only").  cfg 4: 200 cams / 20k pts / 200k obs; cfg 5: 1000 cams / 100k pts /
-1M obs.  The CPU figure is the oracle (kind "port") on cfg 4 only (bounded sample)."""
-import os
-import time
-
+1M obs."""
 from . import ba, synth_ba
 
 FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X FP64 matrix, vendor figure quoted in SURVEY.md section 8
@@ -29,19 +26,10 @@ def run_config(ctx, n_cams, n_points, seed=2024, repeats=2):
     }
 
 
-def run(ctx, with_cfg5=True, with_cpu=True):
+def run(ctx, with_cfg5=True):
+    """GPU timings only; bench.py adds the CPU baseline (the oracle is not importable from here)."""
     out = {}
     sc4, out["cfg4"] = run_config(ctx, 200, 20000)
     if with_cfg5:
         _, out["cfg5"] = run_config(ctx, 1000, 100000, repeats=1)
-    if with_cpu:
-        from oracle import orc_ba   # checker / CPU baseline only
-        threads = len(os.sched_getaffinity(0))
-        t0 = time.perf_counter()
-        P, I, X, s = orc_ba.solve(sc4, threads=threads)
-        out["cpu_baseline"] = {"value": s["iterations"] / s["solve_seconds"], "unit": "LM-iterations/s",
-                               "cores": threads, "kind": "port",
-                               "sample": "cfg4 full solve (%d iterations, %.2f s), oracle/ba_oracle.c" % (s["iterations"], time.perf_counter() - t0),
-                               "final_rms_px": s["final_rms_px"]}
-        out["cfg4"]["rms_diff_vs_cpu_px"] = abs(out["cfg4"]["final_rms_px"] - s["final_rms_px"])
-    return out
+    return sc4, out

@@ -1,0 +1,58 @@
+"""GPU suite: the C++ adapters (reconstructor_amd/host/*.h) driven the way the reference's
+pipeline drives its plugins, checked against the CPU oracle."""
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import orc, orc_ba
+from reconstructor_amd import synth, synth_ba
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "tests", "cpp", "adapter_test")
+
+
+def test_headers_compile_without_gpu():
+    """CPU tier: the adapters build against include/rcn.h with plain g++ (no OpenCV/Eigen)."""
+    import __graft_entry__ as g
+    g.build_cpp_adapter_test()
+    assert os.path.exists(BIN)
+
+
+@pytest.mark.gpu
+def test_cpp_adapter_matches_oracle(tmp_path):
+    assert os.path.exists(BIN), "run __graft_entry__.build() first"
+    q, t = synth.descriptor_set("sift", 2, [300, 420], n_world=900, seed=13)
+    sc = synth_ba.make_scene(5, 60, obs_per_point=4, seed=3)
+    order = [7, 3, 11, 5, 2]
+    inp, outp = tmp_path / "in.bin", tmp_path / "out.bin"
+    with open(inp, "wb") as f:
+        f.write(struct.pack("iii", q.shape[0], t.shape[0], q.shape[1]))
+        f.write(q.tobytes()); f.write(t.tobytes())
+        f.write(struct.pack("ii", 5, 60)); f.write(np.array(order, np.int32).tobytes())
+        for l in range(5):
+            T = np.eye(4); T[:3, :3] = synth_ba.rodrigues(sc["poses"][l, :3]); T[:3, 3] = sc["poses"][l, 3:]
+            f.write(T.astype(np.float64).tobytes())
+        f.write(sc["intrinsics"].astype(np.float64).tobytes())
+        for j in range(60):
+            obs = np.nonzero(sc["obs_pt"] == j)[0]
+            f.write(sc["points"][j].astype(np.float64).tobytes()); f.write(struct.pack("i", len(obs)))
+            for o in obs:
+                f.write(struct.pack("iii", int(sc["obs_cam"][o]), int(sc["obs_uv"][o, 0]), int(sc["obs_uv"][o, 1])))
+    r = subprocess.run([BIN, str(inp), str(outp)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    raw = open(outp, "rb").read()
+    n = struct.unpack_from("i", raw, 0)[0]
+    pairs = np.frombuffer(raw, np.int32, 2 * n, 4).reshape(-1, 2)
+    exp, cnt = orc.match_pair(q, t)
+    assert n == cnt and all(exp[a] == b for a, b in pairs)
+    off = 4 + 8 * n
+    rms = struct.unpack_from("d", raw, off)[0]; iters = struct.unpack_from("i", raw, off + 8)[0]
+    X = np.frombuffer(raw, np.float64, 180, off + 12).reshape(60, 3)
+    P0, I0, X0, s0 = orc_ba.solve(sc, threads=2)
+    assert iters == s0["iterations"] and abs(rms - s0["final_rms_px"]) <= 1e-5
+    assert np.allclose(X, X0, atol=1e-5)
+    g2l = np.frombuffer(raw, np.int32, 5, off + 12 + 180 * 8 + 5 * 128)
+    assert list(g2l) == [0, 1, 2, 3, 4]
