@@ -22,8 +22,12 @@
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-#define RCN_QT 256          // query rows per workgroup (4 waves x 64)
+#define RCN_QT 512          // query rows per workgroup (8 waves x 64)
+#define RCN_GROUP 4         // consecutive pairs (same query image) swept by one workgroup
+#define RCN_NBUF 4          // LDS ring depth (train tiles)
+#define RCN_PD 2            // prefetch distance, tiles
 #define RCN_BT 64           // train rows per LDS tile
 #define RCN_PAD_HN 1.0e30f  // half-norm of padded train rows: never a candidate
 
@@ -124,46 +128,56 @@ __device__ __forceinline__ unsigned umed3(unsigned a, unsigned b, unsigned c)
 struct CoarseArgs {
     const ImgDev *imgs;
     const int32_t *pairs;   // n_pairs x (query slot, train slot)
+    const int2 *groups;     // n_groups x (first pair, count <= RCN_GROUP): consecutive pairs sharing the query image
     uint2 *cand;            // [n_pairs][kq_stride] packed (best, second)
-    int32_t n_pairs, tiles_per_pair, items_per_xcd, kq_stride;
+    int32_t n_groups, tiles_per_pair, items_per_xcd, kq_stride;
     uint32_t idx_mask;      // low bits that carry the train row
 };
 
-// K1: one workgroup = 256 query rows of one pair against every train row of the pair.
+// K1: one workgroup (8 waves, 2 per SIMD) = 512 query rows of one image against every train row
+//   of up to RCN_GROUP consecutive pairs that share that query image; query fragments are
+//   loaded once per work item.
 //   MFMA orientation: A = train tile (rows -> accumulator registers), B = -query (columns ->
 //   lanes), C initialised with the train rows' biased half-norms, so each accumulator
 //   element is  s^2 * (|t|^2/2 - q.t) + BIAS  > 0  and orders like the squared distance for a
 //   fixed query.  Positive floats order like unsigned integers, so the running top-2 per
-//   (lane, column block) is v_and_or + v_med3_u32 + v_min_u32 per element.
+//   (lane, column block) is v_and_or + v_med3_u32 + v_min_u32 per element, software-pipelined
+//   into the MFMA issue gaps of the next row block.
+//   Train tiles (64 rows + a private copy of their half-norms per wave) stream through an LDS
+//   ring of RCN_NBUF buffers by LDS-DMA, RCN_PD tiles ahead, across pair boundaries; one raw
+//   s_barrier per tile behind a counted s_waitcnt vmcnt (never 0 in steady state).
 // ABL (ablation bits, diagnostics only -- results are wrong unless ABL == 0):
-//   1 skip the top-2 epilogue, 2 skip the half-norm init, 4 read the A fragment once per row
-//   block, 8 stage only the first tile.
+//   1 skip the top-2 epilogue, 8 stage only the first tiles.
 template <int DP, int ABL>
-__global__ __launch_bounds__(256, 2) void k_coarse_top2(CoarseArgs a)
+__global__ __launch_bounds__(512, 2) void k_coarse_top2(CoarseArgs a)
 {
     constexpr int KS = DP / 16;
     constexpr int ROWB = DP * 2;
     constexpr int TILEB = RCN_BT * ROWB;
-    constexpr int NINST = TILEB / 4 / 1024;  // 1-KiB LDS-DMA pieces per wave per tile
-    constexpr int BUFB = TILEB + 4 * 256;    // tile + one private copy of its 64 half-norms per wave
+    constexpr int GLSZ = DP == 32 ? 4 : 16;          // bytes per lane per LDS-DMA instruction
+    constexpr int PIECE = 64 * GLSZ;
+    constexpr int NINST = TILEB / 8 / PIECE;         // tile pieces per wave
+    constexpr int NG = NINST + 1;                    // + the half-norm piece
+    constexpr int BUFB = TILEB + 8 * 256;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int b = blockIdx.x;
     const int item = (b & 7) * a.items_per_xcd + (b >> 3);  // XCD x walks a contiguous item range
-    if (item >= a.n_pairs * a.tiles_per_pair) return;
-    const int pair = item / a.tiles_per_pair, qt = item - pair * a.tiles_per_pair;
-    const ImgDev qi = a.imgs[a.pairs[2 * pair]];
-    const ImgDev ti = a.imgs[a.pairs[2 * pair + 1]];
-    if (qt * RCN_QT >= qi.K || ti.K < 2) return;
+    if (item >= a.n_groups * a.tiles_per_pair) return;
+    const int grp = item / a.tiles_per_pair, qt = item - grp * a.tiles_per_pair;
+    const int2 g = a.groups[grp];
+    const int p0 = g.x, R = g.y;
+    const ImgDev qi = a.imgs[a.pairs[2 * p0]];
+    if (qt * RCN_QT >= qi.K) return;
 
     const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
 
-    // query fragments, negated, resident for the whole train sweep
+    // query fragments, negated, resident for the whole item
     half8 bq[2][KS];
 #pragma unroll
     for (int cb = 0; cb < 2; ++cb) {
-        const int qrow = qt * RCN_QT + w * 64 + cb * 32 + r;  // < Kp (Kp is a multiple of 256)
+        const int qrow = qt * RCN_QT + w * 64 + cb * 32 + r;  // < Kp (Kp is a multiple of 512)
         const char *base = reinterpret_cast<const char *>(qi.f16) + (size_t)qrow * ROWB;
         const int sw = swz<DP>(qrow);
 #pragma unroll
@@ -173,114 +187,179 @@ __global__ __launch_bounds__(256, 2) void k_coarse_top2(CoarseArgs a)
             bq[cb][ks] = __builtin_bit_cast(half8, v);
         }
     }
-
-    unsigned m1[2] = {0xFFFFFFFFu, 0xFFFFFFFFu}, m2[2] = {0xFFFFFFFFu, 0xFFFFFFFFu};
     // the mask lives in a VGPR so that (acc & mask) | idx is ONE v_and_or_b32 with idx in an SGPR
     unsigned hmask;
     asm volatile("v_mov_b32 %0, %1" : "=v"(hmask) : "s"(~a.idx_mask));
-    const int nT = (ti.K + RCN_BT - 1) / RCN_BT;
-    const char *timg = reinterpret_cast<const char *>(ti.f16);
 
-    auto stage = [&](int t, int buf) {
-        char *bbase = smem + buf * BUFB;
-#pragma unroll
-        for (int i = 0; i < NINST; ++i) {
-            const int off = w * (TILEB / 4) + i * 1024;
-            const char *src = timg + (size_t)t * TILEB + off + lane * 16;
-            __builtin_amdgcn_global_load_lds(
-                (const __attribute__((address_space(1))) void *)src,
-                (__attribute__((address_space(3))) void *)(bbase + off), 16, 0, 0);
-        }
-        if (!(ABL & 2))
-            __builtin_amdgcn_global_load_lds(
-                (const __attribute__((address_space(1))) void *)(ti.hn + t * RCN_BT + lane),
-                (__attribute__((address_space(3))) void *)(bbase + TILEB + w * 256), 4, 0, 0);
-    };
-
-    stage(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // per-pair train image records, read once with ordinary loads and parked in LDS: inside the
+    // tile loop nothing but LDS-DMA may sit on the vector-memory queue (counted vmcnt)
+    struct TrainRec { const char *f16; const float *hn; int nT; int pad; };
+    TrainRec *tbl = reinterpret_cast<TrainRec *>(smem + RCN_NBUF * BUFB);
+    if (tid < R) {
+        const ImgDev ti = a.imgs[a.pairs[2 * (p0 + tid) + 1]];
+        TrainRec rec;
+        rec.f16 = reinterpret_cast<const char *>(ti.f16);
+        rec.hn = ti.hn;
+        rec.nT = ti.K >= 2 ? (ti.K + RCN_BT - 1) / RCN_BT : 0;
+        rec.pad = 0;
+        tbl[tid] = rec;
+    }
     __syncthreads();
+    auto tiles_of = [&](int rr) -> int { return __builtin_amdgcn_readfirstlane(tbl[rr].nT); };
 
-    // Software pipeline inside each wave: the MFMAs of row block n (32 train rows x 64 queries,
-    // 32 instructions) carry the top-2 epilogue of row block n-1 in their issue gaps: per
-    // k-step 2 MFMAs + 2 accumulator elements x (v_and_or, v_med3_u32, v_min_u32).
-    f32x16 pX0, pX1, pY0, pY1;
+    // ---- staging cursor (runs RCN_PD tiles ahead of the compute cursor, across pairs)
+    int s_pair = 0, s_tile = 0, s_nT = 0, staged = 0;
+    const char *s_timg = nullptr;
+    const float *s_hn = nullptr;
+    auto s_seek = [&]() {   // move to the next pair that has tiles
+        while (s_pair < R) {
+            s_nT = tiles_of(s_pair);
+            if (s_nT > 0) {
+                const unsigned long long pf = reinterpret_cast<unsigned long long>(tbl[s_pair].f16);
+                const unsigned long long ph = reinterpret_cast<unsigned long long>(tbl[s_pair].hn);
+                s_timg = reinterpret_cast<const char *>(((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(pf >> 32)) << 32) |
+                                                        (unsigned)__builtin_amdgcn_readfirstlane((unsigned)pf));
+                s_hn = reinterpret_cast<const float *>(((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(ph >> 32)) << 32) |
+                                                       (unsigned)__builtin_amdgcn_readfirstlane((unsigned)ph));
+                s_tile = 0;
+                return;
+            }
+            ++s_pair;
+        }
+    };
+    auto stage_next = [&]() {
+        if (s_pair >= R) return;
+        if ((ABL & 8) && staged >= RCN_NBUF) { ++staged; }
+        else {
+            char *bbase = smem + (staged % RCN_NBUF) * BUFB;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { pY0[i] = 3.0e38f; pY1[i] = 3.0e38f; }
+            for (int i = 0; i < NINST; ++i) {
+                const int off = (w * NINST + i) * PIECE;
+                const char *src = s_timg + (size_t)s_tile * TILEB + off + lane * GLSZ;
+                if constexpr (DP == 32)
+                    __builtin_amdgcn_global_load_lds(
+                        (const __attribute__((address_space(1))) void *)src,
+                        (__attribute__((address_space(3))) void *)(bbase + off), 4, 0, 0);
+                else
+                    __builtin_amdgcn_global_load_lds(
+                        (const __attribute__((address_space(1))) void *)src,
+                        (__attribute__((address_space(3))) void *)(bbase + off), 16, 0, 0);
+            }
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void *)(s_hn + s_tile * RCN_BT + lane),
+                (__attribute__((address_space(3))) void *)(bbase + TILEB + w * 256), 4, 0, 0);
+            ++staged;
+        }
+        if (++s_tile == s_nT) { ++s_pair; s_seek(); }
+    };
+    s_seek();
+#pragma unroll
+    for (int i = 0; i < RCN_PD; ++i) stage_next();
 
+    unsigned m1[2], m2[2];
+    f32x16 pX0, pX1, pY0, pY1;
     auto top2 = [&](int cb, unsigned u) {
         // med3(m1,m2,u) spelled so that isel forms v_med3_u32 (scheduler sees a plain VALU op)
         const unsigned lo = min(m1[cb], m2[cb]), hi = max(m1[cb], m2[cb]);
         m2[cb] = max(lo, min(hi, u));
         m1[cb] = min(m1[cb], u);
     };
+    // LDS reads of the ring go through inline asm: hipcc would otherwise put s_waitcnt vmcnt(0)
+    // in front of every ds_read that may alias an in-flight LDS-DMA.  Each consumer is preceded
+    // by a wait statement that names the registers it is about to use ("+v"), so neither the
+    // MFMAs nor copies of those registers can be scheduled above the wait.
+    auto lds_read = [&](unsigned addr) -> u32x4 {
+        u32x4 v;
+        asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr));
+        return v;
+    };
     // cur <- hn + A.B for row block (tile, rb); prev (row block before it) is folded into top-2
-    auto step = [&](f32x16 &c0, f32x16 &c1, const f32x16 &p0, const f32x16 &p1, const char *tile,
-                    const float *hnl, int rb, unsigned prev_rowbase) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            float4 v = *reinterpret_cast<const float4 *>(hnl + rb * 32 + 8 * g + 4 * h);
-            c0[4 * g + 0] = v.x; c0[4 * g + 1] = v.y; c0[4 * g + 2] = v.z; c0[4 * g + 3] = v.w;
-        }
-        c1 = c0;
+    auto step = [&](f32x16 &c0, f32x16 &c1, const f32x16 &p0v, const f32x16 &p1v, unsigned tile,
+                    unsigned hnl, int rb, unsigned prev_rowbase) {
         const int lrow = rb * 32 + r;
-        const char *arow = tile + lrow * ROWB;
+        const unsigned arow = tile + lrow * ROWB;
         const int sw = swz<DP>(lrow);
-        half8 av = *reinterpret_cast<const half8 *>(arow + ((h ^ sw) << 4));
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            half8 an = av;   // fragment of k-step ks+1 is in flight while ks computes
-            if (ks + 1 < KS) an = *reinterpret_cast<const half8 *>(arow + ((((ks + 1) * 2 + h) ^ sw) << 4));
+        u32x4 h0, h1, h2, h3, f0, f1;
+        h0 = lds_read(hnl + (rb * 32 + 0 + 4 * h) * 4);
+        h1 = lds_read(hnl + (rb * 32 + 8 + 4 * h) * 4);
+        h2 = lds_read(hnl + (rb * 32 + 16 + 4 * h) * 4);
+        h3 = lds_read(hnl + (rb * 32 + 24 + 4 * h) * 4);
+        f0 = lds_read(arow + ((h ^ sw) << 4));
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(h0), "+v"(h1), "+v"(h2), "+v"(h3), "+v"(f0));
+        c0[0] = __uint_as_float(h0.x); c0[1] = __uint_as_float(h0.y); c0[2] = __uint_as_float(h0.z); c0[3] = __uint_as_float(h0.w);
+        c0[4] = __uint_as_float(h1.x); c0[5] = __uint_as_float(h1.y); c0[6] = __uint_as_float(h1.z); c0[7] = __uint_as_float(h1.w);
+        c0[8] = __uint_as_float(h2.x); c0[9] = __uint_as_float(h2.y); c0[10] = __uint_as_float(h2.z); c0[11] = __uint_as_float(h2.w);
+        c0[12] = __uint_as_float(h3.x); c0[13] = __uint_as_float(h3.y); c0[14] = __uint_as_float(h3.z); c0[15] = __uint_as_float(h3.w);
+        c1 = c0;
+        auto kstep = [&](int ks, u32x4 &cur, u32x4 &nxt) {
+            // naming c1 ties the wait BEHIND the previous k-step's second MFMA
+            if (ks > 0) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(cur), "+v"(c1));
+            // fragment of k-step ks+1 is in flight while ks computes
+            if (ks + 1 < KS) nxt = lds_read(arow + ((((ks + 1) * 2 + h) ^ sw) << 4));
+            const half8 av = __builtin_bit_cast(half8, cur);
             c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bq[0][ks], c0, 0, 0, 0);
             if (!(ABL & 1)) {
 #pragma unroll
                 for (int reg = ks * 16 / KS; reg < (ks + 1) * 16 / KS; ++reg)
-                    top2(0, (__float_as_uint(p0[reg]) & hmask) | (prev_rowbase + (reg & 3) + 8 * (reg >> 2)));
+                    top2(0, (__float_as_uint(p0v[reg]) & hmask) | (prev_rowbase + (reg & 3) + 8 * (reg >> 2)));
             }
             c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bq[1][ks], c1, 0, 0, 0);
             if (!(ABL & 1)) {
 #pragma unroll
                 for (int reg = ks * 16 / KS; reg < (ks + 1) * 16 / KS; ++reg)
-                    top2(1, (__float_as_uint(p1[reg]) & hmask) | (prev_rowbase + (reg & 3) + 8 * (reg >> 2)));
+                    top2(1, (__float_as_uint(p1v[reg]) & hmask) | (prev_rowbase + (reg & 3) + 8 * (reg >> 2)));
             }
-            av = an;
+        };
+#pragma unroll
+        for (int ks = 0; ks < KS; ks += 2) {
+            kstep(ks, f0, f1);
+            kstep(ks + 1, f1, f0);
         }
     };
+    const unsigned smem_base = (unsigned)(size_t)(const __attribute__((address_space(3))) char *)smem;
 
-    int buf = 0;
-    for (int t = 0; t < nT; ++t) {
-        if (t + 1 < nT && !((ABL & 8) && t > 0)) stage(t + 1, buf ^ 1);
-        const char *tile = smem + buf * BUFB;
-        const float *hnl = reinterpret_cast<const float *>(tile + TILEB + w * 256);
-        const unsigned base = (unsigned)(t * RCN_BT);
-        step(pX0, pX1, pY0, pY1, tile, hnl, 0, base - 32u);   // epilogue of (t-1, rb 1)
-        step(pY0, pY1, pX0, pX1, tile, hnl, 1, base);         // epilogue of (t, rb 0)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        buf ^= 1;
-    }
-    if (ABL & 1) asm volatile("" ::"v"(pY0), "v"(pY1), "v"(pX0), "v"(pX1));
-    {   // drain: epilogue of the last row block
-        const unsigned rowbase = (unsigned)((nT - 1) * RCN_BT + 32);
+    int done = 0;   // tiles computed so far (flat over the item's pairs)
+    for (int rr = 0; rr < R; ++rr) {
+        const int nT = tiles_of(rr);
+        if (nT == 0) continue;
+        m1[0] = m1[1] = m2[0] = m2[1] = 0xFFFFFFFFu;
 #pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-            const unsigned idx = rowbase + (reg & 3) + 8 * (reg >> 2);
-            top2(0, (__float_as_uint(pY0[reg]) & hmask) | idx);
-            top2(1, (__float_as_uint(pY1[reg]) & hmask) | idx);
+        for (int i = 0; i < 16; ++i) { pY0[i] = 3.0e38f; pY1[i] = 3.0e38f; }
+        for (int t = 0; t < nT; ++t, ++done) {
+            stage_next();
+            const int ahead = staged - done - 1;   // tiles issued after the one about to be read
+            if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(2 * NG) : "memory");
+            else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(NG) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            const unsigned tile = smem_base + (done % RCN_NBUF) * BUFB;
+            const unsigned hnl = tile + TILEB + w * 256;
+            const unsigned base = (unsigned)(t * RCN_BT);
+            step(pX0, pX1, pY0, pY1, tile, hnl, 0, base - 32u);   // epilogue of (t-1, rb 1)
+            step(pY0, pY1, pX0, pX1, tile, hnl, 1, base);         // epilogue of (t, rb 0)
         }
-    }
-
-    // lane l and l^32 hold the same query, disjoint train rows: merge, then lanes 0..31 store
+        if (ABL & 1) asm volatile("" ::"v"(pY0), "v"(pY1), "v"(pX0), "v"(pX1));
+        {   // drain: epilogue of the pair's last row block
+            const unsigned rowbase = (unsigned)((nT - 1) * RCN_BT + 32);
 #pragma unroll
-    for (int cb = 0; cb < 2; ++cb) {
-        unsigned a1 = m1[cb] | (unsigned)(4 * h), a2 = m2[cb] | (unsigned)(4 * h);
-        if (m1[cb] == 0xFFFFFFFFu) a1 = 0xFFFFFFFFu;
-        if (m2[cb] == 0xFFFFFFFFu) a2 = 0xFFFFFFFFu;
-        unsigned b1 = __shfl_xor(a1, 32), b2 = __shfl_xor(a2, 32);
-        unsigned r1 = min(a1, b1);
-        unsigned r2 = min(max(a1, b1), min(a2, b2));
-        const int qrow = qt * RCN_QT + w * 64 + cb * 32 + r;
-        if (h == 0 && qrow < qi.K) a.cand[(size_t)pair * a.kq_stride + qrow] = make_uint2(r1, r2);
+            for (int reg = 0; reg < 16; ++reg) {
+                const unsigned idx = rowbase + (reg & 3) + 8 * (reg >> 2);
+                top2(0, (__float_as_uint(pY0[reg]) & hmask) | idx);
+                top2(1, (__float_as_uint(pY1[reg]) & hmask) | idx);
+            }
+        }
+        // lane l and l^32 hold the same query, disjoint train rows: merge, then lanes 0..31 store
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+            unsigned a1 = m1[cb] | (unsigned)(4 * h), a2 = m2[cb] | (unsigned)(4 * h);
+            if (m1[cb] == 0xFFFFFFFFu) a1 = 0xFFFFFFFFu;
+            if (m2[cb] == 0xFFFFFFFFu) a2 = 0xFFFFFFFFu;
+            unsigned b1 = __shfl_xor(a1, 32), b2 = __shfl_xor(a2, 32);
+            unsigned r1 = min(a1, b1);
+            unsigned r2 = min(max(a1, b1), min(a2, b2));
+            const int qrow = qt * RCN_QT + w * 64 + cb * 32 + r;
+            if (h == 0 && qrow < qi.K) a.cand[(size_t)(p0 + rr) * a.kq_stride + qrow] = make_uint2(r1, r2);
+        }
     }
 }
 
@@ -833,11 +912,11 @@ static int prepare_all(rcn_ctx *ctx)
 
 template <int DP, int ABL = 0> static hipError_t launch_coarse(rcn_ctx *ctx, const CoarseArgs &ca, int blocks)
 {
-    const size_t lds = 2 * (RCN_BT * DP * 2 + 1024);
+    const size_t lds = (size_t)RCN_NBUF * (RCN_BT * DP * 2 + 8 * 256) + 128;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_coarse_top2<DP, ABL>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    k_coarse_top2<DP, ABL><<<blocks, 256, lds, ctx->stream>>>(ca);
+    k_coarse_top2<DP, ABL><<<blocks, 512, lds, ctx->stream>>>(ca);
     return hipGetLastError();
 }
 
@@ -906,8 +985,20 @@ static int match_grid_impl(rcn_ctx *ctx, const int32_t *pairs_host, int32_t n_pa
     if (mfma) {
         CoarseArgs ca;
         ca.imgs = imgs; ca.pairs = pairs; ca.cand = ctx->cand.as<uint2>();
-        ca.n_pairs = n_pairs; ca.tiles_per_pair = tiles; ca.kq_stride = kq_stride;
-        const int64_t items = (int64_t)n_pairs * tiles;
+        // groups: runs of consecutive pairs that share the query image, cut at RCN_GROUP
+        std::vector<int2> groups;
+        for (int p = 0; p < n_pairs;) {
+            int cnt = 1;
+            while (p + cnt < n_pairs && cnt < RCN_GROUP && slots[2 * (p + cnt)] == slots[2 * p]) ++cnt;
+            groups.push_back(make_int2(p, cnt));
+            p += cnt;
+        }
+        RCN_HIP(ctx->groups_dev.reserve(groups.size() * sizeof(int2)));
+        RCN_HIP(hipMemcpyAsync(ctx->groups_dev.p, groups.data(), groups.size() * sizeof(int2), hipMemcpyHostToDevice, ctx->stream));
+        RCN_HIP(hipStreamSynchronize(ctx->stream));   // `groups` is a local
+        ca.groups = ctx->groups_dev.as<int2>();
+        ca.n_groups = (int)groups.size(); ca.tiles_per_pair = tiles; ca.kq_stride = kq_stride;
+        const int64_t items = (int64_t)groups.size() * tiles;
         ca.items_per_xcd = (int)((items + 7) / 8);
         ca.idx_mask = idx_mask;
         const int blocks = ca.items_per_xcd * 8;
@@ -919,9 +1010,7 @@ static int match_grid_impl(rcn_ctx *ctx, const int32_t *pairs_host, int32_t n_pa
         default:
             switch (ctx->ablate) {   // RCN_COARSE_ABL: timing experiments only
             case 1: e = launch_coarse<256, 1>(ctx, ca, blocks); break;
-            case 3: e = launch_coarse<256, 3>(ctx, ca, blocks); break;
-            case 7: e = launch_coarse<256, 7>(ctx, ca, blocks); break;
-            case 15: e = launch_coarse<256, 15>(ctx, ca, blocks); break;
+            case 9: e = launch_coarse<256, 9>(ctx, ca, blocks); break;
             default: e = launch_coarse<256>(ctx, ca, blocks); break;
             }
             break;
