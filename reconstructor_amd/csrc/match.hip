@@ -467,8 +467,11 @@ __device__ __forceinline__ void list_append(unsigned long long *list, unsigned *
 // K2a: one thread per (pair, query row): decide from the coarse values alone whenever the
 // ratio test fails for every distance pair compatible with the error bound (the common case:
 // queries without a true counterpart have dist0 ~ dist1); the rest go to the survivor list.
-__global__ void k_filter(RerankArgs a)
+#define RCN_FB 1024   // rows per k_filter workgroup: one atomic per list per workgroup
+__global__ __launch_bounds__(RCN_FB) void k_filter(RerankArgs a)
 {
+    __shared__ unsigned wcnt[2][RCN_FB / 64];
+    __shared__ unsigned wbase[2][RCN_FB / 64];
     const int pair = blockIdx.x / a.qblocks;
     const int q = (blockIdx.x - pair * a.qblocks) * blockDim.x + threadIdx.x;
     const ImgDev qi = a.imgs[a.pairs[2 * pair]];
@@ -494,9 +497,22 @@ __global__ void k_filter(RerankArgs a)
             }
         }
     }
+    // workgroup-aggregated append (a single counter word takes only ~88 atomics per microsecond)
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const unsigned long long ms = __ballot(surv), mf = __ballot(fb);
+    if (lane == 0) { wcnt[0][w] = (unsigned)__popcll(ms); wcnt[1][w] = (unsigned)__popcll(mf); }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+        unsigned tot = 0;
+        for (int i = 0; i < nw; ++i) { wbase[threadIdx.x][i] = tot; tot += wcnt[threadIdx.x][i]; }
+        const unsigned base = tot ? atomicAdd(threadIdx.x == 0 ? a.sv_count : a.fb_count, tot) : 0u;
+        for (int i = 0; i < nw; ++i) wbase[threadIdx.x][i] += base;
+    }
+    __syncthreads();
     const unsigned long long entry = ((unsigned long long)pair << 32) | (unsigned)q;
-    list_append(a.sv_list, a.sv_count, surv, entry);
-    list_append(a.fb_list, a.fb_count, fb, entry);
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    if (surv) a.sv_list[wbase[0][w] + __popcll(ms & lt)] = entry;
+    if (fb) a.fb_list[wbase[1][w] + __popcll(mf & lt)] = entry;
 }
 
 // K2: exact fp64 re-rank of the survivors.  One wave = 32 survivors = 64 chains (2 candidates
@@ -605,7 +621,20 @@ __global__ void k_rerank_generic(RerankArgs a)
     }
 }
 
-// K2b: exact brute force of listed rows, one wave per row, grid-stride over the list.
+// K2b: exact brute force of listed rows, one workgroup (4 waves) per row, grid-stride over the
+// list; each thread walks the canonical chain of its train rows, then (value, index)-ordered
+// top-2 pairs are merged across the wave and across the 4 waves.
+__device__ __forceinline__ void merge_top2(double &b0, int &i0, double &b1, int &i1, double c0, int j0, double c1, int j1)
+{
+    const bool mine = (b0 < c0) || (b0 == c0 && i0 < j0);
+    const double f0 = mine ? b0 : c0; const int fi0 = mine ? i0 : j0;
+    const double l0 = mine ? c0 : b0; const int li0 = mine ? j0 : i0;   // the loser of the firsts
+    const double s0 = mine ? b1 : c1; const int si0 = mine ? i1 : j1;   // the winner's own second
+    const bool pick = (l0 < s0) || (l0 == s0 && li0 < si0);
+    b0 = f0; i0 = fi0;
+    b1 = pick ? l0 : s0; i1 = pick ? li0 : si0;
+}
+
 template <bool VEC4>
 __global__ __launch_bounds__(256) void k_exact_rows(const ImgDev *__restrict__ imgs,
                                                      const int32_t *__restrict__ pairs,
@@ -614,11 +643,11 @@ __global__ __launch_bounds__(256) void k_exact_rows(const ImgDev *__restrict__ i
                                                      float ratio, int32_t *__restrict__ out,
                                                      int64_t out_stride)
 {
-    const int lane = threadIdx.x & 63;
-    const unsigned wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const unsigned nwaves = (gridDim.x * blockDim.x) >> 6;
+    __shared__ double sb[4][2];
+    __shared__ int si[4][2];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const unsigned n = *count;
-    for (unsigned it = wave; it < n; it += nwaves) {
+    for (unsigned it = blockIdx.x; it < n; it += gridDim.x) {
         const unsigned long long e = list[it];
         const int pair = (int)(e >> 32), q = (int)(e & 0xFFFFFFFFu);
         const ImgDev qi = imgs[pairs[2 * pair]];
@@ -626,25 +655,23 @@ __global__ __launch_bounds__(256) void k_exact_rows(const ImgDev *__restrict__ i
         const float *qrow = qi.f32 + (size_t)q * D;
         double b0 = INFINITY, b1 = INFINITY;
         int i0 = 0x7FFFFFFF, i1 = 0x7FFFFFFF;
-        for (int j = lane; j < ti.K; j += 64) {
+        for (int j = threadIdx.x; j < ti.K; j += 256) {
             double d = exact_d2<VEC4>(qrow, ti.f32 + (size_t)j * D, D);
             if (d < b0) { b1 = b0; i1 = i0; b0 = d; i0 = j; }          // ascending j: strict <
             else if (d < b1) { b1 = d; i1 = j; }
         }
-        // merge (value, index)-ordered pairs across the wave
         for (int o = 32; o; o >>= 1) {
-            double c0 = __shfl_xor(b0, o), c1 = __shfl_xor(b1, o);
-            int j0 = __shfl_xor(i0, o), j1 = __shfl_xor(i1, o);
-            // first = lexicographic min of (b0,i0),(c0,j0)
-            bool mine = (b0 < c0) || (b0 == c0 && i0 < j0);
-            double f0 = mine ? b0 : c0; int fi0 = mine ? i0 : j0;
-            double l0 = mine ? c0 : b0; int li0 = mine ? j0 : i0;   // the loser of the firsts
-            double s0 = mine ? b1 : c1; int si0 = mine ? i1 : j1;   // winner's own second
-            bool pick = (l0 < s0) || (l0 == s0 && li0 < si0);
-            b0 = f0; i0 = fi0;
-            b1 = pick ? l0 : s0; i1 = pick ? li0 : si0;
+            const double c0 = __shfl_xor(b0, o), c1 = __shfl_xor(b1, o);
+            const int j0 = __shfl_xor(i0, o), j1 = __shfl_xor(i1, o);
+            merge_top2(b0, i0, b1, i1, c0, j0, c1, j1);
         }
-        if (lane == 0) out[(size_t)pair * out_stride + q] = ratio_pass(b0, b1, ratio) ? i0 : -1;
+        __syncthreads();
+        if (lane == 0) { sb[w][0] = b0; sb[w][1] = b1; si[w][0] = i0; si[w][1] = i1; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int k = 1; k < 4; ++k) merge_top2(b0, i0, b1, i1, sb[k][0], si[k][0], sb[k][1], si[k][1]);
+            out[(size_t)pair * out_stride + q] = ratio_pass(b0, b1, ratio) ? i0 : -1;
+        }
     }
 }
 
@@ -1039,16 +1066,16 @@ static int match_grid_impl(rcn_ctx *ctx, const int32_t *pairs_host, int32_t n_pa
     ra.all_to_fallback = mfma ? 0 : 1;
     if (kq_max > 0) {
         const int qblocks = (kq_max + 255) / 256;
-        ra.qblocks = qblocks;
         dim3 g((unsigned)qblocks * (unsigned)n_pairs);
-        k_filter<<<g, 256, 0, ctx->stream>>>(ra);
+        ra.qblocks = (kq_max + RCN_FB - 1) / RCN_FB;
+        k_filter<<<(unsigned)ra.qblocks * (unsigned)n_pairs, RCN_FB, 0, ctx->stream>>>(ra);
         RCN_HIP(hipGetLastError());
         if (mfma) {
             if (vec4) k_rerank_lds<<<ctx->prop.multiProcessorCount * 16, 64, 0, ctx->stream>>>(ra);
             else k_rerank_generic<<<ctx->prop.multiProcessorCount * 8, 256, 0, ctx->stream>>>(ra);
             RCN_HIP(hipGetLastError());
         }
-        const int fb_blocks = ctx->prop.multiProcessorCount * 4;
+        const int fb_blocks = ctx->prop.multiProcessorCount * 8;
         if (vec4) k_exact_rows<true><<<fb_blocks, 256, 0, ctx->stream>>>(imgs, pairs, ra.fb_list, fb_count, ctx->D, ratio, out_dev, out_stride);
         else k_exact_rows<false><<<fb_blocks, 256, 0, ctx->stream>>>(imgs, pairs, ra.fb_list, fb_count, ctx->D, ratio, out_dev, out_stride);
         RCN_HIP(hipGetLastError());
