@@ -93,11 +93,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit("--gpus must equal WORLD_SIZE")
+    # REHEARSAL ONLY (one-GPU box): RCN_BENCH_REHEARSE=1 maps every rank to device 0 and moves the
+    # all-gather through the host with gloo, so the rest of the N>1 path can be exercised.
+    rehearse = os.environ.get("RCN_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     from reconstructor_amd import synth
     from reconstructor_amd.matcher import HipL2Matcher, all_pairs
@@ -123,7 +131,12 @@ def main():
 
     def ingest():
         """RCCL all-gather of the per-image descriptor blocks + per-image ingest (N > 1)."""
-        dist.all_gather_into_tensor(gathered.view(-1), local_dev.view(-1))
+        if rehearse:
+            host = torch.empty(gathered.shape, dtype=torch.float32)
+            dist.all_gather_into_tensor(host.view(-1), local_dev.cpu().view(-1))
+            gathered.copy_(host)
+        else:
+            dist.all_gather_into_tensor(gathered.view(-1), local_dev.view(-1))
         matcher.upload_batch_device(0, n_img, gathered.data_ptr(), K_PER_IMAGE, D)
 
     if world == 1:
@@ -155,10 +168,11 @@ def main():
     matcher.profile(False)
 
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        rdev = torch.device("cpu") if rehearse else dev
+        tmax = torch.tensor([dt], dtype=torch.float64, device=rdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
-        tot = torch.tensor([float(st["pair_distances"]), float(counts.sum().item())], dtype=torch.float64, device=dev)
+        tot = torch.tensor([float(st["pair_distances"]), float(counts.sum().item())], dtype=torch.float64, device=rdev)
         dist.all_reduce(tot)
         pd_step, n_matches = float(tot[0].item()), int(tot[1].item())
     else:
@@ -172,6 +186,10 @@ def main():
         my_pd = float(st["pair_distances"])
         flops = 2.0 * D * my_pd                      # 2*D flop per pair-distance
         achieved = flops / (coarse_ms * 1e-3) / 1e12 if coarse_ms > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r01_match_traffic.json")
+        if world == 1 and n_img == N_IMAGES_1GPU and os.path.exists(tpath):
+            traffic = json.load(open(tpath))["traffic_bytes_per_launch"]   # PMC passes, see the file
         line = {
             "metric": "descriptor pair-distances/s (256-d L2, exact 2-NN + ratio + uniqueness, all image pairs)",
             "value": value, "unit": "pair-distances/s", "n_gpus": world, "steps": args.steps,
@@ -186,7 +204,8 @@ def main():
                        "rows_reranked": int(st["rows_reranked"]), "rows_exact_fallback": int(st["rows_exact_fallback"]), "rows_total": int(st["rows_total"])},
             "roofline": {"bound": "mfma", "kernel": "k_coarse_top2<256>", "achieved": achieved,
                          "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / MFMA_F16_PEAK_TFLOPS, "traffic": None,
+                         "frac": achieved / MFMA_F16_PEAK_TFLOPS, "traffic": traffic,
+                         "traffic_note": "bytes per launch from rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes (profiles/r01_match_traffic.json); kernel is MFMA-bound, algorithmic HBM bytes per launch = 1.86e8",
                          "launch_ms": coarse_ms, "rerank_ms": st["rerank_ms"] / calls,
                          "unique_ms": st["unique_ms"] / calls},
         }
