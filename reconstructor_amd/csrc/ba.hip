@@ -373,116 +373,221 @@ __global__ __launch_bounds__(64) void k_ba_cam_rhs(BaDev d)
 
 // ---------------------------------------------------------------------------------------
 // K7: dense Cholesky of the padded reduced system (npad multiple of 128), lower triangle.
-// Diagonal block (one workgroup, block resident in LDS):
-//   1. blocked factorization, 32-wide sub-panels: unblocked 32x32, row-wise triangular solve of
-//      the rows below, rank-32 update of the trailing square with 16x16 thread tiles;
-//   2. in-place inverse of the factor (dtrti2 order, two threads per row).
+// Diagonal block (one workgroup, block resident in LDS, ~40 workgroup barriers in total):
+//   1. blocked factorization with 32-wide leaves: the 32x32 leaf is factored by ONE wave (LDS
+//      operations of a wave are ordered, so no workgroup barrier inside), rows below by a
+//      row-wise triangular solve, trailing square by 16x16 thread tiles;
+//   2. blocked inverse of the factor: the four leaf inverses in parallel (one wave each, column
+//      per lane, kept in the otherwise unused upper triangle of the block), then the six
+//      off-diagonal 32x32 blocks left to right, in place:
+//          X[i][j] = -Dinv_i * sum_{m=j}^{i-1} L[i][m] X[m][j],   X[j][j] = Dinv_j.
 // Writes L into S and L^-1 into Linv[kb] (used by the panel GEMM and the triangular solves).
 #define DL 129   // LDS row stride of the diagonal block (doubles): row walks are conflict-free
+#define LB 32    // leaf size
+
+// leaf inverse element (r,c), c <= r, of leaf i: strictly-lower entries live transposed in the
+// upper triangle of the leaf's own diagonal block; the diagonal is the reciprocal of L's.
+// broadcast of lane `src`'s double (src wave-uniform): two v_readlane_b32
+__device__ __forceinline__ double rdlane(double v, int src)
+{
+    const unsigned long long b = __double_as_longlong(v);
+    const unsigned lo = __builtin_amdgcn_readlane((unsigned)b, src), hi = __builtin_amdgcn_readlane((unsigned)(b >> 32), src);
+    return __longlong_as_double(((unsigned long long)hi << 32) | lo);
+}
+
+__device__ __forceinline__ double dinv_at(const double *L, const double *rd, int i, int r, int c)
+{
+    return r == c ? rd[LB * i + r] : L[(LB * i + c) * DL + LB * i + r];
+}
+
+template <int NT> __device__ __forceinline__ void trail_update(double *L, int r0, int c0, int t)
+{
+    const int ty = t >> 4, tx = t & 15;
+    double acc[NT][NT];
+#pragma unroll
+    for (int u = 0; u < NT; ++u)
+#pragma unroll
+        for (int v = 0; v < NT; ++v) acc[u][v] = 0.0;
+#pragma unroll 4
+    for (int m = 0; m < LB; ++m) {
+        double a[NT], b[NT];
+#pragma unroll
+        for (int u = 0; u < NT; ++u) {
+            a[u] = L[(r0 + ty + 16 * u) * DL + c0 + m];
+            b[u] = L[(r0 + tx + 16 * u) * DL + c0 + m];
+        }
+#pragma unroll
+        for (int u = 0; u < NT; ++u)
+#pragma unroll
+            for (int v = 0; v < NT; ++v) acc[u][v] += a[u] * b[v];
+    }
+#pragma unroll
+    for (int u = 0; u < NT; ++u)
+#pragma unroll
+        for (int v = 0; v < NT; ++v) {
+            const int i = r0 + ty + 16 * u, c = r0 + tx + 16 * v;
+            if (c <= i) L[i * DL + c] -= acc[u][v];
+        }
+}
+
+#ifdef RCN_STAMP   // diagnostic build only (tools/chol_diag_bench.hip): phase time stamps
+__device__ unsigned long long g_stamps[32];
+#define STAMP(i) do { __syncthreads(); if (threadIdx.x == 0) g_stamps[i] = clock64(); } while (0)
+#else
+#define STAMP(i)
+#endif
 __global__ __launch_bounds__(256) void k_chol_diag(double *S, int ld, int kb, double *Linv, int *flag)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     double *L = reinterpret_cast<double *>(smem_raw);  // [128][DL]
-    __shared__ double xcol[NB + 2];   // + the breakdown flag; 16-byte multiple keeps the dynamic base aligned
-    double &bad = xcol[NB];
-    const int t = threadIdx.x;
+    __shared__ double rd[NB + 2];                       // reciprocals of L's diagonal; [NB] = breakdown flag
+    double *misc = rd + NB;                             // (16-byte multiple keeps the dynamic base aligned)
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     double *A = S + ((size_t)kb * NB) * ld + (size_t)kb * NB;
-    if (t == 0) bad = 0.0;
+    if (t == 0) misc[0] = 0.0;
     for (int i = t; i < NB * NB; i += 256) {
         const int r = i / NB, c = i % NB;
         L[r * DL + c] = c <= r ? A[(size_t)r * ld + c] : 0.0;
     }
     __syncthreads();
-    for (int c0 = 0; c0 < NB; c0 += 32) {
-        // 1a. unblocked Cholesky of the 32x32 diagonal sub-block
-        for (int j = c0; j < c0 + 32; ++j) {
-            const double djj = L[j * DL + j];
-            if (!(djj > 0.0) || !isfinite(djj)) bad = 1.0;   // same value in every thread
-            __syncthreads();
-            if (bad != 0.0) { if (t == 0) *flag = 1; return; }
-            const double dj = sqrt(djj);
-            if (t == 0) L[j * DL + j] = dj;
-            if (t > 0 && j + t < c0 + 32) L[(j + t) * DL + j] /= dj;
-            __syncthreads();
-            const int m = c0 + 32 - j - 1;
-            for (int e = t; e < m * m; e += 256) {
-                const int i = j + 1 + e / m, c = j + 1 + e % m;
-                if (c <= i) L[i * DL + c] -= L[i * DL + j] * L[c * DL + j];
+    STAMP(0);
+    for (int c0 = 0; c0 < NB; c0 += LB) {
+        // 1a. 32x32 leaf by wave 0 alone, entirely in registers: lane l holds row l; a column
+        //     entry of another row arrives by v_readlane (uniform lane index), so there is no
+        //     LDS read-modify-write chain on the critical path
+        if (w == 0) {
+            const int row = lane & 31;
+            double a[LB];
+#pragma unroll
+            for (int c = 0; c < LB; ++c) a[c] = L[(c0 + row) * DL + c0 + c];
+            bool ok = true;
+            double myinv = 0.0;   // lane j keeps 1 / L[j][j]
+#pragma unroll
+            for (int j = 0; j < LB; ++j) {
+                const double djj = rdlane(a[j], j);
+                if (!(djj > 0.0) || !isfinite(djj)) ok = false;      // wave-uniform
+                const double dj = sqrt(djj), inv = 1.0 / dj;
+                a[j] = row == j ? dj : a[j] * inv;
+                if (row == j) myinv = inv;
+                if (lane == 0) rd[c0 + j] = inv;
+                // every lane updates its whole row: entries right of the diagonal are scratch
+#pragma unroll
+                for (int c = j + 1; c < LB; ++c) a[c] -= a[j] * rdlane(a[j], c);
             }
-            __syncthreads();
+            if (!ok && lane == 0) misc[0] = 1.0;
+            if (lane < LB) {
+#pragma unroll
+                for (int c = 0; c < LB; ++c)
+                    if (c <= row) L[(c0 + row) * DL + c0 + c] = a[c];
+            }
+            // leaf inverse straight from the registers: lane c -> column c of D^-1
+            //   x[r] = (delta_rc - sum_{m<r} L[r][m] x[m]) / L[r][r],  L[r][m] = readlane(a[m], r)
+            {
+                double x[LB];
+#pragma unroll
+                for (int r = 0; r < LB; ++r) {
+                    double sacc = r == row ? 1.0 : 0.0;
+#pragma unroll
+                    for (int m = 0; m < r; ++m) sacc -= rdlane(a[m], r) * x[m];
+                    x[r] = sacc * rdlane(myinv, r);
+                }
+                if (lane < LB) {
+#pragma unroll
+                    for (int r = 1; r < LB; ++r)
+                        if (r > row) L[(c0 + row) * DL + c0 + r] = x[r];   // transposed, strictly upper
+                }
+            }
         }
-        const int r0 = c0 + 32;
+        __syncthreads();
+        STAMP(1 + c0 / LB * 3);
+        if (misc[0] != 0.0) { if (t == 0) *flag = 1; return; }
+        const int r0 = c0 + LB;
         if (r0 >= NB) break;
-        // 1b. rows below: L[i, c0:c0+32] <- L[i, c0:c0+32] D^-T, one thread per row
+        // 1b. rows below: L[i, c0:c0+32] <- L[i, c0:c0+32] D^-T, one thread per row, row in registers
         if (t < NB - r0) {
-            double *row = L + (r0 + t) * DL + c0;
-            for (int c = 0; c < 32; ++c) {
+            double *rowp = L + (r0 + t) * DL + c0;
+            double x[LB];
+#pragma unroll
+            for (int c = 0; c < LB; ++c) x[c] = rowp[c];
+#pragma unroll
+            for (int c = 0; c < LB; ++c) {
                 const double *dc = L + (c0 + c) * DL + c0;
-                double v = row[c];
-                for (int m = 0; m < c; ++m) v -= row[m] * dc[m];
-                row[c] = v / dc[c];
+                double v = x[c];
+#pragma unroll
+                for (int m = 0; m < c; ++m) v -= x[m] * dc[m];
+                x[c] = v * rd[c0 + c];
             }
+#pragma unroll
+            for (int c = 0; c < LB; ++c) rowp[c] = x[c];
         }
         __syncthreads();
+        STAMP(2 + c0 / LB * 3);
         // 1c. trailing square -= panel panel^T ; thread (ty,tx) owns rows ty+16u, cols tx+16v
-        {
-            const int T = NB - r0, nt = T / 16;   // 6, 4, 2
-            const int ty = t >> 4, tx = t & 15;
-            double acc[6][6];
-            for (int u = 0; u < 6; ++u)
-                for (int v = 0; v < 6; ++v) acc[u][v] = 0.0;
-            for (int m = 0; m < 32; ++m) {
-                double a[6], b[6];
-                for (int u = 0; u < 6; ++u) {
-                    a[u] = u < nt ? L[(r0 + ty + 16 * u) * DL + c0 + m] : 0.0;
-                    b[u] = u < nt ? L[(r0 + tx + 16 * u) * DL + c0 + m] : 0.0;
-                }
-                for (int u = 0; u < 6; ++u)
-                    for (int v = 0; v < 6; ++v) acc[u][v] += a[u] * b[v];
-            }
-            for (int u = 0; u < nt; ++u)
-                for (int v = 0; v < nt; ++v) {
-                    const int i = r0 + ty + 16 * u, c = r0 + tx + 16 * v;
-                    if (c <= i) L[i * DL + c] -= acc[u][v];
-                }
-        }
+        if (r0 == 32) trail_update<6>(L, r0, c0, t);
+        else if (r0 == 64) trail_update<4>(L, r0, c0, t);
+        else trail_update<2>(L, r0, c0, t);
         __syncthreads();
+        STAMP(3 + c0 / LB * 3);
     }
+    STAMP(13);
     for (int i = t; i < NB * NB; i += 256) {
         const int r = i / NB, c = i % NB;
         if (c <= r) A[(size_t)r * ld + c] = L[r * DL + c];
     }
+    STAMP(14);
+    // 2a. (leaf inverses were produced by wave 0 right after each leaf factorization)
     __syncthreads();
-    // 2. in-place inverse of the lower-triangular factor, column by column from the right:
-    //    new L[j+1:, j] = -(1/Ljj) * T * L[j+1:, j] with T the already inverted trailing block
-    for (int j = NB - 1; j >= 0; --j) {
-        const double ajj = 1.0 / L[j * DL + j];
-        if (t > j && t < NB) xcol[t] = L[t * DL + j];
-        __syncthreads();
-        const int i = j + 1 + (t >> 1);           // two threads per row split the dot product
-        double v = 0.0;
-        if (i < NB) {
-            const int len = i - j, half = (len + 1) >> 1;
-            const int m0 = j + 1 + ((t & 1) ? half : 0), m1 = (t & 1) ? i + 1 : j + 1 + half;
-            const double *Ti = L + i * DL;
-            for (int m = m0; m < m1; ++m) v += Ti[m] * xcol[m];
-        }
-        v += __shfl_xor(v, 1);
-        __syncthreads();                           // every read of column j / T rows is done
-        if (i < NB && (t & 1) == 0) L[i * DL + j] = -ajj * v;
-        if (t == 0) L[j * DL + j] = ajj;
-        __syncthreads();
+    STAMP(15);
+    // 2b. off-diagonal blocks, left to right, in place; thread owns row tr, columns tc+8v
+    {
+        const int tr = t >> 3, tc = t & 7;   // 32 rows x 8 column groups -> 4 columns each
+        for (int j = 0; j < 3; ++j)
+            for (int i = j + 1; i < 4; ++i) {
+                double T4[4] = {0, 0, 0, 0};
+                for (int m = j; m < i; ++m)
+                    for (int k = 0; k < LB; ++k) {
+                        const double lik = L[(LB * i + tr) * DL + LB * m + k];
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) {
+                            const int c = tc + 8 * v;
+                            // X[m][j](k,c): leaf inverse when m == j (lower-triangular), else the finished block
+                            const double xv = m == j ? (c <= k ? dinv_at(L, rd, j, k, c) : 0.0) : L[(LB * m + k) * DL + LB * j + c];
+                            T4[v] += lik * xv;
+                        }
+                    }
+                __syncthreads();   // every read of the original L[i][j] is done
+#pragma unroll
+                for (int v = 0; v < 4; ++v) L[(LB * i + tr) * DL + LB * j + tc + 8 * v] = T4[v];
+                __syncthreads();
+                double X4[4] = {0, 0, 0, 0};
+                for (int k = 0; k <= tr; ++k) {
+                    const double dv = dinv_at(L, rd, i, tr, k);
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) X4[v] -= dv * L[(LB * i + k) * DL + LB * j + tc + 8 * v];
+                }
+                __syncthreads();
+#pragma unroll
+                for (int v = 0; v < 4; ++v) L[(LB * i + tr) * DL + LB * j + tc + 8 * v] = X4[v];
+                __syncthreads();
+            }
     }
+    STAMP(16);
     double *out = Linv + (size_t)kb * NB * NB;
-    for (int i = t; i < NB * NB; i += 256) {
-        const int r = i / NB, c = i % NB;
-        out[i] = c <= r ? L[r * DL + c] : 0.0;
+    for (int idx = t; idx < NB * NB; idx += 256) {
+        const int r = idx / NB, c = idx % NB;
+        double v = 0.0;
+        if (c <= r) v = (r / LB == c / LB) ? dinv_at(L, rd, r / LB, r % LB, c % LB) : L[r * DL + c];
+        out[idx] = v;
     }
+    STAMP(17);
 }
 
 // C(128x128 tile) = beta*C - / = A(128xK) B(128xK)^T on v_mfma_f64_16x16x4_f64.
-//   MODE 0 (panel):   S[i,kb] <- S[i,kb] * Linv_kb^T        for row tiles i > kb   (K = 128, in place)
-//   MODE 1 (trailing): S[i,j] -= S[i,kb] * S[j,kb]^T        for kb < j <= i
+//   MODE 0 (panel):    S[i,kb] <- S[i,kb] * Linv_kb^T       for row tiles i > kb   (K = 128, in place)
+//   MODE 1 (trailing, first tile column):  S[i,kb+1] -= S[i,kb] * S[kb+1,kb]^T   for i > kb
+//   MODE 2 (trailing, the rest):           S[i,j]   -= S[i,kb] * S[j,kb]^T      for kb+1 < j <= i
+// MODE 1 is what the next diagonal block / panel waits for; MODE 2 runs beside them on a
+// second stream (lookahead).
 // 4 waves, each a 64x64 quadrant = 4x4 MFMA tiles; K staged through LDS in KC-deep chunks.
 template <int MODE>
 __global__ __launch_bounds__(256) void k_gemm_nt(double *S, int ld, int kb, int nblk, const double *Linv)
@@ -490,13 +595,14 @@ __global__ __launch_bounds__(256) void k_gemm_nt(double *S, int ld, int kb, int 
     __shared__ double As[128 * LDT], Bs[128 * LDT];
     int ti, tj;
     if (MODE == 0) { ti = kb + 1 + blockIdx.x; tj = kb; }
+    else if (MODE == 1) { ti = kb + 1 + blockIdx.x; tj = kb + 1; }
     else {
         // blockIdx.x enumerates the lower triangle (incl. diagonal) of the m x m trailing tiles
         const int b = blockIdx.x;
         int r = (int)((sqrt(8.0 * b + 1.0) - 1.0) * 0.5);
         while ((r + 1) * (r + 2) / 2 <= b) ++r;
         while (r * (r + 1) / 2 > b) --r;
-        ti = kb + 1 + r; tj = kb + 1 + (b - r * (r + 1) / 2);
+        ti = kb + 2 + r; tj = kb + 2 + (b - r * (r + 1) / 2);
     }
     (void)nblk;
     const double *A = S + ((size_t)ti * NB) * ld + (size_t)kb * NB;                        // [128][K] rows of tile row ti
@@ -918,16 +1024,33 @@ int rcn_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_options *o
         k_ba_S_assemble<<<nc + 1, 256, 0, st>>>(d, Sb, ir);
         k_ba_cam_rhs<<<nc, 64, 0, st>>>(d);
         RCN_HIP(hipGetLastError());
-        // dense Cholesky, right-looking, 128-wide panels
-        for (int kb = 0; kb < nblk; ++kb) {
-            k_chol_diag<<<1, 256, NB * DL * 8, st>>>(d.S, npad, kb, d.Linv, d.flag);
-            const int m = nblk - kb - 1;
-            if (m > 0) {
+        // dense Cholesky, right-looking, 128-wide panels, lookahead 1: the serial chain
+        // [first trailing tile column -> diagonal block -> panel] of step kb+1 runs on `st`
+        // while the rest of step kb's trailing update runs on the auxiliary stream
+        {
+            hipStream_t sb = ctx->aux_stream;
+            RCN_HIP(hipEventRecord(ctx->ba_ev[0], st));
+            RCN_HIP(hipStreamWaitEvent(sb, ctx->ba_ev[0], 0));      // aux starts behind everything queued so far
+            int have_rest = 0;
+            for (int kb = 0; kb < nblk; ++kb) {
+                k_chol_diag<<<1, 256, NB * DL * 8, st>>>(d.S, npad, kb, d.Linv, d.flag);
+                const int m = nblk - kb - 1;
+                if (m <= 0) break;
                 k_gemm_nt<0><<<m, 256, 0, st>>>(d.S, npad, kb, nblk, d.Linv);
-                k_gemm_nt<1><<<m * (m + 1) / 2, 256, 0, st>>>(d.S, npad, kb, nblk, d.Linv);
+                hipEvent_t evP = ctx->ba_ev[1 + (kb & 3)], evT = ctx->ba_ev[5 + (kb & 3)];
+                RCN_HIP(hipEventRecord(evP, st));
+                if (have_rest) RCN_HIP(hipStreamWaitEvent(st, ctx->ba_ev[5 + ((kb - 1) & 3)], 0));   // rest(kb-1) touched column kb+1
+                have_rest = 0;
+                if (m > 1) {
+                    RCN_HIP(hipStreamWaitEvent(sb, evP, 0));
+                    k_gemm_nt<2><<<(m - 1) * m / 2, 256, 0, sb>>>(d.S, npad, kb, nblk, d.Linv);
+                    RCN_HIP(hipEventRecord(evT, sb));
+                    have_rest = 1;
+                }
+                k_gemm_nt<1><<<m, 256, 0, st>>>(d.S, npad, kb, nblk, d.Linv);
             }
+            RCN_HIP(hipGetLastError());
         }
-        RCN_HIP(hipGetLastError());
         for (int kb = 0; kb < nblk; ++kb) k_trsv_fwd<<<nblk - kb, 128, 0, st>>>(d.S, npad, kb, d.Linv, d.rhs, d.yc);
         for (int kb = nblk - 1; kb >= 0; --kb) k_trsv_bwd<<<kb + 1, 128, 0, st>>>(d.S, npad, kb, d.Linv, d.yc, d.rhs);
         RCN_HIP(hipGetLastError());

@@ -31,6 +31,13 @@ int rcn_create(int device_id, rcn_ctx **out)
         return RCN_ERR_HIP;
     }
     ctx->stream = ctx->own_stream;
+    if (hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking) != hipSuccess) {
+        delete ctx;
+        return RCN_ERR_HIP;
+    }
+    for (auto &e : ctx->ba_ev)
+        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { delete ctx; return RCN_ERR_HIP; }
+    ctx->ba_ev_made = true;
     const char *fe = std::getenv("RCN_FORCE_EXACT");
     ctx->force_exact = fe && fe[0] == '1';
     const char *ab = std::getenv("RCN_COARSE_ABL");
@@ -53,6 +60,9 @@ void rcn_destroy(rcn_ctx *ctx)
     if (ctx->ev_made)
         for (auto &row : ctx->ev)
             for (auto &e : row) (void)hipEventDestroy(e);
+    if (ctx->ba_ev_made)
+        for (auto &e : ctx->ba_ev) (void)hipEventDestroy(e);
+    if (ctx->aux_stream) (void)hipStreamDestroy(ctx->aux_stream);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }

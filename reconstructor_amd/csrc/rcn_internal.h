@@ -94,6 +94,9 @@ struct rcn_ctx {
 
     // ---- BA state (ba.hip)
     DevBuf ba_ws[24];
+    hipStream_t aux_stream = nullptr;   // lookahead stream of the Cholesky
+    hipEvent_t ba_ev[9];
+    bool ba_ev_made = false;
 
     void set_error(const std::string &s) { err = s; }
 };

@@ -1,0 +1,48 @@
+// tools/chol_diag_bench.hip -- diagnostic: phase timing of k_chol_diag on one 128x128 SPD block.
+#define RCN_STAMP 1
+#include "../reconstructor_amd/csrc/ba.hip"
+#include <cstdio>
+#include <vector>
+int main()
+{
+    const int n = 128;
+    std::vector<double> A(n * n), M(n * n);
+    srand(3);
+    for (auto &v : M) v = rand() / (double)RAND_MAX - 0.5;
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) {
+            double s = 0; for (int k = 0; k < n; ++k) s += M[i * n + k] * M[j * n + k];
+            A[i * n + j] = s + (i == j ? n : 0);
+        }
+    double *dA, *dLinv; int *dflag;
+    (void)hipMalloc(&dA, n * n * 8); (void)hipMalloc(&dLinv, n * n * 8); (void)hipMalloc(&dflag, 4);
+    (void)hipMemset(dflag, 0, 4);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_chol_diag), hipFuncAttributeMaxDynamicSharedMemorySize, NB * DL * 8);
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    for (int rep = 0; rep < 3; ++rep) {
+        (void)hipMemcpy(dA, A.data(), n * n * 8, hipMemcpyHostToDevice);
+        (void)hipEventRecord(e0);
+        k_chol_diag<<<1, 256, NB * DL * 8>>>(dA, n, 0, dLinv, dflag);
+        (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+        float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+        unsigned long long st[32];
+        (void)hipMemcpyFromSymbol(st, HIP_SYMBOL(g_stamps), sizeof(st));
+        printf("rep %d: %.1f us total; ticks(100MHz?) ", rep, ms * 1e3);
+        const char *names[] = {"load", "leaf0", "trsm0", "trail0", "leaf1", "trsm1", "trail1", "leaf2", "trsm2", "trail2", "leaf3"};
+        for (int i = 1; i <= 10; ++i) printf("%s=%llu ", names[i], st[i] - st[i - 1]);
+        printf("| store=%llu leafinv=%llu blockinv=%llu out=%llu\n", st[14] - st[13], st[15] - st[14], st[16] - st[15], st[17] - st[16]);
+    }
+    // check: L L^T == A and Linv L == I
+    std::vector<double> L(n * n), Li(n * n);
+    (void)hipMemcpy(L.data(), dA, n * n * 8, hipMemcpyDeviceToHost); (void)hipMemcpy(Li.data(), dLinv, n * n * 8, hipMemcpyDeviceToHost);
+    double e1m = 0, e2m = 0;
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j <= i; ++j) {
+            double s = 0, s2 = 0;
+            for (int k = 0; k <= j; ++k) s += L[i * n + k] * L[j * n + k];
+            for (int k = j; k <= i; ++k) s2 += Li[i * n + k] * L[k * n + j];
+            e1m = fmax(e1m, fabs(s - A[i * n + j])); e2m = fmax(e2m, fabs(s2 - (i == j)));
+        }
+    printf("max |LL^T - A| = %.2e, max |Linv L - I| = %.2e\n", e1m, e2m);
+    return 0;
+}
