@@ -42,6 +42,8 @@ int rcn_create(int device_id, rcn_ctx **out)
     ctx->force_exact = fe && fe[0] == '1';
     const char *ab = std::getenv("RCN_COARSE_ABL");
     ctx->ablate = ab ? std::atoi(ab) : 0;
+    const char *ch = std::getenv("RCN_MATCH_CHUNKS");
+    ctx->chunks = ch ? std::atoi(ch) : 1;
     memset(&ctx->last_stats, 0, sizeof(ctx->last_stats));
     *out = ctx;
     return RCN_OK;

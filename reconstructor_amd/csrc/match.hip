@@ -28,6 +28,7 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #define RCN_GROUP 4         // consecutive pairs (same query image) swept by one workgroup
 #define RCN_NBUF 4          // LDS ring depth (train tiles)
 #define RCN_PD 2            // prefetch distance, tiles
+#define RCN_CHUNKS 4        // pair-list chunks: coarse(c+1) overlaps re-rank(c)
 #define RCN_BT 64           // train rows per LDS tile
 #define RCN_PAD_HN 1.0e30f  // half-norm of padded train rows: never a candidate
 
@@ -372,6 +373,7 @@ __device__ __forceinline__ double exact_d2(const float *__restrict__ q, const fl
     if (VEC4) {
         const float4 *q4 = reinterpret_cast<const float4 *>(q);
         const float4 *t4 = reinterpret_cast<const float4 *>(t);
+#pragma unroll 8
         for (int k = 0; k < D / 4; ++k) {
             float4 a = q4[k], b = t4[k];
             double d;
@@ -407,7 +409,7 @@ struct RerankArgs {
     unsigned *fb_count;
     unsigned long long *sv_list;  // rows that survive the coarse filter: exact re-rank
     unsigned *sv_count;
-    int32_t n_pairs, kq_stride, D, qblocks;
+    int32_t n_pairs, kq_stride, D, qblocks, pair_base;
     uint32_t idx_mask;
     float ratio;
     // error model of the coarse pass, in accumulator units unless stated
@@ -472,8 +474,8 @@ __global__ __launch_bounds__(RCN_FB) void k_filter(RerankArgs a)
 {
     __shared__ unsigned wcnt[2][RCN_FB / 64];
     __shared__ unsigned wbase[2][RCN_FB / 64];
-    const int pair = blockIdx.x / a.qblocks;
-    const int q = (blockIdx.x - pair * a.qblocks) * blockDim.x + threadIdx.x;
+    const int pl = blockIdx.x / a.qblocks, pair = a.pair_base + pl;
+    const int q = (blockIdx.x - pl * a.qblocks) * blockDim.x + threadIdx.x;
     const ImgDev qi = a.imgs[a.pairs[2 * pair]];
     const ImgDev ti = a.imgs[a.pairs[2 * pair + 1]];
     bool surv = false, fb = false;
@@ -515,11 +517,15 @@ __global__ __launch_bounds__(RCN_FB) void k_filter(RerankArgs a)
     if (fb) a.fb_list[wbase[1][w] + __popcll(mf & lt)] = entry;
 }
 
-// K2: exact fp64 re-rank of the survivors.  One wave = 32 survivors = 64 chains (2 candidates
-// each).  Rows are staged through LDS in 32-float chunks so that global reads are whole
-// 128-B segments (8 lanes per row) instead of 64 lanes striding 1-KiB rows; each lane then
-// walks its own (query,candidate) chain in ascending k out of LDS.
-#define RR_ROWS 96
+// K2: exact fp64 re-rank of the survivors.  Only the BEST coarse candidate is re-computed:
+// every other row -- the second candidate included -- has accumulator >= trunc(second), hence
+// exact distance >= lbnc, so  ea < lbnc  proves the candidate is the nearest neighbour and
+// ratio_pass(ea, lbnc) proves the ratio test for whatever the true second distance is.  Rows
+// that this does not certify (a few hundred in ten million) go to the exact kernel.
+// One wave = 64 survivors.  Rows are staged through LDS in 32-float chunks so that global reads
+// are whole 128-B segments (8 lanes per row) instead of 64 lanes striding 1-KiB rows; each
+// lane then walks its (query, candidate) chain in ascending k out of LDS.
+#define RR_ROWS 128
 #define RR_LD 36  // floats per LDS row: 32 + 4 pad (conflict-free ds_read_b128 by row)
 __global__ __launch_bounds__(64) void k_rerank_lds(RerankArgs a)
 {
@@ -529,22 +535,22 @@ __global__ __launch_bounds__(64) void k_rerank_lds(RerankArgs a)
     const unsigned n = *a.sv_count;
     const int D = a.D;
     const int nchunk = (D + 31) / 32;
-    for (unsigned g = blockIdx.x; g * 32u < n; g += gridDim.x) {
-        const unsigned sidx = g * 32u + (lane >> 1);
+    for (unsigned g = blockIdx.x; g * 64u < n; g += gridDim.x) {
+        const unsigned sidx = g * 64u + lane;
         const bool live = sidx < n;
-        const unsigned long long e = a.sv_list[live ? sidx : g * 32u];
+        const unsigned long long e = a.sv_list[live ? sidx : g * 64u];
         const int pair = (int)(e >> 32), q = (int)(e & 0xFFFFFFFFu);
         const ImgDev qi = a.imgs[a.pairs[2 * pair]];
         const ImgDev ti = a.imgs[a.pairs[2 * pair + 1]];
         const uint2 c = a.cand[(size_t)pair * a.kq_stride + q];
-        const int myidx = (int)(((lane & 1) ? c.y : c.x) & a.idx_mask);
+        const int ia = (int)(c.x & a.idx_mask);
         __syncthreads();  // previous group's reads of rowptr/tile are done
-        if ((lane & 1) == 0) rowptr[lane >> 1] = qi.f32 + (size_t)q * D;
-        rowptr[32 + lane] = ti.f32 + (size_t)myidx * D;
+        rowptr[lane] = qi.f32 + (size_t)q * D;
+        rowptr[64 + lane] = ti.f32 + (size_t)ia * D;
         __syncthreads();
         double acc = 0.0;
-        const float *qrow = tile + (lane >> 1) * RR_LD;
-        const float *trow = tile + (32 + lane) * RR_LD;
+        const float *qrow = tile + lane * RR_LD;
+        const float *trow = tile + (64 + lane) * RR_LD;
         for (int ch = 0; ch < nchunk; ++ch) {
             const int col = ch * 32 + (lane & 7) * 4;
 #pragma unroll
@@ -567,24 +573,18 @@ __global__ __launch_bounds__(64) void k_rerank_lds(RerankArgs a)
             }
             __syncthreads();
         }
-        // even lane = candidate from c.x, odd lane = candidate from c.y
-        const double other = __shfl_xor(acc, 1);
-        const int oidx = __shfl_xor(myidx, 1);
-        int res = -1;
         bool fb = false;
-        if (live && (lane & 1) == 0) {
-            double ea = acc, eb = other;
-            int ia = myidx, ib = oidx;
-            if (eb < ea || (eb == ea && ib < ia)) { double te = ea; ea = eb; eb = te; ia = ib; }
-            double lbnc = INFINITY;
+        if (live) {
+            bool ok = false;
             if (ti.K > 2) {
                 const double nq2 = qi.nrm2[q];
                 const double lbacc = (double)__uint_as_float(c.y & ~a.idx_mask);
-                lbnc = acc_to_d2(a, nq2, lbacc - coarse_eps(a, nq2)) - a.rel_slack * (nq2 + a.n_max * a.n_max);
+                double lbnc = acc_to_d2(a, nq2, lbacc - coarse_eps(a, nq2)) - a.rel_slack * (nq2 + a.n_max * a.n_max);
+                if (lbnc < 0.0) lbnc = 0.0;
+                ok = acc < lbnc && ratio_pass(acc, lbnc, a.ratio);
             }
-            res = certify(ea, ia, eb, lbnc, a.ratio);
-            if (res == -2) { fb = true; res = -1; }
-            a.out[(size_t)pair * a.out_stride + q] = res;
+            if (ok) a.out[(size_t)pair * a.out_stride + q] = ia;
+            else fb = true;   // out stays -1 until the exact kernel decides
         }
         list_append(a.fb_list, a.fb_count, fb, e);
     }
@@ -679,10 +679,10 @@ __global__ __launch_bounds__(256) void k_exact_rows(const ImgDev *__restrict__ i
 //     == the smallest claiming query index per train row.
 __global__ void k_unique_claim(const ImgDev *__restrict__ imgs, const int32_t *__restrict__ pairs,
                                const int32_t *__restrict__ out, int64_t out_stride,
-                               int32_t *__restrict__ owner, int owner_stride, int qblocks)
+                               int32_t *__restrict__ owner, int owner_stride, int qblocks, int pair_base)
 {
-    const int pair = blockIdx.x / qblocks;
-    const int q = (blockIdx.x - pair * qblocks) * blockDim.x + threadIdx.x;
+    const int pl = blockIdx.x / qblocks, pair = pair_base + pl;
+    const int q = (blockIdx.x - pl * qblocks) * blockDim.x + threadIdx.x;
     if (q >= imgs[pairs[2 * pair]].K) return;
     const int t = out[(size_t)pair * out_stride + q];
     if (t >= 0) atomicMin(owner + (size_t)pair * owner_stride + t, q);
@@ -691,10 +691,10 @@ __global__ void k_unique_claim(const ImgDev *__restrict__ imgs, const int32_t *_
 __global__ void k_unique_emit(const ImgDev *__restrict__ imgs, const int32_t *__restrict__ pairs,
                               int32_t *__restrict__ out, int64_t out_stride,
                               const int32_t *__restrict__ owner, int owner_stride,
-                              int32_t *__restrict__ counts, int qblocks)
+                              int32_t *__restrict__ counts, int qblocks, int pair_base)
 {
-    const int pair = blockIdx.x / qblocks;
-    const int q = (blockIdx.x - pair * qblocks) * blockDim.x + threadIdx.x;
+    const int pl = blockIdx.x / qblocks, pair = pair_base + pl;
+    const int q = (blockIdx.x - pl * qblocks) * blockDim.x + threadIdx.x;
     if (q >= out_stride) return;
     int32_t *o = out + (size_t)pair * out_stride + q;
     bool keep = false;
@@ -751,12 +751,12 @@ int rcn_match_release(rcn_ctx *ctx)
 static int ensure_counters(rcn_ctx *ctx)
 {
     if (!ctx->counters.p) {
-        RCN_HIP(ctx->counters.reserve(64));
-        RCN_HIP(hipMemsetAsync(ctx->counters.p, 0, 64, ctx->stream));
+        RCN_HIP(ctx->counters.reserve(128));
+        RCN_HIP(hipMemsetAsync(ctx->counters.p, 0, 128, ctx->stream));
     }
     return RCN_OK;
 }
-// counters layout: [0] u32 maxabs bits, [2..3] u64 max nrm2 bits, [4] u32 fallback count
+// counters layout: [0] u32 maxabs bits, [2..3] u64 max nrm2 bits, [8 + 2c] fallback / [9 + 2c] survivor count of chunk c
 
 static int upload_common(rcn_ctx *ctx, int32_t img_id, const float *src, bool src_is_device,
                          int32_t K, int32_t D)
@@ -997,8 +997,6 @@ static int match_grid_impl(rcn_ctx *ctx, const int32_t *pairs_host, int32_t n_pa
     RCN_HIP(ctx->sv_list.reserve(std::max<int64_t>(1, rows) * sizeof(unsigned long long)));
     RCN_HIP(hipMemcpyAsync(ctx->pairs_dev.p, slots.data(), slots.size() * sizeof(int32_t),
                            hipMemcpyHostToDevice, ctx->stream));
-    unsigned *fb_count = ctx->counters.as<unsigned>() + 4;
-    RCN_HIP(hipMemsetAsync(fb_count, 0, 16, ctx->stream));
     RCN_HIP(hipMemsetAsync(ctx->owner.p, 0x7f, (size_t)n_pairs * owner_stride * sizeof(int32_t), ctx->stream));
     RCN_HIP(hipMemsetAsync(counts_dev, 0, (size_t)n_pairs * sizeof(int32_t), ctx->stream));
 
@@ -1008,50 +1006,11 @@ static int match_grid_impl(rcn_ctx *ctx, const int32_t *pairs_host, int32_t n_pa
 
     const int evi = ctx->ev_n % 64;
     const bool prof = ctx->profile && ctx->ev_made;
-    if (prof) RCN_HIP(hipEventRecord(ctx->ev[evi][0], ctx->stream));
-    if (mfma) {
-        CoarseArgs ca;
-        ca.imgs = imgs; ca.pairs = pairs; ca.cand = ctx->cand.as<uint2>();
-        // groups: runs of consecutive pairs that share the query image, cut at RCN_GROUP
-        std::vector<int2> groups;
-        for (int p = 0; p < n_pairs;) {
-            int cnt = 1;
-            while (p + cnt < n_pairs && cnt < RCN_GROUP && slots[2 * (p + cnt)] == slots[2 * p]) ++cnt;
-            groups.push_back(make_int2(p, cnt));
-            p += cnt;
-        }
-        RCN_HIP(ctx->groups_dev.reserve(groups.size() * sizeof(int2)));
-        RCN_HIP(hipMemcpyAsync(ctx->groups_dev.p, groups.data(), groups.size() * sizeof(int2), hipMemcpyHostToDevice, ctx->stream));
-        RCN_HIP(hipStreamSynchronize(ctx->stream));   // `groups` is a local
-        ca.groups = ctx->groups_dev.as<int2>();
-        ca.n_groups = (int)groups.size(); ca.tiles_per_pair = tiles; ca.kq_stride = kq_stride;
-        const int64_t items = (int64_t)groups.size() * tiles;
-        ca.items_per_xcd = (int)((items + 7) / 8);
-        ca.idx_mask = idx_mask;
-        const int blocks = ca.items_per_xcd * 8;
-        hipError_t e;
-        switch (ctx->DP) {
-        case 32: e = launch_coarse<32>(ctx, ca, blocks); break;
-        case 64: e = launch_coarse<64>(ctx, ca, blocks); break;
-        case 128: e = launch_coarse<128>(ctx, ca, blocks); break;
-        default:
-            switch (ctx->ablate) {   // RCN_COARSE_ABL: timing experiments only
-            case 1: e = launch_coarse<256, 1>(ctx, ca, blocks); break;
-            case 9: e = launch_coarse<256, 9>(ctx, ca, blocks); break;
-            default: e = launch_coarse<256>(ctx, ca, blocks); break;
-            }
-            break;
-        }
-        RCN_HIP(e);
-    }
 
-    if (prof) RCN_HIP(hipEventRecord(ctx->ev[evi][1], ctx->stream));
     RerankArgs ra;
     memset(&ra, 0, sizeof(ra));
     ra.imgs = imgs; ra.pairs = pairs; ra.cand = ctx->cand.as<uint2>();
     ra.out = out_dev; ra.out_stride = out_stride;
-    ra.fb_list = ctx->fb_list.as<unsigned long long>(); ra.fb_count = fb_count;
-    ra.sv_list = ctx->sv_list.as<unsigned long long>(); ra.sv_count = fb_count + 1;
     ra.n_pairs = n_pairs; ra.kq_stride = kq_stride; ra.D = ctx->D; ra.idx_mask = idx_mask;
     ra.ratio = ratio;
     const double s = ctx->scale, u = std::ldexp(1.0, -11);
@@ -1064,34 +1023,104 @@ static int match_grid_impl(rcn_ctx *ctx, const int32_t *pairs_host, int32_t n_pa
     ra.hn_max = 0.5 * s * s * ctx->max_norm * ctx->max_norm + ctx->bias;
     ra.rel_slack = 1e-9;
     ra.all_to_fallback = mfma ? 0 : 1;
-    if (kq_max > 0) {
-        const int qblocks = (kq_max + 255) / 256;
-        dim3 g((unsigned)qblocks * (unsigned)n_pairs);
-        ra.qblocks = (kq_max + RCN_FB - 1) / RCN_FB;
-        k_filter<<<(unsigned)ra.qblocks * (unsigned)n_pairs, RCN_FB, 0, ctx->stream>>>(ra);
-        RCN_HIP(hipGetLastError());
+
+    // groups: runs of consecutive pairs that share the query image, cut at RCN_GROUP
+    std::vector<int2> &groups = ctx->groups_host;
+    groups.clear();
+    for (int p = 0; p < n_pairs;) {
+        int cnt = 1;
+        while (p + cnt < n_pairs && cnt < RCN_GROUP && slots[2 * (p + cnt)] == slots[2 * p]) ++cnt;
+        groups.push_back(make_int2(p, cnt));
+        p += cnt;
+    }
+    RCN_HIP(ctx->groups_dev.reserve(groups.size() * sizeof(int2)));
+    RCN_HIP(hipMemcpyAsync(ctx->groups_dev.p, groups.data(), groups.size() * sizeof(int2), hipMemcpyHostToDevice, ctx->stream));
+
+    // Chunks of the pair list: the MFMA-bound coarse kernel of chunk c+1 (main stream) runs
+    // beside the memory-bound filter / exact re-rank / uniqueness of chunk c (auxiliary stream).
+    const int n_groups = (int)groups.size();
+    const int n_chunks = (mfma && n_groups >= 64 && kq_max > 0) ? std::max(1, std::min(RCN_CHUNKS, ctx->chunks)) : 1;
+    hipStream_t sa = ctx->stream, sb = n_chunks > 1 ? ctx->aux_stream : ctx->stream;
+    unsigned *ccnt = ctx->counters.as<unsigned>() + 8;     // per chunk: [2c] fallback count, [2c+1] survivor count
+    RCN_HIP(hipMemsetAsync(ccnt, 0, 2 * RCN_CHUNKS * sizeof(unsigned), sa));
+    if (n_chunks > 1) {
+        RCN_HIP(hipEventRecord(ctx->ba_ev[0], sa));
+        RCN_HIP(hipStreamWaitEvent(sb, ctx->ba_ev[0], 0));
+    }
+    if (prof) RCN_HIP(hipEventRecord(ctx->ev[evi][0], sa));
+    int64_t row_prefix = 0;
+    for (int c = 0; c < n_chunks; ++c) {
+        const int g0 = (int)((int64_t)n_groups * c / n_chunks), g1 = (int)((int64_t)n_groups * (c + 1) / n_chunks);
+        if (g1 <= g0) continue;
+        const int p0 = groups[g0].x, p1 = g1 < n_groups ? groups[g1].x : n_pairs, np_c = p1 - p0;
         if (mfma) {
-            if (vec4) k_rerank_lds<<<ctx->prop.multiProcessorCount * 16, 64, 0, ctx->stream>>>(ra);
-            else k_rerank_generic<<<ctx->prop.multiProcessorCount * 8, 256, 0, ctx->stream>>>(ra);
+            CoarseArgs ca;
+            ca.imgs = imgs; ca.pairs = pairs; ca.cand = ctx->cand.as<uint2>();
+            ca.groups = ctx->groups_dev.as<int2>() + g0;
+            ca.n_groups = g1 - g0; ca.tiles_per_pair = tiles; ca.kq_stride = kq_stride;
+            const int64_t items = (int64_t)(g1 - g0) * tiles;
+            ca.items_per_xcd = (int)((items + 7) / 8);
+            ca.idx_mask = idx_mask;
+            const int blocks = ca.items_per_xcd * 8;
+            hipError_t e;
+            switch (ctx->DP) {
+            case 32: e = launch_coarse<32>(ctx, ca, blocks); break;
+            case 64: e = launch_coarse<64>(ctx, ca, blocks); break;
+            case 128: e = launch_coarse<128>(ctx, ca, blocks); break;
+            default:
+                switch (ctx->ablate) {   // RCN_COARSE_ABL: timing experiments only
+                case 1: e = launch_coarse<256, 1>(ctx, ca, blocks); break;
+                case 9: e = launch_coarse<256, 9>(ctx, ca, blocks); break;
+                default: e = launch_coarse<256>(ctx, ca, blocks); break;
+                }
+                break;
+            }
+            RCN_HIP(e);
+        }
+        if (prof && c == n_chunks - 1) RCN_HIP(hipEventRecord(ctx->ev[evi][1], sa));
+        if (n_chunks > 1) {
+            RCN_HIP(hipEventRecord(ctx->ba_ev[1 + (c & 3)], sa));
+            RCN_HIP(hipStreamWaitEvent(sb, ctx->ba_ev[1 + (c & 3)], 0));
+        }
+        int64_t rows_c = 0;
+        for (int p = p0; p < p1; ++p) rows_c += ctx->images.find(pairs_host[2 * p])->second.K;
+        ra.pair_base = p0;
+        ra.fb_list = ctx->fb_list.as<unsigned long long>() + row_prefix; ra.fb_count = ccnt + 2 * c;
+        ra.sv_list = ctx->sv_list.as<unsigned long long>() + row_prefix; ra.sv_count = ccnt + 2 * c + 1;
+        row_prefix += rows_c;
+        if (kq_max > 0) {
+            const int qblocks = (kq_max + 255) / 256;
+            dim3 g((unsigned)qblocks * (unsigned)np_c);
+            ra.qblocks = (kq_max + RCN_FB - 1) / RCN_FB;
+            k_filter<<<(unsigned)ra.qblocks * (unsigned)np_c, RCN_FB, 0, sb>>>(ra);
+            RCN_HIP(hipGetLastError());
+            if (mfma) {
+                if (vec4) k_rerank_lds<<<ctx->prop.multiProcessorCount * 16, 64, 0, sb>>>(ra);
+                else k_rerank_generic<<<ctx->prop.multiProcessorCount * 8, 256, 0, sb>>>(ra);
+                RCN_HIP(hipGetLastError());
+            }
+            const int fb_blocks = ctx->prop.multiProcessorCount * 8;
+            if (vec4) k_exact_rows<true><<<fb_blocks, 256, 0, sb>>>(imgs, pairs, ra.fb_list, ra.fb_count, ctx->D, ratio, out_dev, out_stride);
+            else k_exact_rows<false><<<fb_blocks, 256, 0, sb>>>(imgs, pairs, ra.fb_list, ra.fb_count, ctx->D, ratio, out_dev, out_stride);
+            RCN_HIP(hipGetLastError());
+            if (prof && c == n_chunks - 1) RCN_HIP(hipEventRecord(ctx->ev[evi][2], sb));
+            k_unique_claim<<<g, 256, 0, sb>>>(imgs, pairs, out_dev, out_stride, ctx->owner.as<int32_t>(), owner_stride, qblocks, p0);
             RCN_HIP(hipGetLastError());
         }
-        const int fb_blocks = ctx->prop.multiProcessorCount * 8;
-        if (vec4) k_exact_rows<true><<<fb_blocks, 256, 0, ctx->stream>>>(imgs, pairs, ra.fb_list, fb_count, ctx->D, ratio, out_dev, out_stride);
-        else k_exact_rows<false><<<fb_blocks, 256, 0, ctx->stream>>>(imgs, pairs, ra.fb_list, fb_count, ctx->D, ratio, out_dev, out_stride);
-        RCN_HIP(hipGetLastError());
-        if (prof) RCN_HIP(hipEventRecord(ctx->ev[evi][2], ctx->stream));
-        k_unique_claim<<<g, 256, 0, ctx->stream>>>(imgs, pairs, out_dev, out_stride, ctx->owner.as<int32_t>(), owner_stride, qblocks);
-        RCN_HIP(hipGetLastError());
-    }
-    {
-        const int eblocks = (int)((out_stride + 255) / 256);
-        dim3 g((unsigned)eblocks * (unsigned)n_pairs);
-        k_unique_emit<<<g, 256, 0, ctx->stream>>>(imgs, pairs, out_dev, out_stride, ctx->owner.as<int32_t>(), owner_stride, counts_dev, eblocks);
-        RCN_HIP(hipGetLastError());
+        {
+            const int eblocks = (int)((out_stride + 255) / 256);
+            dim3 g((unsigned)eblocks * (unsigned)np_c);
+            k_unique_emit<<<g, 256, 0, sb>>>(imgs, pairs, out_dev, out_stride, ctx->owner.as<int32_t>(), owner_stride, counts_dev, eblocks, p0);
+            RCN_HIP(hipGetLastError());
+        }
     }
     if (prof && kq_max > 0) {
-        RCN_HIP(hipEventRecord(ctx->ev[evi][3], ctx->stream));
+        RCN_HIP(hipEventRecord(ctx->ev[evi][3], sb));
         ctx->ev_n++;
+    }
+    if (n_chunks > 1) {   // the caller's stream continues behind the auxiliary stream's tail
+        RCN_HIP(hipEventRecord(ctx->ba_ev[5], sb));
+        RCN_HIP(hipStreamWaitEvent(sa, ctx->ba_ev[5], 0));
     }
     // stats: the fallback count is read back lazily in rcn_match_last_stats
     ctx->last_stats.rows_total = rows;
@@ -1138,7 +1167,7 @@ int rcn_desc_clear(rcn_ctx *ctx)
     RCN_HIP(hipSetDevice(ctx->device));
     RCN_HIP(hipStreamSynchronize(ctx->stream));
     rcn_match_release(ctx);
-    if (ctx->counters.p) RCN_HIP(hipMemsetAsync(ctx->counters.p, 0, 64, ctx->stream));
+    if (ctx->counters.p) RCN_HIP(hipMemsetAsync(ctx->counters.p, 0, 128, ctx->stream));
     return RCN_OK;
 }
 
@@ -1228,11 +1257,12 @@ int rcn_match_last_stats(const rcn_ctx *cctx, rcn_match_stats *out)
     if (!ctx || !out) return RCN_ERR_ARG;
     std::lock_guard<std::mutex> lk(ctx->mu);
     if (ctx->last_stats.rows_exact_fallback < 0 && ctx->counters.p) {
-        unsigned n[2] = {0, 0};
-        RCN_HIP(hipMemcpyAsync(n, ctx->counters.as<unsigned>() + 4, 8, hipMemcpyDeviceToHost, ctx->stream));
+        unsigned n[2 * RCN_CHUNKS];
+        RCN_HIP(hipMemcpyAsync(n, ctx->counters.as<unsigned>() + 8, sizeof(n), hipMemcpyDeviceToHost, ctx->stream));
         RCN_HIP(hipStreamSynchronize(ctx->stream));
-        ctx->last_stats.rows_exact_fallback = n[0];
-        ctx->last_stats.rows_reranked = n[1];
+        ctx->last_stats.rows_exact_fallback = 0;
+        ctx->last_stats.rows_reranked = 0;
+        for (int c = 0; c < RCN_CHUNKS; ++c) { ctx->last_stats.rows_exact_fallback += n[2 * c]; ctx->last_stats.rows_reranked += n[2 * c + 1]; }
     }
     if (ctx->ev_n > 0 && ctx->ev_made) {
         RCN_HIP(hipStreamSynchronize(ctx->stream));

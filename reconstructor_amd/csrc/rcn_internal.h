@@ -79,6 +79,7 @@ struct rcn_ctx {
     int32_t D = 0, DP = 0;
     std::map<int32_t, ImgHost> images;
     std::vector<Slab> slabs;
+    std::vector<int2> groups_host;   // kept alive: uploaded asynchronously
     bool prepared = false;
     double scale = 1.0;      // s, power of two
     double bias = 0.0;       // BIAS in accumulator units
@@ -90,6 +91,7 @@ struct rcn_ctx {
     bool ev_made = false;
     int ev_n = 0;          // recorded calls since the last stats read (<= 64)
     int ablate = 0;            // RCN_COARSE_ABL (diagnostics)
+    int chunks = 1;            // RCN_MATCH_CHUNKS: >1 overlaps re-rank(c) with coarse(c+1) on two streams
     bool force_exact = false;  // RCN_FORCE_EXACT=1: skip the MFMA coarse pass (diagnostics)
 
     // ---- BA state (ba.hip)
