@@ -11,8 +11,9 @@ match tables left in HBM.
 
 N > 1 (weak scaling): the image count grows as 100*sqrt(N) so every rank keeps ~4950 pairs.
 Each rank owns n/N images ("detected locally"), one RCCL all-gather over xGMI replicates
-the descriptors, then the pair list is dealt round-robin to ranks; no other exchange.  The
-all-gather and the per-image ingest are INSIDE the timed step for N > 1.
+the descriptors, then the pair list is dealt round-robin to ranks; no other exchange.  Every
+timed step gathers, ingests and matches one whole batch; the all-gather of batch k+1 runs on a
+side stream into a second landing buffer while batch k is matched (double buffering).
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -81,10 +82,14 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--images", type=int, default=0, help="override image count (debug)")
+    ap.add_argument("--kpts", type=int, default=0, help="override keypoints per image (debug, e.g. 4096 = cfg3 shape)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ba", action="store_true", help="skip the BA leg (cfg 4 + cfg 5 LM iterations/s)")
     args = ap.parse_args()
 
+    global K_PER_IMAGE
+    if args.kpts:
+        K_PER_IMAGE = args.kpts
     import torch
     import torch.distributed as dist
 
@@ -127,24 +132,48 @@ def main():
     my_pairs = pairgrid.shard_pairs(pairs, world, rank)
     out = torch.empty((len(my_pairs), K_PER_IMAGE), dtype=torch.int32, device=dev)
     counts = torch.empty((len(my_pairs),), dtype=torch.int32, device=dev)
-    gathered = torch.empty((n_img, K_PER_IMAGE, D), dtype=torch.float32, device=dev) if world > 1 else None
+    # N > 1: two landing buffers; the all-gather of batch k+1 runs on a side stream (RCCL over
+    # xGMI) while batch k is being matched -- every step still gathers, ingests and matches
+    # one whole batch inside the timed region.
+    gathered = [torch.empty((n_img, K_PER_IMAGE, D), dtype=torch.float32, device=dev) for _ in range(2)] if world > 1 else None
+    comm_stream = torch.cuda.Stream(device=dev) if world > 1 else None
+    pending = [None, None]
+    state = {"k": 0, "overlap": world > 1 and not rehearse}
 
-    def ingest():
-        """RCCL all-gather of the per-image descriptor blocks + per-image ingest (N > 1)."""
+    def launch_gather(slot):
+        """Start the all-gather of the next batch into gathered[slot] (asynchronous)."""
         if rehearse:
-            host = torch.empty(gathered.shape, dtype=torch.float32)
+            host = torch.empty(gathered[slot].shape, dtype=torch.float32)
             dist.all_gather_into_tensor(host.view(-1), local_dev.cpu().view(-1))
-            gathered.copy_(host)
-        else:
-            dist.all_gather_into_tensor(gathered.view(-1), local_dev.view(-1))
-        matcher.upload_batch_device(0, n_img, gathered.data_ptr(), K_PER_IMAGE, D)
+            gathered[slot].copy_(host)
+            pending[slot] = None
+            return
+        if state["overlap"]:
+            try:
+                comm_stream.wait_stream(torch.cuda.current_stream(dev))   # slot's previous readers are queued before this point
+                with torch.cuda.stream(comm_stream):
+                    pending[slot] = dist.all_gather_into_tensor(gathered[slot].view(-1), local_dev.view(-1), async_op=True)
+                return
+            except Exception as exc:   # fall back to the in-line collective
+                state["overlap"] = False
+                sys.stderr.write("bench: async all-gather unavailable (%s); using the in-line collective\n" % exc)
+        dist.all_gather_into_tensor(gathered[slot].view(-1), local_dev.view(-1))
+        pending[slot] = None
 
     if world == 1:
         matcher.upload_batch_device(0, n_img, local_dev.data_ptr(), K_PER_IMAGE, D)
+    else:
+        launch_gather(0)
 
     def step():
         if world > 1:
-            ingest()
+            slot = state["k"] & 1
+            if pending[slot] is not None:
+                pending[slot].wait()                      # main stream waits for the collective
+                pending[slot] = None
+            matcher.upload_batch_device(0, n_img, gathered[slot].data_ptr(), K_PER_IMAGE, D)
+            launch_gather(slot ^ 1)                       # next batch travels while this one is matched
+            state["k"] += 1
         matcher.match_grid_device(my_pairs, out.data_ptr(), K_PER_IMAGE, counts.data_ptr())
 
     def fence():
@@ -196,9 +225,9 @@ def main():
             "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f16 MFMA coarse + f64 exact re-rank",
             "data": "synthetic",
-            "config": {"workload": "cfg2: %d images x %d keypoints x %d-d, %d image pairs%s"
+            "config": {"workload": ("cfg2" if K_PER_IMAGE == 2048 else "custom") + ": %d images x %d keypoints x %d-d, %d image pairs%s"
                                    % (n_img, K_PER_IMAGE, D, len(pairs),
-                                      "" if world == 1 else " (weak scaling of cfg2: ~4950 pairs per rank, RCCL all-gather + ingest inside the step)"),
+                                      "" if world == 1 else " (weak scaling of cfg2: ~4950 pairs per rank, RCCL all-gather (double-buffered, overlapped with the previous batch's matching) + ingest inside the step)"),
                        "pairs_per_rank": int(len(my_pairs)), "pair_matches_per_s": len(pairs) * args.steps / dt,
                        "matches_found": n_matches,
                        "rows_reranked": int(st["rows_reranked"]), "rows_exact_fallback": int(st["rows_exact_fallback"]), "rows_total": int(st["rows_total"])},

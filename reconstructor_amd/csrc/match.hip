@@ -44,32 +44,34 @@ template <int DP> __host__ __device__ __forceinline__ int swz(int row)
 }
 
 // ---------------------------------------------------------------------------------------
-// Row statistics at upload: |x|^2 in fp64 (ascending k, fma chain) and the running maxima
-// that fix the global power-of-two scale.
-__global__ void k_rowstats(const float *__restrict__ x, int K, int D, double *__restrict__ nrm2,
-                           unsigned *__restrict__ g_maxabs_bits,
-                           unsigned long long *__restrict__ g_maxnrm2_bits)
+// Row statistics at upload: |x|^2 in fp64 and the running maxima that fix the global
+// power-of-two scale.  One wave per row, coalesced; |x|^2 only feeds error bounds (which carry
+// their own slack), so the summation order is free.
+__global__ __launch_bounds__(256) void k_rowstats(const float *__restrict__ x, int K, int D, double *__restrict__ nrm2,
+                                                  unsigned *__restrict__ g_maxabs_bits,
+                                                  unsigned long long *__restrict__ g_maxnrm2_bits)
 {
-    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
     float ma = 0.f;
-    double acc = 0.0;
-    if (j < K) {
+    double mx = 0.0;
+    for (int j = wave; j < K; j += nwaves) {
         const float *row = x + (size_t)j * D;
-        for (int k = 0; k < D; ++k) {
-            float v = row[k];
+        double acc = 0.0;
+        for (int k = lane; k < D; k += 64) {
+            const float v = row[k];
             ma = fmaxf(ma, fabsf(v));
             acc = fma((double)v, (double)v, acc);
         }
-        nrm2[j] = acc;
+        for (int o = 32; o; o >>= 1) acc += __shfl_xor(acc, o);
+        if (lane == 0) nrm2[j] = acc;
+        mx = fmax(mx, acc);
     }
     // non-negative floats / doubles order like their bit patterns
-    for (int o = 32; o; o >>= 1) {
-        ma = fmaxf(ma, __shfl_xor(ma, o));
-        acc = fmax(acc, __shfl_xor(acc, o));
-    }
-    if ((threadIdx.x & 63) == 0) {
+    for (int o = 32; o; o >>= 1) ma = fmaxf(ma, __shfl_xor(ma, o));
+    if (lane == 0) {
         atomicMax(g_maxabs_bits, __float_as_uint(ma));
-        atomicMax(g_maxnrm2_bits, (unsigned long long)__double_as_longlong(acc));
+        atomicMax(g_maxnrm2_bits, (unsigned long long)__double_as_longlong(mx));
     }
 }
 
@@ -794,7 +796,7 @@ static int upload_common(rcn_ctx *ctx, int32_t img_id, const float *src, bool sr
                                src_is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
                                ctx->stream));
         unsigned *cnt = ctx->counters.as<unsigned>();
-        k_rowstats<<<(K + 255) / 256, 256, 0, ctx->stream>>>(
+        k_rowstats<<<std::min((K + 3) / 4, 4096), 256, 0, ctx->stream>>>(
             im.f32, K, D, im.nrm2, cnt, reinterpret_cast<unsigned long long *>(cnt + 2));
         RCN_HIP(hipGetLastError());
         if (!src_is_device) RCN_HIP(hipStreamSynchronize(ctx->stream));  // host rows are borrowed
@@ -857,7 +859,7 @@ static int upload_batch(rcn_ctx *ctx, int32_t first_id, int32_t n, const float *
     }
     unsigned *cnt = ctx->counters.as<unsigned>();
     const int rows = n * K;
-    k_rowstats<<<(rows + 255) / 256, 256, 0, ctx->stream>>>(src, rows, D, sl.nrm2, cnt,
+    k_rowstats<<<std::min((rows + 3) / 4, 8192), 256, 0, ctx->stream>>>(src, rows, D, sl.nrm2, cnt,
                                                             reinterpret_cast<unsigned long long *>(cnt + 2));
     RCN_HIP(hipGetLastError());
     ctx->prepared = false;

@@ -130,3 +130,15 @@ def test_full_size_properties(matcher):
         passes = np.sqrt(np.float32(d2[i, 0])) < np.float32(0.7) * np.sqrt(np.float32(d2[i, 1]))
         assert out[1][i] in ((idx[i, 0], -1) if passes else (-1,))
     matcher.clear()
+
+
+def test_cfg3_shape_vs_oracle(matcher):
+    """BASELINE cfg-3 shape (4096 keypoints per image, 12 index bits in the packed top-2):
+    one full pair against the oracle, bit-exact, and the certified fast path must carry it."""
+    ims = synth.descriptor_set("superpoint", 2, 4096, seed=77)
+    exp, n = orc.match_pair(ims[0], ims[1])
+    got = matcher.match_pair(ims[0], ims[1])
+    assert np.array_equal(got, exp)
+    st = matcher.stats()
+    assert st["used_mfma_path"] == 1 and st["rows_exact_fallback"] < 0.01 * 4096
+    print("cfg3 pair: matches", n, "reranked", st["rows_reranked"], "fallback", st["rows_exact_fallback"])
