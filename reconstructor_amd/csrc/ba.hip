@@ -592,7 +592,7 @@ __global__ __launch_bounds__(256) void k_chol_diag(double *S, int ld, int kb, do
 template <int MODE>
 __global__ __launch_bounds__(256) void k_gemm_nt(double *S, int ld, int kb, int nblk, const double *Linv)
 {
-    __shared__ double As[128 * LDT], Bs[128 * LDT];
+    __shared__ double As[2][128 * LDT], Bs[2][128 * LDT];
     int ti, tj;
     if (MODE == 0) { ti = kb + 1 + blockIdx.x; tj = kb; }
     else if (MODE == 1) { ti = kb + 1 + blockIdx.x; tj = kb + 1; }
@@ -611,30 +611,53 @@ __global__ __launch_bounds__(256) void k_gemm_nt(double *S, int ld, int kb, int 
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int wr = (w >> 1) * 64, wc = (w & 1) * 64;
     const int fr = lane & 15, fk = lane >> 4;
+    double *C = S + ((size_t)ti * NB) * ld + (size_t)tj * NB;
+    // f64 C/D layout: col = lane & 15, row = (lane >> 4) + 4 * reg.
+    // Trailing update: the accumulators START as the C tile and the A operand is negated, so
+    // C - A B^T comes out of the MFMA chain and is stored once (no read-modify-write pass).
     f64x4 acc[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f64x4){0.0, 0.0, 0.0, 0.0};
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg)
+                acc[i][j][reg] = MODE == 0 ? 0.0 : C[(size_t)(wr + 16 * i + fk + 4 * reg) * ld + wc + 16 * j + fr];
 
-    for (int k0 = 0; k0 < NB; k0 += KC) {
-        __syncthreads();
-        // stage A[128][KC], B[128][KC]
-        for (int i = t; i < 128 * (KC / 2); i += 256) {
-            const int r = i / (KC / 2), c2 = (i % (KC / 2)) * 2;
-            const double2 va = *reinterpret_cast<const double2 *>(A + (size_t)r * ld + k0 + c2);
-            const double2 vb = *reinterpret_cast<const double2 *>(B + (size_t)r * ldb + k0 + c2);
-            As[r * LDT + c2] = va.x; As[r * LDT + c2 + 1] = va.y;
-            Bs[r * LDT + c2] = vb.x; Bs[r * LDT + c2 + 1] = vb.y;
+    // staging: each thread moves KC/2 double2 per operand per chunk; chunk c+1 is fetched into
+    // registers while chunk c is multiplied
+    constexpr int PER = 128 * (KC / 2) / 256;   // double2 per thread per operand
+    double2 ra[PER], rb[PER];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+            const int i = t + 256 * q, r = i / (KC / 2), c2 = (i % (KC / 2)) * 2;
+            ra[q] = *reinterpret_cast<const double2 *>(A + (size_t)r * ld + k0 + c2);
+            rb[q] = *reinterpret_cast<const double2 *>(B + (size_t)r * ldb + k0 + c2);
         }
-        __syncthreads();
+    };
+    auto stash = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+            const int i = t + 256 * q, r = i / (KC / 2), c2 = (i % (KC / 2)) * 2;
+            As[buf][r * LDT + c2] = ra[q].x; As[buf][r * LDT + c2 + 1] = ra[q].y;
+            Bs[buf][r * LDT + c2] = rb[q].x; Bs[buf][r * LDT + c2 + 1] = rb[q].y;
+        }
+    };
+    fetch(0);
+    stash(0);
+    __syncthreads();
+    int buf = 0;
+    for (int k0 = 0; k0 < NB; k0 += KC) {
+        if (k0 + KC < NB) fetch(k0 + KC);
 #pragma unroll
         for (int kk = 0; kk < KC; kk += 4) {
             double a[4], b[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                a[i] = As[(wr + 16 * i + fr) * LDT + kk + fk];
-                b[i] = Bs[(wc + 16 * i + fr) * LDT + kk + fk];
+                const double av = As[buf][(wr + 16 * i + fr) * LDT + kk + fk];
+                a[i] = MODE == 0 ? av : -av;
+                b[i] = Bs[buf][(wc + 16 * i + fr) * LDT + kk + fk];
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i)
@@ -642,21 +665,18 @@ __global__ __launch_bounds__(256) void k_gemm_nt(double *S, int ld, int kb, int 
                 for (int j = 0; j < 4; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
         }
+        if (k0 + KC < NB) stash(buf ^ 1);   // the other buffer was last read one chunk ago
+        __syncthreads();
+        buf ^= 1;
     }
-    __syncthreads();  // MODE 0 writes over A: every wave is done reading
-    // f64 C/D layout: col = lane & 15, row = (lane >> 4) + 4 * reg
-    double *C = S + ((size_t)ti * NB) * ld + (size_t)tj * NB;
+    // MODE 0 writes over A: every wave passed the last barrier after its final read
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int reg = 0; reg < 4; ++reg) {
-                const int row = wr + 16 * i + fk + 4 * reg, col = wc + 16 * j + fr;
-                double *p = C + (size_t)row * ld + col;
-                if (MODE == 0) *p = acc[i][j][reg];
-                else *p -= acc[i][j][reg];
-            }
+            for (int reg = 0; reg < 4; ++reg)
+                C[(size_t)(wr + 16 * i + fk + 4 * reg) * ld + wc + 16 * j + fr] = acc[i][j][reg];
 }
 
 // forward substitution step kb: y_kb = Linv_kb b_kb ; b_i -= L[i,kb] y_kb for i > kb.
