@@ -689,12 +689,14 @@ __global__ __launch_bounds__(128) void k_trsv_fwd(const double *S, int ld, int k
     __syncthreads();
     const double *Li = Linv + (size_t)kb * NB * NB + (size_t)t * NB;
     double s = 0.0;
-    for (int m = 0; m <= t; ++m) s += Li[m] * bk[m];
+#pragma unroll 8
+    for (int m = 0; m < NB; ++m) s += (m <= t ? Li[m] : 0.0) * bk[m];   // Linv is stored with zeros above the diagonal
     yk[t] = s;
     __syncthreads();
     if (i == kb) { y[(size_t)kb * NB + t] = s; return; }
     const double *row = S + ((size_t)i * NB + t) * ld + (size_t)kb * NB;
     double u = 0.0;
+#pragma unroll 16
     for (int m = 0; m < NB; ++m) u += row[m] * yk[m];
     b[(size_t)i * NB + t] -= u;
 }
@@ -708,12 +710,14 @@ __global__ __launch_bounds__(128) void k_trsv_bwd(const double *S, int ld, int k
     __syncthreads();
     const double *Lk = Linv + (size_t)kb * NB * NB;
     double s = 0.0;
-    for (int m = t; m < NB; ++m) s += Lk[(size_t)m * NB + t] * yk[m];
+#pragma unroll 16
+    for (int m = 0; m < NB; ++m) s += Lk[(size_t)m * NB + t] * yk[m];   // zeros above the diagonal
     xk[t] = s;
     __syncthreads();
     if (j == kb) { x[(size_t)kb * NB + t] = s; return; }
     const double *blk = S + ((size_t)kb * NB) * ld + (size_t)j * NB;  // L[kb, j] tile, rows m, col t
     double u = 0.0;
+#pragma unroll 16
     for (int m = 0; m < NB; ++m) u += blk[(size_t)m * ld + t] * xk[m];
     y[(size_t)j * NB + t] -= u;
 }
