@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "librcn.so")
+SO_PATH = os.environ.get("RCN_LIB", os.path.join(_HERE, "librcn.so"))   # RCN_LIB: A/B another build of the same ABI
 
 RCN_OK = 0
 ERRORS = {-1: "RCN_ERR_ARG", -2: "RCN_ERR_HIP", -3: "RCN_ERR_NO_DEVICE",

@@ -289,24 +289,26 @@ __global__ __launch_bounds__(512, 2) void k_coarse_top2(CoarseArgs a)
         h3 = lds_read(hnl + (rb * 32 + 24 + 4 * h) * 4);
         f0 = lds_read(arow + ((h ^ sw) << 4));
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(h0), "+v"(h1), "+v"(h2), "+v"(h3), "+v"(f0));
-        c0[0] = __uint_as_float(h0.x); c0[1] = __uint_as_float(h0.y); c0[2] = __uint_as_float(h0.z); c0[3] = __uint_as_float(h0.w);
-        c0[4] = __uint_as_float(h1.x); c0[5] = __uint_as_float(h1.y); c0[6] = __uint_as_float(h1.z); c0[7] = __uint_as_float(h1.w);
-        c0[8] = __uint_as_float(h2.x); c0[9] = __uint_as_float(h2.y); c0[10] = __uint_as_float(h2.z); c0[11] = __uint_as_float(h2.w);
-        c0[12] = __uint_as_float(h3.x); c0[13] = __uint_as_float(h3.y); c0[14] = __uint_as_float(h3.z); c0[15] = __uint_as_float(h3.w);
-        c1 = c0;
+        // the half-norm tuple is the C input of the first k-step of BOTH column blocks (D may differ
+        // from C), so no accumulator is initialised by copies
+        f32x16 hnv;
+        hnv[0] = __uint_as_float(h0.x); hnv[1] = __uint_as_float(h0.y); hnv[2] = __uint_as_float(h0.z); hnv[3] = __uint_as_float(h0.w);
+        hnv[4] = __uint_as_float(h1.x); hnv[5] = __uint_as_float(h1.y); hnv[6] = __uint_as_float(h1.z); hnv[7] = __uint_as_float(h1.w);
+        hnv[8] = __uint_as_float(h2.x); hnv[9] = __uint_as_float(h2.y); hnv[10] = __uint_as_float(h2.z); hnv[11] = __uint_as_float(h2.w);
+        hnv[12] = __uint_as_float(h3.x); hnv[13] = __uint_as_float(h3.y); hnv[14] = __uint_as_float(h3.z); hnv[15] = __uint_as_float(h3.w);
         auto kstep = [&](int ks, u32x4 &cur, u32x4 &nxt) {
             // naming c1 ties the wait BEHIND the previous k-step's second MFMA
             if (ks > 0) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(cur), "+v"(c1));
             // fragment of k-step ks+1 is in flight while ks computes
             if (ks + 1 < KS) nxt = lds_read(arow + ((((ks + 1) * 2 + h) ^ sw) << 4));
             const half8 av = __builtin_bit_cast(half8, cur);
-            c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bq[0][ks], c0, 0, 0, 0);
+            c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bq[0][ks], ks == 0 ? hnv : c0, 0, 0, 0);
             if (!(ABL & 1)) {
 #pragma unroll
                 for (int reg = ks * 16 / KS; reg < (ks + 1) * 16 / KS; ++reg)
                     top2(0, (__float_as_uint(p0v[reg]) & hmask) | (prev_rowbase + (reg & 3) + 8 * (reg >> 2)));
             }
-            c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bq[1][ks], c1, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bq[1][ks], ks == 0 ? hnv : c1, 0, 0, 0);
             if (!(ABL & 1)) {
 #pragma unroll
                 for (int reg = ks * 16 / KS; reg < (ks + 1) * 16 / KS; ++reg)
