@@ -383,10 +383,14 @@ __global__ __launch_bounds__(64) void k_ba_cam_rhs(BaDev d)
 //          X[i][j] = -Dinv_i * sum_{m=j}^{i-1} L[i][m] X[m][j],   X[j][j] = Dinv_j.
 // Writes L into S and L^-1 into Linv[kb] (used by the panel GEMM and the triangular solves).
 #define DL 129   // LDS row stride of the diagonal block (doubles): row walks are conflict-free
-#define LB 32    // leaf size
+#define LB 16    // leaf size
+#define NBL (NB / LB)
 
 // leaf inverse element (r,c), c <= r, of leaf i: strictly-lower entries live transposed in the
 // upper triangle of the leaf's own diagonal block; the diagonal is the reciprocal of L's.
+// element (r,c), c <= r, of the inverse of 32x32 leaf i32 once stage 2b has run: inside a 16x16
+// diagonal block it is the 16-leaf inverse, otherwise the off-diagonal block stored in place
+#define DINV32_DECL
 // broadcast of lane `src`'s double (src wave-uniform): two v_readlane_b32
 __device__ __forceinline__ double rdlane(double v, int src)
 {
@@ -398,6 +402,12 @@ __device__ __forceinline__ double rdlane(double v, int src)
 __device__ __forceinline__ double dinv_at(const double *L, const double *rd, int i, int r, int c)
 {
     return r == c ? rd[LB * i + r] : L[(LB * i + c) * DL + LB * i + r];
+}
+
+__device__ __forceinline__ double dinv32_at(const double *L, const double *rd, int i32, int r, int c)
+{
+    const int gr = 32 * i32 + r, gc = 32 * i32 + c;
+    return (gr / LB == gc / LB) ? dinv_at(L, rd, gr / LB, gr % LB, gc % LB) : L[gr * DL + gc];
 }
 
 template <int NT> __device__ __forceinline__ void trail_update(double *L, int r0, int c0, int t)
@@ -456,7 +466,7 @@ __global__ __launch_bounds__(256) void k_chol_diag(double *S, int ld, int kb, do
         //     entry of another row arrives by v_readlane (uniform lane index), so there is no
         //     LDS read-modify-write chain on the critical path
         if (w == 0) {
-            const int row = lane & 31;
+            const int row = lane & (LB - 1);
             double a[LB];
 #pragma unroll
             for (int c = 0; c < LB; ++c) a[c] = L[(c0 + row) * DL + c0 + c];
@@ -499,7 +509,7 @@ __global__ __launch_bounds__(256) void k_chol_diag(double *S, int ld, int kb, do
             }
         }
         __syncthreads();
-        STAMP(1 + c0 / LB * 3);
+        STAMP(1);
         if (misc[0] != 0.0) { if (t == 0) *flag = 1; return; }
         const int r0 = c0 + LB;
         if (r0 >= NB) break;
@@ -521,13 +531,19 @@ __global__ __launch_bounds__(256) void k_chol_diag(double *S, int ld, int kb, do
             for (int c = 0; c < LB; ++c) rowp[c] = x[c];
         }
         __syncthreads();
-        STAMP(2 + c0 / LB * 3);
+        STAMP(2);
         // 1c. trailing square -= panel panel^T ; thread (ty,tx) owns rows ty+16u, cols tx+16v
-        if (r0 == 32) trail_update<6>(L, r0, c0, t);
-        else if (r0 == 64) trail_update<4>(L, r0, c0, t);
-        else trail_update<2>(L, r0, c0, t);
+        switch ((NB - r0) / 16) {
+        case 7: trail_update<7>(L, r0, c0, t); break;
+        case 6: trail_update<6>(L, r0, c0, t); break;
+        case 5: trail_update<5>(L, r0, c0, t); break;
+        case 4: trail_update<4>(L, r0, c0, t); break;
+        case 3: trail_update<3>(L, r0, c0, t); break;
+        case 2: trail_update<2>(L, r0, c0, t); break;
+        default: trail_update<1>(L, r0, c0, t); break;
+        }
         __syncthreads();
-        STAMP(3 + c0 / LB * 3);
+        STAMP(3);
     }
     STAMP(13);
     for (int i = t; i < NB * NB; i += 256) {
@@ -538,36 +554,64 @@ __global__ __launch_bounds__(256) void k_chol_diag(double *S, int ld, int kb, do
     // 2a. (leaf inverses were produced by wave 0 right after each leaf factorization)
     __syncthreads();
     STAMP(15);
-    // 2b. off-diagonal blocks, left to right, in place; thread owns row tr, columns tc+8v
+    // 2b. the 32x32 leaf inverses from the 16x16 ones: for each 32-block the off-diagonal
+    //     16x16 block becomes  -Dinv_hi * (L_hi,lo * Dinv_lo)  in place.
+    {
+        const int tr = t >> 4, tc = t & 15;   // one element of a 16x16 block per thread
+        double tv[4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int i = 2 * b + 1, j = 2 * b;
+            double acc = 0.0;
+            for (int k = tc; k < LB; ++k) acc += L[(LB * i + tr) * DL + LB * j + k] * dinv_at(L, rd, j, k, tc);
+            tv[b] = acc;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int b = 0; b < 4; ++b) L[(LB * (2 * b + 1) + tr) * DL + LB * (2 * b) + tc] = tv[b];
+        __syncthreads();
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int i = 2 * b + 1, j = 2 * b;
+            double acc = 0.0;
+            for (int k = 0; k <= tr; ++k) acc -= dinv_at(L, rd, i, tr, k) * L[(LB * i + k) * DL + LB * j + tc];
+            tv[b] = acc;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int b = 0; b < 4; ++b) L[(LB * (2 * b + 1) + tr) * DL + LB * (2 * b) + tc] = tv[b];
+        __syncthreads();
+    }
+    // 2c. off-diagonal 32x32 blocks, left to right, in place; thread owns row tr, columns tc+8v
     {
         const int tr = t >> 3, tc = t & 7;   // 32 rows x 8 column groups -> 4 columns each
         for (int j = 0; j < 3; ++j)
             for (int i = j + 1; i < 4; ++i) {
                 double T4[4] = {0, 0, 0, 0};
                 for (int m = j; m < i; ++m)
-                    for (int k = 0; k < LB; ++k) {
-                        const double lik = L[(LB * i + tr) * DL + LB * m + k];
+                    for (int k = 0; k < 32; ++k) {
+                        const double lik = L[(32 * i + tr) * DL + 32 * m + k];
 #pragma unroll
                         for (int v = 0; v < 4; ++v) {
                             const int c = tc + 8 * v;
                             // X[m][j](k,c): leaf inverse when m == j (lower-triangular), else the finished block
-                            const double xv = m == j ? (c <= k ? dinv_at(L, rd, j, k, c) : 0.0) : L[(LB * m + k) * DL + LB * j + c];
+                            const double xv = m == j ? (c <= k ? dinv32_at(L, rd, j, k, c) : 0.0) : L[(32 * m + k) * DL + 32 * j + c];
                             T4[v] += lik * xv;
                         }
                     }
                 __syncthreads();   // every read of the original L[i][j] is done
 #pragma unroll
-                for (int v = 0; v < 4; ++v) L[(LB * i + tr) * DL + LB * j + tc + 8 * v] = T4[v];
+                for (int v = 0; v < 4; ++v) L[(32 * i + tr) * DL + 32 * j + tc + 8 * v] = T4[v];
                 __syncthreads();
                 double X4[4] = {0, 0, 0, 0};
                 for (int k = 0; k <= tr; ++k) {
-                    const double dv = dinv_at(L, rd, i, tr, k);
+                    const double dv = dinv32_at(L, rd, i, tr, k);
 #pragma unroll
-                    for (int v = 0; v < 4; ++v) X4[v] -= dv * L[(LB * i + k) * DL + LB * j + tc + 8 * v];
+                    for (int v = 0; v < 4; ++v) X4[v] -= dv * L[(32 * i + k) * DL + 32 * j + tc + 8 * v];
                 }
                 __syncthreads();
 #pragma unroll
-                for (int v = 0; v < 4; ++v) L[(LB * i + tr) * DL + LB * j + tc + 8 * v] = X4[v];
+                for (int v = 0; v < 4; ++v) L[(32 * i + tr) * DL + 32 * j + tc + 8 * v] = X4[v];
                 __syncthreads();
             }
     }
@@ -576,7 +620,7 @@ __global__ __launch_bounds__(256) void k_chol_diag(double *S, int ld, int kb, do
     for (int idx = t; idx < NB * NB; idx += 256) {
         const int r = idx / NB, c = idx % NB;
         double v = 0.0;
-        if (c <= r) v = (r / LB == c / LB) ? dinv_at(L, rd, r / LB, r % LB, c % LB) : L[r * DL + c];
+        if (c <= r) v = (r / LB == c / LB) ? dinv_at(L, rd, r / LB, r % LB, c % LB) : L[r * DL + c];   // all off-diagonal entries are in place
         out[idx] = v;
     }
     STAMP(17);

@@ -28,9 +28,8 @@ int main()
         unsigned long long st[32];
         (void)hipMemcpyFromSymbol(st, HIP_SYMBOL(g_stamps), sizeof(st));
         printf("rep %d: %.1f us total; ticks(100MHz?) ", rep, ms * 1e3);
-        const char *names[] = {"load", "leaf0", "trsm0", "trail0", "leaf1", "trsm1", "trail1", "leaf2", "trsm2", "trail2", "leaf3"};
-        for (int i = 1; i <= 10; ++i) printf("%s=%llu ", names[i], st[i] - st[i - 1]);
-        printf("| store=%llu leafinv=%llu blockinv=%llu out=%llu\n", st[14] - st[13], st[15] - st[14], st[16] - st[15], st[17] - st[16]);
+        printf("factor(all leaves+trsm+trail)=%llu | store=", st[13] - st[0]);
+        printf("%llu leafinv=%llu blockinv=%llu out=%llu\n", st[14] - st[13], st[15] - st[14], st[16] - st[15], st[17] - st[16]);
     }
     // check: L L^T == A and Linv L == I
     std::vector<double> L(n * n), Li(n * n);
