@@ -104,3 +104,37 @@ def test_cfg5_properties(gpu_ctx):
     assert np.array_equal(P[0], sc["poses"][0]) and np.array_equal(P[1, 3:], sc["poses"][1, 3:])
     assert np.array_equal(I[:, 2:4], sc["intrinsics"][:, 2:4])
     assert np.abs(X - sc["points_gt"]).mean() < 0.05
+
+
+def test_edge_cases_match_oracle(gpu_ctx):
+    """Two cameras (3 free camera parameters), a camera nobody observes, options away from the
+    defaults: GPU follows the oracle."""
+    from reconstructor_amd import ba
+    # 2 cameras: camera 0 fixed, camera 1 rotation only
+    sc = synth_ba.make_scene(2, 30, obs_per_point=2, seed=12)
+    P0, I0, X0, s0 = orc_ba.solve(sc)
+    P1, I1, X1, s1 = ba.solve_scene(gpu_ctx, sc)
+    assert s1["reduced_dim"] == 3 and s1["iterations"] == s0["iterations"]
+    assert abs(s1["final_rms_px"] - s0["final_rms_px"]) <= RMS_TOL_PX
+    # a camera without observations (its blocks are regularised by the LM diagonal only)
+    sc = synth_ba.make_scene(12, 200, obs_per_point=5, seed=13)
+    keep = sc["obs_cam"] != 7
+    sc["obs_cam"], sc["obs_pt"], sc["obs_uv"] = sc["obs_cam"][keep], sc["obs_pt"][keep], np.ascontiguousarray(sc["obs_uv"][keep])
+    P0, I0, X0, s0 = orc_ba.solve(sc)
+    P1, I1, X1, s1 = ba.solve_scene(gpu_ctx, sc)
+    assert s1["iterations"] == s0["iterations"] and abs(s1["final_rms_px"] - s0["final_rms_px"]) <= RMS_TOL_PX
+    assert np.allclose(P1[7], sc["poses"][7], atol=1e-9)
+    # no Jacobi scaling, tiny trust region, nothing fixed but the defaults of the gauge
+    o0 = orc_ba.default_options(12)
+    o0.jacobi_scaling = 0
+    o0.initial_trust_region_radius = 10.0
+    o0.max_iterations = 8
+    o1 = ba.default_options(gpu_ctx, 12)
+    o1.jacobi_scaling = 0
+    o1.initial_trust_region_radius = 10.0
+    o1.max_iterations = 8
+    sc = synth_ba.make_scene(12, 200, obs_per_point=6, seed=14)
+    P0, I0, X0, s0 = orc_ba.solve(sc, o0)
+    P1, I1, X1, s1 = ba.solve_scene(gpu_ctx, sc, o1)
+    assert s1["iterations"] == s0["iterations"] and s1["termination"] == s0["termination"]
+    assert np.allclose(s1["cost_trace"], s0["cost_trace"], rtol=1e-7)
