@@ -762,6 +762,20 @@ static int ensure_counters(rcn_ctx *ctx)
 }
 // counters layout: [0] u32 maxabs bits, [2..3] u64 max nrm2 bits, [8 + 2c] fallback / [9 + 2c] survivor count of chunk c
 
+// rcn_match_pair keeps two scratch images resident (ids INT32_MIN, INT32_MIN+1) so that the next
+// call can reuse their allocations; they must not pin D when nothing else is resident.
+static int drop_scratch_if_alone(rcn_ctx *ctx, int32_t D)
+{
+    if (ctx->images.empty() || ctx->D == D) return RCN_OK;
+    for (const auto &kv : ctx->images)
+        if (kv.first != INT32_MIN && kv.first != INT32_MIN + 1) return RCN_OK;   // user images decide
+    RCN_HIP(hipStreamSynchronize(ctx->stream));
+    for (auto &kv : ctx->images) free_image(kv.second);
+    ctx->images.clear();
+    ctx->prepared = false;
+    return RCN_OK;
+}
+
 static int upload_common(rcn_ctx *ctx, int32_t img_id, const float *src, bool src_is_device,
                          int32_t K, int32_t D)
 {
@@ -769,6 +783,7 @@ static int upload_common(rcn_ctx *ctx, int32_t img_id, const float *src, bool sr
         if (ctx) ctx->set_error("rcn_desc_upload: bad argument");
         return RCN_ERR_ARG;
     }
+    { int rcd = drop_scratch_if_alone(ctx, D); if (rcd) return rcd; }
     if (!ctx->images.empty() && ctx->D != D) {
         ctx->set_error("rcn_desc_upload: all resident images must share D");
         return RCN_ERR_ARG;
@@ -778,21 +793,33 @@ static int upload_common(rcn_ctx *ctx, int32_t img_id, const float *src, bool sr
     if (rc) return rc;
     ctx->D = D;
     ctx->DP = pad_dim(D);
+    int Kp = (K + RCN_QT - 1) / RCN_QT * RCN_QT;
+    if (Kp == 0) Kp = RCN_QT;
+    const int DPa = ctx->DP ? ctx->DP : 32;
+    ImgHost im;
     auto it = ctx->images.find(img_id);
     if (it != ctx->images.end()) {
-        RCN_HIP(hipStreamSynchronize(ctx->stream));
-        free_image(it->second);
+        // same id again (the per-pair plugin path re-uploads on every call): keep the
+        // allocations when they are large enough; stream order protects in-flight readers
+        ImgHost &o = it->second;
+        if (o.slab < 0 && o.cap_rows >= Kp && o.cap_D == D) im = o;
+        else {
+            RCN_HIP(hipStreamSynchronize(ctx->stream));
+            free_image(o);
+        }
         ctx->images.erase(it);
     }
-    ImgHost im;
     im.K = K;
-    im.Kp = (K + RCN_QT - 1) / RCN_QT * RCN_QT;
-    if (im.Kp == 0) im.Kp = RCN_QT;
-    const int DPa = ctx->DP ? ctx->DP : 32;
-    RCN_HIP(hipMalloc(&im.f32, std::max<size_t>(16, (size_t)K * D * sizeof(float))));
-    RCN_HIP(hipMalloc(&im.f16, (size_t)im.Kp * DPa * sizeof(_Float16)));
-    RCN_HIP(hipMalloc(&im.hn, (size_t)im.Kp * sizeof(float)));
-    RCN_HIP(hipMalloc(&im.nrm2, std::max<size_t>(8, (size_t)K * sizeof(double))));
+    im.Kp = Kp;
+    im.dirty = true;
+    if (!im.f32) {
+        im.slab = -1;
+        im.cap_rows = Kp; im.cap_D = D;
+        RCN_HIP(hipMalloc(&im.f32, (size_t)Kp * D * sizeof(float)));
+        RCN_HIP(hipMalloc(&im.f16, (size_t)Kp * DPa * sizeof(_Float16)));
+        RCN_HIP(hipMalloc(&im.hn, (size_t)Kp * sizeof(float)));
+        RCN_HIP(hipMalloc(&im.nrm2, (size_t)Kp * sizeof(double)));
+    }
     if (K > 0) {
         RCN_HIP(hipMemcpyAsync(im.f32, src, (size_t)K * D * sizeof(float),
                                src_is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
@@ -815,6 +842,7 @@ static int upload_batch(rcn_ctx *ctx, int32_t first_id, int32_t n, const float *
         return RCN_ERR_ARG;
     }
     if (n == 0) return RCN_OK;
+    { int rcd = drop_scratch_if_alone(ctx, D); if (rcd) return rcd; }
     if (!ctx->images.empty() && ctx->D != D) {
         ctx->set_error("rcn_desc_upload_batch_device: all resident images must share D");
         return RCN_ERR_ARG;
@@ -850,7 +878,7 @@ static int upload_batch(rcn_ctx *ctx, int32_t first_id, int32_t n, const float *
     sl.f32 = src;
     for (int i = 0; i < n; ++i) {
         ImgHost im;
-        im.K = K; im.Kp = Kp; im.slab = si;
+        im.K = K; im.Kp = Kp; im.slab = si; im.dirty = true;
         im.f32 = const_cast<float *>(src) + (size_t)i * K * D;
         im.f16 = sl.f16 + (size_t)i * Kp * DPa;
         im.hn = sl.hn + (size_t)i * Kp;
@@ -899,18 +927,28 @@ static int prepare_all(rcn_ctx *ctx)
     int ex;
     (void)std::frexp((double)maxabs, &ex);  // maxabs = m * 2^ex, m in [0.5,1)
     const double s = std::ldexp(1.0, 14 - ex);
+    // the norm bound is rounded UP to a 1/16-octave grid so that it (and BIAS) stays put while
+    // images of similar norm come and go: then only new images need converting
+    int en;
+    const double mn = std::frexp(maxn2 * (1.0 + 1e-12), &en);            // in [0.5, 1)
+    const double maxn2q = std::ldexp(std::ceil(mn * 32.0) / 32.0, en);
+    const double bias = 0.5625 * s * s * maxn2q + 1.0;  // accumulator >= s^2 Nmax^2/16 > 0 for every (q,t)
+    const bool moved = s != ctx->scale || bias != ctx->bias;
     ctx->scale = s;
-    ctx->max_norm = std::sqrt(maxn2) * (1.0 + 1e-12);
-    ctx->bias = 0.5625 * s * s * maxn2 + 1.0;  // accumulator >= s^2 Nmax^2/16 > 0 for every (q,t)
+    ctx->max_norm = std::sqrt(maxn2q);
+    ctx->bias = bias;
     const double hs2 = 0.5 * s * s;
 
     std::vector<ImgDev> table;
     table.reserve(ctx->images.size());
     int slot = 0;
+    std::vector<char> slab_dirty(ctx->slabs.size(), 0);
     for (auto &kv : ctx->images) {
         ImgHost &im = kv.second;
         im.slot = slot++;
-        if (ctx->DP && im.slab < 0) {
+        const bool need = moved || im.dirty;
+        if (need && im.slab >= 0) slab_dirty[im.slab] = 1;
+        if (ctx->DP && im.slab < 0 && need) {
             switch (ctx->DP) {
             case 32: launch_prepare<32>(ctx, im, (float)s, hs2, ctx->bias); break;
             case 64: launch_prepare<64>(ctx, im, (float)s, hs2, ctx->bias); break;
@@ -919,11 +957,13 @@ static int prepare_all(rcn_ctx *ctx)
             }
             RCN_HIP(hipGetLastError());
         }
+        im.dirty = false;
         table.push_back(ImgDev{im.f32, im.f16, im.hn, im.nrm2, im.K, im.Kp});
     }
     if (ctx->DP)
-        for (const Slab &sl : ctx->slabs) {
-            if (!sl.live) continue;
+        for (size_t si = 0; si < ctx->slabs.size(); ++si) {
+            const Slab &sl = ctx->slabs[si];
+            if (!sl.live || !slab_dirty[si]) continue;
             switch (ctx->DP) {
             case 32: launch_prepare_batch<32>(ctx, sl, (float)s, hs2, ctx->bias); break;
             case 64: launch_prepare_batch<64>(ctx, sl, (float)s, hs2, ctx->bias); break;
@@ -1175,7 +1215,14 @@ int rcn_desc_clear(rcn_ctx *ctx)
     return RCN_OK;
 }
 
-int rcn_desc_count(const rcn_ctx *ctx) { return ctx ? (int)ctx->images.size() : 0; }
+int rcn_desc_count(const rcn_ctx *ctx)
+{
+    if (!ctx) return 0;
+    int n = 0;
+    for (const auto &kv : ctx->images)
+        if (kv.first != INT32_MIN && kv.first != INT32_MIN + 1) ++n;   // rcn_match_pair's scratch images do not count
+    return n;
+}
 
 int rcn_match_grid_device(rcn_ctx *ctx, const int32_t *pairs_host, int32_t n_pairs, float ratio,
                           int32_t *out_dev, int64_t out_stride, int32_t *counts_dev)
@@ -1221,6 +1268,7 @@ int rcn_match_pair(rcn_ctx *ctx, const float *q_host, int32_t K1, const float *t
     // a private two-image context state would serialise callers anyway; reuse a scratch ctx
     // slot pair under the lock (ids INT32_MIN, INT32_MIN+1 are reserved for this call)
     std::lock_guard<std::mutex> lk(ctx->mu);
+    { int rcd = drop_scratch_if_alone(ctx, D); if (rcd) return rcd; }
     if (!ctx->images.empty() && ctx->D != D) {
         ctx->set_error("rcn_match_pair: D differs from the resident images' D");
         return RCN_ERR_ARG;
@@ -1243,14 +1291,7 @@ int rcn_match_pair(rcn_ctx *ctx, const float *q_host, int32_t K1, const float *t
         RCN_HIP(hipStreamSynchronize(ctx->stream));
         if (out_count) *out_count = cnt;
     }
-    // drop the scratch images again
-    for (int32_t id : {ida, idb}) {
-        auto it = ctx->images.find(id);
-        if (it != ctx->images.end()) {
-            free_image(it->second);
-            ctx->images.erase(it);
-        }
-    }
+    // the two scratch images stay resident: the next call reuses their allocations
     ctx->prepared = false;
     return rc;
 }

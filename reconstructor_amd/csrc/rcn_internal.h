@@ -55,6 +55,8 @@ struct ImgHost {
     int32_t K = 0, Kp = 0;
     int32_t slot = -1;  // row in the device image table
     int32_t slab = -1;  // >= 0: buffers are views into ctx->slabs[slab] (batch upload)
+    int32_t cap_rows = 0, cap_D = 0;   // capacity of the owned allocations
+    bool dirty = true;  // fp16 copy / half-norms not yet built for the current scale
 };
 
 // One batch of equally shaped images (rcn_desc_upload_batch_device): one allocation per array.
@@ -81,7 +83,7 @@ struct rcn_ctx {
     std::vector<Slab> slabs;
     std::vector<int2> groups_host;   // kept alive: uploaded asynchronously
     bool prepared = false;
-    double scale = 1.0;      // s, power of two
+    double scale = 0.0;      // s, power of two (0 = nothing prepared yet)
     double bias = 0.0;       // BIAS in accumulator units
     double max_norm = 0.0;   // max |x| over resident rows
     DevBuf img_table, pairs_dev, groups_dev, cand, best, owner, fb_list, sv_list, counters, stats_dev, out_tmp, cnt_tmp;
