@@ -55,8 +55,8 @@ void rcn_destroy(rcn_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     rcn_match_release(ctx);
-    DevBuf *bufs[] = {&ctx->img_table, &ctx->pairs_dev, &ctx->groups_dev, &ctx->cand, &ctx->best, &ctx->owner,
-                      &ctx->fb_list, &ctx->sv_list, &ctx->counters, &ctx->stats_dev, &ctx->out_tmp, &ctx->cnt_tmp};
+    DevBuf *bufs[] = {&ctx->img_table, &ctx->pairs_dev, &ctx->groups_dev, &ctx->cand, &ctx->owner,
+                      &ctx->fb_list, &ctx->sv_list, &ctx->counters, &ctx->out_tmp, &ctx->cnt_tmp};
     for (DevBuf *b : bufs) b->release();
     for (DevBuf &b : ctx->ba_ws) b.release();
     if (ctx->ev_made)

@@ -86,7 +86,7 @@ struct rcn_ctx {
     double scale = 0.0;      // s, power of two (0 = nothing prepared yet)
     double bias = 0.0;       // BIAS in accumulator units
     double max_norm = 0.0;   // max |x| over resident rows
-    DevBuf img_table, pairs_dev, groups_dev, cand, best, owner, fb_list, sv_list, counters, stats_dev, out_tmp, cnt_tmp;
+    DevBuf img_table, pairs_dev, groups_dev, cand, owner, fb_list, sv_list, counters, out_tmp, cnt_tmp;
     rcn_match_stats last_stats;
     bool profile = false;
     hipEvent_t ev[64][4];
