@@ -142,3 +142,40 @@ def test_cfg3_shape_vs_oracle(matcher):
     st = matcher.stats()
     assert st["used_mfma_path"] == 1 and st["rows_exact_fallback"] < 0.01 * 4096
     print("cfg3 pair: matches", n, "reranked", st["rows_reranked"], "fallback", st["rows_exact_fallback"])
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_random_grids_vs_oracle(matcher, seed):
+    """Randomised differential test: ragged image sizes (including 0, 1, 2 and non-multiples of
+    the 64-row tile / 512-row work item), descriptor lengths on and off the MFMA path, pair lists
+    with repeats, both orientations and self pairs, integer-valued data with exact ties."""
+    rng = np.random.default_rng(1000 + seed)
+    D = int(rng.choice([3, 8, 32, 40, 64, 100, 128, 256, 260]))
+    n = int(rng.integers(2, 8))
+    ks = [int(rng.choice([0, 1, 2, 63, 64, 65, 200, 511, 512, 513, 700])) for _ in range(n)]
+    kind = int(rng.integers(0, 3))
+    ims = []
+    for k in ks:
+        if kind == 0:
+            a = rng.standard_normal((k, D)).astype(np.float32)
+        elif kind == 1:
+            a = rng.integers(0, 4, (k, D)).astype(np.float32)            # many exact ties
+        else:
+            a = (rng.standard_normal((k, D)) * 10.0 ** rng.integers(-3, 4)).astype(np.float32)
+        ims.append(np.ascontiguousarray(a))
+    if kind == 0 and n >= 2 and ks[0] and ks[1]:                            # plant true matches
+        m = min(ks[0], ks[1])
+        ims[1][:m] = ims[0][:m] + (rng.standard_normal((m, D)) * 0.05).astype(np.float32)
+    P = int(rng.integers(1, 25))
+    pairs = rng.integers(0, n, (P, 2)).astype(np.int32)
+    if rng.random() < 0.5:
+        pairs = pairs[np.lexsort((pairs[:, 1], pairs[:, 0]))]               # runs that share the query image
+    matcher.clear()
+    for i, im in enumerate(ims):
+        matcher.upload(i, im if im.shape[0] else np.zeros((0, D), np.float32))
+    kmax = max(1, max(ks))
+    out, counts = matcher.match_grid(pairs, kmax)
+    exp, ec = orc.match_grid([im if im.shape[0] else np.zeros((0, D), np.float32) for im in ims], pairs, threads=2)
+    assert np.array_equal(out, exp), (seed, D, ks, pairs.tolist())
+    assert np.array_equal(counts, ec)
+    matcher.clear()
