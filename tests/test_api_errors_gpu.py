@@ -1,0 +1,54 @@
+"""GPU suite: error behaviour of the C ABI (status codes, never a crash, message available)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from reconstructor_amd import _lib, synth_ba
+
+pytestmark = pytest.mark.gpu
+
+
+def test_matcher_errors(gpu_ctx):
+    from reconstructor_amd.matcher import HipL2Matcher
+    m = HipL2Matcher(ctx=gpu_ctx)
+    m.clear()
+    a = np.random.default_rng(0).standard_normal((70, 32)).astype(np.float32)
+    m.upload(0, a)
+    m.upload(1, a[:50])
+    with pytest.raises(_lib.RcnError) as e:                       # image 5 is not resident
+        m.match_grid(np.array([[0, 5]], np.int32), 70)
+    assert e.value.code == -5 and "not resident" in str(e.value)
+    with pytest.raises(_lib.RcnError) as e:                       # out_stride smaller than K of the query image
+        m.match_grid(np.array([[0, 1]], np.int32), 10)
+    assert e.value.code == -1
+    with pytest.raises(_lib.RcnError) as e:                       # D differs from the resident images
+        m.upload(2, np.zeros((5, 16), np.float32))
+    assert e.value.code == -1
+    out, counts = m.match_grid(np.zeros((0, 2), np.int32), 70)    # empty grid is fine
+    assert out.shape[0] == 0
+    assert gpu_ctx.lib.rcn_desc_count(gpu_ctx.h) == 2
+    m.clear()
+    assert gpu_ctx.lib.rcn_desc_count(gpu_ctx.h) == 0
+    rc = gpu_ctx.lib.rcn_match_pair(gpu_ctx.h, None, 4, None, 4, 8, 0.7, None, None)   # null pointers
+    assert rc == -1
+
+
+def test_ba_errors(gpu_ctx):
+    from reconstructor_amd import ba
+    sc = synth_ba.make_scene(3, 10, obs_per_point=3, seed=1)
+    bad = dict(sc)
+    bad["obs_pt"] = sc["obs_pt"][::-1].copy()                     # not landmark-major
+    with pytest.raises(_lib.RcnError) as e:
+        ba.solve_scene(gpu_ctx, bad)
+    assert e.value.code == -1 and "landmark-major" in str(e.value)
+    bad = dict(sc)
+    bad["obs_cam"] = sc["obs_cam"].copy(); bad["obs_cam"][0] = 9  # camera index out of range
+    with pytest.raises(_lib.RcnError):
+        ba.solve_scene(gpu_ctx, bad)
+    rc = gpu_ctx.lib.rcn_ba_solve(gpu_ctx.h, None, None, None)
+    assert rc == -1
+    # a degenerate problem (no observations) terminates cleanly
+    P, I, X, s = ba.solve_flat(gpu_ctx, sc["poses"], sc["intrinsics"], sc["points"],
+                               np.zeros((0, 2)), np.zeros(0, np.int32), np.zeros(0, np.int32))
+    assert s["iterations"] == 0 and np.array_equal(P, sc["poses"])
