@@ -166,6 +166,9 @@ typedef struct {
     int32_t bound_projections;
     int32_t reduced_dim;        /* rows of the reduced camera system */
     double  solve_seconds;      /* wall time of the LM loop, inputs resident */
+    double  schur_seconds;      /* HIP-event time, summed over iterations: point blocks + Schur build */
+    double  cholesky_seconds;   /* dense factorisation of the reduced system */
+    double  trisolve_seconds;   /* triangular solves + back-substitution + model/candidate evaluation */
     double  cost_trace[160];    /* cost after each iteration, [0] = initial */
 } rcn_ba_summary;
 

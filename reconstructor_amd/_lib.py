@@ -63,7 +63,9 @@ class BaSummary(C.Structure):
                 ("unsuccessful_steps", C.c_int32), ("invalid_steps", C.c_int32),
                 ("termination", C.c_int32), ("line_search_backtracks", C.c_int32),
                 ("bound_projections", C.c_int32), ("reduced_dim", C.c_int32),
-                ("solve_seconds", C.c_double), ("cost_trace", C.c_double * 160)]
+                ("solve_seconds", C.c_double), ("schur_seconds", C.c_double),
+                ("cholesky_seconds", C.c_double), ("trisolve_seconds", C.c_double),
+                ("cost_trace", C.c_double * 160)]
 
 
 _LIB = None

@@ -23,6 +23,12 @@ def run_config(ctx, n_cams, n_points, seed=2024, repeats=2):
         "initial_rms_px": best["initial_rms_px"], "final_rms_px": best["final_rms_px"],
         "termination": ba.TERMINATION.get(best["termination"], "?"), "reduced_dim": n,
         "cholesky_flop_per_iteration": chol_flop,
+        "phase_seconds": {"schur": best["schur_seconds"], "cholesky": best["cholesky_seconds"],
+                          "triangular_solves_and_step": best["trisolve_seconds"]},
+        # dense factorisation on v_mfma_f64_16x16x4_f64 against the FP64 matrix peak
+        "cholesky_roofline": {"bound": "mfma", "achieved": chol_flop * best["iterations"] / max(best["cholesky_seconds"], 1e-12) / 1e12,
+                              "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                              "frac": chol_flop * best["iterations"] / max(best["cholesky_seconds"], 1e-12) / 1e12 / FP64_MFMA_PEAK_TFLOPS},
     }
 
 

@@ -1083,6 +1083,7 @@ int rcn_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_options *o
             RCN_HIP(hipGetLastError());
         }
         const double ir = 1.0 / radius;
+        RCN_HIP(hipEventRecord(ctx->ba_tev[0], st));
         RCN_HIP(hipMemsetAsync(d.flag, 0, sizeof(int), st));
         RCN_HIP(hipMemsetAsync(Sb, 0, sizeof(double) * 100 * (size_t)nc * nc, st));
         if (npad > n) RCN_HIP(hipMemsetAsync(d.S + (size_t)n * npad, 0, sizeof(double) * (size_t)(npad - n) * npad, st));
@@ -1092,6 +1093,7 @@ int rcn_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_options *o
         k_ba_S_assemble<<<nc + 1, 256, 0, st>>>(d, Sb, ir);
         k_ba_cam_rhs<<<nc, 64, 0, st>>>(d);
         RCN_HIP(hipGetLastError());
+        RCN_HIP(hipEventRecord(ctx->ba_tev[1], st));
         // dense Cholesky, right-looking, 128-wide panels, lookahead 1: the serial chain
         // [first trailing tile column -> diagonal block -> panel] of step kb+1 runs on `st`
         // while the rest of step kb's trailing update runs on the auxiliary stream
@@ -1119,6 +1121,7 @@ int rcn_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_options *o
             }
             RCN_HIP(hipGetLastError());
         }
+        RCN_HIP(hipEventRecord(ctx->ba_tev[2], st));
         for (int kb = 0; kb < nblk; ++kb) k_trsv_fwd<<<nblk - kb, 128, 0, st>>>(d.S, npad, kb, d.Linv, d.rhs, d.yc);
         for (int kb = nblk - 1; kb >= 0; --kb) k_trsv_bwd<<<kb + 1, 128, 0, st>>>(d.S, npad, kb, d.Linv, d.yc, d.rhs);
         RCN_HIP(hipGetLastError());
@@ -1135,7 +1138,14 @@ int rcn_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_options *o
         RCN_HIP(eval(false, d.poses2, d.intr2, d.pts2, 1));
         int hflag = 0;
         RCN_HIP(hipMemcpyAsync(&hflag, d.flag, sizeof(int), hipMemcpyDeviceToHost, st));
+        RCN_HIP(hipEventRecord(ctx->ba_tev[3], st));
         RCN_HIP(read_scal(10));
+        {
+            float ms = 0.f;
+            RCN_HIP(hipEventElapsedTime(&ms, ctx->ba_tev[0], ctx->ba_tev[1])); sum->schur_seconds += 1e-3 * ms;
+            RCN_HIP(hipEventElapsedTime(&ms, ctx->ba_tev[1], ctx->ba_tev[2])); sum->cholesky_seconds += 1e-3 * ms;
+            RCN_HIP(hipEventElapsedTime(&ms, ctx->ba_tev[2], ctx->ba_tev[3])); sum->trisolve_seconds += 1e-3 * ms;
+        }
         reuse_diag = true;
         const double model_change = hs[2];
         const bool solve_ok = hflag == 0 && hs[9] == 0.0 && std::isfinite(model_change);

@@ -37,6 +37,8 @@ int rcn_create(int device_id, rcn_ctx **out)
     }
     for (auto &e : ctx->ba_ev)
         if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { delete ctx; return RCN_ERR_HIP; }
+    for (auto &e : ctx->ba_tev)
+        if (hipEventCreate(&e) != hipSuccess) { delete ctx; return RCN_ERR_HIP; }
     ctx->ba_ev_made = true;
     const char *fe = std::getenv("RCN_FORCE_EXACT");
     ctx->force_exact = fe && fe[0] == '1';
@@ -63,7 +65,7 @@ void rcn_destroy(rcn_ctx *ctx)
         for (auto &row : ctx->ev)
             for (auto &e : row) (void)hipEventDestroy(e);
     if (ctx->ba_ev_made)
-        for (auto &e : ctx->ba_ev) (void)hipEventDestroy(e);
+        { for (auto &e : ctx->ba_ev) (void)hipEventDestroy(e); for (auto &e : ctx->ba_tev) (void)hipEventDestroy(e); }
     if (ctx->aux_stream) (void)hipStreamDestroy(ctx->aux_stream);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;

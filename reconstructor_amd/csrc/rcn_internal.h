@@ -100,6 +100,7 @@ struct rcn_ctx {
     DevBuf ba_ws[24];
     hipStream_t aux_stream = nullptr;   // lookahead stream of the Cholesky
     hipEvent_t ba_ev[9];
+    hipEvent_t ba_tev[4];            // phase timing of rcn_ba_solve
     bool ba_ev_made = false;
 
     void set_error(const std::string &s) { err = s; }
