@@ -513,34 +513,48 @@ __global__ __launch_bounds__(256) void k_chol_diag(double *S, int ld, int kb, do
         if (misc[0] != 0.0) { if (t == 0) *flag = 1; return; }
         const int r0 = c0 + LB;
         if (r0 >= NB) break;
-        // 1b. rows below: L[i, c0:c0+32] <- L[i, c0:c0+32] D^-T, one thread per row, row in registers
-        if (t < NB - r0) {
-            double *rowp = L + (r0 + t) * DL + c0;
-            double x[LB];
+        // 1b. rows below: X = A * D^-T as 16x16 MFMA tiles (one wave per tile), in place:
+        //     X[r][c] = sum_{k<=c} A[r][k] * Dinv[c][k]
+        {
+            const int leaf = c0 / LB, ntile = (NB - r0) / 16;
+            for (int tile = w; tile < ntile; tile += 4) {
+                double *At = L + (r0 + 16 * tile) * DL + c0;
+                f64x4 acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-            for (int c = 0; c < LB; ++c) x[c] = rowp[c];
+                for (int kk = 0; kk < LB; kk += 4) {
+                    const int k = kk + (lane >> 4), c = lane & 15;
+                    const double a = At[(lane & 15) * DL + k];
+                    const double b = k <= c ? dinv_at(L, rd, leaf, c, k) : 0.0;
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+                }
 #pragma unroll
-            for (int c = 0; c < LB; ++c) {
-                const double *dc = L + (c0 + c) * DL + c0;
-                double v = x[c];
-#pragma unroll
-                for (int m = 0; m < c; ++m) v -= x[m] * dc[m];
-                x[c] = v * rd[c0 + c];
+                for (int reg = 0; reg < 4; ++reg) At[((lane >> 4) + 4 * reg) * DL + (lane & 15)] = acc[reg];
             }
-#pragma unroll
-            for (int c = 0; c < LB; ++c) rowp[c] = x[c];
         }
         __syncthreads();
         STAMP(2);
-        // 1c. trailing square -= panel panel^T ; thread (ty,tx) owns rows ty+16u, cols tx+16v
-        switch ((NB - r0) / 16) {
-        case 7: trail_update<7>(L, r0, c0, t); break;
-        case 6: trail_update<6>(L, r0, c0, t); break;
-        case 5: trail_update<5>(L, r0, c0, t); break;
-        case 4: trail_update<4>(L, r0, c0, t); break;
-        case 3: trail_update<3>(L, r0, c0, t); break;
-        case 2: trail_update<2>(L, r0, c0, t); break;
-        default: trail_update<1>(L, r0, c0, t); break;
+        // 1c. trailing square -= panel panel^T, lower 16x16 tiles on MFMA: the accumulator starts
+        //     as the C tile and the A operand is negated
+        {
+            const int nt = (NB - r0) / 16, ntile = nt * (nt + 1) / 2;
+            for (int tile = w; tile < ntile; tile += 4) {
+                int tr = (int)((sqrtf(8.f * tile + 1.f) - 1.f) * 0.5f);
+                while ((tr + 1) * (tr + 2) / 2 <= tile) ++tr;
+                while (tr * (tr + 1) / 2 > tile) --tr;
+                const int tcn = tile - tr * (tr + 1) / 2;
+                double *Ct = L + (r0 + 16 * tr) * DL + r0 + 16 * tcn;
+                const double *Pa = L + (r0 + 16 * tr) * DL + c0, *Pb = L + (r0 + 16 * tcn) * DL + c0;
+                f64x4 acc;
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) acc[reg] = Ct[((lane >> 4) + 4 * reg) * DL + (lane & 15)];
+#pragma unroll
+                for (int kk = 0; kk < LB; kk += 4) {
+                    const int k = kk + (lane >> 4);
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-Pa[(lane & 15) * DL + k], Pb[(lane & 15) * DL + k], acc, 0, 0, 0);
+                }
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) Ct[((lane >> 4) + 4 * reg) * DL + (lane & 15)] = acc[reg];
+            }
         }
         __syncthreads();
         STAMP(3);
@@ -554,64 +568,59 @@ __global__ __launch_bounds__(256) void k_chol_diag(double *S, int ld, int kb, do
     // 2a. (leaf inverses were produced by wave 0 right after each leaf factorization)
     __syncthreads();
     STAMP(15);
-    // 2b. the 32x32 leaf inverses from the 16x16 ones: for each 32-block the off-diagonal
-    //     16x16 block becomes  -Dinv_hi * (L_hi,lo * Dinv_lo)  in place.
+    // 2b. the 32x32 leaf inverses from the 16x16 ones: in every 32-block the off-diagonal 16x16
+    //     block becomes  -Dinv_hi * (L_hi,lo * Dinv_lo)  in place (one wave per 32-block).
     {
-        const int tr = t >> 4, tc = t & 15;   // one element of a 16x16 block per thread
-        double tv[4];
+        const int i = 2 * w + 1, j = 2 * w;
+        double *Bt = L + (LB * i) * DL + LB * j;
+        f64x4 acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            const int i = 2 * b + 1, j = 2 * b;
-            double acc = 0.0;
-            for (int k = tc; k < LB; ++k) acc += L[(LB * i + tr) * DL + LB * j + k] * dinv_at(L, rd, j, k, tc);
-            tv[b] = acc;
+        for (int kk = 0; kk < LB; kk += 4) {       // T = L_ij * Dinv_j
+            const int k = kk + (lane >> 4), c = lane & 15;
+            const double b = c <= k ? dinv_at(L, rd, j, k, c) : 0.0;
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Bt[(lane & 15) * DL + k], b, acc, 0, 0, 0);
         }
-        __syncthreads();
 #pragma unroll
-        for (int b = 0; b < 4; ++b) L[(LB * (2 * b + 1) + tr) * DL + LB * (2 * b) + tc] = tv[b];
-        __syncthreads();
+        for (int reg = 0; reg < 4; ++reg) Bt[((lane >> 4) + 4 * reg) * DL + (lane & 15)] = acc[reg];
+        acc = (f64x4){0.0, 0.0, 0.0, 0.0};       // same wave: LDS order makes T visible
 #pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            const int i = 2 * b + 1, j = 2 * b;
-            double acc = 0.0;
-            for (int k = 0; k <= tr; ++k) acc -= dinv_at(L, rd, i, tr, k) * L[(LB * i + k) * DL + LB * j + tc];
-            tv[b] = acc;
+        for (int kk = 0; kk < LB; kk += 4) {       // X = -Dinv_i * T
+            const int k = kk + (lane >> 4), r = lane & 15;
+            const double a = k <= r ? -dinv_at(L, rd, i, r, k) : 0.0;
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Bt[k * DL + (lane & 15)], acc, 0, 0, 0);
         }
-        __syncthreads();
 #pragma unroll
-        for (int b = 0; b < 4; ++b) L[(LB * (2 * b + 1) + tr) * DL + LB * (2 * b) + tc] = tv[b];
-        __syncthreads();
+        for (int reg = 0; reg < 4; ++reg) Bt[((lane >> 4) + 4 * reg) * DL + (lane & 15)] = acc[reg];
     }
-    // 2c. off-diagonal 32x32 blocks, left to right, in place; thread owns row tr, columns tc+8v
+    __syncthreads();
+    // 2c. off-diagonal 32x32 blocks, left to right, in place:
+    //         X[i][j] = -Dinv32_i * sum_{m=j}^{i-1} L[i][m] X[m][j],   X[j][j] = Dinv32_j.
+    //     Wave w owns the 16x16 quadrant (w>>1, w&1) of the block; two MFMA passes per block.
     {
-        const int tr = t >> 3, tc = t & 7;   // 32 rows x 8 column groups -> 4 columns each
+        const int qr = (w >> 1) * 16, qc = (w & 1) * 16;
         for (int j = 0; j < 3; ++j)
             for (int i = j + 1; i < 4; ++i) {
-                double T4[4] = {0, 0, 0, 0};
+                f64x4 acc = {0.0, 0.0, 0.0, 0.0};
                 for (int m = j; m < i; ++m)
-                    for (int k = 0; k < 32; ++k) {
-                        const double lik = L[(32 * i + tr) * DL + 32 * m + k];
-#pragma unroll
-                        for (int v = 0; v < 4; ++v) {
-                            const int c = tc + 8 * v;
-                            // X[m][j](k,c): leaf inverse when m == j (lower-triangular), else the finished block
-                            const double xv = m == j ? (c <= k ? dinv32_at(L, rd, j, k, c) : 0.0) : L[(32 * m + k) * DL + 32 * j + c];
-                            T4[v] += lik * xv;
-                        }
+                    for (int kk = 0; kk < 32; kk += 4) {
+                        const int k = kk + (lane >> 4), c = qc + (lane & 15);
+                        const double a = L[(32 * i + qr + (lane & 15)) * DL + 32 * m + k];
+                        const double b = m == j ? (c <= k ? dinv32_at(L, rd, j, k, c) : 0.0) : L[(32 * m + k) * DL + 32 * j + c];
+                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
                     }
                 __syncthreads();   // every read of the original L[i][j] is done
 #pragma unroll
-                for (int v = 0; v < 4; ++v) L[(32 * i + tr) * DL + 32 * j + tc + 8 * v] = T4[v];
+                for (int reg = 0; reg < 4; ++reg) L[(32 * i + qr + (lane >> 4) + 4 * reg) * DL + 32 * j + qc + (lane & 15)] = acc[reg];
                 __syncthreads();
-                double X4[4] = {0, 0, 0, 0};
-                for (int k = 0; k <= tr; ++k) {
-                    const double dv = dinv32_at(L, rd, i, tr, k);
-#pragma unroll
-                    for (int v = 0; v < 4; ++v) X4[v] -= dv * L[(32 * i + k) * DL + 32 * j + tc + 8 * v];
+                acc = (f64x4){0.0, 0.0, 0.0, 0.0};
+                for (int kk = 0; kk < 32; kk += 4) {
+                    const int k = kk + (lane >> 4), r = qr + (lane & 15);
+                    const double a = k <= r ? -dinv32_at(L, rd, i, r, k) : 0.0;
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, L[(32 * i + k) * DL + 32 * j + qc + (lane & 15)], acc, 0, 0, 0);
                 }
                 __syncthreads();
 #pragma unroll
-                for (int v = 0; v < 4; ++v) L[(32 * i + tr) * DL + 32 * j + tc + 8 * v] = X4[v];
+                for (int reg = 0; reg < 4; ++reg) L[(32 * i + qr + (lane >> 4) + 4 * reg) * DL + 32 * j + qc + (lane & 15)] = acc[reg];
                 __syncthreads();
             }
     }
