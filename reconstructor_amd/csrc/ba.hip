@@ -450,8 +450,9 @@ __global__ __launch_bounds__(256) void k_chol_diag(double *S, int ld, int kb, do
 {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     double *L = reinterpret_cast<double *>(smem_raw);  // [128][DL]
-    __shared__ double rd[NB + 2];                       // reciprocals of L's diagonal; [NB] = breakdown flag
+    __shared__ double rd[NB + 2 + 64];                  // reciprocals of L's diagonal; [NB] = breakdown flag; [NB+2..] pivot column line
     double *misc = rd + NB;                             // (16-byte multiple keeps the dynamic base aligned)
+    double *colb = rd + NB + 2;
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     double *A = S + ((size_t)kb * NB) * ld + (size_t)kb * NB;
     if (t == 0) misc[0] = 0.0;
@@ -462,27 +463,34 @@ __global__ __launch_bounds__(256) void k_chol_diag(double *S, int ld, int kb, do
     __syncthreads();
     STAMP(0);
     for (int c0 = 0; c0 < NB; c0 += LB) {
-        // 1a. 32x32 leaf by wave 0 alone, entirely in registers: lane l holds row l; a column
-        //     entry of another row arrives by v_readlane (uniform lane index), so there is no
-        //     LDS read-modify-write chain on the critical path
+        // 1a. 16x16 leaf by wave 0 alone: lane l holds row l in registers; the pivot column is
+        //     broadcast through a small LDS line (one ds_write + uniform-address reads per pivot;
+        //     LDS operations of one wave are ordered, so no workgroup barrier inside)
         if (w == 0) {
             const int row = lane & (LB - 1);
             double a[LB];
 #pragma unroll
             for (int c = 0; c < LB; ++c) a[c] = L[(c0 + row) * DL + c0 + c];
             bool ok = true;
-            double myinv = 0.0;   // lane j keeps 1 / L[j][j]
 #pragma unroll
             for (int j = 0; j < LB; ++j) {
-                const double djj = rdlane(a[j], j);
+                colb[lane] = a[j];
+                const double djj = colb[j];
                 if (!(djj > 0.0) || !isfinite(djj)) ok = false;      // wave-uniform
-                const double dj = sqrt(djj), inv = 1.0 / dj;
+                // 1/sqrt and sqrt from v_rsq_f64 + Newton steps
+                double inv = __builtin_amdgcn_rsq(djj);
+                inv = inv * (1.5 - 0.5 * djj * inv * inv);
+                inv = inv * (1.5 - 0.5 * djj * inv * inv);
+                double dj = djj * inv;
+                dj = fma(0.5 * inv, fma(-dj, dj, djj), dj);
+                inv = fma(inv, fma(-dj, inv, 1.0), inv);
                 a[j] = row == j ? dj : a[j] * inv;
-                if (row == j) myinv = inv;
                 if (lane == 0) rd[c0 + j] = inv;
-                // every lane updates its whole row: entries right of the diagonal are scratch
+                // every lane updates its whole row (entries right of the diagonal are scratch):
+                //   a[c] -= L[row][j] * L[c][j],   L[c][j] = colb[c] * inv
+                const double tj = a[j] * inv;
 #pragma unroll
-                for (int c = j + 1; c < LB; ++c) a[c] -= a[j] * rdlane(a[j], c);
+                for (int c = j + 1; c < LB; ++c) a[c] = fma(-tj, colb[c], a[c]);
             }
             if (!ok && lane == 0) misc[0] = 1.0;
             if (lane < LB) {
@@ -490,16 +498,18 @@ __global__ __launch_bounds__(256) void k_chol_diag(double *S, int ld, int kb, do
                 for (int c = 0; c < LB; ++c)
                     if (c <= row) L[(c0 + row) * DL + c0 + c] = a[c];
             }
-            // leaf inverse straight from the registers: lane c -> column c of D^-1
-            //   x[r] = (delta_rc - sum_{m<r} L[r][m] x[m]) / L[r][r],  L[r][m] = readlane(a[m], r)
+            // leaf inverse, lane c -> column c of D^-1 by forward substitution; row r of the
+            // factor comes back as uniform-address LDS reads
             {
+                const double *Lw = L + c0 * DL + c0;
                 double x[LB];
 #pragma unroll
                 for (int r = 0; r < LB; ++r) {
-                    double sacc = r == row ? 1.0 : 0.0;
+                    double s0 = r == row ? 1.0 : 0.0, s1 = 0.0;      // two chains halve the dependent depth
 #pragma unroll
-                    for (int m = 0; m < r; ++m) sacc -= rdlane(a[m], r) * x[m];
-                    x[r] = sacc * rdlane(myinv, r);
+                    for (int m = 0; m + 1 < r; m += 2) { s0 = fma(-Lw[r * DL + m], x[m], s0); s1 = fma(-Lw[r * DL + m + 1], x[m + 1], s1); }
+                    if (r & 1) s0 = fma(-Lw[r * DL + r - 1], x[r - 1], s0);
+                    x[r] = (s0 + s1) * rd[c0 + r];
                 }
                 if (lane < LB) {
 #pragma unroll
