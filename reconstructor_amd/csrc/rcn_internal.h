@@ -97,7 +97,8 @@ struct rcn_ctx {
     bool force_exact = false;  // RCN_FORCE_EXACT=1: skip the MFMA coarse pass (diagnostics)
 
     // ---- BA state (ba.hip)
-    DevBuf ba_ws[24];
+    DevBuf ba_ws[28];
+    bool ba_atomics = false;   // RCN_BA_SCHUR_ATOMICS=1: atomic Schur accumulation instead of the gather form
     hipStream_t aux_stream = nullptr;   // lookahead stream of the Cholesky
     hipEvent_t ba_ev[9];
     hipEvent_t ba_tev[4];            // phase timing of rcn_ba_solve
