@@ -179,3 +179,16 @@ def test_random_grids_vs_oracle(matcher, seed):
     assert np.array_equal(out, exp), (seed, D, ks, pairs.tolist())
     assert np.array_equal(counts, ec)
     matcher.clear()
+
+
+@pytest.mark.parametrize("kind", ["superpoint", "sift"])
+def test_power_of_two_scale_invariance(matcher, kind):
+    """Scaling every descriptor by 2^k commutes with every operation of the canonical matcher
+    (no under/overflow here), so the match table must not change: exercises the global
+    power-of-two scale, the bias and the error-bound constants end to end."""
+    ims = synth.descriptor_set(kind, 2, [600, 700], n_world=1500, seed=31)
+    base = matcher.match_pair(ims[0], ims[1])
+    assert np.array_equal(base, orc.match_pair(ims[0], ims[1])[0])
+    for k in (-40, -7, 9, 33):
+        f = np.float32(2.0 ** k)
+        assert np.array_equal(matcher.match_pair(ims[0] * f, ims[1] * f), base), k

@@ -71,3 +71,11 @@ def test_ragged_and_threads_agree():
         if ims[a].shape[0]:
             assert np.array_equal(o1[p, :ims[a].shape[0]], indep.numpy_match_pair(ims[a], ims[b]))
         assert (o1[p, ims[a].shape[0]:] == -1).all()
+
+
+def test_oracle_power_of_two_scale_invariance():
+    ims = synth.descriptor_set("superpoint", 2, [120, 150], n_world=300, seed=31)
+    base, _ = orc.match_pair(ims[0], ims[1])
+    for k in (-40, 9, 33):
+        f = np.float32(2.0 ** k)
+        assert np.array_equal(orc.match_pair(ims[0] * f, ims[1] * f)[0], base)
