@@ -220,10 +220,12 @@ def main():
         if world == 1 and n_img == N_IMAGES_1GPU and os.path.exists(tpath):
             traffic = json.load(open(tpath))["traffic_bytes_per_launch"]   # PMC passes, see the file
         line = {
-            "metric": "descriptor pair-distances/s (256-d L2, exact 2-NN + ratio + uniqueness, all image pairs)",
+            "metric": "descriptor pair-distances/s + BA LM-iterations/s (1k cams, 100k pts)",
+            "metric_note": "value = 256-d L2 pair-distances/s of the whole step (exact 2-NN + ratio + uniqueness over all image pairs); BA LM-iterations/s are in `ba` (single GPU: BA does not shard)",
             "value": value, "unit": "pair-distances/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f16 MFMA coarse + f64 exact re-rank",
+            "scaling": "weak", "vs_baseline": None, "dtype": "f16+f64",
+            "dtype_note": "f16 MFMA (f32 accumulate) coarse pass, f64 exact re-rank; indices bit-exact vs the f64 oracle",
             "data": "synthetic",
             "config": {"workload": ("cfg2" if K_PER_IMAGE == 2048 else "custom") + ": %d images x %d keypoints x %d-d, %d image pairs%s"
                                    % (n_img, K_PER_IMAGE, D, len(pairs),
@@ -245,6 +247,7 @@ def main():
             line["cpu_baseline"] = None
         if not args.no_ba and world == 1:
             line["ba"] = ba_leg(matcher.ctx, not args.no_cpu_baseline)
+            line["ba_lm_iterations_per_s"] = line["ba"]["cfg5"]["lm_iterations_per_s"]   # 1k cams / 100k pts / 1M obs
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
