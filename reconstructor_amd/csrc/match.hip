@@ -472,7 +472,8 @@ __device__ __forceinline__ void list_append(unsigned long long *list, unsigned *
 
 // K2a: one thread per (pair, query row): decide from the coarse values alone whenever the
 // ratio test fails for every distance pair compatible with the error bound (the common case:
-// queries without a true counterpart have dist0 ~ dist1); the rest go to the survivor list.
+// queries without a true counterpart have dist0 ~ dist1) or passes for every such pair (clear
+// matches: dist0 << dist1); only the undecided rows go to the survivor list.
 #define RCN_FB 1024   // rows per k_filter workgroup: one atomic per list per workgroup
 __global__ __launch_bounds__(RCN_FB) void k_filter(RerankArgs a)
 {
@@ -500,6 +501,22 @@ __global__ __launch_bounds__(RCN_FB) void k_filter(RerankArgs a)
                 const double ub1 = acc_to_d2(a, nq2, hi + eps) + slack;
                 if (lb0 < 0.0) lb0 = 0.0;
                 surv = ratio_pass(lb0, ub1, a.ratio);
+                // certified PASS from the coarse values alone: the best candidate's exact
+                // distance is <= ub0, every other row's is >= lbnc (acc >= trunc(second)).
+                // sqrtf, the fp32 conversion and the product with a positive ratio are monotone,
+                // so the test holding at (ub0, lbnc) holds for the exact pair; ub0 < lbnc makes
+                // the candidate the unique nearest neighbour.  No distance needs recomputing.
+                if (surv && ti.K > 2) {
+                    const double hi0 = (double)__uint_as_float((c.x & ~a.idx_mask) + a.idx_mask + 1u);
+                    const double lo1 = (double)__uint_as_float(c.y & ~a.idx_mask);
+                    const double ub0 = acc_to_d2(a, nq2, hi0 + eps) + slack;
+                    double lbnc = acc_to_d2(a, nq2, lo1 - eps) - slack;
+                    if (lbnc < 0.0) lbnc = 0.0;
+                    if (ub0 >= 0.0 && ub0 < lbnc && ratio_pass(ub0, lbnc, a.ratio)) {
+                        *o = (int32_t)(c.x & a.idx_mask);
+                        surv = false;
+                    }
+                }
             }
         }
     }
