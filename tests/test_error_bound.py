@@ -54,3 +54,35 @@ def test_mixed_magnitudes():
     t = (rng.standard_normal((80, 64)) * 10.0 ** rng.integers(-6, 1, (80, 1))).astype(np.float32)
     acc, exact, eps, s, bias = _emulate(q, t)
     assert (np.abs(acc - exact) <= eps[:, None]).all() and (acc > 0).all()
+
+
+@pytest.mark.parametrize("kind,K", [("superpoint", 400), ("sift", 300)])
+def test_filter_decisions_agree_with_exact_knn(kind, K):
+    """k_filter's two certificates (match.hip), emulated: rows it certifies as 'no match' or as
+    'match = coarse best' must agree with the exact 2-NN + ratio test of the oracle."""
+    from oracle import orc
+    ims = synth.descriptor_set(kind, 2, K, n_world=2 * K, seed=9)
+    q, t = ims[0], ims[1]
+    acc, exact, eps, s, bias = _emulate(q, t)
+    K2 = t.shape[0]
+    bits = max(1, int(np.ceil(np.log2(K2))))
+    mask = np.uint32((1 << bits) - 1)
+    packed = (acc.astype(np.float32).view(np.uint32) & ~mask) | np.arange(K2, dtype=np.uint32)[None, :]
+    packed.sort(axis=1)
+    c0, c1 = packed[:, 0], packed[:, 1]
+    f = lambda u: u.astype(np.uint32).view(np.float32).astype(np.float64)
+    nq2 = (q.astype(np.float64) ** 2).sum(1)
+    d2 = lambda a_: nq2 + (2.0 / (s * s)) * (a_ - bias)
+    lo0, hi0 = f(c0 & ~mask), f((c0 & ~mask) + mask + np.uint32(1))
+    lo1, hi1 = f(c1 & ~mask), f((c1 & ~mask) + mask + np.uint32(1))
+    lb0, ub1 = np.maximum(d2(lo0 - eps), 0.0), d2(hi1 + eps)
+    ub0, lbnc = d2(hi0 + eps), np.maximum(d2(lo1 - eps), 0.0)
+    rp = lambda a_, b_: np.sqrt(a_.astype(np.float32)) < np.float32(0.7) * np.sqrt(b_.astype(np.float32))
+    cert_fail = ~rp(lb0, ub1)
+    cert_pass = ~cert_fail & (ub0 < lbnc) & rp(ub0, lbnc)
+    idx, dd = orc.knn2(q, t)
+    truth = np.where(rp(dd[:, 0], dd[:, 1]), idx[:, 0], -1)
+    assert (truth[cert_fail] == -1).all()
+    assert (truth[cert_pass] == (c0 & mask).astype(np.int64)[cert_pass]).all()
+    # the certificates decide nearly everything on descriptor-like data
+    assert (cert_fail | cert_pass).mean() > 0.98 and cert_pass.sum() > 0
