@@ -56,7 +56,8 @@ int rcn_desc_upload_device(rcn_ctx *ctx, int32_t img_id, const float *desc_dev, 
  * buffer is BORROWED (zero copy) until rcn_desc_clear / re-upload of those ids: the caller
  * keeps it alive and unchanged.  One stats launch + one conversion launch for the whole
  * batch; calling it again with the same shape reuses every allocation (per-step ingest of
- * an all-gather landing buffer). */
+ * an all-gather landing buffer).  When D % 4 == 0 the block must be 16-byte aligned
+ * (RCN_ERR_ARG otherwise; hipMalloc / torch allocations are). */
 int rcn_desc_upload_batch_device(rcn_ctx *ctx, int32_t first_img_id, int32_t n_images,
                                  const float *desc_dev, int32_t K, int32_t D);
 int rcn_desc_clear(rcn_ctx *ctx);

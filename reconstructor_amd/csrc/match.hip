@@ -47,6 +47,7 @@ template <int DP> __host__ __device__ __forceinline__ int swz(int row)
 // Row statistics at upload: |x|^2 in fp64 and the running maxima that fix the global
 // power-of-two scale.  One wave per row, coalesced; |x|^2 only feeds error bounds (which carry
 // their own slack), so the summation order is free.
+template <bool VEC4>
 __global__ __launch_bounds__(256) void k_rowstats(const float *__restrict__ x, int K, int D, double *__restrict__ nrm2,
                                                   unsigned *__restrict__ g_maxabs_bits,
                                                   unsigned long long *__restrict__ g_maxnrm2_bits)
@@ -55,23 +56,55 @@ __global__ __launch_bounds__(256) void k_rowstats(const float *__restrict__ x, i
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
     float ma = 0.f;
     double mx = 0.0;
-    for (int j = wave; j < K; j += nwaves) {
-        const float *row = x + (size_t)j * D;
-        double acc = 0.0;
-        for (int k = lane; k < D; k += 64) {
-            const float v = row[k];
-            ma = fmaxf(ma, fabsf(v));
-            acc = fma((double)v, (double)v, acc);
+    if (VEC4) {
+        // D % 4 == 0, 16-B aligned rows: 16 lanes per row, 4 rows per wave step, float4 loads
+        const int sub = lane & 15, rsel = lane >> 4, nv = D >> 2;
+        for (int j0 = wave * 4; j0 < K; j0 += nwaves * 4) {
+            const int j = j0 + rsel;
+            double acc = 0.0;
+            if (j < K) {
+                const float4 *row = reinterpret_cast<const float4 *>(x + (size_t)j * D);
+                for (int k = sub; k < nv; k += 16) {
+                    const float4 v = row[k];
+                    ma = fmaxf(fmaxf(ma, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+                    acc = fma((double)v.x, (double)v.x, acc);
+                    acc = fma((double)v.y, (double)v.y, acc);
+                    acc = fma((double)v.z, (double)v.z, acc);
+                    acc = fma((double)v.w, (double)v.w, acc);
+                }
+            }
+            for (int o = 8; o; o >>= 1) acc += __shfl_xor(acc, o);
+            if (sub == 0 && j < K) nrm2[j] = acc;
+            mx = fmax(mx, acc);
         }
-        for (int o = 32; o; o >>= 1) acc += __shfl_xor(acc, o);
-        if (lane == 0) nrm2[j] = acc;
-        mx = fmax(mx, acc);
+        for (int o = 32; o >= 16; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o));
+    } else {
+        for (int j = wave; j < K; j += nwaves) {
+            const float *row = x + (size_t)j * D;
+            double acc = 0.0;
+            for (int k = lane; k < D; k += 64) {
+                const float v = row[k];
+                ma = fmaxf(ma, fabsf(v));
+                acc = fma((double)v, (double)v, acc);
+            }
+            for (int o = 32; o; o >>= 1) acc += __shfl_xor(acc, o);
+            if (lane == 0) nrm2[j] = acc;
+            mx = fmax(mx, acc);
+        }
     }
-    // non-negative floats / doubles order like their bit patterns
+    // non-negative floats / doubles order like their bit patterns.  One atomic pair per
+    // workgroup, and only when it would raise the maximum (a single word takes ~100 atomics/us).
+    __shared__ float s_ma[4];
+    __shared__ double s_mx[4];
     for (int o = 32; o; o >>= 1) ma = fmaxf(ma, __shfl_xor(ma, o));
-    if (lane == 0) {
-        atomicMax(g_maxabs_bits, __float_as_uint(ma));
-        atomicMax(g_maxnrm2_bits, (unsigned long long)__double_as_longlong(mx));
+    if (lane == 0) { s_ma[threadIdx.x >> 6] = ma; s_mx[threadIdx.x >> 6] = mx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w) { ma = fmaxf(ma, s_ma[w]); mx = fmax(mx, s_mx[w]); }
+        const unsigned a = __float_as_uint(ma);
+        const unsigned long long m = (unsigned long long)__double_as_longlong(mx);
+        if (a > __hip_atomic_load(g_maxabs_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(g_maxabs_bits, a);
+        if (m > __hip_atomic_load(g_maxnrm2_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(g_maxnrm2_bits, m);
     }
 }
 
@@ -696,6 +729,87 @@ __global__ __launch_bounds__(256) void k_exact_rows(const ImgDev *__restrict__ i
     }
 }
 
+// K2b for D % 4 == 0: same result as k_exact_rows, but train rows reach the lanes through LDS.
+// Each wave stages 64 consecutive train rows (and the query row) in 32-float chunks with whole
+// 128-B global segments (8 lanes per row) and every lane walks its own row's chain out of LDS,
+// carrying the fp64 accumulator across chunks -- the row-per-lane global access pattern of the
+// simple kernel is latency-bound (0.22 ms for 351 rows at cfg 2).
+#define EX_LD 36   // floats per staged row: 32 + 4 pad
+__global__ __launch_bounds__(256) void k_exact_rows_lds(const ImgDev *__restrict__ imgs,
+                                                         const int32_t *__restrict__ pairs,
+                                                         const unsigned long long *__restrict__ list,
+                                                         const unsigned *__restrict__ count, int D,
+                                                         float ratio, int32_t *__restrict__ out,
+                                                         int64_t out_stride)
+{
+    __shared__ __attribute__((aligned(16))) float tile[4][65 * EX_LD];
+    __shared__ double sb[4][2];
+    __shared__ int si[4][2];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const unsigned n = *count;
+    const int nchunk = (D + 31) / 32;
+    float *tw = tile[w];
+    for (unsigned it = blockIdx.x; it < n; it += gridDim.x) {
+        const unsigned long long e = list[it];
+        const int pair = (int)(e >> 32), q = (int)(e & 0xFFFFFFFFu);
+        const ImgDev qi = imgs[pairs[2 * pair]];
+        const ImgDev ti = imgs[pairs[2 * pair + 1]];
+        const float *qrow = qi.f32 + (size_t)q * D;
+        double b0 = INFINITY, b1 = INFINITY;
+        int i0 = 0x7FFFFFFF, i1 = 0x7FFFFFFF;
+        for (int base0 = 0; base0 < ti.K; base0 += 256) {      // uniform trip count over the waves
+            const int base = base0 + w * 64;
+            const int j = base + lane;
+            double acc = 0.0;
+            for (int ch = 0; ch < nchunk; ++ch) {
+                const int col = ch * 32 + (lane & 7) * 4;
+                float4 v[9];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int r = base + i * 8 + (lane >> 3);
+                    v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (col < D && r < ti.K) v[i] = *reinterpret_cast<const float4 *>(ti.f32 + (size_t)r * D + col);
+                }
+                v[8] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (lane < 8 && col < D) v[8] = *reinterpret_cast<const float4 *>(qrow + col);
+                __syncthreads();                                // previous chunk's LDS reads are done
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    *reinterpret_cast<float4 *>(tw + (i * 8 + (lane >> 3)) * EX_LD + (lane & 7) * 4) = v[i];
+                if (lane < 8) *reinterpret_cast<float4 *>(tw + 64 * EX_LD + lane * 4) = v[8];
+                __syncthreads();
+                const int kmax = min(32, D - ch * 32);
+                const float *trow = tw + lane * EX_LD, *qs = tw + 64 * EX_LD;
+                for (int k4 = 0; k4 < kmax; k4 += 4) {
+                    const float4 x = *reinterpret_cast<const float4 *>(qs + k4);
+                    const float4 y = *reinterpret_cast<const float4 *>(trow + k4);
+                    double d;
+                    d = (double)x.x - (double)y.x; acc = fma(d, d, acc);
+                    d = (double)x.y - (double)y.y; acc = fma(d, d, acc);
+                    d = (double)x.z - (double)y.z; acc = fma(d, d, acc);
+                    d = (double)x.w - (double)y.w; acc = fma(d, d, acc);
+                }
+            }
+            if (j < ti.K) {
+                if (acc < b0) { b1 = b0; i1 = i0; b0 = acc; i0 = j; }   // ascending j per lane: strict <
+                else if (acc < b1) { b1 = acc; i1 = j; }
+            }
+        }
+        for (int o = 32; o; o >>= 1) {
+            const double c0 = __shfl_xor(b0, o), c1 = __shfl_xor(b1, o);
+            const int j0 = __shfl_xor(i0, o), j1 = __shfl_xor(i1, o);
+            merge_top2(b0, i0, b1, i1, c0, j0, c1, j1);
+        }
+        __syncthreads();
+        if (lane == 0) { sb[w][0] = b0; sb[w][1] = b1; si[w][0] = i0; si[w][1] = i1; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int k = 1; k < 4; ++k) merge_top2(b0, i0, b1, i1, sb[k][0], si[k][0], sb[k][1], si[k][1]);
+            out[(size_t)pair * out_stride + q] = ratio_pass(b0, b1, ratio) ? i0 : -1;
+        }
+    }
+}
+
 // K3: uniqueness (FeatureMatcher.cpp:58-62): ascending query order, first claim wins
 //     == the smallest claiming query index per train row.
 __global__ void k_unique_claim(const ImgDev *__restrict__ imgs, const int32_t *__restrict__ pairs,
@@ -738,6 +852,16 @@ static int pad_dim(int D)
     if (D <= 128) return 128;
     if (D <= 256) return 256;
     return 0;  // no MFMA path
+}
+
+static hipError_t launch_rowstats(rcn_ctx *ctx, const float *x, int rows, int D, double *nrm2, unsigned *cnt)
+{
+    unsigned long long *mx = reinterpret_cast<unsigned long long *>(cnt + 2);
+    if (D % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0)
+        k_rowstats<true><<<std::max(1, std::min((rows + 15) / 16, 4096)), 256, 0, ctx->stream>>>(x, rows, D, nrm2, cnt, mx);
+    else
+        k_rowstats<false><<<std::max(1, std::min((rows + 3) / 4, 4096)), 256, 0, ctx->stream>>>(x, rows, D, nrm2, cnt, mx);
+    return hipGetLastError();
 }
 
 static void free_image(ImgHost &im)
@@ -842,9 +966,7 @@ static int upload_common(rcn_ctx *ctx, int32_t img_id, const float *src, bool sr
                                src_is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
                                ctx->stream));
         unsigned *cnt = ctx->counters.as<unsigned>();
-        k_rowstats<<<std::min((K + 3) / 4, 4096), 256, 0, ctx->stream>>>(
-            im.f32, K, D, im.nrm2, cnt, reinterpret_cast<unsigned long long *>(cnt + 2));
-        RCN_HIP(hipGetLastError());
+        RCN_HIP(launch_rowstats(ctx, im.f32, K, D, im.nrm2, cnt));
         if (!src_is_device) RCN_HIP(hipStreamSynchronize(ctx->stream));  // host rows are borrowed
     }
     ctx->images[img_id] = im;
@@ -859,6 +981,10 @@ static int upload_batch(rcn_ctx *ctx, int32_t first_id, int32_t n, const float *
         return RCN_ERR_ARG;
     }
     if (n == 0) return RCN_OK;
+    if (D % 4 == 0 && (reinterpret_cast<uintptr_t>(src) & 15) != 0) {
+        ctx->set_error("rcn_desc_upload_batch_device: the borrowed block must be 16-byte aligned when D % 4 == 0");
+        return RCN_ERR_ARG;
+    }
     { int rcd = drop_scratch_if_alone(ctx, D); if (rcd) return rcd; }
     if (!ctx->images.empty() && ctx->D != D) {
         ctx->set_error("rcn_desc_upload_batch_device: all resident images must share D");
@@ -906,9 +1032,7 @@ static int upload_batch(rcn_ctx *ctx, int32_t first_id, int32_t n, const float *
     }
     unsigned *cnt = ctx->counters.as<unsigned>();
     const int rows = n * K;
-    k_rowstats<<<std::min((rows + 3) / 4, 8192), 256, 0, ctx->stream>>>(src, rows, D, sl.nrm2, cnt,
-                                                            reinterpret_cast<unsigned long long *>(cnt + 2));
-    RCN_HIP(hipGetLastError());
+    RCN_HIP(launch_rowstats(ctx, src, rows, D, sl.nrm2, cnt));
     ctx->prepared = false;
     return RCN_OK;
 }
@@ -1161,7 +1285,7 @@ static int match_grid_impl(rcn_ctx *ctx, const int32_t *pairs_host, int32_t n_pa
                 RCN_HIP(hipGetLastError());
             }
             const int fb_blocks = ctx->prop.multiProcessorCount * 8;
-            if (vec4) k_exact_rows<true><<<fb_blocks, 256, 0, sb>>>(imgs, pairs, ra.fb_list, ra.fb_count, ctx->D, ratio, out_dev, out_stride);
+            if (vec4) k_exact_rows_lds<<<fb_blocks, 256, 0, sb>>>(imgs, pairs, ra.fb_list, ra.fb_count, ctx->D, ratio, out_dev, out_stride);
             else k_exact_rows<false><<<fb_blocks, 256, 0, sb>>>(imgs, pairs, ra.fb_list, ra.fb_count, ctx->D, ratio, out_dev, out_stride);
             RCN_HIP(hipGetLastError());
             if (prof && c == n_chunks - 1) RCN_HIP(hipEventRecord(ctx->ev[evi][2], sb));

@@ -32,6 +32,13 @@ def test_matcher_errors(gpu_ctx):
     assert gpu_ctx.lib.rcn_desc_count(gpu_ctx.h) == 0
     rc = gpu_ctx.lib.rcn_match_pair(gpu_ctx.h, None, 4, None, 4, 8, 0.7, None, None)   # null pointers
     assert rc == -1
+    import torch
+    buf = torch.zeros(2 * 8 * 32 + 4, device="cuda")
+    with pytest.raises(_lib.RcnError) as e:                       # borrowed block not 16-byte aligned
+        m.upload_batch_device(0, 2, buf.data_ptr() + 4, 8, 32)
+    assert e.value.code == -1 and "aligned" in str(e.value)
+    m.upload_batch_device(0, 2, buf.data_ptr(), 8, 32)
+    m.clear()
 
 
 def test_ba_errors(gpu_ctx):
