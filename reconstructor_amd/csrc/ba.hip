@@ -40,6 +40,7 @@ struct BaDev {
     double *sc, *sp, *dgc, *dgp;       // Jacobi scale, clamped diag(Js'Js)
     double *Vinv, *gps, *rhs, *S, *Linv, *yc, *stc, *stp, *dlc, *dlp;
     double *partial, *scal;            // reduction scratch, scalars
+    double *WY;                        // per observation [2][3][10]: scaled W_o = Jc'Jp and Y_o = W_o Vinv, camera index fastest
     int *flag;
 };
 
@@ -418,84 +419,123 @@ __global__ void k_pair_sort(const int *off, unsigned long long *list, int nkeys)
     }
 }
 
-// contribution of the observation pair (o, o2) to elements e = lane, lane + 64 of its block
-__device__ __forceinline__ void schur_pair(const BaDev &d, int o, int o2, int lane, int dc, int dc2, int offc, int offc2, double *acc)
+// ---- MFMA form of the gather (default).  k_ba_wy tabulates, per observation, the scaled
+// W_o = Jc' Jp (10 x 3) and Y_o = W_o Vinv (both [m][a], camera coordinate fastest; rows beyond the
+// camera's tangent size are zero).  A block (c, c2) is then  - [Y_o1 Y_o2 ...] [W_o1' W_o2' ...]^T,
+// a 10 x 3P by 3P x 10 product: ceil(3P/4) v_mfma_f64_16x16x4_f64 steps per wave with two
+// 8-byte gathers per lane and step, instead of ~30 loads and ~40 flops per lane and pair.
+__global__ __launch_bounds__(256) void k_ba_wy(BaDev d)
 {
-    const int j = d.opt[o];
-    const double *jc = d.Jc + 20 * (size_t)o, *jp = d.Jp + 6 * (size_t)o;
-    const double *jc2 = d.Jc + 20 * (size_t)o2, *jp2 = d.Jp + 6 * (size_t)o2;
-    const double *Vi = d.Vinv + 9 * (size_t)j;
-    const double sp0 = d.sp[3 * (size_t)j], sp1 = d.sp[3 * (size_t)j + 1], sp2 = d.sp[3 * (size_t)j + 2];
-#pragma unroll
-    for (int rep = 0; rep < 2; ++rep) {
-        const int e = lane + 64 * rep, a = e / 10, b = e % 10;
-        if (e >= 100 || a >= dc || b >= dc2) continue;
-        const double sa = d.sc[offc + a], sb = d.sc[offc2 + b];
-        const double ja0 = jc[a] * sa, ja1 = jc[10 + a] * sa, jb0 = jc2[b] * sb, jb1 = jc2[10 + b] * sb;
-        const double wa0 = (ja0 * jp[0] + ja1 * jp[3]) * sp0, wa1 = (ja0 * jp[1] + ja1 * jp[4]) * sp1,
-                     wa2 = (ja0 * jp[2] + ja1 * jp[5]) * sp2;
-        const double wb0 = (jb0 * jp2[0] + jb1 * jp2[3]) * sp0, wb1 = (jb0 * jp2[1] + jb1 * jp2[4]) * sp1,
-                     wb2 = (jb0 * jp2[2] + jb1 * jp2[5]) * sp2;
-        const double y0 = wa0 * Vi[0] + wa1 * Vi[3] + wa2 * Vi[6];
-        const double y1 = wa0 * Vi[1] + wa1 * Vi[4] + wa2 * Vi[7];
-        const double y2 = wa0 * Vi[2] + wa1 * Vi[5] + wa2 * Vi[8];
-        acc[rep] -= y0 * wb0 + y1 * wb1 + y2 * wb2;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int o = (int)(idx / 10), a = (int)(idx - 10 * (long)o);
+    if (o >= d.no) return;
+    const int c = d.ocam[o], j = d.opt[o];
+    double w[3] = {0.0, 0.0, 0.0}, y[3] = {0.0, 0.0, 0.0};
+    if (a < d.cam_dim[c]) {
+        const double *jc = d.Jc + 20 * (size_t)o, *jp = d.Jp + 6 * (size_t)o, *Vi = d.Vinv + 9 * (size_t)j;
+        const double sa = d.sc[d.cam_off[c] + a];
+        const double ja0 = jc[a] * sa, ja1 = jc[10 + a] * sa;
+        for (int m = 0; m < 3; ++m) w[m] = (ja0 * jp[m] + ja1 * jp[3 + m]) * d.sp[3 * (size_t)j + m];
+        for (int m = 0; m < 3; ++m) y[m] = w[0] * Vi[m] + w[1] * Vi[3 + m] + w[2] * Vi[6 + m];
     }
+    double *out = d.WY + 60 * (size_t)o;
+    for (int m = 0; m < 3; ++m) { out[10 * m + a] = w[m]; out[30 + 10 * m + a] = y[m]; }
 }
 
-// one wave per strictly-lower block (c, c2 < c): Sb block = - sum over its pairs of Y_o W_o2^T
-__global__ __launch_bounds__(256) void k_ba_schur_gather(BaDev d, const int *off, const unsigned long long *list, double *Sb)
+// acc -= [Y of the listed first observations] [W of the listed second observations]^T for `cnt`
+// (<= 64) pairs held one per lane in `pr` (o << 32 | o2)
+__device__ __forceinline__ f64x4 schur_mfma_chunk(const double *__restrict__ WY, unsigned long long pr, int cnt, int lane, f64x4 acc)
+{
+    const int i = lane & 15, kk = lane >> 4, K = 3 * cnt;
+    for (int k0 = 0; k0 < K; k0 += 16) {   // four MFMA steps per trip: eight gathers in flight per lane
+        double a[4], b[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int k = k0 + 4 * u + kk, p = k / 3, m = k - 3 * p;
+            const unsigned long long e = __shfl(pr, p & 63);
+            a[u] = 0.0; b[u] = 0.0;
+            if (k < K && i < 10) {
+                a[u] = WY[60 * (size_t)(e >> 32) + 30 + 10 * m + i];
+                b[u] = WY[60 * (size_t)(e & 0xFFFFFFFFu) + 10 * m + i];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-a[u], b[u], acc, 0, 0, 0);
+    }
+    return acc;
+}
+
+// one wave per strictly-lower block (c, c2 < c), written straight into the dense reduced system
+__global__ __launch_bounds__(256) void k_ba_schur_mfma(BaDev d, const int *off, const unsigned long long *list)
 {
     const int lane = threadIdx.x & 63;
-    const int blk = blockIdx.x * 4 + (threadIdx.x >> 6);          // index into the strictly lower triangle
+    const int blk = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int nlow = d.nc * (d.nc - 1) / 2;
     if (blk >= nlow) return;
     int c = (int)((sqrt(8.0 * blk + 1.0) + 1.0) * 0.5);
     while (c * (c + 1) / 2 <= blk) ++c;
     while (c * (c - 1) / 2 > blk) --c;
     const int c2 = blk - c * (c - 1) / 2, key = c * d.nc + c2;
-    const int dc = d.cam_dim[c], dc2 = d.cam_dim[c2], offc = d.cam_off[c], offc2 = d.cam_off[c2];
-    double acc[2] = {0.0, 0.0};
-    if (dc > 0 && dc2 > 0) {
-        const int e0 = off[key], e1 = off[key + 1];
-        double acc2[2] = {0.0, 0.0};     // two independent pairs in flight (fixed pairing: order stays fixed)
-        int en = e0;
-        for (; en + 1 < e1; en += 2) {
-            const unsigned long long pa = list[en], pb = list[en + 1];
-            schur_pair(d, (int)(pa >> 32), (int)(pa & 0xFFFFFFFFu), lane, dc, dc2, offc, offc2, acc);
-            schur_pair(d, (int)(pb >> 32), (int)(pb & 0xFFFFFFFFu), lane, dc, dc2, offc, offc2, acc2);
-        }
-        if (en < e1) { const unsigned long long pa = list[en]; schur_pair(d, (int)(pa >> 32), (int)(pa & 0xFFFFFFFFu), lane, dc, dc2, offc, offc2, acc); }
-        acc[0] += acc2[0]; acc[1] += acc2[1];
+    const int dc = d.cam_dim[c], dc2 = d.cam_dim[c2];
+    if (dc == 0 || dc2 == 0) return;
+    f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+    const int e0 = off[key], e1 = off[key + 1];
+    for (int base = e0; base < e1; base += 64) {
+        const int cnt = min(64, e1 - base);
+        const unsigned long long pr = lane < cnt ? list[base + lane] : 0ull;
+        acc = schur_mfma_chunk(d.WY, pr, cnt, lane, acc);
     }
-    double *out = Sb + (size_t)key * 100;
-    out[lane] = acc[0];
-    if (lane + 64 < 100) out[lane + 64] = acc[1];
+    // C/D layout: column = lane & 15, row = (lane >> 4) + 4 * reg
+    const int col = lane & 15, r0 = lane >> 4;
+    double *out = d.S + (size_t)d.cam_off[c] * d.npad + d.cam_off[c2];
+    if (col < dc2)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg)
+            if (r0 + 4 * reg < dc) out[(size_t)(r0 + 4 * reg) * d.npad + col] = acc[reg];
 }
 
-// diagonal blocks (c, c): ~1000 observations each -> one 16-wave workgroup per camera; wave w takes
-// the observations w, w+16, ... of the per-camera list, partial blocks are summed in wave order
-__global__ __launch_bounds__(1024) void k_ba_schur_diag(BaDev d, const int *off, const unsigned long long *list, double *Sb)
+// diagonal blocks: one 16-wave workgroup per camera; wave w takes the observations w, w+16, ... of
+// the camera (a pair (o, o)) and the listed pairs of the key (c, c); the 16 partial blocks are
+// summed in wave order and  scaled U + D/radius  is added before the store into S.
+__global__ __launch_bounds__(1024) void k_ba_schur_diag_mfma(BaDev d, const int *off, const unsigned long long *list, double inv_radius)
 {
-    __shared__ double part[16][100];
+    __shared__ double part[16][256];
     const int c = blockIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int dc = d.cam_dim[c], offc = d.cam_off[c], key = c * d.nc + c;
-    double acc[2] = {0.0, 0.0};
-    if (dc > 0) {
-        for (int en = d.cam_obs_off[c] + w; en < d.cam_obs_off[c + 1]; en += 16) { const int o = d.cam_obs[en]; schur_pair(d, o, o, lane, dc, dc, offc, offc, acc); }
-        for (int en = off[key] + w; en < off[key + 1]; en += 16) {   // the same camera seen twice by one landmark
-            const unsigned long long pr = list[en];
-            schur_pair(d, (int)(pr >> 32), (int)(pr & 0xFFFFFFFFu), lane, dc, dc, offc, offc, acc);
+    if (dc == 0) return;
+    f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+    const int o0 = d.cam_obs_off[c], o1 = d.cam_obs_off[c + 1];
+    for (int base = o0 + w; base < o1; base += 16 * 64) {
+        const int cnt = min(64, (o1 - base + 15) / 16);
+        unsigned long long pr = 0ull;
+        if (lane < cnt) { const unsigned o = (unsigned)d.cam_obs[base + 16 * lane]; pr = ((unsigned long long)o << 32) | o; }
+        acc = schur_mfma_chunk(d.WY, pr, cnt, lane, acc);
+    }
+    for (int base = off[key] + w; base < off[key + 1]; base += 16 * 64) {   // the same camera seen twice by one landmark
+        const int cnt = min(64, (off[key + 1] - base + 15) / 16);
+        const unsigned long long pr = lane < cnt ? list[base + 16 * lane] : 0ull;
+        acc = schur_mfma_chunk(d.WY, pr, cnt, lane, acc);
+    }
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) part[w][((lane >> 4) + 4 * reg) * 16 + (lane & 15)] = acc[reg];
+    __syncthreads();
+    if (threadIdx.x < 256) {
+        const int a = threadIdx.x >> 4, b = threadIdx.x & 15;
+        if (a < dc && b < dc) {
+            double v = 0.0;
+            for (int k = 0; k < 16; ++k) v += part[k][threadIdx.x];
+            v += d.Uraw[100 * (size_t)c + 10 * a + b] * d.sc[offc + a] * d.sc[offc + b];
+            if (a == b) v += d.dgc[offc + a] * inv_radius;
+            d.S[(size_t)(offc + a) * d.npad + offc + b] = v;
         }
     }
-    part[w][lane] = acc[0];
-    if (lane + 64 < 100) part[w][lane + 64] = acc[1];
-    __syncthreads();
-    if (threadIdx.x < 100) {
-        double s = 0.0;
-        for (int k = 0; k < 16; ++k) s += part[k][threadIdx.x];
-        Sb[(size_t)key * 100 + threadIdx.x] = s;
-    }
+}
+
+// padded rows of the dense system: identity (the gather form writes every other lower block itself)
+__global__ void k_ba_S_pad(BaDev d)
+{
+    const int i = d.n + blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < d.npad) d.S[(size_t)i * d.npad + i] = 1.0;
 }
 
 // dense padded reduced system from the block buffer: lower blocks (c2 <= c) of
@@ -1051,12 +1091,15 @@ __global__ __launch_bounds__(256) void k_ba_plus(BaDev d, double alpha, double *
     s = block_sum(bad, sh); if (threadIdx.x == 0) partial[3 * nblocks + blockIdx.x] = s;
 }
 
-// projected gradient max-norm of the unscaled gradient (gcraw / gpraw)
+// projected gradient max-norm of the unscaled gradient (gcraw / gpraw); *out zeroed by the caller.
+// max is order-independent and non-negative doubles order like their bit patterns, so one
+// integer atomicMax per workgroup keeps the result deterministic.
 __global__ __launch_bounds__(256) void k_ba_gradmax(BaDev d, double *out)
 {
     __shared__ double sh[4];
+    const int t0 = blockIdx.x * 256 + threadIdx.x, stride = gridDim.x * 256;
     double m = 0.0;
-    for (int i = threadIdx.x; i < d.nc; i += 256)
+    for (int i = t0; i < d.nc; i += stride)
         for (int k = 0; k < d.cam_dim[i]; ++k) {
             double g = d.gcraw[10 * (size_t)i + k];
             const int col = d.cols[10 * i + k];
@@ -1068,11 +1111,14 @@ __global__ __launch_bounds__(256) void k_ba_gradmax(BaDev d, double *out)
             }
             m = fmax(m, fabs(g));
         }
-    for (int i = threadIdx.x; i < 3 * d.np; i += 256) m = fmax(m, fabs(d.gpraw[i]));
+    for (int i = t0; i < 3 * d.np; i += stride) m = fmax(m, fabs(d.gpraw[i]));
     for (int o = 32; o; o >>= 1) m = fmax(m, __shfl_down(m, o));
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = m;
     __syncthreads();
-    if (threadIdx.x == 0) *out = fmax(fmax(sh[0], sh[1]), fmax(sh[2], sh[3]));
+    if (threadIdx.x == 0) {
+        m = fmax(fmax(sh[0], sh[1]), fmax(sh[2], sh[3]));
+        atomicMax(reinterpret_cast<unsigned long long *>(out), (unsigned long long)__double_as_longlong(m));
+    }
 }
 
 // =========================================================================================
@@ -1203,6 +1249,7 @@ int rcn_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_options *o
     int *pk = ws.get<int>(gather ? 3 * (size_t)nkeys + 4 + (nkeys + 1023) / 1024 : 4);
     int *pk_cnt = pk, *pk_off = pk + nkeys + 1, *pk_fill = pk + 2 * nkeys + 2, *pk_sums = pk + 3 * (size_t)nkeys + 4;
     unsigned long long *pk_list = ws.get<unsigned long long>(gather ? std::max<size_t>(npairs_lower, 1) : 1);
+    d.WY = ws.get<double>(gather ? 60 * (size_t)std::max(no, 1) : 1);
     const int eb = (no + 255) / 256, pbk = (std::max(nc, np) + 255) / 256;
     d.partial = ws.get<double>(4 * (size_t)std::max(std::max(eb, pbk), 1) + 16);
     d.scal = ws.get<double>(32);
@@ -1282,7 +1329,8 @@ int rcn_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_options *o
     int invalid_run = 0, termination = 0, iter = 0;
     for (;;) {
         if (need_gradient) {
-            k_ba_gradmax<<<1, 256, 0, st>>>(d, d.scal + 6);
+            RCN_HIP(hipMemsetAsync(d.scal + 6, 0, sizeof(double), st));
+            k_ba_gradmax<<<std::max(1, std::min(1024, (std::max(nc, 3 * np) + 255) / 256)), 256, 0, st>>>(d, d.scal + 6);
             RCN_HIP(hipGetLastError());
             RCN_HIP(read_scal(8));
             need_gradient = false;
@@ -1305,11 +1353,14 @@ int rcn_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_options *o
         RCN_HIP(hipMemsetAsync(d.rhs, 0, sizeof(double) * npad, st));
         if (np > 0) k_ba_point_solve<<<(np + 127) / 128, 128, 0, st>>>(d, ir);
         if (gather) {
-            if (nc > 1) k_ba_schur_gather<<<(nc * (nc - 1) / 2 + 3) / 4, 256, 0, st>>>(d, pk_off, pk_list, Sb);
-            k_ba_schur_diag<<<nc, 1024, 0, st>>>(d, pk_off, pk_list, Sb);
+            if (no > 0) k_ba_wy<<<(unsigned)((10 * (size_t)no + 255) / 256), 256, 0, st>>>(d);
+            if (nc > 1) k_ba_schur_mfma<<<(nc * (nc - 1) / 2 + 3) / 4, 256, 0, st>>>(d, pk_off, pk_list);
+            k_ba_schur_diag_mfma<<<nc, 1024, 0, st>>>(d, pk_off, pk_list, ir);
+            if (npad > n) k_ba_S_pad<<<(npad - n + 127) / 128, 128, 0, st>>>(d);
+        } else {
+            if (np > 0) k_ba_schur<<<np, std::min(256, std::max(64, 64 * ((kmax * kmax + 7) / 8))), 0, st>>>(d, Sb);
+            k_ba_S_assemble<<<nc + 1, 256, 0, st>>>(d, Sb, ir);
         }
-        else if (np > 0) k_ba_schur<<<np, std::min(256, std::max(64, 64 * ((kmax * kmax + 7) / 8))), 0, st>>>(d, Sb);
-        k_ba_S_assemble<<<nc + 1, 256, 0, st>>>(d, Sb, ir);
         k_ba_cam_rhs<<<nc, 64, 0, st>>>(d);
         RCN_HIP(hipGetLastError());
         RCN_HIP(hipEventRecord(ctx->ba_tev[1], st));
