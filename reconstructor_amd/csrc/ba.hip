@@ -38,7 +38,7 @@ struct BaDev {
     double *r, *Jc, *Jp;               // per observation: residual 2, camera Jacobian 2x10, point 2x3
     double *Uraw, *gcraw, *Vraw, *gpraw; // unscaled J'J / J'r blocks
     double *sc, *sp, *dgc, *dgp;       // Jacobi scale, clamped diag(Js'Js)
-    double *Vinv, *gps, *rhs, *S, *Linv, *yc, *stc, *stp, *dlc, *dlp;
+    double *Vinv, *gps, *rhs, *S, *L, *Linv, *yc, *stc, *stp, *dlc, *dlp;   // S: reduced system, L: its sub-diagonal Cholesky tiles
     double *partial, *scal;            // reduction scratch, scalars
     double *WY;                        // per observation [2][3][10]: scaled W_o = Jc'Jp and Y_o = W_o Vinv, camera index fastest
     int *flag;
@@ -861,21 +861,82 @@ __global__ __launch_bounds__(256) void k_chol_diag(double *S, int ld, int kb, do
     STAMP(17);
 }
 
-// C(128x128 tile) = beta*C - / = A(128xK) B(128xK)^T on v_mfma_f64_16x16x4_f64.
-//   MODE 0 (panel):    S[i,kb] <- S[i,kb] * Linv_kb^T       for row tiles i > kb   (K = 128, in place)
-//   MODE 1 (trailing, first tile column):  S[i,kb+1] -= S[i,kb] * S[kb+1,kb]^T   for i > kb
-//   MODE 2 (trailing, the rest):           S[i,j]   -= S[i,kb] * S[j,kb]^T      for kb+1 < j <= i
-// MODE 1 is what the next diagonal block / panel waits for; MODE 2 runs beside them on a
-// second stream (lookahead).
-// 4 waves, each a 64x64 quadrant = 4x4 MFMA tiles; K staged through LDS in KC-deep chunks.
+// Dense blocked Cholesky, GEMM side.  S holds the reduced system and its trailing updates; the
+// panels  P[i,kb] = S[i,kb] Linv_kb^T  (the sub-diagonal tiles of L) are written to a separate
+// matrix L, so no kernel ever overwrites an operand another workgroup is still reading.
+//
+// k_gemm_q<0> (panel)  and  k_gemm_q<1> (first trailing tile column: S[i,kb+1] -= L[i,kb] L[kb+1,kb]^T)
+// are the serial chain the next diagonal block waits for, so they are built for latency: a
+// 128x128 tile is split over four workgroups (64x64 quadrants) and each workgroup brings its whole
+// K = 128 operand strips into LDS with one burst of LDS-DMA row copies (one 1-KiB row per wave
+// instruction, no staging registers, a single memory latency) before a straight run of
+// v_mfma_f64_16x16x4_f64.  k_gemm_nt (the rest of the trailing update, S[i,j] -= L[i,kb] L[j,kb]^T
+// for kb+1 < j <= i) runs beside them on a second stream (lookahead) and is built for throughput.
+#define QLD 130   // doubles per LDS row: 128 + 2 -> the 16 rows x 2 k of a half-wave ds_read_b64 hit distinct banks
 template <int MODE>
-__global__ __launch_bounds__(256) void k_gemm_nt(double *S, int ld, int kb, int nblk, const double *Linv)
+__global__ __launch_bounds__(256) void k_gemm_q(double *S, double *L, int ld, int kb, const double *Linv)
 {
+    extern __shared__ __attribute__((aligned(16))) double qlds[];
+    double *As = qlds, *Bs = qlds + 64 * QLD;
+    const int tile = blockIdx.x >> 2, qi = (blockIdx.x >> 1) & 1, qj = blockIdx.x & 1;
+    const int ti = kb + 1 + tile, tj = MODE == 0 ? kb : kb + 1;
+    const double *A = (MODE == 0 ? S : L) + ((size_t)ti * NB + 64 * qi) * ld + (size_t)kb * NB;
+    const double *B = MODE == 0 ? Linv + (size_t)kb * NB * NB + (size_t)(64 * qj) * NB
+                                : L + ((size_t)tj * NB + 64 * qj) * ld + (size_t)kb * NB;
+    const int ldb = MODE == 0 ? NB : ld;
+    double *C = (MODE == 0 ? L : S) + ((size_t)ti * NB + 64 * qi) * ld + (size_t)tj * NB + 64 * qj;
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int wr = (w >> 1) * 32, wc = (w & 1) * 32;
+    const int fr = lane & 15, fk = lane >> 4;
+    for (int r = w; r < 64; r += 4) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(A + (size_t)r * ld + 2 * lane),
+                                         (__attribute__((address_space(3))) void *)(As + r * QLD), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(B + (size_t)r * ldb + 2 * lane),
+                                         (__attribute__((address_space(3))) void *)(Bs + r * QLD), 16, 0, 0);
+    }
+    // f64 C/D layout: col = lane & 15, row = (lane >> 4) + 4 * reg.  The accumulators start as the
+    // C tile and the A operand is negated, so C - A B^T comes straight out of the MFMA chain.
+    f64x4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg)
+                acc[i][j][reg] = MODE == 0 ? 0.0 : C[(size_t)(wr + 16 * i + fk + 4 * reg) * ld + wc + 16 * j + fr];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+#pragma unroll 8
+    for (int kk = 0; kk < NB; kk += 4) {
+        double a[2], b[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const double av = As[(wr + 16 * i + fr) * QLD + kk + fk];
+            a[i] = MODE == 0 ? av : -av;
+            b[i] = Bs[(wc + 16 * i + fr) * QLD + kk + fk];
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg)
+                C[(size_t)(wr + 16 * i + fk + 4 * reg) * ld + wc + 16 * j + fr] = acc[i][j][reg];
+}
+
+// 4 waves, each a 64x64 quadrant = 4x4 MFMA tiles; K staged through LDS in KC-deep chunks.
+__global__ __launch_bounds__(256) void k_gemm_nt(double *S, const double *L, int ld, int kb)
+{
+    constexpr int MODE = 2;
     __shared__ double As[2][128 * LDT], Bs[2][128 * LDT];
     int ti, tj;
-    if (MODE == 0) { ti = kb + 1 + blockIdx.x; tj = kb; }
-    else if (MODE == 1) { ti = kb + 1 + blockIdx.x; tj = kb + 1; }
-    else {
+    {
         // blockIdx.x enumerates the lower triangle (incl. diagonal) of the m x m trailing tiles
         const int b = blockIdx.x;
         int r = (int)((sqrt(8.0 * b + 1.0) - 1.0) * 0.5);
@@ -883,10 +944,9 @@ __global__ __launch_bounds__(256) void k_gemm_nt(double *S, int ld, int kb, int 
         while (r * (r + 1) / 2 > b) --r;
         ti = kb + 2 + r; tj = kb + 2 + (b - r * (r + 1) / 2);
     }
-    (void)nblk;
-    const double *A = S + ((size_t)ti * NB) * ld + (size_t)kb * NB;                        // [128][K] rows of tile row ti
-    const double *B = MODE == 0 ? Linv + (size_t)kb * NB * NB : S + ((size_t)tj * NB) * ld + (size_t)kb * NB;
-    const int ldb = MODE == 0 ? NB : ld;
+    const double *A = L + ((size_t)ti * NB) * ld + (size_t)kb * NB;                        // [128][K] rows of tile row ti
+    const double *B = L + ((size_t)tj * NB) * ld + (size_t)kb * NB;
+    const int ldb = ld;
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int wr = (w >> 1) * 64, wc = (w & 1) * 64;
     const int fr = lane & 15, fk = lane >> 4;
@@ -948,7 +1008,6 @@ __global__ __launch_bounds__(256) void k_gemm_nt(double *S, int ld, int kb, int 
         __syncthreads();
         buf ^= 1;
     }
-    // MODE 0 writes over A: every wave passed the last barrier after its final read
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -960,7 +1019,7 @@ __global__ __launch_bounds__(256) void k_gemm_nt(double *S, int ld, int kb, int 
 
 // forward substitution step kb: y_kb = Linv_kb b_kb ; b_i -= L[i,kb] y_kb for i > kb.
 // every workgroup recomputes y_kb (16k fma) and updates one 128-row tile.
-__global__ __launch_bounds__(128) void k_trsv_fwd(const double *S, int ld, int kb, const double *Linv, double *b, double *y)
+__global__ __launch_bounds__(128) void k_trsv_fwd(const double *S /* = L: sub-diagonal tiles */, int ld, int kb, const double *Linv, double *b, double *y)
 {
     __shared__ double yk[NB], bk[NB];
     const int t = threadIdx.x, i = kb + blockIdx.x;
@@ -981,7 +1040,7 @@ __global__ __launch_bounds__(128) void k_trsv_fwd(const double *S, int ld, int k
 }
 
 // backward substitution step kb (descending): x_kb = Linv_kb^T y_kb ; y_j -= L[kb,j]^T x_kb for j < kb
-__global__ __launch_bounds__(128) void k_trsv_bwd(const double *S, int ld, int kb, const double *Linv, double *y, double *x)
+__global__ __launch_bounds__(128) void k_trsv_bwd(const double *S /* = L: sub-diagonal tiles */, int ld, int kb, const double *Linv, double *y, double *x)
 {
     __shared__ double xk[NB], yk[NB];
     const int t = threadIdx.x, j = blockIdx.x;  // j = 0..kb ; j == kb writes x
@@ -1239,6 +1298,7 @@ int rcn_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_options *o
     d.dlc = vecs + 8 * nvec; d.dlp = vecs + 9 * nvec; d.gps = vecs + 10 * nvec;
     d.Vinv = ws.get<double>(9 * (size_t)np);
     d.S = ws.get<double>((size_t)npad * npad);
+    d.L = ws.get<double>((size_t)npad * npad);
     d.Linv = ws.get<double>((size_t)nblk * NB * NB);
     double *Sb = ws.get<double>(100 * (size_t)nc * nc);
     // gather lists of the Schur build (RCN_BA_SCHUR_ATOMICS=1 falls back to the atomic form)
@@ -1279,6 +1339,9 @@ int rcn_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_options *o
     RCN_HIP(hipMemsetAsync(vecs, 0, sizeof(double) * 12 * nvec, st));
     RCN_HIP(hipMemsetAsync(d.S, 0, sizeof(double) * (size_t)npad * npad, st));   // upper part / padding never rewritten
     RCN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_chol_diag), hipFuncAttributeMaxDynamicSharedMemorySize, NB * DL * 8));
+    constexpr int QLDS = 2 * 64 * QLD * 8;
+    RCN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_q<0>), hipFuncAttributeMaxDynamicSharedMemorySize, QLDS));
+    RCN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_q<1>), hipFuncAttributeMaxDynamicSharedMemorySize, QLDS));
     if (gather && np > 0) {
         RCN_HIP(hipMemsetAsync(pk, 0, sizeof(int) * (3 * (size_t)nkeys + 4 + (nkeys + 1023) / 1024), st));
         const int thr = std::min(256, std::max(64, (kmax * kmax + 63) / 64 * 64));
@@ -1376,24 +1439,24 @@ int rcn_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_options *o
                 k_chol_diag<<<1, 256, NB * DL * 8, st>>>(d.S, npad, kb, d.Linv, d.flag);
                 const int m = nblk - kb - 1;
                 if (m <= 0) break;
-                k_gemm_nt<0><<<m, 256, 0, st>>>(d.S, npad, kb, nblk, d.Linv);
+                k_gemm_q<0><<<4 * m, 256, QLDS, st>>>(d.S, d.L, npad, kb, d.Linv);
                 hipEvent_t evP = ctx->ba_ev[1 + (kb & 3)], evT = ctx->ba_ev[5 + (kb & 3)];
                 RCN_HIP(hipEventRecord(evP, st));
                 if (have_rest) RCN_HIP(hipStreamWaitEvent(st, ctx->ba_ev[5 + ((kb - 1) & 3)], 0));   // rest(kb-1) touched column kb+1
                 have_rest = 0;
                 if (m > 1) {
                     RCN_HIP(hipStreamWaitEvent(sb, evP, 0));
-                    k_gemm_nt<2><<<(m - 1) * m / 2, 256, 0, sb>>>(d.S, npad, kb, nblk, d.Linv);
+                    k_gemm_nt<<<(m - 1) * m / 2, 256, 0, sb>>>(d.S, d.L, npad, kb);
                     RCN_HIP(hipEventRecord(evT, sb));
                     have_rest = 1;
                 }
-                k_gemm_nt<1><<<m, 256, 0, st>>>(d.S, npad, kb, nblk, d.Linv);
+                k_gemm_q<1><<<4 * m, 256, QLDS, st>>>(d.S, d.L, npad, kb, d.Linv);
             }
             RCN_HIP(hipGetLastError());
         }
         RCN_HIP(hipEventRecord(ctx->ba_tev[2], st));
-        for (int kb = 0; kb < nblk; ++kb) k_trsv_fwd<<<nblk - kb, 128, 0, st>>>(d.S, npad, kb, d.Linv, d.rhs, d.yc);
-        for (int kb = nblk - 1; kb >= 0; --kb) k_trsv_bwd<<<kb + 1, 128, 0, st>>>(d.S, npad, kb, d.Linv, d.yc, d.rhs);
+        for (int kb = 0; kb < nblk; ++kb) k_trsv_fwd<<<nblk - kb, 128, 0, st>>>(d.L, npad, kb, d.Linv, d.rhs, d.yc);
+        for (int kb = nblk - 1; kb >= 0; --kb) k_trsv_bwd<<<kb + 1, 128, 0, st>>>(d.L, npad, kb, d.Linv, d.yc, d.rhs);
         RCN_HIP(hipGetLastError());
         RCN_HIP(hipMemcpyAsync(d.yc, d.rhs, sizeof(double) * npad, hipMemcpyDeviceToDevice, st));
         k_ba_backsub<<<std::max((std::max(n, np) + 127) / 128, 1), 128, 0, st>>>(d);
