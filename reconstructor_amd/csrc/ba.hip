@@ -23,10 +23,9 @@
 #include <cmath>
 
 #define NB 128        // Cholesky block size
-#define KC 16         // k-chunk staged through LDS per step
-#define LDT 18        // LDS row stride (doubles) of a k-chunk: conflict-free ds_read_b64
 
 typedef double f64x4 __attribute__((ext_vector_type(4)));
+typedef double f64x2 __attribute__((ext_vector_type(2)));
 
 struct BaDev {
     int nc, np, no, n, npad, mode;
@@ -866,94 +865,94 @@ __global__ __launch_bounds__(256) void k_chol_diag(double *S, int ld, int kb, do
 // matrix L, so no kernel ever overwrites an operand another workgroup is still reading.
 //
 // k_gemm_q<0> (panel)  and  k_gemm_q<1> (first trailing tile column: S[i,kb+1] -= L[i,kb] L[kb+1,kb]^T)
-// are the serial chain the next diagonal block waits for, so they are built for latency: a
-// 128x128 tile is split over four workgroups (64x64 quadrants) and each workgroup brings its whole
-// K = 128 operand strips into LDS with one burst of LDS-DMA row copies (one 1-KiB row per wave
-// instruction, no staging registers, a single memory latency) before a straight run of
-// v_mfma_f64_16x16x4_f64.  k_gemm_nt (the rest of the trailing update, S[i,j] -= L[i,kb] L[j,kb]^T
-// for kb+1 < j <= i) runs beside them on a second stream (lookahead) and is built for throughput.
-#define QLD 130   // doubles per LDS row: 128 + 2 -> the 16 rows x 2 k of a half-wave ds_read_b64 hit distinct banks
+// are the serial chain the next diagonal block waits for, so they are built for latency and for
+// running BESIDE the bulk update, whose two resident workgroups per CU hold 128 KB of LDS and
+// ~420 of the 512 VGPRs of a SIMD: no LDS, no barrier, at most 96 VGPRs.  One wave owns one 16x16
+// output tile (a 128x128 tile = 64 waves) and loads its operands straight into MFMA layout, K in
+// two halves of 64: per half 8 + 8 sixteen-byte loads per lane (lane group fk takes k = 8 g + 2 fk
+// and + 1 of every 8-wide group g, so a load instruction covers 16 rows x one 64-B line), then 16
+// v_mfma_f64_16x16x4_f64.  The four workgroups that share a 32-row A strip carry the same
+// (blockIdx & 7), i.e. run on the same XCD and share the strip in its L2.
+// k_gemm_nt_ring (the rest of the trailing update, S[i,j] -= L[i,kb] L[j,kb]^T for kb+1 < j <= i)
+// runs beside them on a second stream (lookahead) and is built for throughput.
 template <int MODE>
-__global__ __launch_bounds__(256) void k_gemm_q(double *S, double *L, int ld, int kb, const double *Linv)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(96)))
+void k_gemm_q(double *S, double *L, int ld, int kb, int m, const double *Linv)
 {
-    extern __shared__ __attribute__((aligned(16))) double qlds[];
-    double *As = qlds, *Bs = qlds + 64 * QLD;
-    const int tile = blockIdx.x >> 2, qi = (blockIdx.x >> 1) & 1, qj = blockIdx.x & 1;
-    const int ti = kb + 1 + tile, tj = MODE == 0 ? kb : kb + 1;
-    const double *A = (MODE == 0 ? S : L) + ((size_t)ti * NB + 64 * qi) * ld + (size_t)kb * NB;
-    const double *B = MODE == 0 ? Linv + (size_t)kb * NB * NB + (size_t)(64 * qj) * NB
-                                : L + ((size_t)tj * NB + 64 * qj) * ld + (size_t)kb * NB;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int strip = 8 * (slot >> 2) + xcd, qj = slot & 3;      // strip: 32 rows of the tile column, qj: 32 output columns
+    if (strip >= 4 * m) return;
+    const int tj = MODE == 0 ? kb : kb + 1;
+    const size_t row0 = (size_t)(kb + 1) * NB + 32 * (size_t)strip;
+    const double *A = (MODE == 0 ? S : L) + row0 * ld + (size_t)kb * NB;
+    const double *B = MODE == 0 ? Linv + (size_t)kb * NB * NB + (size_t)(32 * qj) * NB
+                                : L + ((size_t)tj * NB + 32 * qj) * ld + (size_t)kb * NB;
     const int ldb = MODE == 0 ? NB : ld;
-    double *C = (MODE == 0 ? L : S) + ((size_t)ti * NB + 64 * qi) * ld + (size_t)tj * NB + 64 * qj;
-    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-    const int wr = (w >> 1) * 32, wc = (w & 1) * 32;
+    double *C = (MODE == 0 ? L : S) + row0 * ld + (size_t)tj * NB + 32 * qj;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int wr = (w >> 1) * 16, wc = (w & 1) * 16;
     const int fr = lane & 15, fk = lane >> 4;
-    for (int r = w; r < 64; r += 4) {
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(A + (size_t)r * ld + 2 * lane),
-                                         (__attribute__((address_space(3))) void *)(As + r * QLD), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(B + (size_t)r * ldb + 2 * lane),
-                                         (__attribute__((address_space(3))) void *)(Bs + r * QLD), 16, 0, 0);
-    }
+    const f64x2 *ap = reinterpret_cast<const f64x2 *>(A + (size_t)(wr + fr) * ld + 2 * fk);
+    const f64x2 *bp = reinterpret_cast<const f64x2 *>(B + (size_t)(wc + fr) * ldb + 2 * fk);
     // f64 C/D layout: col = lane & 15, row = (lane >> 4) + 4 * reg.  The accumulators start as the
     // C tile and the A operand is negated, so C - A B^T comes straight out of the MFMA chain.
-    f64x4 acc[2][2];
+    f64x4 acc;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int reg = 0; reg < 4; ++reg) acc[reg] = MODE == 0 ? 0.0 : C[(size_t)(wr + fk + 4 * reg) * ld + wc + fr];
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+    for (int half = 0; half < 2; ++half) {
+        f64x2 a[8], b[8];
 #pragma unroll
-            for (int reg = 0; reg < 4; ++reg)
-                acc[i][j][reg] = MODE == 0 ? 0.0 : C[(size_t)(wr + 16 * i + fk + 4 * reg) * ld + wc + 16 * j + fr];
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-#pragma unroll 8
-    for (int kk = 0; kk < NB; kk += 4) {
-        double a[2], b[2];
+        for (int g = 0; g < 8; ++g) { a[g] = ap[4 * (8 * half + g)]; b[g] = bp[4 * (8 * half + g)]; }
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const double av = As[(wr + 16 * i + fr) * QLD + kk + fk];
-            a[i] = MODE == 0 ? av : -av;
-            b[i] = Bs[(wc + 16 * i + fr) * QLD + kk + fk];
-        }
+        for (int g = 0; g < 8; ++g)
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+            for (int h = 0; h < 2; ++h)
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(MODE == 0 ? a[g][h] : -a[g][h], b[g][h], acc, 0, 0, 0);
     }
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int reg = 0; reg < 4; ++reg)
-                C[(size_t)(wr + 16 * i + fk + 4 * reg) * ld + wc + 16 * j + fr] = acc[i][j][reg];
+    for (int reg = 0; reg < 4; ++reg) C[(size_t)(wr + fk + 4 * reg) * ld + wc + fr] = acc[reg];
 }
 
-// 4 waves, each a 64x64 quadrant = 4x4 MFMA tiles; K staged through LDS in KC-deep chunks.
-__global__ __launch_bounds__(256) void k_gemm_nt(double *S, const double *L, int ld, int kb)
+// Tile mapping of the bulk update: the lower triangle of the mt x mt trailing tiles is cut into
+// 8x8-tile super-tiles and every super-tile belongs to ONE XCD (workgroups go round-robin to the 8
+// XCDs, so blockIdx & 7 names the XCD): its 64 workgroups read only 16 panel tiles (2 MB), which
+// stay in that XCD's 4-MB L2.
+#define ST 8
+__host__ __device__ inline int gemm_nt_grid(int mt) { const int R = (mt + ST - 1) / ST, ns = R * (R + 1) / 2; return 8 * ((ns + 7) / 8) * ST * ST; }
+
+// Bulk trailing update, LDS-DMA form:  S[i,j] -= L[i, kb..] L[j, kb..]^T  over nst 8-wide k-stages
+// (K = 8 nst: 128 for one panel).  Operands reach LDS by LDS-DMA only -- no staging registers --
+// through a 4-stage ring, three stages (24 k) ahead of the MFMAs, behind counted vmcnt waits and one
+// raw s_barrier per stage.  A stage holds, per operand, 128 rows x 8 doubles as eight 1-KiB
+// row groups in PIECE-MAJOR order (slot = piece * 16 + row, 16 B per slot): each DMA lane picks
+// the global 16 B that belongs in its linear LDS slot, so a ds_read_b128 of 16 rows x one piece
+// is one whole 256-B bank row (conflict-free without padding) and yields the operands of two
+// MFMA steps (lane group fk supplies k = 2 fk and 2 fk + 1).
+#define GST 4
+#define GSTAGE_BYTES (2 * 128 * 8 * 8)   // A + B, 16 KiB
+template <int DBG>   // DBG != 0: timing experiments of tools/gemm_nt_bench only (1: no C load, 2: no C store, 4: no operand DMA)
+__global__ __launch_bounds__(256, 2) void k_gemm_nt_ring(double *S, const double *L, int ld, int kb, int mt, int nst)
 {
-    constexpr int MODE = 2;
-    __shared__ double As[2][128 * LDT], Bs[2][128 * LDT];
+    extern __shared__ __attribute__((aligned(16))) char gsm[];
     int ti, tj;
     {
-        // blockIdx.x enumerates the lower triangle (incl. diagonal) of the m x m trailing tiles
-        const int b = blockIdx.x;
-        int r = (int)((sqrt(8.0 * b + 1.0) - 1.0) * 0.5);
-        while ((r + 1) * (r + 2) / 2 <= b) ++r;
-        while (r * (r + 1) / 2 > b) --r;
-        ti = kb + 2 + r; tj = kb + 2 + (b - r * (r + 1) / 2);
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        const int sidx = (slot / (ST * ST)) * 8 + xcd, within = slot % (ST * ST);
+        int sr = (int)((sqrt(8.0 * sidx + 1.0) - 1.0) * 0.5);
+        while ((sr + 1) * (sr + 2) / 2 <= sidx) ++sr;
+        while (sr * (sr + 1) / 2 > sidx) --sr;
+        const int sc = sidx - sr * (sr + 1) / 2;
+        const int r = sr * ST + within / ST, c = sc * ST + within % ST;
+        if (r >= mt || c > r) return;
+        ti = kb + 2 + r; tj = kb + 2 + c;
     }
-    const double *A = L + ((size_t)ti * NB) * ld + (size_t)kb * NB;                        // [128][K] rows of tile row ti
+    const double *A = L + ((size_t)ti * NB) * ld + (size_t)kb * NB;
     const double *B = L + ((size_t)tj * NB) * ld + (size_t)kb * NB;
-    const int ldb = ld;
+    double *C = S + ((size_t)ti * NB) * ld + (size_t)tj * NB;
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int wr = (w >> 1) * 64, wc = (w & 1) * 64;
     const int fr = lane & 15, fk = lane >> 4;
-    double *C = S + ((size_t)ti * NB) * ld + (size_t)tj * NB;
-    // f64 C/D layout: col = lane & 15, row = (lane >> 4) + 4 * reg.
-    // Trailing update: the accumulators START as the C tile and the A operand is negated, so
-    // C - A B^T comes out of the MFMA chain and is stored once (no read-modify-write pass).
     f64x4 acc[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -961,52 +960,50 @@ __global__ __launch_bounds__(256) void k_gemm_nt(double *S, const double *L, int
         for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg)
-                acc[i][j][reg] = MODE == 0 ? 0.0 : C[(size_t)(wr + 16 * i + fk + 4 * reg) * ld + wc + 16 * j + fr];
-
-    // staging: each thread moves KC/2 double2 per operand per chunk; chunk c+1 is fetched into
-    // registers while chunk c is multiplied
-    constexpr int PER = 128 * (KC / 2) / 256;   // double2 per thread per operand
-    double2 ra[PER], rb[PER];
-    auto fetch = [&](int k0) {
+                acc[i][j][reg] = (DBG & 1) ? 0.0 : C[(size_t)(wr + 16 * i + fk + 4 * reg) * ld + wc + 16 * j + fr];
+    // wave w copies row groups 2w, 2w+1 of both operands: 4 DMA instructions per stage
+    const double *srcA = A + (size_t)(32 * w + fr) * ld + 2 * fk;
+    const double *srcB = B + (size_t)(32 * w + fr) * ld + 2 * fk;
+    auto issue = [&](int s) {
+        char *buf = gsm + (s % GST) * GSTAGE_BYTES + 2048 * w;
+        const int k0 = 8 * s;
+        if (DBG & 4) return;
 #pragma unroll
-        for (int q = 0; q < PER; ++q) {
-            const int i = t + 256 * q, r = i / (KC / 2), c2 = (i % (KC / 2)) * 2;
-            ra[q] = *reinterpret_cast<const double2 *>(A + (size_t)r * ld + k0 + c2);
-            rb[q] = *reinterpret_cast<const double2 *>(B + (size_t)r * ldb + k0 + c2);
+        for (int q = 0; q < 2; ++q) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(srcA + (size_t)(16 * q) * ld + k0),
+                                             (__attribute__((address_space(3))) void *)(buf + 1024 * q), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(srcB + (size_t)(16 * q) * ld + k0),
+                                             (__attribute__((address_space(3))) void *)(buf + 8192 + 1024 * q), 16, 0, 0);
         }
     };
-    auto stash = [&](int buf) {
-#pragma unroll
-        for (int q = 0; q < PER; ++q) {
-            const int i = t + 256 * q, r = i / (KC / 2), c2 = (i % (KC / 2)) * 2;
-            As[buf][r * LDT + c2] = ra[q].x; As[buf][r * LDT + c2 + 1] = ra[q].y;
-            Bs[buf][r * LDT + c2] = rb[q].x; Bs[buf][r * LDT + c2 + 1] = rb[q].y;
-        }
+    auto lds_read = [&](unsigned addr) -> f64x2 {
+        f64x2 v;
+        asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr));
+        return v;
     };
-    fetch(0);
-    stash(0);
-    __syncthreads();
-    int buf = 0;
-    for (int k0 = 0; k0 < NB; k0 += KC) {
-        if (k0 + KC < NB) fetch(k0 + KC);
+    const unsigned base = (unsigned)(size_t)(const __attribute__((address_space(3))) char *)gsm;
+    const unsigned offA = (unsigned)((wr >> 4) * 1024 + fk * 256 + fr * 16);
+    const unsigned offB = (unsigned)(8192 + (wc >> 4) * 1024 + fk * 256 + fr * 16);
+    for (int s = 0; s < GST - 1 && s < nst; ++s) issue(s);
+    for (int s = 0; s < nst; ++s) {
+        const int ahead = min(nst - 1 - s, GST - 2);   // stages issued after stage s
+        if (ahead >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (ahead == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();            // stage s landed for every wave; everyone is done with stage s-1
+        if (s + GST - 1 < nst) issue(s + GST - 1);   // into the buffer of stage s-1
+        const unsigned st = base + (unsigned)((s % GST) * GSTAGE_BYTES);
+        f64x2 a0 = lds_read(st + offA), a1 = lds_read(st + offA + 1024), a2 = lds_read(st + offA + 2048), a3 = lds_read(st + offA + 3072);
+        f64x2 b0 = lds_read(st + offB), b1 = lds_read(st + offB + 1024), b2 = lds_read(st + offB + 2048), b3 = lds_read(st + offB + 3072);
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3));
+        const f64x2 a[4] = {-a0, -a1, -a2, -a3}, b[4] = {b0, b1, b2, b3};
 #pragma unroll
-        for (int kk = 0; kk < KC; kk += 4) {
-            double a[4], b[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const double av = As[buf][(wr + 16 * i + fr) * LDT + kk + fk];
-                a[i] = MODE == 0 ? av : -av;
-                b[i] = Bs[buf][(wc + 16 * i + fr) * LDT + kk + fk];
-            }
+        for (int h = 0; h < 2; ++h)
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
-        }
-        if (k0 + KC < NB) stash(buf ^ 1);   // the other buffer was last read one chunk ago
-        __syncthreads();
-        buf ^= 1;
+                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i][h], b[j][h], acc[i][j], 0, 0, 0);
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -1014,7 +1011,7 @@ __global__ __launch_bounds__(256) void k_gemm_nt(double *S, const double *L, int
         for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg)
-                C[(size_t)(wr + 16 * i + fk + 4 * reg) * ld + wc + 16 * j + fr] = acc[i][j][reg];
+                if (!(DBG & 2) || acc[i][j][reg] == 1.2345e300) C[(size_t)(wr + 16 * i + fk + 4 * reg) * ld + wc + 16 * j + fr] = acc[i][j][reg];
 }
 
 // forward substitution step kb: y_kb = Linv_kb b_kb ; b_i -= L[i,kb] y_kb for i > kb.
@@ -1339,9 +1336,7 @@ int rcn_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_options *o
     RCN_HIP(hipMemsetAsync(vecs, 0, sizeof(double) * 12 * nvec, st));
     RCN_HIP(hipMemsetAsync(d.S, 0, sizeof(double) * (size_t)npad * npad, st));   // upper part / padding never rewritten
     RCN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_chol_diag), hipFuncAttributeMaxDynamicSharedMemorySize, NB * DL * 8));
-    constexpr int QLDS = 2 * 64 * QLD * 8;
-    RCN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_q<0>), hipFuncAttributeMaxDynamicSharedMemorySize, QLDS));
-    RCN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_q<1>), hipFuncAttributeMaxDynamicSharedMemorySize, QLDS));
+    RCN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_nt_ring<0>), hipFuncAttributeMaxDynamicSharedMemorySize, GST * GSTAGE_BYTES));
     if (gather && np > 0) {
         RCN_HIP(hipMemsetAsync(pk, 0, sizeof(int) * (3 * (size_t)nkeys + 4 + (nkeys + 1023) / 1024), st));
         const int thr = std::min(256, std::max(64, (kmax * kmax + 63) / 64 * 64));
@@ -1439,18 +1434,18 @@ int rcn_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_options *o
                 k_chol_diag<<<1, 256, NB * DL * 8, st>>>(d.S, npad, kb, d.Linv, d.flag);
                 const int m = nblk - kb - 1;
                 if (m <= 0) break;
-                k_gemm_q<0><<<4 * m, 256, QLDS, st>>>(d.S, d.L, npad, kb, d.Linv);
+                k_gemm_q<0><<<32 * ((4 * m + 7) / 8), 256, 0, st>>>(d.S, d.L, npad, kb, m, d.Linv);
                 hipEvent_t evP = ctx->ba_ev[1 + (kb & 3)], evT = ctx->ba_ev[5 + (kb & 3)];
                 RCN_HIP(hipEventRecord(evP, st));
                 if (have_rest) RCN_HIP(hipStreamWaitEvent(st, ctx->ba_ev[5 + ((kb - 1) & 3)], 0));   // rest(kb-1) touched column kb+1
                 have_rest = 0;
                 if (m > 1) {
                     RCN_HIP(hipStreamWaitEvent(sb, evP, 0));
-                    k_gemm_nt<<<(m - 1) * m / 2, 256, 0, sb>>>(d.S, d.L, npad, kb);
+                    k_gemm_nt_ring<0><<<gemm_nt_grid(m - 1), 256, GST * GSTAGE_BYTES, sb>>>(d.S, d.L, npad, kb, m - 1, NB / 8);
                     RCN_HIP(hipEventRecord(evT, sb));
                     have_rest = 1;
                 }
-                k_gemm_q<1><<<4 * m, 256, QLDS, st>>>(d.S, d.L, npad, kb, d.Linv);
+                k_gemm_q<1><<<32 * ((4 * m + 7) / 8), 256, 0, st>>>(d.S, d.L, npad, kb, m, d.Linv);
             }
             RCN_HIP(hipGetLastError());
         }

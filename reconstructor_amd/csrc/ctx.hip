@@ -1,5 +1,6 @@
 // ctx.hip -- context lifetime of the C ABI (include/rcn.h).
 #include "rcn_internal.h"
+#include <vector>
 
 #include <cstdlib>
 
@@ -31,7 +32,21 @@ int rcn_create(int device_id, rcn_ctx **out)
         return RCN_ERR_HIP;
     }
     ctx->stream = ctx->own_stream;
-    if (hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking) != hipSuccess) {
+    // The auxiliary stream carries throughput work (bulk trailing updates of the Cholesky) beside
+    // the latency chain on the main stream.  Its CU mask leaves one CU per XCD free (mask bits
+    // interleave over the XCDs: bit i -> XCD i % 8), so the chain's single-workgroup diagonal
+    // kernel (132 KB of LDS) never queues behind the bulk kernel's resident workgroups.
+    {
+        const int ncu = ctx->prop.multiProcessorCount;
+        std::vector<uint32_t> mask((ncu + 31) / 32, 0xFFFFFFFFu);
+        if (ncu % 32) mask.back() = (1u << (ncu % 32)) - 1u;
+        if (ncu >= 64 && !getenv("RCN_NO_CU_MASK")) mask[0] &= ~0xFFu;
+        if (hipExtStreamCreateWithCUMask(&ctx->aux_stream, (uint32_t)mask.size(), mask.data()) != hipSuccess) {
+            (void)hipGetLastError();
+            ctx->aux_stream = nullptr;
+        }
+    }
+    if (!ctx->aux_stream && hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking) != hipSuccess) {
         delete ctx;
         return RCN_ERR_HIP;
     }
