@@ -537,6 +537,25 @@ __global__ void k_ba_S_pad(BaDev d)
     if (i < d.npad) d.S[(size_t)i * d.npad + i] = 1.0;
 }
 
+// Forward substitution for free: the reduced right-hand side rides through the factorisation as
+// row n of the padded system (a padding row: zero elsewhere) under a huge diagonal entry, so the
+// panel kernels leave  y = L^-1 b  in that row of the factor:  [S b; b' beta] = [L 0; y' .][L 0; y' .]'.
+#define RCN_RHS_BETA 1.0e200
+__global__ void k_ba_S_rhs_row(BaDev d)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j > d.n) return;
+    d.S[(size_t)d.n * d.npad + j] = j < d.n ? d.rhs[j] : RCN_RHS_BETA;
+}
+// y out of row n of the factor: sub-diagonal tiles live in L, the last diagonal tile in S
+__global__ void k_ba_y_from_row(BaDev d)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= d.npad) return;
+    const int last0 = (d.npad / NB - 1) * NB;
+    d.yc[j] = j < d.n ? (j < last0 ? d.L : d.S)[(size_t)d.n * d.npad + j] : 0.0;
+}
+
 // dense padded reduced system from the block buffer: lower blocks (c2 <= c) of
 // S = blockdiag(scaled U + dgc/radius) + Sb ; padded diagonal = 1.  One workgroup per camera row.
 __global__ __launch_bounds__(256) void k_ba_S_assemble(BaDev d, const double *Sb, double inv_radius)
@@ -1420,6 +1439,8 @@ int rcn_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_options *o
             k_ba_S_assemble<<<nc + 1, 256, 0, st>>>(d, Sb, ir);
         }
         k_ba_cam_rhs<<<nc, 64, 0, st>>>(d);
+        const bool rhs_row = npad > n && !ctx->ba_trsv_fwd;
+        if (rhs_row) k_ba_S_rhs_row<<<(n + 1 + 255) / 256, 256, 0, st>>>(d);
         RCN_HIP(hipGetLastError());
         RCN_HIP(hipEventRecord(ctx->ba_tev[1], st));
         // dense Cholesky, right-looking, 128-wide panels, lookahead 1: the serial chain
@@ -1450,7 +1471,8 @@ int rcn_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_options *o
             RCN_HIP(hipGetLastError());
         }
         RCN_HIP(hipEventRecord(ctx->ba_tev[2], st));
-        for (int kb = 0; kb < nblk; ++kb) k_trsv_fwd<<<nblk - kb, 128, 0, st>>>(d.L, npad, kb, d.Linv, d.rhs, d.yc);
+        if (rhs_row) k_ba_y_from_row<<<(npad + 255) / 256, 256, 0, st>>>(d);
+        else for (int kb = 0; kb < nblk; ++kb) k_trsv_fwd<<<nblk - kb, 128, 0, st>>>(d.L, npad, kb, d.Linv, d.rhs, d.yc);
         for (int kb = nblk - 1; kb >= 0; --kb) k_trsv_bwd<<<kb + 1, 128, 0, st>>>(d.L, npad, kb, d.Linv, d.yc, d.rhs);
         RCN_HIP(hipGetLastError());
         RCN_HIP(hipMemcpyAsync(d.yc, d.rhs, sizeof(double) * npad, hipMemcpyDeviceToDevice, st));

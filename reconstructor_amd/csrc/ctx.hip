@@ -61,6 +61,8 @@ int rcn_create(int device_id, rcn_ctx **out)
     ctx->ablate = ab ? std::atoi(ab) : 0;
     const char *bat = std::getenv("RCN_BA_SCHUR_ATOMICS");
     ctx->ba_atomics = bat && bat[0] == '1';
+    const char *btf = getenv("RCN_BA_TRSV_FWD");
+    ctx->ba_trsv_fwd = btf && btf[0] == '1';
     const char *ch = std::getenv("RCN_MATCH_CHUNKS");
     ctx->chunks = ch ? std::atoi(ch) : 1;
     memset(&ctx->last_stats, 0, sizeof(ctx->last_stats));

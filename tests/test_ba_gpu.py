@@ -149,3 +149,19 @@ def test_solve_is_bit_reproducible(gpu_ctx):
     P2, I2, X2, s2 = ba.solve_scene(gpu_ctx, sc)
     assert np.array_equal(P1, P2) and np.array_equal(I1, I2) and np.array_equal(X1, X2)
     assert np.array_equal(s1["cost_trace"], s2["cost_trace"])
+
+
+@pytest.mark.parametrize("env", ["RCN_BA_TRSV_FWD", "RCN_BA_SCHUR_ATOMICS"])
+def test_alternative_device_paths_agree(gpu_ctx, env, monkeypatch):
+    """The default solve carries the right-hand side through the factorisation as an extra row and
+    builds the Schur complement by MFMA gathers; the separate forward substitution and the atomic
+    Schur build (environment switches read at rcn_create) must land on the same optimum."""
+    from reconstructor_amd import _lib, ba
+    sc = synth_ba.make_scene(40, 3000, obs_per_point=6, seed=33)
+    P0, I0, X0, s0 = ba.solve_scene(gpu_ctx, sc)
+    monkeypatch.setenv(env, "1")
+    alt = _lib.Context(0)
+    P1, I1, X1, s1 = ba.solve_scene(alt, sc)
+    assert s1["iterations"] == s0["iterations"]
+    assert abs(s1["final_rms_px"] - s0["final_rms_px"]) < 1e-9
+    assert np.allclose(P1, P0, rtol=0, atol=1e-8) and np.allclose(X1, X0, rtol=0, atol=1e-7)
