@@ -28,7 +28,7 @@ typedef double f64x4 __attribute__((ext_vector_type(4)));
 typedef double f64x2 __attribute__((ext_vector_type(2)));
 
 struct BaDev {
-    int nc, np, no, n, npad, mode;
+    int nc, np, no, n, npad, mode, use_wy;   // use_wy: the per-observation W/Y table is current (MFMA Schur path)
     double ub;
     double *poses, *intr, *pts;        // current point
     double *poses2, *intr2, *pts2;     // candidate
@@ -443,7 +443,11 @@ __global__ __launch_bounds__(256) void k_ba_wy(BaDev d)
 
 // acc -= [Y of the listed first observations] [W of the listed second observations]^T for `cnt`
 // (<= 64) pairs held one per lane in `pr` (o << 32 | o2)
-__device__ __forceinline__ f64x4 schur_mfma_chunk(const double *__restrict__ WY, unsigned long long pr, int cnt, int lane, f64x4 acc)
+// RHS: column 10 of the B operand carries the scaled point gradient of the pair's landmark, so
+// column 10 of the block comes out as  - sum Y_o gp_j(o)  -- the camera's reduced right-hand side.
+template <bool RHS>
+__device__ __forceinline__ f64x4 schur_mfma_chunk(const double *__restrict__ WY, unsigned long long pr, int cnt, int lane, f64x4 acc,
+                                                  const int *__restrict__ opt = nullptr, const double *__restrict__ gps = nullptr)
 {
     const int i = lane & 15, kk = lane >> 4, K = 3 * cnt;
     for (int k0 = 0; k0 < K; k0 += 16) {   // four MFMA steps per trip: eight gathers in flight per lane
@@ -457,6 +461,7 @@ __device__ __forceinline__ f64x4 schur_mfma_chunk(const double *__restrict__ WY,
                 a[u] = WY[60 * (size_t)(e >> 32) + 30 + 10 * m + i];
                 b[u] = WY[60 * (size_t)(e & 0xFFFFFFFFu) + 10 * m + i];
             }
+            if (RHS && k < K && i == 10) b[u] = gps[3 * (size_t)opt[(unsigned)(e & 0xFFFFFFFFu)] + m];
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-a[u], b[u], acc, 0, 0, 0);
@@ -482,7 +487,7 @@ __global__ __launch_bounds__(256) void k_ba_schur_mfma(BaDev d, const int *off, 
     for (int base = e0; base < e1; base += 64) {
         const int cnt = min(64, e1 - base);
         const unsigned long long pr = lane < cnt ? list[base + lane] : 0ull;
-        acc = schur_mfma_chunk(d.WY, pr, cnt, lane, acc);
+        acc = schur_mfma_chunk<false>(d.WY, pr, cnt, lane, acc);
     }
     // C/D layout: column = lane & 15, row = (lane >> 4) + 4 * reg
     const int col = lane & 15, r0 = lane >> 4;
@@ -495,7 +500,8 @@ __global__ __launch_bounds__(256) void k_ba_schur_mfma(BaDev d, const int *off, 
 
 // diagonal blocks: one 16-wave workgroup per camera; wave w takes the observations w, w+16, ... of
 // the camera (a pair (o, o)) and the listed pairs of the key (c, c); the 16 partial blocks are
-// summed in wave order and  scaled U + D/radius  is added before the store into S.
+// summed in wave order and  scaled U + D/radius  is added before the store into S; column 10 of
+// the same product is the camera's reduced right-hand side.
 __global__ __launch_bounds__(1024) void k_ba_schur_diag_mfma(BaDev d, const int *off, const unsigned long long *list, double inv_radius)
 {
     __shared__ double part[16][256];
@@ -508,12 +514,12 @@ __global__ __launch_bounds__(1024) void k_ba_schur_diag_mfma(BaDev d, const int 
         const int cnt = min(64, (o1 - base + 15) / 16);
         unsigned long long pr = 0ull;
         if (lane < cnt) { const unsigned o = (unsigned)d.cam_obs[base + 16 * lane]; pr = ((unsigned long long)o << 32) | o; }
-        acc = schur_mfma_chunk(d.WY, pr, cnt, lane, acc);
+        acc = schur_mfma_chunk<true>(d.WY, pr, cnt, lane, acc, d.opt, d.gps);
     }
     for (int base = off[key] + w; base < off[key + 1]; base += 16 * 64) {   // the same camera seen twice by one landmark
         const int cnt = min(64, (off[key + 1] - base + 15) / 16);
         const unsigned long long pr = lane < cnt ? list[base + 16 * lane] : 0ull;
-        acc = schur_mfma_chunk(d.WY, pr, cnt, lane, acc);
+        acc = schur_mfma_chunk<false>(d.WY, pr, cnt, lane, acc);
     }
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) part[w][((lane >> 4) + 4 * reg) * 16 + (lane & 15)] = acc[reg];
@@ -526,6 +532,10 @@ __global__ __launch_bounds__(1024) void k_ba_schur_diag_mfma(BaDev d, const int 
             v += d.Uraw[100 * (size_t)c + 10 * a + b] * d.sc[offc + a] * d.sc[offc + b];
             if (a == b) v += d.dgc[offc + a] * inv_radius;
             d.S[(size_t)(offc + a) * d.npad + offc + b] = v;
+        } else if (a < dc && b == 10) {   // reduced right-hand side: scaled gc - sum_o Y_o gp
+            double v = 0.0;
+            for (int k = 0; k < 16; ++k) v += part[k][threadIdx.x];
+            d.rhs[offc + a] = d.gcraw[10 * (size_t)c + a] * d.sc[offc + a] + v;
         }
     }
 }
@@ -1085,12 +1095,15 @@ __global__ void k_ba_backsub(BaDev d)
     if (j >= d.np) return;
     double tt[3] = {d.gps[3 * (size_t)j], d.gps[3 * (size_t)j + 1], d.gps[3 * (size_t)j + 2]};
     for (int o = d.pt_off[j]; o < d.pt_off[j + 1]; ++o) {
-        const int c = d.ocam[o];
-        double W[30];
-        load_W(d, o, c, j, W);
-        for (int a = 0; a < d.cam_dim[c]; ++a) {
-            const double y = d.yc[d.cam_off[c] + a];
-            tt[0] -= W[3 * a] * y; tt[1] -= W[3 * a + 1] * y; tt[2] -= W[3 * a + 2] * y;
+        const int c = d.ocam[o], dc = d.cam_dim[c];
+        const double *y = d.yc + d.cam_off[c];
+        if (d.use_wy) {   // tabulated W_o, [m][a]
+            const double *W = d.WY + 60 * (size_t)o;
+            for (int a = 0; a < dc; ++a) { tt[0] -= W[a] * y[a]; tt[1] -= W[10 + a] * y[a]; tt[2] -= W[20 + a] * y[a]; }
+        } else {
+            double W[30];
+            load_W(d, o, c, j, W);
+            for (int a = 0; a < dc; ++a) { tt[0] -= W[3 * a] * y[a]; tt[1] -= W[3 * a + 1] * y[a]; tt[2] -= W[3 * a + 2] * y[a]; }
         }
     }
     const double *Vi = d.Vinv + 9 * (size_t)j;
@@ -1319,6 +1332,7 @@ int rcn_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_options *o
     double *Sb = ws.get<double>(100 * (size_t)nc * nc);
     // gather lists of the Schur build (RCN_BA_SCHUR_ATOMICS=1 falls back to the atomic form)
     const bool gather = !ctx->ba_atomics;
+    d.use_wy = gather ? 1 : 0;
     size_t npairs_lower = 0;
     for (int j = 0; j < np; ++j) { const size_t k = pt_off[j + 1] - pt_off[j]; npairs_lower += k * k; }   // upper bound
     const int nkeys = nc * nc;
@@ -1437,8 +1451,8 @@ int rcn_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_options *o
         } else {
             if (np > 0) k_ba_schur<<<np, std::min(256, std::max(64, 64 * ((kmax * kmax + 7) / 8))), 0, st>>>(d, Sb);
             k_ba_S_assemble<<<nc + 1, 256, 0, st>>>(d, Sb, ir);
+            k_ba_cam_rhs<<<nc, 64, 0, st>>>(d);
         }
-        k_ba_cam_rhs<<<nc, 64, 0, st>>>(d);
         const bool rhs_row = npad > n && !ctx->ba_trsv_fwd;
         if (rhs_row) k_ba_S_rhs_row<<<(n + 1 + 255) / 256, 256, 0, st>>>(d);
         RCN_HIP(hipGetLastError());
