@@ -176,6 +176,43 @@ typedef struct {
 int rcn_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *problem, const rcn_ba_options *options,
                  rcn_ba_summary *summary);
 
+/* ---- landmark validity sweep -------------------------------------------------------------
+ * SequentialReconstructor::checkLandmarkValidity (SequentialReconstructor.cpp:869-954), the check
+ * the reference runs on the observation graph before and after every bundle adjustment:
+ *   - walk each landmark's triangulatedFeatures in order; an observation whose L1 reprojection
+ *     error |u - x| + |v - y| (calcProjectionError :852-867, PinholeCamera::project Camera.h:59-76)
+ *     exceeds max_projection_error, or whose camera-frame depth is negative, is erased -- with the
+ *     reference's loop, which skips the element that slides into the erased slot (:877-898);
+ *     fewer than two observations left after an erase marks the landmark an outlier;
+ *   - a landmark none of whose surviving observation pairs subtends more than
+ *     min_triangulation_angle "degrees" (calcTriangulationAngle :815-836, pi = 3.1415) is an outlier.
+ * Defaults of the reference: 4.0 px and 1.0 (SequentialReconstructor.h:256-257).
+ *   poses34    n_cams x 12   rows of [R | t] of imgIdx2camPose (world -> camera)
+ *   intrinsics n_cams x 6    fx fy cx cy k1 k2
+ *   points     n_points x 3
+ *   pt_off     n_points + 1  CSR over the tracks, observations in triangulatedFeatures order
+ *   obs_cam    n_obs ; obs_xy n_obs x 2 integer pixel coordinates (Feature<int>::featCoord)
+ * out_inlier[n_points]: 1 = keep the landmark (the vector<bool> the reference returns);
+ * out_keep[n_obs]: 1 = the observation is still in its track afterwards (the reference erases in
+ * place); out_n_inliers may be NULL. */
+typedef struct {
+    int32_t        n_cams, n_points, n_obs, reserved;
+    const double  *poses34;
+    const double  *intrinsics;
+    const double  *points;
+    const int32_t *pt_off;
+    const int32_t *obs_cam;
+    const int32_t *obs_xy;
+} rcn_landmark_problem;
+int rcn_landmark_validity(rcn_ctx *ctx, const rcn_landmark_problem *problem, double max_projection_error,
+                          double min_triangulation_angle, uint8_t *out_inlier, uint8_t *out_keep,
+                          int32_t *out_n_inliers);
+/* Same with every pointer (inputs and outputs, out_n_inliers_dev required) in DEVICE memory, e.g.
+ * the arrays a bundle adjustment just left in HBM; asynchronous on the ctx stream, no graph check. */
+int rcn_landmark_validity_device(rcn_ctx *ctx, const rcn_landmark_problem *problem_dev, double max_projection_error,
+                                 double min_triangulation_angle, uint8_t *out_inlier_dev, uint8_t *out_keep_dev,
+                                 int32_t *out_n_inliers_dev);
+
 #ifdef __cplusplus
 }
 #endif

@@ -19,6 +19,7 @@ SYMBOLS = [
     "rcn_synchronize", "rcn_desc_upload", "rcn_desc_upload_device", "rcn_desc_upload_batch_device", "rcn_desc_clear",
     "rcn_desc_count", "rcn_match_pair", "rcn_match_grid", "rcn_match_grid_device",
     "rcn_match_last_stats", "rcn_match_profile", "rcn_ba_default_options", "rcn_ba_solve",
+    "rcn_landmark_validity", "rcn_landmark_validity_device",
 ]
 
 
@@ -40,6 +41,13 @@ class BaProblem(C.Structure):
                 ("reserved", C.c_int32),
                 ("poses", C.c_void_p), ("intrinsics", C.c_void_p), ("points", C.c_void_p),
                 ("obs_uv", C.c_void_p), ("obs_cam", C.c_void_p), ("obs_pt", C.c_void_p)]
+
+
+class LandmarkProblem(C.Structure):
+    _fields_ = [("n_cams", C.c_int32), ("n_points", C.c_int32), ("n_obs", C.c_int32),
+                ("reserved", C.c_int32),
+                ("poses34", C.c_void_p), ("intrinsics", C.c_void_p), ("points", C.c_void_p),
+                ("pt_off", C.c_void_p), ("obs_cam", C.c_void_p), ("obs_xy", C.c_void_p)]
 
 
 class BaOptions(C.Structure):
@@ -119,6 +127,9 @@ def load():
     L.rcn_ba_default_options.argtypes = [i32, C.POINTER(BaOptions)]
     L.rcn_ba_solve.restype = C.c_int
     L.rcn_ba_solve.argtypes = [vp, C.POINTER(BaProblem), C.POINTER(BaOptions), C.POINTER(BaSummary)]
+    for fn in (L.rcn_landmark_validity, L.rcn_landmark_validity_device):
+        fn.restype = C.c_int
+        fn.argtypes = [vp, C.POINTER(LandmarkProblem), C.c_double, C.c_double, vp, vp, vp]
     _LIB = L
     return L
 

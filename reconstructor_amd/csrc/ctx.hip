@@ -80,6 +80,7 @@ void rcn_destroy(rcn_ctx *ctx)
                       &ctx->fb_list, &ctx->sv_list, &ctx->counters, &ctx->out_tmp, &ctx->cnt_tmp};
     for (DevBuf *b : bufs) b->release();
     for (DevBuf &b : ctx->ba_ws) b.release();
+    ctx->lm_ws.release();
     if (ctx->ev_made)
         for (auto &row : ctx->ev)
             for (auto &e : row) (void)hipEventDestroy(e);

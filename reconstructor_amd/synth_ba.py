@@ -95,3 +95,46 @@ def make_scene(n_cams, n_points, obs_per_point=10, seed=2024, noise_px=0.5, inte
             "poses": p0, "intrinsics": i0, "points": x0,
             "obs_uv": np.ascontiguousarray(uv), "obs_cam": np.ascontiguousarray(obs_cam),
             "obs_pt": np.ascontiguousarray(obs_pt)}
+
+
+def poses_to_34(poses):
+    """(n,6) angle-axis * angle, translation -> (n,12) rows of [R | t] (world -> camera), the
+    layout of imgIdx2camPose that the landmark validity sweep reads."""
+    out = np.zeros((len(poses), 3, 4))
+    for i, p in enumerate(np.asarray(poses, np.float64)):
+        out[i, :, :3] = rodrigues(p[:3])
+        out[i, :, 3] = p[3:]
+    return out.reshape(len(poses), 12)
+
+
+def make_validity_case(n_cams, n_points, obs_per_point=10, seed=7, defect_rate=0.15):
+    """Input of the landmark validity sweep with every kind of defect the reference tests for:
+    ragged tracks (0 .. obs_per_point observations), observations displaced around the 4-px L1
+    threshold, landmarks pushed behind some of their cameras, narrow-baseline tracks (angle
+    around the 1-degree threshold) and a few cameras with radial distortion."""
+    sc = make_scene(n_cams, n_points, obs_per_point=obs_per_point, seed=seed)
+    rng = np.random.default_rng(seed + 1000)
+    k = min(obs_per_point, n_cams)
+    poses, intr, pts = sc["poses_gt"].copy(), sc["intr_gt"].copy(), sc["points_gt"].copy()
+    intr[rng.random(n_cams) < 0.2, 4:] = rng.normal(0, 1e-3, (1, 2))
+    cam = sc["obs_cam"].reshape(n_points, k).copy()
+    # narrow-baseline tracks: every observation from a run of neighbouring cameras
+    narrow = rng.random(n_points) < defect_rate / 2
+    start = rng.integers(0, n_cams, n_points)
+    width = rng.integers(1, 4, n_points)
+    cam[narrow] = (start[narrow, None] + rng.integers(0, 4, (narrow.sum(), k)) % width[narrow, None]) % n_cams
+    # a few landmarks far out along a viewing ray (tiny triangulation angle) or behind cameras
+    far = rng.random(n_points) < defect_rate / 3
+    pts[far] *= rng.choice([40.0, 400.0, -4.0], (far.sum(), 1))
+    uv, depth = project(poses[cam.reshape(-1)], intr[cam.reshape(-1)], np.repeat(pts, k, axis=0))
+    uv = uv + 0.5 * rng.standard_normal(uv.shape)
+    bump = rng.random(len(uv)) < defect_rate
+    uv[bump] += rng.uniform(-5, 5, (bump.sum(), 2))
+    xy = np.trunc(np.nan_to_num(uv, nan=0.0, posinf=1e6, neginf=-1e6)).astype(np.int64).clip(-2**31 + 1, 2**31 - 1).astype(np.int32)
+    # ragged tracks
+    length = np.where(rng.random(n_points) < defect_rate, rng.integers(0, 4, n_points), rng.integers(2, k + 1, n_points))
+    sel = (np.arange(k)[None, :] < length[:, None]).reshape(-1)
+    pt_off = np.concatenate([[0], np.cumsum(length)]).astype(np.int32)
+    return {"poses34": poses_to_34(poses), "intrinsics": intr, "points": pts, "pt_off": pt_off,
+            "obs_cam": np.ascontiguousarray(cam.reshape(-1)[sel].astype(np.int32)),
+            "obs_xy": np.ascontiguousarray(xy[sel])}

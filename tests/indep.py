@@ -57,3 +57,55 @@ def numpy_match_pair(q, t, ratio=0.7):
     order = np.argsort(d2, axis=1, kind="stable")
     r = np.arange(K1)
     return ratio_unique(order[:, 0], d2[r, order[:, 0]], d2[r, order[:, 1]], K2, ratio)
+
+
+# ---- landmark validity sweep: literal transcription of the control flow with Python lists -----
+def validity_python(poses34, intr, points, pt_off, obs_cam, obs_xy, max_err=4.0, min_angle=1.0):
+    """checkLandmarkValidity with an actual list and `del`, numpy float64 scalars (round-to-nearest,
+    one operation at a time).  Slow: small cases only."""
+    import math
+    poses34 = np.asarray(poses34, np.float64).reshape(-1, 3, 4)
+    inl, keep = [], np.zeros(len(obs_cam), bool)
+    for j in range(len(points)):
+        X = np.asarray(points[j], np.float64)
+        track = list(range(pt_off[j], pt_off[j + 1]))
+        ok = True
+        i = 0
+        while i < len(track):
+            o = track[i]
+            P, K = poses34[obs_cam[o]], intr[obs_cam[o]]
+            l = [((P[r, 0] * X[0] + P[r, 1] * X[1]) + P[r, 2] * X[2]) + P[r, 3] for r in range(3)]
+            with np.errstate(all="ignore"):
+                x, y = np.float64(l[0]) / np.float64(l[2]), np.float64(l[1]) / np.float64(l[2])
+                rad = x * x + y * y
+                dist = K[4] * rad + (K[5] * rad) * rad
+                u, v = K[0] * (x + dist) + K[2], K[1] * (y + dist) + K[3]
+                resid = abs(u - float(obs_xy[o][0])) + abs(v - float(obs_xy[o][1]))
+            if resid > max_err or l[2] < 0:
+                del track[i]
+                if len(track) < 2:
+                    ok = False
+            i += 1
+        angle_ok = False
+        for a in track:
+            for b in track:
+                if a == b:
+                    continue
+                Pa, Pb = poses34[obs_cam[a]], poses34[obs_cam[b]]
+                ca = [((-Pa[0, c]) * Pa[0, 3] + (-Pa[1, c]) * Pa[1, 3]) + (-Pa[2, c]) * Pa[2, 3] for c in range(3)]
+                cb = [((-Pb[0, c]) * Pb[0, 3] + (-Pb[1, c]) * Pb[1, 3]) + (-Pb[2, c]) * Pb[2, 3] for c in range(3)]
+                r1 = [X[c] - ca[c] for c in range(3)]
+                r2 = [X[c] - cb[c] for c in range(3)]
+                dot = (r1[0] * r2[0] + r1[1] * r2[1]) + r1[2] * r2[2]
+                n1 = np.sqrt((r1[0] * r1[0] + r1[1] * r1[1]) + r1[2] * r1[2])
+                n2 = np.sqrt((r2[0] * r2[0] + r2[1] * r2[1]) + r2[2] * r2[2])
+                with np.errstate(all="ignore"):
+                    cosv = np.float64(dot) / (n1 * n2)
+                ang = 180.0 * math.acos(cosv) / 3.1415 if -1.0 <= cosv <= 1.0 else float("nan")
+                if ang > min_angle:
+                    angle_ok = True
+        if not angle_ok:
+            ok = False
+        inl.append(ok)
+        keep[track] = True
+    return np.array(inl, bool), keep

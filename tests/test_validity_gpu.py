@@ -1,0 +1,82 @@
+"""GPU suite: rcn_landmark_validity (validity.hip) against the oracle -- boolean outputs, bit-exact."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import orc_validity as ov
+from reconstructor_amd import _lib, synth_ba, validity
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "validity_small.npz")
+
+
+def _args(c):
+    return c["poses34"], c["intrinsics"], c["points"], c["pt_off"], c["obs_cam"], c["obs_xy"]
+
+
+def test_golden_fixture(gpu_ctx):
+    g = np.load(GOLD)
+    inl, keep = validity.check_landmark_validity(gpu_ctx, *_args(g))
+    assert (inl == g["inlier"]).all() and (keep == g["keep"]).all()
+
+
+@pytest.mark.parametrize("nc,npts,k,seed,rate", [(10, 300, 6, 1, 0.3), (25, 5000, 8, 2, 0.15), (200, 20000, 10, 3, 0.15)])
+def test_seeded_cases_match_oracle(gpu_ctx, nc, npts, k, seed, rate):
+    c = synth_ba.make_validity_case(nc, npts, obs_per_point=k, seed=seed, defect_rate=rate)
+    want = ov.landmark_validity(**c)
+    got = validity.check_landmark_validity(gpu_ctx, *_args(c))
+    assert (got[0] == want[0]).all() and (got[1] == want[1]).all()
+    assert 0 < want[0].sum() < npts
+    # thresholds travel through the ABI
+    want2 = ov.landmark_validity(**c, max_err=1.5, min_angle=3.0)
+    got2 = validity.check_landmark_validity(gpu_ctx, *_args(c), max_projection_error=1.5, min_triangulation_angle=3.0)
+    assert (got2[0] == want2[0]).all() and (got2[1] == want2[1]).all() and want2[0].sum() < want[0].sum()
+
+
+def test_edge_cases(gpu_ctx):
+    I34 = np.array([[1, 0, 0, 0.5, 0, 1, 0, 0, 0, 0, 1, 0], [1, 0, 0, -0.5, 0, 1, 0, 0, 0, 0, 1, 0]], float)
+    K = np.tile([600.0, 600, 256, 168, 0, 0], (2, 1))
+    X = np.array([[0.0, 0, 5], [0.0, 0, -5], [0.0, 0, 0], [0.0, 0, 5], [1.0, 1, 5]])
+    pt_off = np.array([0, 2, 4, 6, 6, 7], np.int32)                    # track 3 empty, track 4 single
+    cam = np.array([0, 1, 0, 1, 0, 1, 0], np.int32)
+    xy = np.array([[316, 168], [196, 168], [316, 168], [196, 168], [256, 168], [256, 168], [0, 0]], np.int32)
+    want = ov.landmark_validity(I34, K, X, pt_off, cam, xy)
+    got = validity.check_landmark_validity(gpu_ctx, I34, K, X, pt_off, cam, xy)
+    assert (got[0] == want[0]).all() and (got[1] == want[1]).all()
+    assert want[0].tolist() == [True, False, True, False, False]     # depth 0 keeps both; rays 180 degrees apart
+    # nothing at all
+    inl, keep = validity.check_landmark_validity(gpu_ctx, I34, K, np.zeros((0, 3)), [0], np.zeros(0, np.int32), np.zeros((0, 2), np.int32))
+    assert len(inl) == 0 and len(keep) == 0
+    # malformed graph: status code, not a crash
+    with pytest.raises(_lib.RcnError) as e:
+        validity.check_landmark_validity(gpu_ctx, I34, K, X, pt_off, cam + 5, xy)
+    assert e.value.code == -1 and "obs_cam" in str(e.value)
+    with pytest.raises(_lib.RcnError):
+        validity.check_landmark_validity(gpu_ctx, I34, K, X, pt_off[::-1].copy(), cam, xy)
+
+
+def test_full_size_properties_and_device_entry(gpu_ctx):
+    """cfg 5 of the BA (1000 cameras, 100k landmarks, ~1M observations): the oracle still finishes in
+    a second, so compare outright; then the device-pointer entry on the same arrays."""
+    import ctypes as C
+    import torch
+    c = synth_ba.make_validity_case(1000, 100000, obs_per_point=10, seed=9, defect_rate=0.1)
+    want = ov.landmark_validity(**c)
+    got = validity.check_landmark_validity(gpu_ctx, *_args(c))
+    assert (got[0] == want[0]).all() and (got[1] == want[1]).all()
+    # every erased observation belongs to a track; inlier landmarks keep >= 2 observations
+    cnt = np.add.reduceat(got[1].astype(np.int64), c["pt_off"][:-1].clip(max=len(got[1]) - 1))
+    length = np.diff(c["pt_off"])
+    assert (cnt[(length > 0) & got[0]] >= 2).all()
+    dev = {k: torch.from_numpy(np.ascontiguousarray(v)).cuda() for k, v in c.items()}
+    inl_d = torch.zeros(len(c["points"]), dtype=torch.uint8, device="cuda")
+    keep_d = torch.zeros(len(c["obs_cam"]), dtype=torch.uint8, device="cuda")
+    n_d = torch.zeros(1, dtype=torch.int32, device="cuda")
+    pb = _lib.LandmarkProblem(1000, 100000, len(c["obs_cam"]), 0, dev["poses34"].data_ptr(), dev["intrinsics"].data_ptr(),
+                              dev["points"].data_ptr(), dev["pt_off"].data_ptr(), dev["obs_cam"].data_ptr(), dev["obs_xy"].data_ptr())
+    torch.cuda.synchronize()
+    gpu_ctx.check(gpu_ctx.lib.rcn_landmark_validity_device(gpu_ctx.h, C.byref(pb), 4.0, 1.0, inl_d.data_ptr(), keep_d.data_ptr(), n_d.data_ptr()))
+    gpu_ctx.check(gpu_ctx.lib.rcn_synchronize(gpu_ctx.h))
+    assert (inl_d.cpu().numpy().astype(bool) == want[0]).all() and (keep_d.cpu().numpy().astype(bool) == want[1]).all()
+    assert int(n_d.item()) == int(want[0].sum())
