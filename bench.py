@@ -80,6 +80,54 @@ def ba_leg(ctx, with_cpu):
                                "sample": "cfg4 full solve (%d iterations, %.2f s), oracle/ba_oracle.c" % (s["iterations"], time.perf_counter() - t0),
                                "final_rms_px": s["final_rms_px"]}
         out["cfg4"]["rms_diff_vs_cpu_px"] = abs(out["cfg4"]["final_rms_px"] - s["final_rms_px"])
+    out["landmark_sweep"] = sweep_leg(ctx, with_cpu)
+    return out
+
+
+def sweep_leg(ctx, with_cpu):
+    """Landmark validity sweep (checkLandmarkValidity) on the cfg-5 observation
+    graph: 1000 cameras, 100k landmarks, ragged tracks of up to 10 observations, inputs resident in
+    HBM (rcn_landmark_validity_device), timed over 20 back-to-back sweeps."""
+    import ctypes as C
+    import torch
+    from reconstructor_amd import _lib, synth_ba
+    c = synth_ba.make_validity_case(1000, 100000, obs_per_point=10, seed=9, defect_rate=0.1)
+    dev = {k: torch.from_numpy(np.ascontiguousarray(v)).cuda() for k, v in c.items()}
+    n_pts, n_obs = len(c["points"]), len(c["obs_cam"])
+    inl = torch.zeros(n_pts, dtype=torch.uint8, device="cuda")
+    keep = torch.zeros(n_obs, dtype=torch.uint8, device="cuda")
+    cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
+    pb = _lib.LandmarkProblem(1000, n_pts, n_obs, 0, dev["poses34"].data_ptr(), dev["intrinsics"].data_ptr(), dev["points"].data_ptr(),
+                              dev["pt_off"].data_ptr(), dev["obs_cam"].data_ptr(), dev["obs_xy"].data_ptr())
+    torch.cuda.synchronize()
+
+    def sweep():
+        ctx.check(ctx.lib.rcn_landmark_validity_device(ctx.h, C.byref(pb), 4.0, 1.0, inl.data_ptr(), keep.data_ptr(), cnt.data_ptr()))
+    for _ in range(3):
+        sweep()
+    ctx.check(ctx.lib.rcn_synchronize(ctx.h))
+    reps = 20
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        sweep()
+    ctx.check(ctx.lib.rcn_synchronize(ctx.h))
+    dt = (time.perf_counter() - t0) / reps
+    # streamed once per sweep: obs_cam 4 + obs_xy 8 + keep 1 B per observation, point 24 + offset 4 + flag 1 B per
+    # landmark (poses / intrinsics / centres, 168 B per camera, stay in L2)
+    alg = 13.0 * n_obs + 29.0 * n_pts
+    out = {"workload": "1000 cams / 100000 landmarks / %d observations" % n_obs, "landmarks_per_s": n_pts / dt,
+           "observations_per_s": n_obs / dt, "ms_per_sweep": 1e3 * dt, "valid_landmarks": int(cnt.item()),
+           "roofline": {"bound": "hbm", "achieved": alg / dt * 1e-9, "peak": 8000.0, "unit": "GB/s",
+                        "frac": alg / dt * 1e-9 / 8000.0, "traffic": None}}
+    if with_cpu:
+        from oracle import orc_validity
+        t0 = time.perf_counter()
+        for _ in range(5):
+            inl0, keep0 = orc_validity.landmark_validity(**c)
+        dtc = (time.perf_counter() - t0) / 5
+        out["cpu_baseline"] = {"value": n_pts / dtc, "unit": "landmarks/s", "cores": 1, "kind": "port",
+                               "sample": "5 full sweeps, oracle/validity_oracle.c, %.2f s" % (5 * dtc)}
+        out["equal_to_cpu"] = bool((inl.cpu().numpy().astype(bool) == inl0).all() and (keep.cpu().numpy().astype(bool) == keep0).all())
     return out
 
 

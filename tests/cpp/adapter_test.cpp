@@ -1,6 +1,7 @@
 // adapter_test.cpp -- exercises the C++ adapters exactly as the reference's pipeline would:
 //   featMatcher->matchFeatures(features1, features2, curMatches, shape1, shape2)   (SequentialReconstructor.cpp:232)
 //   BundleAdjuster().adjust(features, landmarks, imgIdx2camPose, imgIdx2camIntrinsics, imgIdxOrder)   (:1064-1069)
+//   checkLandmarkValidity() / removeOutlierLandmarks()                               (:1071-1074)
 // Reads a small binary problem written by tests/test_cpp_adapter.py, writes the results back.
 #include <cstdio>
 #include <cstdlib>
@@ -8,6 +9,7 @@
 
 #include "../../reconstructor_amd/host/HipBundleAdjuster.h"
 #include "../../reconstructor_amd/host/HipFeatureMatcher.h"
+#include "../../reconstructor_amd/host/HipLandmarkValidity.h"
 
 using namespace reconstructor::Core;
 
@@ -63,6 +65,7 @@ int main(int argc, char **argv)
             int32_t rec[3]; rd(f, rec, 12);
             const int g = order[rec[0]];
             feats[g].push_back(std::make_shared<Feature<>>(FeatCoord<>(rec[1], rec[2]), FeatDesc()));
+            feats[g].back()->landmarkId = j;
             lm.triangulatedFeatures.emplace_back(g, (int)feats[g].size() - 1);
         }
         landmarks.push_back(lm);
@@ -75,7 +78,21 @@ int main(int argc, char **argv)
     for (auto &lm : landmarks) { double X[3] = {lm.x, lm.y, lm.z}; fwrite(X, 8, 3, o); }
     for (int l = 0; l < nc; ++l) fwrite(poses[order[l]].m, 8, 16, o);
     for (int l = 0; l < nc; ++l) { int32_t v = g2l[order[l]]; fwrite(&v, 4, 1, o); }
+    // ---- validity sweep on the adjusted scene, with the thresholds read from the input
+    double thr[2];
+    rd(f, thr, 16);
+    LandmarkValidator validator(hm->context());
+    validator.maxProjectionError = thr[0]; validator.minTriangulationAngle = thr[1];
+    auto inlierIds = validator.checkLandmarkValidity(feats, landmarks, poses, intr);
+    for (size_t j = 0; j < landmarks.size(); ++j) {
+        int32_t rec[2] = {inlierIds[j] ? 1 : 0, (int32_t)landmarks[j].triangulatedFeatures.size()};
+        fwrite(rec, 4, 2, o);
+    }
+    LandmarkValidator::removeOutlierLandmarks(feats, landmarks, inlierIds);
+    int32_t left = (int32_t)landmarks.size(), unassigned = 0;
+    for (auto &kv : feats) for (auto &ft : kv.second) unassigned += ft->landmarkId == -1;
+    fwrite(&left, 4, 1, o); fwrite(&unassigned, 4, 1, o);
     fclose(f); fclose(o);
-    printf("adapter_test ok: %d matches, BA %d iterations, rms %.6f\n", n, bundleAdjuster.summary.iterations, bundleAdjuster.summary.final_rms_px);
+    printf("adapter_test ok: %d matches, BA %d iterations, rms %.6f, %d landmarks valid\n", n, bundleAdjuster.summary.iterations, bundleAdjuster.summary.final_rms_px, left);
     return 0;
 }

@@ -7,7 +7,7 @@ import subprocess
 import numpy as np
 import pytest
 
-from oracle import orc, orc_ba
+from oracle import orc, orc_ba, orc_validity
 from reconstructor_amd import synth, synth_ba
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -41,6 +41,7 @@ def test_cpp_adapter_matches_oracle(tmp_path):
             f.write(sc["points"][j].astype(np.float64).tobytes()); f.write(struct.pack("i", len(obs)))
             for o in obs:
                 f.write(struct.pack("iii", int(sc["obs_cam"][o]), int(sc["obs_uv"][o, 0]), int(sc["obs_uv"][o, 1])))
+        f.write(struct.pack("dd", 0.8, 140.0))   # thresholds of the validity sweep: tight enough for a mixed outcome
     r = subprocess.run([BIN, str(inp), str(outp)], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
     raw = open(outp, "rb").read()
@@ -56,3 +57,16 @@ def test_cpp_adapter_matches_oracle(tmp_path):
     assert np.allclose(X, X0, atol=1e-5)
     g2l = np.frombuffer(raw, np.int32, 5, off + 12 + 180 * 8 + 5 * 128)
     assert list(g2l) == [0, 1, 2, 3, 4]
+    # landmark validity sweep on the adjusted scene: the adapter's own outputs feed the oracle
+    T = np.frombuffer(raw, np.float64, 5 * 16, off + 12 + 180 * 8).reshape(5, 4, 4)
+    voff = off + 12 + 180 * 8 + 5 * 128 + 20
+    rec = np.frombuffer(raw, np.int32, 120, voff).reshape(60, 2)
+    left, unassigned = np.frombuffer(raw, np.int32, 2, voff + 480)
+    pt_off = np.concatenate([[0], np.cumsum(np.bincount(sc["obs_pt"], minlength=60))]).astype(np.int32)
+    inl, keep = orc_validity.landmark_validity(T[:, :3, :].reshape(5, 12), sc["intrinsics"], X, pt_off, sc["obs_cam"],
+                                               sc["obs_uv"].astype(np.int32), max_err=0.8, min_angle=140.0)
+    assert (rec[:, 0].astype(bool) == inl).all() and 0 < inl.sum() < 60
+    assert (rec[:, 1] == np.add.reduceat(keep.astype(np.int32), pt_off[:-1])).all()
+    kept = np.add.reduceat(keep.astype(np.int32), pt_off[:-1])
+    # removeOutlierLandmarks resets landmarkId only for the observations still in an outlier's track
+    assert left == inl.sum() and unassigned == kept[~inl].sum()
