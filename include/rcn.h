@@ -213,6 +213,28 @@ int rcn_landmark_validity_device(rcn_ctx *ctx, const rcn_landmark_problem *probl
                                  double min_triangulation_angle, uint8_t *out_inlier_dev, uint8_t *out_keep_dev,
                                  int32_t *out_n_inliers_dev);
 
+/* ---- epipolar filter of a pair's matches --------------------------------------------------
+ * GeometricFilter::estimateFundamental (GeometricFilter.cpp:39-61) as the pair loop uses it
+ * (SequentialReconstructor.cpp:237-269): cv::findFundamentalMat(pts1, pts2, mask) with OpenCV's
+ * defaults -- RANSAC over 7-point samples for >= 15 points, LMedS for 8..14, threshold 3 px,
+ * confidence 0.99, at most 1000 iterations, cv::RNG seeded the same way at every call -- of which
+ * the reference keeps only the inlier mask.
+ *   xy1, xy2   n x 2 integer pixel coordinates of the matched features (featuresToCvPoints,
+ *              utils.cpp:165-177), in ascending query-feature order (the std::map's order)
+ *   out_mask   n bytes, 1 = inlier
+ *   out_count  inliers; -1: no model was found (the reference then stores no match for the pair,
+ *              :252-255; mask all 0); -2: fewer than 7 points, not filtered (mask all 1, :237). */
+int rcn_fmat_filter(rcn_ctx *ctx, const int32_t *xy1, const int32_t *xy2, int32_t n, uint8_t *out_mask,
+                    int32_t *out_count);
+/* All pairs of a grid in one launch: pair p owns points pair_off[p] .. pair_off[p+1] of xy1 / xy2 /
+ * out_mask; out_counts[p] as above; out_iterations (may be NULL) = sampling iterations executed. */
+int rcn_fmat_filter_grid(rcn_ctx *ctx, int32_t n_pairs, const int32_t *pair_off, const int32_t *xy1,
+                         const int32_t *xy2, uint8_t *out_mask, int32_t *out_counts, int32_t *out_iterations);
+/* Same with every pointer in DEVICE memory (all required); asynchronous on the ctx stream. */
+int rcn_fmat_filter_grid_device(rcn_ctx *ctx, int32_t n_pairs, const int32_t *pair_off_dev, const int32_t *xy1_dev,
+                                const int32_t *xy2_dev, uint8_t *out_mask_dev, int32_t *out_counts_dev,
+                                int32_t *out_iterations_dev);
+
 #ifdef __cplusplus
 }
 #endif

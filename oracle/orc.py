@@ -14,7 +14,7 @@ _LIB = None
 
 def build(force=False):
     so = os.path.join(_HERE, "liborc.so")
-    srcs = [os.path.join(_HERE, f) for f in ("match_oracle.c", "ba_oracle.c", "validity_oracle.c", "Makefile")]
+    srcs = [os.path.join(_HERE, f) for f in ("match_oracle.c", "ba_oracle.c", "validity_oracle.c", "fmat_oracle.c", "Makefile")]
     stale = (not os.path.exists(so)) or any(
         os.path.getmtime(s) > os.path.getmtime(so) for s in srcs)
     if force or stale:
@@ -48,9 +48,10 @@ def _sig():
     L.orc_match_grid.restype = None
     L.orc_match_grid.argtypes = [_f32p, _i64p, C.c_int, C.c_int, _i32p, C.c_int, C.c_float,
                                  _i32p, C.c_int64, _i32p, C.c_int]
-    from . import orc_ba, orc_validity
+    from . import orc_ba, orc_fmat, orc_validity
     orc_ba.register(L)
     orc_validity.register(L)
+    orc_fmat.register(L)
 
 
 RATIO = np.float32(0.7)  # FeatureMatcher.h:45  `const float ratioThresh = 0.7`

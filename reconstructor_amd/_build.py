@@ -9,7 +9,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 SO = os.path.join(HERE, "librcn.so")
-SOURCES = ["ctx.hip", "match.hip", "ba.hip", "validity.hip"]
+SOURCES = ["ctx.hip", "match.hip", "ba.hip", "validity.hip", "fmat.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
          "-munsafe-fp-atomics"]

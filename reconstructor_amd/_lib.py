@@ -20,6 +20,7 @@ SYMBOLS = [
     "rcn_desc_count", "rcn_match_pair", "rcn_match_grid", "rcn_match_grid_device",
     "rcn_match_last_stats", "rcn_match_profile", "rcn_ba_default_options", "rcn_ba_solve",
     "rcn_landmark_validity", "rcn_landmark_validity_device",
+    "rcn_fmat_filter", "rcn_fmat_filter_grid", "rcn_fmat_filter_grid_device",
 ]
 
 
@@ -130,6 +131,11 @@ def load():
     for fn in (L.rcn_landmark_validity, L.rcn_landmark_validity_device):
         fn.restype = C.c_int
         fn.argtypes = [vp, C.POINTER(LandmarkProblem), C.c_double, C.c_double, vp, vp, vp]
+    L.rcn_fmat_filter.restype = C.c_int
+    L.rcn_fmat_filter.argtypes = [vp, vp, vp, i32, vp, vp]
+    for fn in (L.rcn_fmat_filter_grid, L.rcn_fmat_filter_grid_device):
+        fn.restype = C.c_int
+        fn.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp]
     _LIB = L
     return L
 

@@ -81,6 +81,7 @@ void rcn_destroy(rcn_ctx *ctx)
     for (DevBuf *b : bufs) b->release();
     for (DevBuf &b : ctx->ba_ws) b.release();
     ctx->lm_ws.release();
+    ctx->fm_ws.release();
     if (ctx->ev_made)
         for (auto &row : ctx->ev)
             for (auto &e : row) (void)hipEventDestroy(e);
