@@ -109,3 +109,119 @@ def validity_python(poses34, intr, points, pt_off, obs_cam, obs_xy, max_err=4.0,
         inl.append(ok)
         keep[track] = True
     return np.array(inl, bool), keep
+
+
+# ---- epipolar filter: same control flow, different numerics (SVD null space, numpy.roots) --------
+def fmat_python(xy1, xy2):
+    """findFundamentalMat's default path re-derived with numpy linear algebra: the sampling sequence
+    and the accept logic are transcribed, the 7-point models come from an SVD null space and
+    numpy.roots (ordered smallest, largest, middle like the closed form).  Returns (mask, count, iters)."""
+    import math
+    m1 = np.asarray(xy1, np.float64).reshape(-1, 2)
+    m2 = np.asarray(xy2, np.float64).reshape(-1, 2)
+    n = len(m1)
+    if n < 7:
+        return np.ones(n, bool), -2, 0
+    state = [(1 << 64) - 1]
+
+    def nxt():
+        s = state[0]
+        s = ((s & 0xFFFFFFFF) * 4164903690 + (s >> 32)) & ((1 << 64) - 1)
+        state[0] = s
+        return s & 0xFFFFFFFF
+
+    def collinear(m):
+        i = 6
+        for j in range(i):
+            dx1, dy1 = m[j] - m[i]
+            for k in range(j):
+                dx2, dy2 = m[k] - m[i]
+                if abs(dx2 * dy1 - dy2 * dx1) <= np.finfo(np.float32).eps * (abs(dx1) + abs(dy1) + abs(dx2) + abs(dy2)):
+                    return True
+        return False
+
+    def draw():
+        for _ in range(10000):
+            idx = []
+            while len(idx) < 7:
+                v = nxt() % n
+                if v not in idx:
+                    idx.append(v)
+            if not collinear(m1[idx]) and not collinear(m2[idx]):
+                return idx
+        return None
+
+    def seven(idx):
+        A = np.array([[x1 * x0, x1 * y0, x1, y1 * x0, y1 * y0, y1, x0, y0, 1.0]
+                      for (x0, y0), (x1, y1) in zip(m1[idx], m2[idx])])
+        _, sv, vt = np.linalg.svd(A)
+        if sv[6] <= 1e-12 * sv[0]:
+            return []
+        f1, f2 = vt[7].reshape(3, 3), vt[8].reshape(3, 3)
+        lam = np.array([-1.0, 0.0, 1.0, 2.0])
+        coef = np.polyfit(lam, [np.linalg.det(l * f1 + (1 - l) * f2) for l in lam], 3)
+        roots = np.roots(coef)
+        real = sorted(r.real for r in roots if abs(r.imag) < 1e-9 * max(1.0, abs(r.real)))
+        if len(real) == 3:
+            real = [real[0], real[2], real[1]]
+        out = []
+        for l in real:
+            F = l * f1 + (1 - l) * f2
+            out.append(F / F[2, 2] if abs(F[2, 2]) > 1e-300 else F)
+        return out
+
+    def errors(F):
+        h1 = np.c_[m1, np.ones(n)]
+        h2 = np.c_[m2, np.ones(n)]
+        l2 = h1 @ F.T
+        l1 = h2 @ F
+        d2 = (h2 * l2).sum(1) ** 2 / (l2[:, 0] ** 2 + l2[:, 1] ** 2)
+        d1 = (h1 * l1).sum(1) ** 2 / (l1[:, 0] ** 2 + l1[:, 1] ** 2)
+        return np.maximum(d1, d2).astype(np.float32)
+
+    def niters_for(ep, max_iters):
+        num = max(1 - 0.99, 2.2250738585072014e-308)
+        den = 1 - (1 - ep) ** 7
+        if den < 2.2250738585072014e-308:
+            return 0
+        num, den = math.log(num), math.log(den)
+        return max_iters if den >= 0 or -num >= max_iters * (-den) else int(round(num / den))   # banker's rounding = cvRound
+
+    if n == 7:
+        ok = len(seven(list(range(7)))) > 0
+        return np.full(7, ok), (7 if ok else -1), 1
+    best, done = None, 0
+    if n >= 15:
+        niters, max_good, mask = 1000, 0, np.zeros(n, bool)
+        it = 0
+        while it < niters:
+            idx = draw()
+            if idx is None:
+                break
+            done = it + 1
+            for F in seven(idx):
+                cur = errors(F) <= 9.0
+                g = int(cur.sum())
+                if g > max(max_good, 6):
+                    mask, max_good = cur, g
+                    niters = niters_for((n - g) / n, niters)
+            it += 1
+        return (mask, max_good, done) if max_good > 0 else (np.zeros(n, bool), -1, done)
+    niters = max(niters_for(0.45, 1000), 3)
+    min_med = float("inf")
+    for it in range(niters):
+        idx = draw()
+        if idx is None:
+            break
+        done = it + 1
+        for F in seven(idx):
+            e = np.sort(errors(F))
+            med = float(e[n // 2]) if n % 2 else float(np.float32(e[n // 2 - 1] + e[n // 2])) * 0.5
+            if med < min_med:
+                min_med, best = med, F
+    if best is None:
+        return np.zeros(n, bool), -1, done
+    sigma = max(2.5 * 1.4826 * (1 + 5.0 / (n - 7)) * math.sqrt(min_med), 0.001)
+    mask = errors(best) <= sigma * sigma
+    g = int(mask.sum())
+    return (mask, g, done) if g >= 7 else (np.zeros(n, bool), -1, done)

@@ -1,0 +1,104 @@
+"""GPU suite: rcn_fmat_filter* (fmat.hip) against the oracle -- inlier masks, counts and iteration
+counts, bit-exact."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from oracle import orc_fmat as of
+from reconstructor_amd import _lib, fmat, synth_fmat
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "fmat_small.npz")
+
+
+def test_golden_fixture(gpu_ctx):
+    g = np.load(GOLD)
+    mask, counts, iters = fmat.filter_grid(gpu_ctx, g["pair_off"], g["xy1"], g["xy2"])
+    assert (counts == g["counts"]).all() and (iters == g["iterations"]).all() and (mask == g["mask"]).all()
+
+
+@pytest.mark.parametrize("frac,seed", [(0.1, 1), (0.3, 2), (0.6, 3)])
+def test_seeded_grids_match_oracle(gpu_ctx, frac, seed):
+    sizes = [0, 6, 7, 14, 15, 16] + list(np.random.default_rng(seed).integers(15, 900, 120))
+    off, a, b = synth_fmat.grid(sizes, frac, seed=seed)
+    want = of.filter_grid(off, a, b, threads=8)
+    got = fmat.filter_grid(gpu_ctx, off, a, b)
+    assert (got[1] == want[1]).all() and (got[2] == want[2]).all() and (got[0] == want[0]).all()
+    assert (want[1][6:] >= 7).all()
+
+
+def test_single_pair_entry_and_sizes_beyond_the_lds_copy(gpu_ctx):
+    for n, seed in [(7, 1), (20, 2), (2048, 3), (2049, 4), (5000, 5)]:
+        a, b, _ = synth_fmat.two_view(n, 0.3, seed=seed)
+        m0, c0, _ = of.filter_pair(a, b)
+        m1, c1 = fmat.estimate_fundamental_inliers(gpu_ctx, a, b)
+        assert c0 == c1 and (m0 == m1).all()
+    m, c = fmat.estimate_fundamental_inliers(gpu_ctx, a[:4], b[:4])
+    assert c == -2 and m.all()
+    same = np.tile([[100, 100]], (30, 1)).astype(np.int32)
+    m, c = fmat.estimate_fundamental_inliers(gpu_ctx, same, same)          # the draw gives up: no model
+    assert c == -1 and not m.any()
+
+
+def test_errors(gpu_ctx):
+    a, b, _ = synth_fmat.two_view(20, 0.2, seed=1)
+    with pytest.raises(_lib.RcnError):
+        fmat.filter_grid(gpu_ctx, [0, 30, 20], np.r_[a, a], np.r_[b, b])     # offsets not monotone
+    rc = gpu_ctx.lib.rcn_fmat_filter(gpu_ctx.h, None, None, 5, None, None)
+    assert rc == -1
+    mask, counts, iters = fmat.filter_grid(gpu_ctx, [0], a[:0], b[:0])       # empty grid
+    assert len(counts) == 0
+
+
+def test_matcher_output_through_the_filter(gpu_ctx):
+    """The slice of the pair loop this repo covers (SequentialReconstructor.cpp:202-269): match every
+    pair, then keep the epipolar inliers -- GPU path against the oracles' composition."""
+    from oracle import orc
+    from reconstructor_amd import synth
+    from reconstructor_amd.matcher import HipL2Matcher, all_pairs
+    K, n_img = 220, 4
+    ims = synth.descriptor_set("superpoint", n_img, K, n_world=500, seed=8)
+    rng = np.random.default_rng(8)
+    coords = [rng.integers(0, 500, (K, 2)).astype(np.int32) for _ in range(n_img)]
+    m = HipL2Matcher(ctx=gpu_ctx)
+    m.clear()
+    for i, im in enumerate(ims):
+        m.upload(i, im)
+    pairs = all_pairs(n_img)
+    table, _ = m.match_grid(pairs, K)
+    m.clear()
+    exp_table, _ = orc.match_grid(ims, pairs, threads=2)
+    assert np.array_equal(table, exp_table)
+    out, counts = fmat.apply_geometric_filter(gpu_ctx, coords, pairs, table)
+    off, a, b = fmat.matches_to_csr(coords, pairs, exp_table)
+    mask, ocounts, _ = of.filter_grid(off, a, b)
+    assert (counts == ocounts).all()
+    for p in range(len(pairs)):
+        q = np.flatnonzero(exp_table[p] >= 0)
+        keep = mask[off[p]:off[p + 1]] if len(q) >= 7 else np.ones(len(q), bool)
+        want = np.full(K, -1, np.int32)
+        want[q[keep]] = exp_table[p, q[keep]]
+        assert np.array_equal(out[p], want)
+
+
+def test_full_size_grid_properties_and_device_entry(gpu_ctx):
+    """cfg-2-sized grid (4950 pairs, ~500 matches each): counts never exceed the pair's size, the
+    mask sums equal the counts, outliers are rejected; a 600-pair prefix is compared outright."""
+    import torch
+    sizes = np.random.default_rng(0).integers(300, 700, 4950)
+    off, a, b = synth_fmat.grid(sizes[:600], 0.3, seed=11)
+    want = of.filter_grid(off, a, b, threads=16)
+    d = {k: torch.from_numpy(v).cuda() for k, v in (("off", off), ("a", a), ("b", b))}
+    mask_d = torch.zeros(int(off[-1]), dtype=torch.uint8, device="cuda")
+    cnt_d = torch.zeros(600, dtype=torch.int32, device="cuda")
+    it_d = torch.zeros(600, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    gpu_ctx.check(gpu_ctx.lib.rcn_fmat_filter_grid_device(gpu_ctx.h, 600, d["off"].data_ptr(), d["a"].data_ptr(), d["b"].data_ptr(),
+                                                          mask_d.data_ptr(), cnt_d.data_ptr(), it_d.data_ptr()))
+    gpu_ctx.check(gpu_ctx.lib.rcn_synchronize(gpu_ctx.h))
+    assert (cnt_d.cpu().numpy() == want[1]).all() and (it_d.cpu().numpy() == want[2]).all()
+    assert (mask_d.cpu().numpy().astype(bool) == want[0]).all()
+    sums = np.add.reduceat(want[0].astype(np.int64), off[:-1])
+    assert (sums == want[1]).all() and (want[1] <= np.diff(off)).all()
