@@ -223,17 +223,22 @@ int rcn_landmark_validity_device(rcn_ctx *ctx, const rcn_landmark_problem *probl
  *              utils.cpp:165-177), in ascending query-feature order (the std::map's order)
  *   out_mask   n bytes, 1 = inlier
  *   out_count  inliers; -1: no model was found (the reference then stores no match for the pair,
- *              :252-255; mask all 0); -2: fewer than 7 points, not filtered (mask all 1, :237). */
+ *              :252-255; mask all 0); -2: fewer than 7 points, not filtered (mask all 1, :237).
+ *   out_F      may be NULL; 9 doubles, row-major: the winning 7-point hypothesis (F(3,3) = 1), zeros
+ *              when there is none.  (OpenCV returns a refit on the inliers instead; no caller in the
+ *              reference reads the matrix.) */
 int rcn_fmat_filter(rcn_ctx *ctx, const int32_t *xy1, const int32_t *xy2, int32_t n, uint8_t *out_mask,
-                    int32_t *out_count);
+                    int32_t *out_count, double *out_F);
 /* All pairs of a grid in one launch: pair p owns points pair_off[p] .. pair_off[p+1] of xy1 / xy2 /
- * out_mask; out_counts[p] as above; out_iterations (may be NULL) = sampling iterations executed. */
+ * out_mask; out_counts[p] as above; out_iterations (may be NULL) = sampling iterations executed;
+ * out_F (may be NULL) = 9 doubles per pair. */
 int rcn_fmat_filter_grid(rcn_ctx *ctx, int32_t n_pairs, const int32_t *pair_off, const int32_t *xy1,
-                         const int32_t *xy2, uint8_t *out_mask, int32_t *out_counts, int32_t *out_iterations);
-/* Same with every pointer in DEVICE memory (all required); asynchronous on the ctx stream. */
+                         const int32_t *xy2, uint8_t *out_mask, int32_t *out_counts, int32_t *out_iterations,
+                         double *out_F);
+/* Same with every pointer in DEVICE memory (all required but out_F_dev); asynchronous on the ctx stream. */
 int rcn_fmat_filter_grid_device(rcn_ctx *ctx, int32_t n_pairs, const int32_t *pair_off_dev, const int32_t *xy1_dev,
                                 const int32_t *xy2_dev, uint8_t *out_mask_dev, int32_t *out_counts_dev,
-                                int32_t *out_iterations_dev);
+                                int32_t *out_iterations_dev, double *out_F_dev);
 
 #ifdef __cplusplus
 }

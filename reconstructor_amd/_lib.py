@@ -132,10 +132,10 @@ def load():
         fn.restype = C.c_int
         fn.argtypes = [vp, C.POINTER(LandmarkProblem), C.c_double, C.c_double, vp, vp, vp]
     L.rcn_fmat_filter.restype = C.c_int
-    L.rcn_fmat_filter.argtypes = [vp, vp, vp, i32, vp, vp]
+    L.rcn_fmat_filter.argtypes = [vp, vp, vp, i32, vp, vp, vp]
     for fn in (L.rcn_fmat_filter_grid, L.rcn_fmat_filter_grid_device):
         fn.restype = C.c_int
-        fn.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp]
+        fn.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp]
     _LIB = L
     return L
 

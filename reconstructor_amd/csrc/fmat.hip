@@ -30,6 +30,7 @@ struct FmatArgs {
     int32_t n_pairs;
     uint8_t *mask;
     int32_t *counts, *iters;
+    double *F;   // optional: the winning matrix of every pair, 9 doubles (zeros when there is none)
 };
 
 __device__ __forceinline__ unsigned rng_next(unsigned long long &s)
@@ -233,6 +234,7 @@ __global__ __launch_bounds__(256) void k_fmat_filter(FmatArgs a)
         if (n < 7) {   // not filtered by the reference (SequentialReconstructor.cpp:237)
             for (int i = t; i < n; i += 256) mask[i] = 1;
             if (t == 0) { a.counts[pair] = -2; a.iters[pair] = 0; }
+            if (a.F && t < 9) a.F[9 * (size_t)pair + t] = 0.0;
             continue;
         }
         Pts pts;
@@ -384,17 +386,18 @@ __global__ __launch_bounds__(256) void k_fmat_filter(FmatArgs a)
         }
         __syncthreads();
         if (sCtl[7] < 0) for (int i = t; i < n; i += 256) mask[i] = 0;
+        if (a.F && t < 9) a.F[9 * (size_t)pair + t] = sCtl[7] < 0 ? 0.0 : bestF[t];
     }
 }
 
 }  // namespace
 
 static int fmat_launch(rcn_ctx *ctx, int32_t n_pairs, const int32_t *off, const int32_t *xy1, const int32_t *xy2,
-                       uint8_t *mask, int32_t *counts, int32_t *iters)
+                       uint8_t *mask, int32_t *counts, int32_t *iters, double *F)
 {
     if (n_pairs <= 0) return RCN_OK;
     FmatArgs a;
-    a.off = off; a.xy1 = xy1; a.xy2 = xy2; a.n_pairs = n_pairs; a.mask = mask; a.counts = counts; a.iters = iters;
+    a.off = off; a.xy1 = xy1; a.xy2 = xy2; a.n_pairs = n_pairs; a.mask = mask; a.counts = counts; a.iters = iters; a.F = F;
     const int blocks = std::min<int>(n_pairs, ctx->prop.multiProcessorCount * 8);
     k_fmat_filter<<<blocks, 256, 0, ctx->stream>>>(a);
     RCN_HIP(hipGetLastError());
@@ -402,7 +405,8 @@ static int fmat_launch(rcn_ctx *ctx, int32_t n_pairs, const int32_t *off, const 
 }
 
 extern "C" int rcn_fmat_filter_grid(rcn_ctx *ctx, int32_t n_pairs, const int32_t *pair_off, const int32_t *xy1,
-                                    const int32_t *xy2, uint8_t *out_mask, int32_t *out_counts, int32_t *out_iterations)
+                                    const int32_t *xy2, uint8_t *out_mask, int32_t *out_counts, int32_t *out_iterations,
+                                    double *out_F)
 {
     if (!ctx) return RCN_ERR_ARG;
     if (n_pairs < 0 || (n_pairs > 0 && (!pair_off || !out_counts))) { ctx->set_error("rcn_fmat_filter_grid: bad argument"); return RCN_ERR_ARG; }
@@ -417,30 +421,33 @@ extern "C" int rcn_fmat_filter_grid(rcn_ctx *ctx, int32_t n_pairs, const int32_t
     hipStream_t st = ctx->stream;
     auto al = [](size_t b) { return (b + 255) / 256 * 256; };
     const size_t b_off = 4 * ((size_t)n_pairs + 1), b_xy = 8 * N, b_mask = N, b_cnt = 4 * (size_t)n_pairs;
-    RCN_HIP(ctx->fm_ws.reserve(al(b_off) + 2 * al(b_xy) + al(b_mask) + 2 * al(b_cnt) + 256));
+    const size_t b_F = out_F ? 72 * (size_t)n_pairs : 0;
+    RCN_HIP(ctx->fm_ws.reserve(al(b_off) + 2 * al(b_xy) + al(b_mask) + 2 * al(b_cnt) + al(b_F) + 256));
     char *base = ctx->fm_ws.as<char>();
     size_t o = 0;
     auto take = [&](size_t b) { char *q = base + o; o += al(b); return q; };
     int32_t *d_off = (int32_t *)take(b_off), *d_1 = (int32_t *)take(b_xy), *d_2 = (int32_t *)take(b_xy);
     uint8_t *d_mask = (uint8_t *)take(b_mask);
     int32_t *d_cnt = (int32_t *)take(b_cnt), *d_it = (int32_t *)take(b_cnt);
+    double *d_F = out_F ? (double *)take(b_F) : nullptr;
     RCN_HIP(hipMemcpyAsync(d_off, pair_off, b_off, hipMemcpyHostToDevice, st));
     if (N > 0) {
         RCN_HIP(hipMemcpyAsync(d_1, xy1, b_xy, hipMemcpyHostToDevice, st));
         RCN_HIP(hipMemcpyAsync(d_2, xy2, b_xy, hipMemcpyHostToDevice, st));
     }
-    int rc = fmat_launch(ctx, n_pairs, d_off, d_1, d_2, d_mask, d_cnt, d_it);
+    int rc = fmat_launch(ctx, n_pairs, d_off, d_1, d_2, d_mask, d_cnt, d_it, d_F);
     if (rc) return rc;
     if (N > 0) RCN_HIP(hipMemcpyAsync(out_mask, d_mask, b_mask, hipMemcpyDeviceToHost, st));
     RCN_HIP(hipMemcpyAsync(out_counts, d_cnt, b_cnt, hipMemcpyDeviceToHost, st));
     if (out_iterations) RCN_HIP(hipMemcpyAsync(out_iterations, d_it, b_cnt, hipMemcpyDeviceToHost, st));
+    if (out_F) RCN_HIP(hipMemcpyAsync(out_F, d_F, b_F, hipMemcpyDeviceToHost, st));
     RCN_HIP(hipStreamSynchronize(st));
     return RCN_OK;
 }
 
 extern "C" int rcn_fmat_filter_grid_device(rcn_ctx *ctx, int32_t n_pairs, const int32_t *pair_off_dev, const int32_t *xy1_dev,
                                            const int32_t *xy2_dev, uint8_t *out_mask_dev, int32_t *out_counts_dev,
-                                           int32_t *out_iterations_dev)
+                                           int32_t *out_iterations_dev, double *out_F_dev)
 {
     if (!ctx) return RCN_ERR_ARG;
     if (n_pairs < 0 || (n_pairs > 0 && (!pair_off_dev || !xy1_dev || !xy2_dev || !out_mask_dev || !out_counts_dev || !out_iterations_dev))) {
@@ -449,14 +456,14 @@ extern "C" int rcn_fmat_filter_grid_device(rcn_ctx *ctx, int32_t n_pairs, const 
     }
     std::lock_guard<std::mutex> lk(ctx->mu);
     RCN_HIP(hipSetDevice(ctx->device));
-    return fmat_launch(ctx, n_pairs, pair_off_dev, xy1_dev, xy2_dev, out_mask_dev, out_counts_dev, out_iterations_dev);
+    return fmat_launch(ctx, n_pairs, pair_off_dev, xy1_dev, xy2_dev, out_mask_dev, out_counts_dev, out_iterations_dev, out_F_dev);
 }
 
 extern "C" int rcn_fmat_filter(rcn_ctx *ctx, const int32_t *xy1, const int32_t *xy2, int32_t n, uint8_t *out_mask,
-                               int32_t *out_count)
+                               int32_t *out_count, double *out_F)
 {
     if (!ctx) return RCN_ERR_ARG;
     if (n < 0 || !out_count || (n > 0 && (!xy1 || !xy2 || !out_mask))) { ctx->set_error("rcn_fmat_filter: bad argument"); return RCN_ERR_ARG; }
     const int32_t off[2] = {0, n};
-    return rcn_fmat_filter_grid(ctx, 1, off, xy1, xy2, out_mask, out_count, nullptr);
+    return rcn_fmat_filter_grid(ctx, 1, off, xy1, xy2, out_mask, out_count, nullptr, out_F);
 }

@@ -8,16 +8,18 @@ import ctypes as C
 import numpy as np
 
 
-def estimate_fundamental_inliers(ctx, xy1, xy2):
-    """One pair: (mask[n] bool, count).  count -1: no model, -2: fewer than 7 points (unfiltered)."""
+def estimate_fundamental_inliers(ctx, xy1, xy2, with_matrix=False):
+    """One pair: (mask[n] bool, count[, F 3x3]).  count -1: no model, -2: fewer than 7 points (unfiltered)."""
     xy1 = np.ascontiguousarray(xy1, np.int32).reshape(-1, 2)
     xy2 = np.ascontiguousarray(xy2, np.int32).reshape(-1, 2)
     if len(xy1) != len(xy2):
         raise ValueError("one point of the second image per point of the first")
     mask = np.zeros(len(xy1), np.uint8)
     cnt = C.c_int32(0)
-    ctx.check(ctx.lib.rcn_fmat_filter(ctx.h, xy1.ctypes.data, xy2.ctypes.data, len(xy1), mask.ctypes.data, C.addressof(cnt)))
-    return mask.astype(bool), cnt.value
+    F = np.zeros((3, 3))
+    ctx.check(ctx.lib.rcn_fmat_filter(ctx.h, xy1.ctypes.data, xy2.ctypes.data, len(xy1), mask.ctypes.data, C.addressof(cnt),
+                                      F.ctypes.data if with_matrix else None))
+    return (mask.astype(bool), cnt.value, F) if with_matrix else (mask.astype(bool), cnt.value)
 
 
 def filter_grid(ctx, pair_off, xy1, xy2):
@@ -30,7 +32,7 @@ def filter_grid(ctx, pair_off, xy1, xy2):
     counts = np.zeros(P, np.int32)
     iters = np.zeros(P, np.int32)
     ctx.check(ctx.lib.rcn_fmat_filter_grid(ctx.h, P, pair_off.ctypes.data, xy1.ctypes.data, xy2.ctypes.data,
-                                           mask.ctypes.data, counts.ctypes.data, iters.ctypes.data))
+                                           mask.ctypes.data, counts.ctypes.data, iters.ctypes.data, None))
     return mask.astype(bool), counts, iters
 
 

@@ -1,5 +1,6 @@
 // adapter_test.cpp -- exercises the C++ adapters exactly as the reference's pipeline would:
 //   featMatcher->matchFeatures(features1, features2, curMatches, shape1, shape2)   (SequentialReconstructor.cpp:232)
+//   featFilter->estimateFundamental(featuresMatched1, featuresMatched2, inlierMatchIds)           (:250)
 //   BundleAdjuster().adjust(features, landmarks, imgIdx2camPose, imgIdx2camIntrinsics, imgIdxOrder)   (:1064-1069)
 //   checkLandmarkValidity() / removeOutlierLandmarks()                               (:1071-1074)
 // Reads a small binary problem written by tests/test_cpp_adapter.py, writes the results back.
@@ -9,6 +10,7 @@
 
 #include "../../reconstructor_amd/host/HipBundleAdjuster.h"
 #include "../../reconstructor_amd/host/HipFeatureMatcher.h"
+#include "../../reconstructor_amd/host/HipGeometricFilter.h"
 #include "../../reconstructor_amd/host/HipLandmarkValidity.h"
 
 using namespace reconstructor::Core;
@@ -40,6 +42,31 @@ int main(int argc, char **argv)
     int32_t n = (int32_t)curMatches.size();
     fwrite(&n, 4, 1, o);
     for (auto &[q, t] : curMatches) { int32_t p[2] = {q, t}; fwrite(p, 4, 2, o); }
+
+    // ---- epipolar filter on those matches, as SequentialReconstructor.cpp:237-269 does: feature
+    //      coordinates follow the descriptors in the input (K1 + K2 integer pairs)
+    {
+        std::vector<int32_t> c1(2 * (size_t)K1), c2(2 * (size_t)K2);
+        rd(f, c1.data(), 8 * (size_t)K1); rd(f, c2.data(), 8 * (size_t)K2);
+        for (int i = 0; i < K1; ++i) f1[i]->featCoord = FeatCoord<>(c1[2 * i], c1[2 * i + 1]);
+        for (int i = 0; i < K2; ++i) f2[i]->featCoord = FeatCoord<>(c2[2 * i], c2[2 * i + 1]);
+        std::map<int, int> filtered;
+        HipL2Matcher *hm0 = static_cast<HipL2Matcher *>(featMatcher.get());
+        auto featFilter = std::make_unique<GeometricFilter>(hm0->context());
+        if (curMatches.size() >= 7) {
+            std::vector<FeaturePtr<>> featuresMatched1, featuresMatched2;
+            for (const auto &[featIdx1, featIdx2] : curMatches) { featuresMatched1.push_back(f1[featIdx1]); featuresMatched2.push_back(f2[featIdx2]); }
+            std::vector<bool> inlierMatchIds;
+            featFilter->estimateFundamental(featuresMatched1, featuresMatched2, inlierMatchIds);
+            if (inlierMatchIds.size() != 0) {
+                int curMatchId = 0;
+                for (const auto &[featIdx1, featIdx2] : curMatches) { if (inlierMatchIds[curMatchId]) filtered[featIdx1] = featIdx2; ++curMatchId; }
+            }
+        } else filtered = curMatches;
+        int32_t nf = (int32_t)filtered.size();
+        fwrite(&nf, 4, 1, o);
+        for (auto &[q, t] : filtered) { int32_t p[2] = {q, t}; fwrite(p, 4, 2, o); }
+    }
 
     // ---- BA: nc, np, order[nc], poses 4x4 (row-major) per cam, intr 6 per cam, points, then per
     //      landmark: count + (local cam, x, y)

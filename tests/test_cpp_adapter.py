@@ -7,7 +7,7 @@ import subprocess
 import numpy as np
 import pytest
 
-from oracle import orc, orc_ba, orc_validity
+from oracle import orc, orc_ba, orc_fmat, orc_validity
 from reconstructor_amd import synth, synth_ba
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -25,12 +25,22 @@ def test_headers_compile_without_gpu():
 def test_cpp_adapter_matches_oracle(tmp_path):
     assert os.path.exists(BIN), "run __graft_entry__.build() first"
     q, t = synth.descriptor_set("sift", 2, [300, 420], n_world=900, seed=13)
+    # feature coordinates: matched features see one two-view geometry, the rest are arbitrary
+    exp_pre, _ = orc.match_pair(q, t)
+    rng = np.random.default_rng(5)
+    cq = rng.integers(0, 500, (len(q), 2)).astype(np.int32)
+    ct = rng.integers(0, 500, (len(t), 2)).astype(np.int32)
+    mq = np.flatnonzero(exp_pre >= 0)
+    from reconstructor_amd import synth_fmat
+    g1, g2, _ = synth_fmat.two_view(len(mq), 0.3, seed=6)
+    cq[mq], ct[exp_pre[mq]] = g1, g2
     sc = synth_ba.make_scene(5, 60, obs_per_point=4, seed=3)
     order = [7, 3, 11, 5, 2]
     inp, outp = tmp_path / "in.bin", tmp_path / "out.bin"
     with open(inp, "wb") as f:
         f.write(struct.pack("iii", q.shape[0], t.shape[0], q.shape[1]))
         f.write(q.tobytes()); f.write(t.tobytes())
+        f.write(cq.tobytes()); f.write(ct.tobytes())
         f.write(struct.pack("ii", 5, 60)); f.write(np.array(order, np.int32).tobytes())
         for l in range(5):
             T = np.eye(4); T[:3, :3] = synth_ba.rodrigues(sc["poses"][l, :3]); T[:3, 3] = sc["poses"][l, 3:]
@@ -49,7 +59,11 @@ def test_cpp_adapter_matches_oracle(tmp_path):
     pairs = np.frombuffer(raw, np.int32, 2 * n, 4).reshape(-1, 2)
     exp, cnt = orc.match_pair(q, t)
     assert n == cnt and all(exp[a] == b for a, b in pairs)
-    off = 4 + 8 * n
+    nf = struct.unpack_from("i", raw, 4 + 8 * n)[0]
+    fpairs = np.frombuffer(raw, np.int32, 2 * nf, 8 + 8 * n).reshape(-1, 2)
+    mask, cnt_f, _ = orc_fmat.filter_pair(cq[mq], ct[exp[mq]])
+    assert cnt_f >= 7 and nf == cnt_f and np.array_equal(fpairs[:, 0], mq[mask]) and np.array_equal(fpairs[:, 1], exp[mq][mask])
+    off = 4 + 8 * n + 4 + 8 * nf
     rms = struct.unpack_from("d", raw, off)[0]; iters = struct.unpack_from("i", raw, off + 8)[0]
     X = np.frombuffer(raw, np.float64, 180, off + 12).reshape(60, 3)
     P0, I0, X0, s0 = orc_ba.solve(sc, threads=2)

@@ -37,6 +37,12 @@ def test_single_pair_entry_and_sizes_beyond_the_lds_copy(gpu_ctx):
         assert c0 == c1 and (m0 == m1).all()
     m, c = fmat.estimate_fundamental_inliers(gpu_ctx, a[:4], b[:4])
     assert c == -2 and m.all()
+    # the winning matrix: rank 2, F(3,3) = 1, and it reproduces the mask
+    a, b, _ = synth_fmat.two_view(200, 0.3, seed=9)
+    m, c, F = fmat.estimate_fundamental_inliers(gpu_ctx, a, b, with_matrix=True)
+    assert F[2, 2] == 1.0 and abs(np.linalg.det(F)) < 1e-12 * np.abs(F).max() ** 3 + 1e-18
+    err = np.array([of.epi_error(F, a[i], b[i]) for i in range(200)])
+    assert ((err <= 9.0) == m).all() and m.sum() == c
     same = np.tile([[100, 100]], (30, 1)).astype(np.int32)
     m, c = fmat.estimate_fundamental_inliers(gpu_ctx, same, same)          # the draw gives up: no model
     assert c == -1 and not m.any()
@@ -46,7 +52,7 @@ def test_errors(gpu_ctx):
     a, b, _ = synth_fmat.two_view(20, 0.2, seed=1)
     with pytest.raises(_lib.RcnError):
         fmat.filter_grid(gpu_ctx, [0, 30, 20], np.r_[a, a], np.r_[b, b])     # offsets not monotone
-    rc = gpu_ctx.lib.rcn_fmat_filter(gpu_ctx.h, None, None, 5, None, None)
+    rc = gpu_ctx.lib.rcn_fmat_filter(gpu_ctx.h, None, None, 5, None, None, None)
     assert rc == -1
     mask, counts, iters = fmat.filter_grid(gpu_ctx, [0], a[:0], b[:0])       # empty grid
     assert len(counts) == 0
@@ -96,7 +102,7 @@ def test_full_size_grid_properties_and_device_entry(gpu_ctx):
     it_d = torch.zeros(600, dtype=torch.int32, device="cuda")
     torch.cuda.synchronize()
     gpu_ctx.check(gpu_ctx.lib.rcn_fmat_filter_grid_device(gpu_ctx.h, 600, d["off"].data_ptr(), d["a"].data_ptr(), d["b"].data_ptr(),
-                                                          mask_d.data_ptr(), cnt_d.data_ptr(), it_d.data_ptr()))
+                                                          mask_d.data_ptr(), cnt_d.data_ptr(), it_d.data_ptr(), None))
     gpu_ctx.check(gpu_ctx.lib.rcn_synchronize(gpu_ctx.h))
     assert (cnt_d.cpu().numpy() == want[1]).all() and (it_d.cpu().numpy() == want[2]).all()
     assert (mask_d.cpu().numpy().astype(bool) == want[0]).all()
