@@ -142,41 +142,42 @@ static int solve_cubic(const double *c, double *r)
 }
 
 /* Two vectors spanning the null space of the 7x9 matrix A (row-major, destroyed): Gauss-Jordan with
- * complete pivoting; the two columns never chosen as pivots are the free variables.  f2 <- free
- * variable of the LAST free column = 1, f1 <- the other (any basis spans the same pencil).
- * Returns 0 when the matrix has rank < 7 (a pivot is exactly 0). */
+ * complete pivoting and no row exchanges -- step k takes the largest |entry| among the rows and
+ * columns not used yet (first one in row-major order on ties), scales that row and clears the pivot
+ * column in every other row.  The two columns never chosen are the free variables: f1 <- first free
+ * variable = 1, f2 <- second (any basis spans the same pencil).  Returns 0 when the rank is < 7. */
 static int null_space_7x9(double *A, double *f1, double *f2)
 {
-    int piv_col[7], used[9] = {0};
+    int piv_row[7], piv_col[7], row_used[7] = {0}, col_used[9] = {0};
     for (int k = 0; k < 7; ++k) {
         int pr = -1, pc = -1;
         double best = 0;
-        for (int r = k; r < 7; ++r)
+        for (int r = 0; r < 7; ++r) {
+            if (row_used[r]) continue;
             for (int c = 0; c < 9; ++c) {
-                if (used[c]) continue;
+                if (col_used[c]) continue;
                 const double v = fabs(A[9 * r + c]);
                 if (v > best) { best = v; pr = r; pc = c; }
             }
+        }
         if (pr < 0) return 0;
-        if (pr != k)
-            for (int c = 0; c < 9; ++c) { const double t = A[9 * k + c]; A[9 * k + c] = A[9 * pr + c]; A[9 * pr + c] = t; }
-        used[pc] = 1; piv_col[k] = pc;
-        const double inv = 1. / A[9 * k + pc];
-        for (int c = 0; c < 9; ++c) A[9 * k + c] *= inv;
+        row_used[pr] = 1; col_used[pc] = 1; piv_row[k] = pr; piv_col[k] = pc;
+        const double inv = 1. / A[9 * pr + pc];
+        for (int c = 0; c < 9; ++c) A[9 * pr + c] *= inv;
         for (int r = 0; r < 7; ++r) {
-            if (r == k) continue;
+            if (r == pr) continue;
             const double m = A[9 * r + pc];
             if (m == 0) continue;
-            for (int c = 0; c < 9; ++c) A[9 * r + c] -= m * A[9 * k + c];
+            for (int c = 0; c < 9; ++c) A[9 * r + c] -= m * A[9 * pr + c];
         }
     }
     int fc[2], nf = 0;
-    for (int c = 0; c < 9; ++c) if (!used[c]) fc[nf++] = c;
+    for (int c = 0; c < 9; ++c) if (!col_used[c]) fc[nf++] = c;
     double *out[2] = {f1, f2};
     for (int b = 0; b < 2; ++b) {
         for (int c = 0; c < 9; ++c) out[b][c] = 0;
         out[b][fc[b]] = 1;
-        for (int k = 0; k < 7; ++k) out[b][piv_col[k]] = -A[9 * k + fc[b]];
+        for (int k = 0; k < 7; ++k) out[b][piv_col[k]] = -A[9 * piv_row[k] + fc[b]];
     }
     return 1;
 }

@@ -8,10 +8,13 @@
 // its header for what is taken from memory of OpenCV 4.x and the one deliberate difference); this file
 // follows the oracle operation by operation with contraction off, so that the masks agree bit for bit.
 //
-//   F1 k_fmat_filter  one workgroup per pair, rounds of 32 hypotheses:
-//        lane 0        draws the 32 samples (the RNG stream and its rejections are sequential)
-//        32 lanes      one 7-point solve each: Gauss-Jordan of the 7x9 design matrix in LDS, cubic, <= 3 matrices
-//        4 waves       score <= 96 matrices against all n points (points resident in LDS as float2)
+//   F1 k_fmat_filter  one wave per pair, rounds of 32 hypotheses:
+//        lane 0        draws the 32 index sets (the RNG stream is sequential); a collinear sample, which
+//                      makes the reference redraw, is detected by 32 lanes at once and sends the round
+//                      down a slow path that replays the reference's loop literally
+//        32 lanes      one 7-point solve each, 7x9 design matrix in registers (Gauss-Jordan with
+//                      complete pivoting by selects), cubic, <= 3 matrices
+//        64 lanes      score <= 96 matrices against all n points (points resident in LDS as float2)
 //        lane 0        replays the sequential accept / shrink-the-iteration-count logic over the round
 //      and a final pass that writes the mask of the winning matrix.                      [fp64 VALU]
 #include "rcn_internal.h"
@@ -21,7 +24,7 @@
 namespace {
 
 #define FM_B 32            // hypotheses per round
-#define FM_NLDS 2048       // points kept in LDS; larger pairs read them from global memory
+#define FM_NLDS 1024       // points kept in LDS; larger pairs read them from global memory
 #define FM_MAX_ITERS 1000
 #define FM_MAX_ATTEMPTS 10000
 
@@ -106,52 +109,92 @@ __device__ int solve_cubic(const double *c, double *r)
     return n;
 }
 
-// seven correspondences (s1, s2: 7 x 2 floats) -> up to three matrices in F (27 doubles).
-// A: 63 doubles and ff: 18 doubles of scratch in LDS (dynamically indexed).
-__device__ int run_7point(const float *s1, const float *s2, double *A, double *ff, double *F)
+// seven correspondences (s1, s2: 7 x 2 floats, in registers) -> up to three matrices in F (27 doubles,
+// LDS).  The 7x9 design matrix lives in registers: every loop is fully unrolled and the pivot row /
+// column -- which are data dependent -- are picked with selects, never with indexed addressing.
+__device__ int run_7point(const float *s1, const float *s2, double *F)
 {
 #pragma clang fp contract(off)
+    double A[7][9];
+#pragma unroll
     for (int i = 0; i < 7; ++i) {
         const double x0 = s1[2 * i], y0 = s1[2 * i + 1], x1 = s2[2 * i], y1 = s2[2 * i + 1];
-        double *row = A + 9 * i;
-        row[0] = x1 * x0; row[1] = x1 * y0; row[2] = x1;
-        row[3] = y1 * x0; row[4] = y1 * y0; row[5] = y1;
-        row[6] = x0; row[7] = y0; row[8] = 1;
+        A[i][0] = x1 * x0; A[i][1] = x1 * y0; A[i][2] = x1;
+        A[i][3] = y1 * x0; A[i][4] = y1 * y0; A[i][5] = y1;
+        A[i][6] = x0; A[i][7] = y0; A[i][8] = 1;
     }
-    // null space: Gauss-Jordan with complete pivoting (oracle: null_space_7x9)
-    unsigned used = 0, piv = 0;
+    // null space: Gauss-Jordan, complete pivoting, no row exchanges (oracle: null_space_7x9)
+    unsigned row_used = 0, col_used = 0;
+    int prk[7], pck[7];
+    bool singular = false;
+#pragma unroll
     for (int k = 0; k < 7; ++k) {
         int pr = -1, pc = -1;
         double best = 0;
-        for (int r = k; r < 7; ++r)
+#pragma unroll
+        for (int r = 0; r < 7; ++r)
+#pragma unroll
             for (int c = 0; c < 9; ++c) {
-                if (used >> c & 1) continue;
-                const double v = fabs(A[9 * r + c]);
-                if (v > best) { best = v; pr = r; pc = c; }
+                const double v = fabs(A[r][c]);
+                const bool ok = !(row_used >> r & 1) && !(col_used >> c & 1) && v > best;
+                best = ok ? v : best; pr = ok ? r : pr; pc = ok ? c : pc;
             }
-        if (pr < 0) return 0;
-        if (pr != k)
-            for (int c = 0; c < 9; ++c) { const double t = A[9 * k + c]; A[9 * k + c] = A[9 * pr + c]; A[9 * pr + c] = t; }
-        used |= 1u << pc; piv |= (unsigned)pc << (4 * k);
-        const double inv = 1. / A[9 * k + pc];
-        for (int c = 0; c < 9; ++c) A[9 * k + c] *= inv;
+        singular |= pr < 0;
+        pr = pr < 0 ? 0 : pr; pc = pc < 0 ? 0 : pc;
+        row_used |= 1u << pr; col_used |= 1u << pc;
+        prk[k] = pr; pck[k] = pc;
+        double prow[9], pval = 0;
+#pragma unroll
+        for (int c = 0; c < 9; ++c) {
+            double v = 0;
+#pragma unroll
+            for (int r = 0; r < 7; ++r) v = r == pr ? A[r][c] : v;
+            prow[c] = v;
+            pval = c == pc ? v : pval;
+        }
+        const double inv = 1. / pval;
+#pragma unroll
+        for (int c = 0; c < 9; ++c) prow[c] *= inv;
+#pragma unroll
         for (int r = 0; r < 7; ++r) {
-            if (r == k) continue;
-            const double m = A[9 * r + pc];
-            if (m == 0) continue;
-            for (int c = 0; c < 9; ++c) A[9 * r + c] -= m * A[9 * k + c];
+            double m = 0;
+#pragma unroll
+            for (int c = 0; c < 9; ++c) m = c == pc ? A[r][c] : m;
+#pragma unroll
+            for (int c = 0; c < 9; ++c) {
+                const double upd = A[r][c] - m * prow[c];
+                A[r][c] = r == pr ? prow[c] : (m == 0 ? A[r][c] : upd);
+            }
         }
     }
-    int fc[2], nf = 0;
-    for (int c = 0; c < 9; ++c) if (!(used >> c & 1)) { if (nf < 2) fc[nf] = c; ++nf; }
-    for (int b = 0; b < 2; ++b) {
-        double *o = ff + 9 * b;
-        for (int c = 0; c < 9; ++c) o[c] = 0;
-        o[fc[b]] = 1;
-        for (int k = 0; k < 7; ++k) o[piv >> (4 * k) & 15] = -A[9 * k + fc[b]];
+    if (singular) return 0;
+    // the two free columns, ascending
+    int fc0 = -1, fc1 = -1;
+#pragma unroll
+    for (int c = 0; c < 9; ++c) {
+        const bool fr = !(col_used >> c & 1);
+        fc1 = fr && fc0 >= 0 && fc1 < 0 ? c : fc1;
+        fc0 = fr && fc0 < 0 ? c : fc0;
+    }
+    double g1[9], g2[9];   // basis vectors: free variable = 1, pivot variables = -A[piv_row][free col]
+#pragma unroll
+    for (int c = 0; c < 9; ++c) { g1[c] = c == fc0 ? 1.0 : 0.0; g2[c] = c == fc1 ? 1.0 : 0.0; }
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+        double v0 = 0, v1 = 0;
+#pragma unroll
+        for (int r = 0; r < 7; ++r)
+#pragma unroll
+            for (int c = 0; c < 9; ++c) {
+                v0 = r == prk[k] && c == fc0 ? A[r][c] : v0;
+                v1 = r == prk[k] && c == fc1 ? A[r][c] : v1;
+            }
+#pragma unroll
+        for (int c = 0; c < 9; ++c) { g1[c] = c == pck[k] ? -v0 : g1[c]; g2[c] = c == pck[k] ? -v1 : g2[c]; }
     }
     double f1[9], f2[9], c[4], r[3];
-    for (int i = 0; i < 9; ++i) { f2[i] = ff[9 + i]; f1[i] = ff[i] - f2[i]; }
+#pragma unroll
+    for (int i = 0; i < 9; ++i) { f2[i] = g2[i]; f1[i] = g1[i] - g2[i]; }
     double t0 = f2[4] * f2[8] - f2[5] * f2[7], t1 = f2[3] * f2[8] - f2[5] * f2[6], t2 = f2[3] * f2[7] - f2[4] * f2[6];
     c[3] = f2[0] * t0 - f2[1] * t1 + f2[2] * t2;
     c[2] = f1[0] * t0 - f1[1] * t1 + f1[2] * t2 -
@@ -164,12 +207,16 @@ __device__ int run_7point(const float *s1, const float *s2, double *A, double *f
     c[0] = f1[0] * t0 - f1[1] * t1 + f1[2] * t2;
     const int n = solve_cubic(c, r);
     if (n < 1 || n > 3) return 0;
-    for (int k = 0; k < n; ++k) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        if (k >= n) break;
         double *fm = F + 9 * k;
         double lambda = r[k], mu = 1.;
         const double s = f1[8] * r[k] + f2[8];
-        if (fabs(s) > DBL_EPSILON) { mu = 1. / s; lambda *= mu; fm[8] = 1.; }
-        else fm[8] = 0.;
+        double f8 = 0.;
+        if (fabs(s) > DBL_EPSILON) { mu = 1. / s; lambda *= mu; f8 = 1.; }
+        fm[8] = f8;
+#pragma unroll
         for (int i = 0; i < 8; ++i) fm[i] = f1[i] * lambda + f2[i] * mu;
     }
     return n;
@@ -192,6 +239,31 @@ __device__ __forceinline__ float epi_error(const double *F, float p1x, float p1y
     return (float)fmax(d1 * d1 * s1, d2 * d2 * s2);
 }
 
+// epi_error(...) <= 9.0 without the two divisions whenever the answer is clear: with t = d^2 and
+// q = a^2 + b^2 the stored error is fl32(fl(fl(d d) fl(1/q))), within 1e-7 relative of t/q, so
+// t <= 8.9999 q on both sides is an inlier and t >= 9.0001 q on either side an outlier; anything
+// in between (or a degenerate q) takes the exact path.
+__device__ __forceinline__ bool epi_inlier9(const double *F, float p1x, float p1y, float p2x, float p2y)
+{
+#pragma clang fp contract(off)
+    double a, b, c;
+    a = F[0] * p1x + F[1] * p1y + F[2];
+    b = F[3] * p1x + F[4] * p1y + F[5];
+    c = F[6] * p1x + F[7] * p1y + F[8];
+    const double q2 = a * a + b * b;
+    const double d2 = p2x * a + p2y * b + c, t2 = d2 * d2;
+    a = F[0] * p2x + F[3] * p2y + F[6];
+    b = F[1] * p2x + F[4] * p2y + F[7];
+    c = F[2] * p2x + F[5] * p2y + F[8];
+    const double q1 = a * a + b * b;
+    const double d1 = p1x * a + p1y * b + c, t1 = d1 * d1;
+    const bool sane = q1 > 0 && q2 > 0 && q1 < DBL_MAX && q2 < DBL_MAX;
+    if (sane && t1 <= 8.9999 * q1 && t2 <= 8.9999 * q2) return true;
+    if (sane && (t1 >= 9.0001 * q1 || t2 >= 9.0001 * q2)) return false;
+    const double s1 = 1. / q1, s2 = 1. / q2;
+    return (float)fmax(d1 * d1 * s1, d2 * d2 * s2) <= 9.0;
+}
+
 __device__ __forceinline__ bool last_point_collinear(const float *m, int count)
 {
 #pragma clang fp contract(off)
@@ -206,6 +278,15 @@ __device__ __forceinline__ bool last_point_collinear(const float *m, int count)
     return false;
 }
 
+#ifdef RCN_FM_PROF   // diagnostic build only (tools/fmat_prof.hip): cycles per phase, summed over pairs
+__device__ unsigned long long g_fm_prof[8];
+#define FM_T(i) do { const unsigned long long now_ = clock64(); if (lane == 0) atomicAdd(&g_fm_prof[i], now_ - tprev_); tprev_ = clock64(); } while (0)
+#define FM_T0() unsigned long long tprev_ = clock64()
+#else
+#define FM_T(i)
+#define FM_T0()
+#endif
+
 struct Pts {   // the pair's points: LDS copy when it fits, else the global arrays
     const float2 *l1, *l2;
     const int32_t *g1, *g2;
@@ -216,15 +297,16 @@ struct Pts {   // the pair's points: LDS copy when it fits, else the global arra
     }
 };
 
-__global__ __launch_bounds__(256) void k_fmat_filter(FmatArgs a)
+// One workgroup of four waves per pair: wave 0 samples, solves and runs the accept logic, all four
+// score the round's matrices (matrix m goes to wave m % 4), and five or six pairs share a CU so
+// that the serial parts of one overlap with the parallel parts of the others.
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_fmat_filter(FmatArgs a)
 {
 #pragma clang fp contract(off)
     __shared__ float2 P1[FM_NLDS], P2[FM_NLDS];
-    __shared__ double sA[FM_B][63], sff[FM_B][18], sF[FM_B][27], bestF[9];
-    __shared__ float sS1[FM_B][14], sS2[FM_B][14];
-    __shared__ int sNm[FM_B], sGood[FM_B * 3];
-    __shared__ double sMed[FM_B * 3];
-    __shared__ int sCtl[8];   // 0: hypotheses drawn this round, 1: stop, 2: niters, 3: max_good, 4: iterations done, 5: draw failed
+    __shared__ double sF[FM_B][27], bestF[9], sMed[FM_B * 3];
+    __shared__ int sIdx[FM_B][7], sNm[FM_B], sGood[FM_B * 3];
+    __shared__ int sCtl[8];   // 0: hypotheses drawn this round, 1: stop, 2: niters, 3: max_good, 4: iterations done, 5: draw failed, 6/7: verdicts
     __shared__ unsigned long long sRng;
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     for (int pair = blockIdx.x; pair < a.n_pairs; pair += gridDim.x) {
@@ -246,6 +328,7 @@ __global__ __launch_bounds__(256) void k_fmat_filter(FmatArgs a)
                 P2[i] = make_float2((float)pts.g2[2 * i], (float)pts.g2[2 * i + 1]);
             }
         const bool ransac = n >= 15;
+        FM_T0();
         if (t == 0) {
             sRng = ~0ull;
             sCtl[1] = 0; sCtl[3] = 0; sCtl[4] = 0; sCtl[5] = 0;
@@ -258,71 +341,153 @@ __global__ __launch_bounds__(256) void k_fmat_filter(FmatArgs a)
         double min_median = DBL_MAX;   // lane 0 only
         bool have_best = false;        // lane 0 only
         for (int base = 0;; base += FM_B) {
-            // ---- draw
-            if (t == 0) {
-                unsigned long long rng = sRng;
+            // ---- draw: lane 0 produces the index sets (the RNG stream is sequential); the rare
+            // collinear sample, which makes the reference redraw, is detected by all lanes below
+            // Every lane runs the draw on wave-uniform values (readfirstlane), so it executes on the
+            // scalar unit; x % n is a multiply-high by floor((2^32-1)/n) plus at most two corrections.
+            const unsigned long long rng0 = sRng;
+            if (w == 0) {
+                unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)rng0), hi = __builtin_amdgcn_readfirstlane((unsigned)(rng0 >> 32));
+                const unsigned un = (unsigned)__builtin_amdgcn_readfirstlane(n);
+                const unsigned M = 0xFFFFFFFFu / un;
+                const int niters = __builtin_amdgcn_readfirstlane(sCtl[2]);
                 int drawn = 0;
-                const int niters = sCtl[2];
                 for (; drawn < FM_B && base + drawn < niters; ++drawn) {
-                    float *s1 = sS1[drawn], *s2 = sS2[drawn];
-                    bool ok = false;
-                    if (n == 7) {
-                        for (int i = 0; i < 7; ++i) { pts.get(i, s1[2 * i], s1[2 * i + 1], s2[2 * i], s2[2 * i + 1]); }
-                        ok = true;
-                    } else {
+                    int idx[7];
+#pragma unroll
+                    for (int j = 0; j < 7; ++j) idx[j] = j;            // n == 7: the sample is the data set
+                    if (un != 7)
+                        for (int i = 0; i < 7;) {
+                            const unsigned long long st = (unsigned long long)lo * 4164903690U + hi;
+                            lo = (unsigned)st; hi = (unsigned)(st >> 32);
+                            unsigned v = lo - __umulhi(lo, M) * un;
+                            while (v >= un) v -= un;
+                            bool dup = false;
+#pragma unroll
+                            for (int j = 0; j < 7; ++j) dup |= j < i && idx[j] == (int)v;
+                            if (dup) continue;
+#pragma unroll
+                            for (int j = 0; j < 7; ++j) idx[j] = j == i ? (int)v : idx[j];
+                            ++i;
+                        }
+                    if (lane < 7) {
+                        int mine = idx[0];
+#pragma unroll
+                        for (int j = 1; j < 7; ++j) mine = lane == j ? idx[j] : mine;
+                        sIdx[drawn][lane] = mine;
+                    }
+                }
+                if (lane == 0) { sRng = (unsigned long long)hi << 32 | lo; sCtl[0] = drawn; }
+            }
+            __syncthreads();
+            FM_T(0);
+            int drawn = sCtl[0];
+            float s1[14], s2[14];
+            bool coll = false;
+            if (t < drawn) {
+#pragma unroll
+                for (int i = 0; i < 7; ++i) pts.get(sIdx[lane][i], s1[2 * i], s1[2 * i + 1], s2[2 * i], s2[2 * i + 1]);
+                coll = n != 7 && (last_point_collinear(s1, 7) || last_point_collinear(s2, 7));
+            }
+            if (t < 64 && __ballot(coll)) sCtl[5] = 2;      // (wave 0) flag the slow path for everybody
+            __syncthreads();
+            const bool slow = sCtl[5] == 2;
+            __syncthreads();                                // everyone has read the flag before lane 0 clears it
+            if (slow) {
+                // slow path, exactly the reference's loop: redo the round's draws one by one with the
+                // collinearity test inside
+                if (t == 0) {
+                    sCtl[5] = 0;
+                    unsigned long long rng = rng0;
+                    int d2 = 0;
+                    const int niters = sCtl[2];
+                    for (; d2 < FM_B && base + d2 < niters; ++d2) {
+                        bool ok = false;
                         for (int attempt = 0; attempt < FM_MAX_ATTEMPTS && !ok; ++attempt) {
                             int idx[7];
+                            float q1[14], q2[14];
                             for (int i = 0; i < 7;) {
                                 const int v = (int)(rng_next(rng) % (unsigned)n);
                                 bool dup = false;
-                                for (int j = 0; j < i; ++j) dup |= idx[j] == v;
+#pragma unroll
+                                for (int j = 0; j < 7; ++j) dup |= j < i && idx[j] == v;
                                 if (dup) continue;
-                                idx[i] = v;
-                                pts.get(v, s1[2 * i], s1[2 * i + 1], s2[2 * i], s2[2 * i + 1]);
+#pragma unroll
+                                for (int j = 0; j < 7; ++j) {
+                                    if (j == i) { idx[j] = v; pts.get(v, q1[2 * j], q1[2 * j + 1], q2[2 * j], q2[2 * j + 1]); }
+                                }
                                 ++i;
                             }
-                            ok = !last_point_collinear(s1, 7) && !last_point_collinear(s2, 7);
+                            ok = !last_point_collinear(q1, 7) && !last_point_collinear(q2, 7);
+                            if (ok) {
+#pragma unroll
+                                for (int i = 0; i < 7; ++i) sIdx[d2][i] = idx[i];
+                            }
                         }
+                        if (!ok) { sCtl[5] = 1; break; }
                     }
-                    if (!ok) { sCtl[5] = 1; break; }
+                    sRng = rng;
+                    sCtl[0] = d2;
                 }
-                sRng = rng;
-                sCtl[0] = drawn;
+                __syncthreads();
+                drawn = sCtl[0];
+                if (t < drawn) {
+#pragma unroll
+                    for (int i = 0; i < 7; ++i) pts.get(sIdx[lane][i], s1[2 * i], s1[2 * i + 1], s2[2 * i], s2[2 * i + 1]);
+                }
             }
+            FM_T(1);
+            // ---- solve: one hypothesis per lane, in registers
+            if (t < drawn) sNm[t] = run_7point(s1, s2, sF[t]);
             __syncthreads();
-            const int drawn = sCtl[0];
-            // ---- solve
-            if (t < drawn) sNm[t] = run_7point(sS1[t], sS2[t], sA[t], sff[t], sF[t]);
-            __syncthreads();
-            // ---- score: wave w takes models w, w+4, ... of the round (model m = 3 * hypothesis + k)
-            for (int m = w; m < 3 * drawn; m += 4) {
-                const int h = m / 3, k = m - 3 * h;
-                if (k >= sNm[h]) continue;
-                const double *F = sF[h] + 9 * k;
-                if (ransac) {
+            FM_T(2);
+            // ---- score
+            if (ransac) {
+                for (int m = w; m < 3 * drawn; m += 4) {        // each wave walks its share of the models, lanes walk the points
+                    const int h = m / 3, k = m - 3 * h;
+                    if (k >= sNm[h]) continue;
+                    double F[9];
+#pragma unroll
+                    for (int i = 0; i < 9; ++i) F[i] = sF[h][9 * k + i];
+                    // A matrix is accepted only if it beats the best count so far (and 6).  The best at
+                    // the start of the round is a lower bound of the best at this matrix's turn, so once
+                    // even all remaining points could not lift the count above it the matrix is dropped
+                    // (its stored count stays <= the bound: never accepted, exactly as if fully counted).
+                    const int bound = sCtl[3] > 6 ? sCtl[3] : 6;
                     int good = 0;
                     for (int i0 = 0; i0 < n; i0 += 64) {
                         const int i = i0 + lane;
                         bool in = false;
-                        if (i < n) { float ax, ay, bx, by; pts.get(i, ax, ay, bx, by); in = epi_error(F, ax, ay, bx, by) <= 9.0; }
+                        if (i < n) { float ax, ay, bx, by; pts.get(i, ax, ay, bx, by); in = epi_inlier9(F, ax, ay, bx, by); }
                         good += (int)__popcll(__ballot(in));
+                        if (good + (n - i0 - 64) <= bound) break;
                     }
                     if (lane == 0) sGood[m] = good;
-                } else if (n > 7) {       // LMedS: n <= 14, one lane sorts the errors
-                    if (lane == 0) {
-                        float e[14];
-                        for (int i = 0; i < n; ++i) {
-                            float ax, ay, bx, by; pts.get(i, ax, ay, bx, by);
-                            const float v = epi_error(F, ax, ay, bx, by);
-                            int p = i;
-                            while (p > 0 && e[p - 1] > v) { e[p] = e[p - 1]; --p; }
-                            e[p] = v;
-                        }
-                        sMed[m] = n % 2 != 0 ? (double)e[n / 2] : (double)(e[n / 2 - 1] + e[n / 2]) * 0.5;
+                }
+            } else if (n > 7) {                                 // LMedS, n <= 14: one model per lane
+                for (int m = t; m < 3 * drawn; m += 256) {
+                    const int h = m / 3, k = m - 3 * h;
+                    if (k >= sNm[h]) continue;
+                    double F[9];
+#pragma unroll
+                    for (int i = 0; i < 9; ++i) F[i] = sF[h][9 * k + i];
+                    float e[14];
+#pragma unroll
+                    for (int i = 0; i < 14; ++i) e[i] = 3.0e38f;
+                    for (int i = 0; i < n; ++i) {               // insertion into the sorted prefix, register resident
+                        float ax, ay, bx, by; pts.get(i, ax, ay, bx, by);
+                        float v = epi_error(F, ax, ay, bx, by);
+#pragma unroll
+                        for (int p = 0; p < 14; ++p) { const float lo = fminf(e[p], v), hi = fmaxf(e[p], v); e[p] = lo; v = hi; }
                     }
+                    float em1 = 0.f, e0 = 0.f;   // e[n/2 - 1], e[n/2]
+#pragma unroll
+                    for (int p = 0; p < 14; ++p) { em1 = p == n / 2 - 1 ? e[p] : em1; e0 = p == n / 2 ? e[p] : e0; }
+                    sMed[m] = n % 2 != 0 ? (double)e0 : (double)(em1 + e0) * 0.5;
                 }
             }
             __syncthreads();
+            FM_T(3);
             // ---- accept, in sequence order
             if (t == 0) {
                 int niters = sCtl[2], max_good = sCtl[3], done = sCtl[4];
@@ -348,45 +513,44 @@ __global__ __launch_bounds__(256) void k_fmat_filter(FmatArgs a)
                 sCtl[1] = stop; sCtl[2] = niters; sCtl[3] = max_good; sCtl[4] = done;
                 if (stop) {   // final threshold (squared) into sMed[0], verdict into sCtl[6]
                     double thr2 = 9.0;
-                    int verdict = have_best ? 1 : 0;
                     if (!ransac && n > 7 && have_best) {
                         double sigma = 2.5 * 1.4826 * (1 + 5. / (n - 7)) * sqrt(min_median);
                         sigma = fmax(sigma, 0.001);
                         thr2 = sigma * sigma;
                     }
-                    sMed[0] = thr2; sCtl[6] = verdict;
+                    sMed[0] = thr2; sCtl[6] = have_best ? 1 : 0;
                 }
             }
             __syncthreads();
+            FM_T(4);
             if (sCtl[1]) break;
         }
         // ---- mask of the winning matrix
         const bool have = sCtl[6] != 0;
         const double thr2 = sMed[0];
+        double F[9];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) F[i] = bestF[i];
         int good = 0;
         for (int i0 = 0; i0 < n; i0 += 256) {
             const int i = i0 + t;
             bool in = false;
             if (i < n && have) {
                 if (n == 7) in = true;
-                else { float ax, ay, bx, by; pts.get(i, ax, ay, bx, by); in = epi_error(bestF, ax, ay, bx, by) <= thr2; }
+                else { float ax, ay, bx, by; pts.get(i, ax, ay, bx, by); in = epi_error(F, ax, ay, bx, by) <= thr2; }
             }
             if (i < n) mask[i] = in ? 1 : 0;
             good += (int)__popcll(__ballot(in));
         }
         if (lane == 0) sGood[w] = good;
         __syncthreads();
-        if (t == 0) {
-            const int total = sGood[0] + sGood[1] + sGood[2] + sGood[3];
-            int verdict = have ? total : -1;
-            if (have && !ransac && n > 7 && total < 7) verdict = -1;     // LMedS: fewer than 7 inliers is a failure
-            a.counts[pair] = verdict;
-            a.iters[pair] = sCtl[4];
-            sCtl[7] = verdict;
-        }
-        __syncthreads();
-        if (sCtl[7] < 0) for (int i = t; i < n; i += 256) mask[i] = 0;
-        if (a.F && t < 9) a.F[9 * (size_t)pair + t] = sCtl[7] < 0 ? 0.0 : bestF[t];
+        good = sGood[0] + sGood[1] + sGood[2] + sGood[3];
+        int verdict = have ? good : -1;
+        if (have && !ransac && n > 7 && good < 7) verdict = -1;     // LMedS: fewer than 7 inliers is a failure
+        if (t == 0) { a.counts[pair] = verdict; a.iters[pair] = sCtl[4]; }
+        if (verdict < 0) for (int i = t; i < n; i += 256) mask[i] = 0;
+        if (a.F && t < 9) a.F[9 * (size_t)pair + t] = verdict < 0 ? 0.0 : bestF[t];
+        FM_T(5);
     }
 }
 
@@ -398,7 +562,7 @@ static int fmat_launch(rcn_ctx *ctx, int32_t n_pairs, const int32_t *off, const 
     if (n_pairs <= 0) return RCN_OK;
     FmatArgs a;
     a.off = off; a.xy1 = xy1; a.xy2 = xy2; a.n_pairs = n_pairs; a.mask = mask; a.counts = counts; a.iters = iters; a.F = F;
-    const int blocks = std::min<int>(n_pairs, ctx->prop.multiProcessorCount * 8);
+    const int blocks = std::min<int>(n_pairs, ctx->prop.multiProcessorCount * 24);
     k_fmat_filter<<<blocks, 256, 0, ctx->stream>>>(a);
     RCN_HIP(hipGetLastError());
     return RCN_OK;
