@@ -82,6 +82,7 @@ void rcn_destroy(rcn_ctx *ctx)
     for (DevBuf &b : ctx->ba_ws) b.release();
     ctx->lm_ws.release();
     ctx->fm_ws.release();
+    ctx->fm_state.release();
     if (ctx->ev_made)
         for (auto &row : ctx->ev)
             for (auto &e : row) (void)hipEventDestroy(e);

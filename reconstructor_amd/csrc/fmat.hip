@@ -8,15 +8,8 @@
 // its header for what is taken from memory of OpenCV 4.x and the one deliberate difference); this file
 // follows the oracle operation by operation with contraction off, so that the masks agree bit for bit.
 //
-//   F1 k_fmat_filter  one wave per pair, rounds of 32 hypotheses:
-//        lane 0        draws the 32 index sets (the RNG stream is sequential); a collinear sample, which
-//                      makes the reference redraw, is detected by 32 lanes at once and sends the round
-//                      down a slow path that replays the reference's loop literally
-//        32 lanes      one 7-point solve each, 7x9 design matrix in registers (Gauss-Jordan with
-//                      complete pivoting by selects), cubic, <= 3 matrices
-//        64 lanes      score <= 96 matrices against all n points (points resident in LDS as float2)
-//        lane 0        replays the sequential accept / shrink-the-iteration-count logic over the round
-//      and a final pass that writes the mask of the winning matrix.                      [fp64 VALU]
+//   F1-F5  round-synchronous RANSAC / LMedS, every phase its own launch over ALL pairs (see the
+//          comment above FmState): begin -> [solve -> score -> accept] x 32 -> finish.       [fp64 VALU]
 #include "rcn_internal.h"
 
 #include <cfloat>
@@ -278,14 +271,31 @@ __device__ __forceinline__ bool last_point_collinear(const float *m, int count)
     return false;
 }
 
-#ifdef RCN_FM_PROF   // diagnostic build only (tools/fmat_prof.hip): cycles per phase, summed over pairs
-__device__ unsigned long long g_fm_prof[8];
-#define FM_T(i) do { const unsigned long long now_ = clock64(); if (lane == 0) atomicAdd(&g_fm_prof[i], now_ - tprev_); tprev_ = clock64(); } while (0)
-#define FM_T0() unsigned long long tprev_ = clock64()
-#else
-#define FM_T(i)
-#define FM_T0()
-#endif
+// ---------------------------------------------------------------------------------------------
+// Round-synchronous form: every pair advances by up to FM_B hypotheses per round, and each phase of
+// a round is its own launch over ALL pairs, so that every phase runs with full lanes:
+//   k_fm_begin   per pair: RNG seed, iteration budget, first round of index sets
+//   k_fm_solve   one lane per hypothesis (FM_B lanes = one pair, two pairs per wave): collinearity
+//                test of the sample (a hit sends the pair through the reference's literal redraw
+//                loop, run by one lane), 7-point solve in registers
+//   k_fm_score   one workgroup per pair: <= 3 FM_B matrices against the pair's points (LDS), with
+//                the exact pruning bound; LMedS pairs: one matrix per lane
+//   k_fm_accept  per pair (scalar work, one lane): the reference's sequential accept / shrink logic
+//                over the round, then the next round's index sets
+//   k_fm_finish  per pair: mask of the winning matrix, count, iterations
+// Rounds are enqueued back to back without host round trips: FM_MAX_ITERS / FM_B of them, each
+// launch returning at once when no pair is active any more (a device counter).
+struct FmState {            // per pair, structure of arrays
+    unsigned long long *rng;
+    int *niters, *max_good, *done, *stop, *have, *drawn, *fail, *base;
+    double *min_med, *bestF;   // [P], [P][9]
+    int *idx;                  // [P][FM_B][7]
+    double *F;                 // [P][FM_B][27]
+    int *nm;                   // [P][FM_B]
+    int *good;                 // [P][3 FM_B]
+    double *med;               // [P][3 FM_B]
+    int *active;               // pairs still running
+};
 
 struct Pts {   // the pair's points: LDS copy when it fits, else the global arrays
     const float2 *l1, *l2;
@@ -297,261 +307,282 @@ struct Pts {   // the pair's points: LDS copy when it fits, else the global arra
     }
 };
 
-// One workgroup of four waves per pair: wave 0 samples, solves and runs the accept logic, all four
-// score the round's matrices (matrix m goes to wave m % 4), and five or six pairs share a CU so
-// that the serial parts of one overlap with the parallel parts of the others.
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_fmat_filter(FmatArgs a)
+// index sets of the next round for one pair (one lane): draws only -- the collinearity test of the
+// samples is done by k_fm_solve with one lane per sample
+__device__ void draw_round(const FmState &st, int pair, int n)
+{
+    unsigned long long rng = st.rng[pair];
+    const int niters = st.niters[pair], base = st.base[pair];
+    const unsigned un = (unsigned)n, M = 0xFFFFFFFFu / un;
+    int drawn = 0;
+    for (; drawn < FM_B && base + drawn < niters; ++drawn) {
+        int idx[7];
+#pragma unroll
+        for (int j = 0; j < 7; ++j) idx[j] = j;            // n == 7: the sample is the data set
+        if (n != 7)
+            for (int i = 0; i < 7;) {
+                const unsigned lo = rng_next(rng);
+                unsigned v = lo - __umulhi(lo, M) * un;     // lo % n: multiply-high by floor((2^32-1)/n), <= 2 corrections
+                while (v >= un) v -= un;
+                bool dup = false;
+#pragma unroll
+                for (int j = 0; j < 7; ++j) dup |= j < i && idx[j] == (int)v;
+                if (dup) continue;
+#pragma unroll
+                for (int j = 0; j < 7; ++j) idx[j] = j == i ? (int)v : idx[j];
+                ++i;
+            }
+        int *o = st.idx + ((size_t)pair * FM_B + drawn) * 7;
+#pragma unroll
+        for (int j = 0; j < 7; ++j) o[j] = idx[j];
+    }
+    st.rng[pair] = rng;
+    st.drawn[pair] = drawn;
+}
+
+__global__ void k_fm_begin(FmatArgs a, FmState st)
+{
+    const int pair = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pair >= a.n_pairs) return;
+    const int n = a.off[pair + 1] - a.off[pair];
+    st.base[pair] = 0; st.max_good[pair] = 0; st.done[pair] = 0; st.have[pair] = 0; st.fail[pair] = 0; st.drawn[pair] = 0;
+    st.min_med[pair] = DBL_MAX;
+    st.rng[pair] = ~0ull;
+    if (n < 7) { st.stop[pair] = 1; st.niters[pair] = 0; return; }
+    int ni = FM_MAX_ITERS;
+    if (n < 15) { ni = update_num_iters(0.99, 0.45, 7, FM_MAX_ITERS); if (ni < 3) ni = 3; }
+    if (n == 7) ni = 1;
+    st.niters[pair] = ni; st.stop[pair] = 0;
+    atomicAdd(st.active, 1);
+    *reinterpret_cast<unsigned long long *>(st.med + (size_t)pair * 3 * FM_B) = st.rng[pair];   // pre-round state, see k_fm_accept
+    draw_round(st, pair, n);
+}
+
+// FM_B lanes per pair; blockDim = 64 -> two pairs per workgroup
+__global__ __launch_bounds__(64) void k_fm_solve(FmatArgs a, FmState st)
+{
+#pragma clang fp contract(off)
+    if (*st.active == 0) return;
+    const int lane = threadIdx.x, h = lane & (FM_B - 1);
+    const int pair = blockIdx.x * (64 / FM_B) + lane / FM_B;
+    const bool live = pair < a.n_pairs && !st.stop[pair];
+    int drawn = live ? st.drawn[pair] : 0;
+    const int o0 = live ? a.off[pair] : 0, n = live ? a.off[pair + 1] - o0 : 0;
+    Pts pts;
+    pts.l1 = nullptr; pts.l2 = nullptr; pts.g1 = a.xy1 + 2 * (size_t)o0; pts.g2 = a.xy2 + 2 * (size_t)o0;
+    float s1[14], s2[14];
+    bool coll = false;
+    if (h < drawn) {
+        const int *ix = st.idx + ((size_t)pair * FM_B + h) * 7;
+#pragma unroll
+        for (int i = 0; i < 7; ++i) pts.get(ix[i], s1[2 * i], s1[2 * i + 1], s2[2 * i], s2[2 * i + 1]);
+        coll = n != 7 && (last_point_collinear(s1, 7) || last_point_collinear(s2, 7));
+    }
+    const unsigned long long cm = __ballot(coll);
+    const unsigned mine = (unsigned)(cm >> (lane & ~(FM_B - 1)));     // the collinear flags of this lane's pair
+    if (cm) {
+        // Slow path, exactly the reference's loop: one lane redoes the pair's draws of this round one by
+        // one with the collinearity test inside, starting from the RNG state before the round (parked by
+        // k_fm_begin / k_fm_accept in the pair's med[] row).  The new index sets reach the other lanes
+        // through LDS.
+        __shared__ int sIdx[64 / FM_B][FM_B][7], sDrawn[64 / FM_B];
+        const int slot = lane / FM_B;
+        if (mine && h == 0) {
+            unsigned long long rng = *reinterpret_cast<const unsigned long long *>(st.med + (size_t)pair * 3 * FM_B);
+            const int niters = st.niters[pair], base = st.base[pair];
+            int d2 = 0;
+            bool failed = false;
+            for (; d2 < FM_B && base + d2 < niters; ++d2) {
+                bool ok = false;
+                int idx[7];
+                for (int attempt = 0; attempt < FM_MAX_ATTEMPTS && !ok; ++attempt) {
+                    float q1[14], q2[14];
+                    for (int i = 0; i < 7;) {
+                        const int v = (int)(rng_next(rng) % (unsigned)n);
+                        bool dup = false;
+#pragma unroll
+                        for (int j = 0; j < 7; ++j) dup |= j < i && idx[j] == v;
+                        if (dup) continue;
+#pragma unroll
+                        for (int j = 0; j < 7; ++j)
+                            if (j == i) { idx[j] = v; pts.get(v, q1[2 * j], q1[2 * j + 1], q2[2 * j], q2[2 * j + 1]); }
+                        ++i;
+                    }
+                    ok = !last_point_collinear(q1, 7) && !last_point_collinear(q2, 7);
+                }
+                if (!ok) { failed = true; break; }
+#pragma unroll
+                for (int j = 0; j < 7; ++j) sIdx[slot][d2][j] = idx[j];
+            }
+            st.rng[pair] = rng; st.drawn[pair] = d2; st.fail[pair] = failed ? 1 : 0;
+            sDrawn[slot] = d2;
+        }
+        __syncthreads();
+        if (mine) {
+            drawn = sDrawn[slot];
+            if (h < drawn) {
+                int *ix = st.idx + ((size_t)pair * FM_B + h) * 7;
+#pragma unroll
+                for (int i = 0; i < 7; ++i) { const int v = sIdx[slot][h][i]; ix[i] = v; pts.get(v, s1[2 * i], s1[2 * i + 1], s2[2 * i], s2[2 * i + 1]); }
+            }
+        }
+    }
+    if (h < drawn) st.nm[(size_t)pair * FM_B + h] = run_7point(s1, s2, st.F + ((size_t)pair * FM_B + h) * 27);
+}
+
+__global__ __launch_bounds__(256) void k_fm_score(FmatArgs a, FmState st)
 {
 #pragma clang fp contract(off)
     __shared__ float2 P1[FM_NLDS], P2[FM_NLDS];
-    __shared__ double sF[FM_B][27], bestF[9], sMed[FM_B * 3];
-    __shared__ int sIdx[FM_B][7], sNm[FM_B], sGood[FM_B * 3];
-    __shared__ int sCtl[8];   // 0: hypotheses drawn this round, 1: stop, 2: niters, 3: max_good, 4: iterations done, 5: draw failed, 6/7: verdicts
-    __shared__ unsigned long long sRng;
-    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-    for (int pair = blockIdx.x; pair < a.n_pairs; pair += gridDim.x) {
-        const int o0 = a.off[pair], n = a.off[pair + 1] - o0;
-        uint8_t *mask = a.mask + o0;
-        __syncthreads();
-        if (n < 7) {   // not filtered by the reference (SequentialReconstructor.cpp:237)
-            for (int i = t; i < n; i += 256) mask[i] = 1;
-            if (t == 0) { a.counts[pair] = -2; a.iters[pair] = 0; }
-            if (a.F && t < 9) a.F[9 * (size_t)pair + t] = 0.0;
-            continue;
-        }
-        Pts pts;
-        pts.g1 = a.xy1 + 2 * (size_t)o0; pts.g2 = a.xy2 + 2 * (size_t)o0;
-        pts.l1 = n <= FM_NLDS ? P1 : nullptr; pts.l2 = n <= FM_NLDS ? P2 : nullptr;
-        if (n <= FM_NLDS)
-            for (int i = t; i < n; i += 256) {
-                P1[i] = make_float2((float)pts.g1[2 * i], (float)pts.g1[2 * i + 1]);
-                P2[i] = make_float2((float)pts.g2[2 * i], (float)pts.g2[2 * i + 1]);
-            }
-        const bool ransac = n >= 15;
-        FM_T0();
-        if (t == 0) {
-            sRng = ~0ull;
-            sCtl[1] = 0; sCtl[3] = 0; sCtl[4] = 0; sCtl[5] = 0;
-            int ni = FM_MAX_ITERS;
-            if (!ransac) { ni = update_num_iters(0.99, 0.45, 7, FM_MAX_ITERS); if (ni < 3) ni = 3; }
-            if (n == 7) ni = 1;
-            sCtl[2] = ni;
+    if (*st.active == 0) return;
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6, pair = blockIdx.x;
+    if (st.stop[pair]) return;
+    const int drawn = st.drawn[pair];
+    if (drawn == 0) return;
+    const int o0 = a.off[pair], n = a.off[pair + 1] - o0;
+    if (n == 7) return;
+    Pts pts;
+    pts.g1 = a.xy1 + 2 * (size_t)o0; pts.g2 = a.xy2 + 2 * (size_t)o0;
+    pts.l1 = n <= FM_NLDS ? P1 : nullptr; pts.l2 = n <= FM_NLDS ? P2 : nullptr;
+    if (n <= FM_NLDS) {
+        for (int i = t; i < n; i += 256) {
+            P1[i] = make_float2((float)pts.g1[2 * i], (float)pts.g1[2 * i + 1]);
+            P2[i] = make_float2((float)pts.g2[2 * i], (float)pts.g2[2 * i + 1]);
         }
         __syncthreads();
-        double min_median = DBL_MAX;   // lane 0 only
-        bool have_best = false;        // lane 0 only
-        for (int base = 0;; base += FM_B) {
-            // ---- draw: lane 0 produces the index sets (the RNG stream is sequential); the rare
-            // collinear sample, which makes the reference redraw, is detected by all lanes below
-            // Every lane runs the draw on wave-uniform values (readfirstlane), so it executes on the
-            // scalar unit; x % n is a multiply-high by floor((2^32-1)/n) plus at most two corrections.
-            const unsigned long long rng0 = sRng;
-            if (w == 0) {
-                unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)rng0), hi = __builtin_amdgcn_readfirstlane((unsigned)(rng0 >> 32));
-                const unsigned un = (unsigned)__builtin_amdgcn_readfirstlane(n);
-                const unsigned M = 0xFFFFFFFFu / un;
-                const int niters = __builtin_amdgcn_readfirstlane(sCtl[2]);
-                int drawn = 0;
-                for (; drawn < FM_B && base + drawn < niters; ++drawn) {
-                    int idx[7];
-#pragma unroll
-                    for (int j = 0; j < 7; ++j) idx[j] = j;            // n == 7: the sample is the data set
-                    if (un != 7)
-                        for (int i = 0; i < 7;) {
-                            const unsigned long long st = (unsigned long long)lo * 4164903690U + hi;
-                            lo = (unsigned)st; hi = (unsigned)(st >> 32);
-                            unsigned v = lo - __umulhi(lo, M) * un;
-                            while (v >= un) v -= un;
-                            bool dup = false;
-#pragma unroll
-                            for (int j = 0; j < 7; ++j) dup |= j < i && idx[j] == (int)v;
-                            if (dup) continue;
-#pragma unroll
-                            for (int j = 0; j < 7; ++j) idx[j] = j == i ? (int)v : idx[j];
-                            ++i;
-                        }
-                    if (lane < 7) {
-                        int mine = idx[0];
-#pragma unroll
-                        for (int j = 1; j < 7; ++j) mine = lane == j ? idx[j] : mine;
-                        sIdx[drawn][lane] = mine;
-                    }
-                }
-                if (lane == 0) { sRng = (unsigned long long)hi << 32 | lo; sCtl[0] = drawn; }
-            }
-            __syncthreads();
-            FM_T(0);
-            int drawn = sCtl[0];
-            float s1[14], s2[14];
-            bool coll = false;
-            if (t < drawn) {
-#pragma unroll
-                for (int i = 0; i < 7; ++i) pts.get(sIdx[lane][i], s1[2 * i], s1[2 * i + 1], s2[2 * i], s2[2 * i + 1]);
-                coll = n != 7 && (last_point_collinear(s1, 7) || last_point_collinear(s2, 7));
-            }
-            if (t < 64 && __ballot(coll)) sCtl[5] = 2;      // (wave 0) flag the slow path for everybody
-            __syncthreads();
-            const bool slow = sCtl[5] == 2;
-            __syncthreads();                                // everyone has read the flag before lane 0 clears it
-            if (slow) {
-                // slow path, exactly the reference's loop: redo the round's draws one by one with the
-                // collinearity test inside
-                if (t == 0) {
-                    sCtl[5] = 0;
-                    unsigned long long rng = rng0;
-                    int d2 = 0;
-                    const int niters = sCtl[2];
-                    for (; d2 < FM_B && base + d2 < niters; ++d2) {
-                        bool ok = false;
-                        for (int attempt = 0; attempt < FM_MAX_ATTEMPTS && !ok; ++attempt) {
-                            int idx[7];
-                            float q1[14], q2[14];
-                            for (int i = 0; i < 7;) {
-                                const int v = (int)(rng_next(rng) % (unsigned)n);
-                                bool dup = false;
-#pragma unroll
-                                for (int j = 0; j < 7; ++j) dup |= j < i && idx[j] == v;
-                                if (dup) continue;
-#pragma unroll
-                                for (int j = 0; j < 7; ++j) {
-                                    if (j == i) { idx[j] = v; pts.get(v, q1[2 * j], q1[2 * j + 1], q2[2 * j], q2[2 * j + 1]); }
-                                }
-                                ++i;
-                            }
-                            ok = !last_point_collinear(q1, 7) && !last_point_collinear(q2, 7);
-                            if (ok) {
-#pragma unroll
-                                for (int i = 0; i < 7; ++i) sIdx[d2][i] = idx[i];
-                            }
-                        }
-                        if (!ok) { sCtl[5] = 1; break; }
-                    }
-                    sRng = rng;
-                    sCtl[0] = d2;
-                }
-                __syncthreads();
-                drawn = sCtl[0];
-                if (t < drawn) {
-#pragma unroll
-                    for (int i = 0; i < 7; ++i) pts.get(sIdx[lane][i], s1[2 * i], s1[2 * i + 1], s2[2 * i], s2[2 * i + 1]);
-                }
-            }
-            FM_T(1);
-            // ---- solve: one hypothesis per lane, in registers
-            if (t < drawn) sNm[t] = run_7point(s1, s2, sF[t]);
-            __syncthreads();
-            FM_T(2);
-            // ---- score
-            if (ransac) {
-                for (int m = w; m < 3 * drawn; m += 4) {        // each wave walks its share of the models, lanes walk the points
-                    const int h = m / 3, k = m - 3 * h;
-                    if (k >= sNm[h]) continue;
-                    double F[9];
-#pragma unroll
-                    for (int i = 0; i < 9; ++i) F[i] = sF[h][9 * k + i];
-                    // A matrix is accepted only if it beats the best count so far (and 6).  The best at
-                    // the start of the round is a lower bound of the best at this matrix's turn, so once
-                    // even all remaining points could not lift the count above it the matrix is dropped
-                    // (its stored count stays <= the bound: never accepted, exactly as if fully counted).
-                    const int bound = sCtl[3] > 6 ? sCtl[3] : 6;
-                    int good = 0;
-                    for (int i0 = 0; i0 < n; i0 += 64) {
-                        const int i = i0 + lane;
-                        bool in = false;
-                        if (i < n) { float ax, ay, bx, by; pts.get(i, ax, ay, bx, by); in = epi_inlier9(F, ax, ay, bx, by); }
-                        good += (int)__popcll(__ballot(in));
-                        if (good + (n - i0 - 64) <= bound) break;
-                    }
-                    if (lane == 0) sGood[m] = good;
-                }
-            } else if (n > 7) {                                 // LMedS, n <= 14: one model per lane
-                for (int m = t; m < 3 * drawn; m += 256) {
-                    const int h = m / 3, k = m - 3 * h;
-                    if (k >= sNm[h]) continue;
-                    double F[9];
-#pragma unroll
-                    for (int i = 0; i < 9; ++i) F[i] = sF[h][9 * k + i];
-                    float e[14];
-#pragma unroll
-                    for (int i = 0; i < 14; ++i) e[i] = 3.0e38f;
-                    for (int i = 0; i < n; ++i) {               // insertion into the sorted prefix, register resident
-                        float ax, ay, bx, by; pts.get(i, ax, ay, bx, by);
-                        float v = epi_error(F, ax, ay, bx, by);
-#pragma unroll
-                        for (int p = 0; p < 14; ++p) { const float lo = fminf(e[p], v), hi = fmaxf(e[p], v); e[p] = lo; v = hi; }
-                    }
-                    float em1 = 0.f, e0 = 0.f;   // e[n/2 - 1], e[n/2]
-#pragma unroll
-                    for (int p = 0; p < 14; ++p) { em1 = p == n / 2 - 1 ? e[p] : em1; e0 = p == n / 2 ? e[p] : e0; }
-                    sMed[m] = n % 2 != 0 ? (double)e0 : (double)(em1 + e0) * 0.5;
-                }
-            }
-            __syncthreads();
-            FM_T(3);
-            // ---- accept, in sequence order
-            if (t == 0) {
-                int niters = sCtl[2], max_good = sCtl[3], done = sCtl[4];
-                bool stop = sCtl[5] != 0 || drawn == 0;
-                for (int h = 0; h < drawn; ++h) {
-                    if (base + h >= niters) { stop = true; break; }
-                    done = base + h + 1;
-                    for (int k = 0; k < sNm[h]; ++k) {
-                        const int m = 3 * h + k;
-                        bool take = false;
-                        if (n == 7) { take = !have_best; max_good = 7; }
-                        else if (ransac) {
-                            const int good = sGood[m];
-                            if (good > (max_good > 6 ? max_good : 6)) {
-                                take = true; max_good = good;
-                                niters = update_num_iters(0.99, (double)(n - good) / n, 7, niters);
-                            }
-                        } else if (sMed[m] < min_median) { take = true; min_median = sMed[m]; }
-                        if (take) { have_best = true; for (int i = 0; i < 9; ++i) bestF[i] = sF[h][9 * k + i]; }
-                    }
-                }
-                if (base + drawn >= niters) stop = true;
-                sCtl[1] = stop; sCtl[2] = niters; sCtl[3] = max_good; sCtl[4] = done;
-                if (stop) {   // final threshold (squared) into sMed[0], verdict into sCtl[6]
-                    double thr2 = 9.0;
-                    if (!ransac && n > 7 && have_best) {
-                        double sigma = 2.5 * 1.4826 * (1 + 5. / (n - 7)) * sqrt(min_median);
-                        sigma = fmax(sigma, 0.001);
-                        thr2 = sigma * sigma;
-                    }
-                    sMed[0] = thr2; sCtl[6] = have_best ? 1 : 0;
-                }
-            }
-            __syncthreads();
-            FM_T(4);
-            if (sCtl[1]) break;
-        }
-        // ---- mask of the winning matrix
-        const bool have = sCtl[6] != 0;
-        const double thr2 = sMed[0];
-        double F[9];
-#pragma unroll
-        for (int i = 0; i < 9; ++i) F[i] = bestF[i];
-        int good = 0;
-        for (int i0 = 0; i0 < n; i0 += 256) {
-            const int i = i0 + t;
-            bool in = false;
-            if (i < n && have) {
-                if (n == 7) in = true;
-                else { float ax, ay, bx, by; pts.get(i, ax, ay, bx, by); in = epi_error(F, ax, ay, bx, by) <= thr2; }
-            }
-            if (i < n) mask[i] = in ? 1 : 0;
-            good += (int)__popcll(__ballot(in));
-        }
-        if (lane == 0) sGood[w] = good;
-        __syncthreads();
-        good = sGood[0] + sGood[1] + sGood[2] + sGood[3];
-        int verdict = have ? good : -1;
-        if (have && !ransac && n > 7 && good < 7) verdict = -1;     // LMedS: fewer than 7 inliers is a failure
-        if (t == 0) { a.counts[pair] = verdict; a.iters[pair] = sCtl[4]; }
-        if (verdict < 0) for (int i = t; i < n; i += 256) mask[i] = 0;
-        if (a.F && t < 9) a.F[9 * (size_t)pair + t] = verdict < 0 ? 0.0 : bestF[t];
-        FM_T(5);
     }
+    const double *Fp = st.F + (size_t)pair * FM_B * 27;
+    const int *nm = st.nm + (size_t)pair * FM_B;
+    if (n >= 15) {
+        // A matrix is accepted only if it beats the best count so far (and 6).  The best at the start
+        // of the round is a lower bound of the best at this matrix's turn, so once even all remaining
+        // points could not lift the count above it the matrix is dropped (its stored count stays
+        // <= the bound: never accepted, exactly as if fully counted).
+        const int mg = st.max_good[pair], bound = mg > 6 ? mg : 6;
+        for (int m = w; m < 3 * drawn; m += 4) {
+            const int h = m / 3, k = m - 3 * h;
+            if (k >= nm[h]) continue;
+            double F[9];
+#pragma unroll
+            for (int i = 0; i < 9; ++i) F[i] = Fp[27 * h + 9 * k + i];
+            int good = 0;
+            for (int i0 = 0; i0 < n; i0 += 64) {
+                const int i = i0 + lane;
+                bool in = false;
+                if (i < n) { float ax, ay, bx, by; pts.get(i, ax, ay, bx, by); in = epi_inlier9(F, ax, ay, bx, by); }
+                good += (int)__popcll(__ballot(in));
+                if (good + (n - i0 - 64) <= bound) break;
+            }
+            if (lane == 0) st.good[(size_t)pair * 3 * FM_B + m] = good;
+        }
+    } else {                                               // LMedS, 8 <= n <= 14: one matrix per lane
+        for (int m = t; m < 3 * drawn; m += 256) {
+            const int h = m / 3, k = m - 3 * h;
+            if (k >= nm[h]) continue;
+            double F[9];
+#pragma unroll
+            for (int i = 0; i < 9; ++i) F[i] = Fp[27 * h + 9 * k + i];
+            float e[14];
+#pragma unroll
+            for (int i = 0; i < 14; ++i) e[i] = 3.0e38f;
+            for (int i = 0; i < n; ++i) {                   // insertion into the sorted prefix, register resident
+                float ax, ay, bx, by; pts.get(i, ax, ay, bx, by);
+                float v = epi_error(F, ax, ay, bx, by);
+#pragma unroll
+                for (int p = 0; p < 14; ++p) { const float lo = fminf(e[p], v), hi = fmaxf(e[p], v); e[p] = lo; v = hi; }
+            }
+            float em1 = 0.f, e0 = 0.f;   // e[n/2 - 1], e[n/2]
+#pragma unroll
+            for (int p = 0; p < 14; ++p) { em1 = p == n / 2 - 1 ? e[p] : em1; e0 = p == n / 2 ? e[p] : e0; }
+            st.med[(size_t)pair * 3 * FM_B + m] = n % 2 != 0 ? (double)e0 : (double)(em1 + e0) * 0.5;
+        }
+    }
+}
+
+// one lane per pair: the sequential accept logic over the finished round, then the next round's draws
+__global__ void k_fm_accept(FmatArgs a, FmState st)
+{
+#pragma clang fp contract(off)
+    if (*st.active == 0) return;
+    const int pair = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pair >= a.n_pairs || st.stop[pair]) return;
+    const int n = a.off[pair + 1] - a.off[pair];
+    const bool ransac = n >= 15;
+    const int drawn = st.drawn[pair], base = st.base[pair];
+    int niters = st.niters[pair], max_good = st.max_good[pair], done = st.done[pair];
+    bool have_best = st.have[pair] != 0;
+    double min_median = st.min_med[pair];
+    bool stop = st.fail[pair] != 0 || drawn == 0;
+    const int *nm = st.nm + (size_t)pair * FM_B, *gd = st.good + (size_t)pair * 3 * FM_B;
+    const double *md = st.med + (size_t)pair * 3 * FM_B, *Fp = st.F + (size_t)pair * FM_B * 27;
+    for (int h = 0; h < drawn; ++h) {
+        if (base + h >= niters) { stop = true; break; }
+        done = base + h + 1;
+        for (int k = 0; k < nm[h]; ++k) {
+            const int m = 3 * h + k;
+            bool take = false;
+            if (n == 7) { take = !have_best; max_good = 7; }
+            else if (ransac) {
+                const int good = gd[m];
+                if (good > (max_good > 6 ? max_good : 6)) {
+                    take = true; max_good = good;
+                    niters = update_num_iters(0.99, (double)(n - good) / n, 7, niters);
+                }
+            } else if (md[m] < min_median) { take = true; min_median = md[m]; }
+            if (take) { have_best = true; for (int i = 0; i < 9; ++i) st.bestF[9 * (size_t)pair + i] = Fp[27 * h + 9 * k + i]; }
+        }
+    }
+    if (base + drawn >= niters) stop = true;
+    st.niters[pair] = niters; st.max_good[pair] = max_good; st.done[pair] = done; st.have[pair] = have_best ? 1 : 0;
+    st.min_med[pair] = min_median; st.base[pair] = base + FM_B;
+    if (stop) { st.stop[pair] = 1; st.drawn[pair] = 0; atomicSub(st.active, 1); return; }
+    // the pre-round RNG state, for the slow path of k_fm_solve (parked in the pair's med[] row, which the
+    // scoring of RANSAC pairs does not use and LMedS pairs overwrite only after k_fm_solve has run)
+    *reinterpret_cast<unsigned long long *>(st.med + (size_t)pair * 3 * FM_B) = st.rng[pair];
+    draw_round(st, pair, n);
+}
+
+__global__ __launch_bounds__(256) void k_fm_finish(FmatArgs a, FmState st)
+{
+#pragma clang fp contract(off)
+    __shared__ int sGood[4];
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6, pair = blockIdx.x;
+    const int o0 = a.off[pair], n = a.off[pair + 1] - o0;
+    uint8_t *mask = a.mask + o0;
+    if (n < 7) {   // not filtered by the reference (SequentialReconstructor.cpp:237)
+        for (int i = t; i < n; i += 256) mask[i] = 1;
+        if (t == 0) { a.counts[pair] = -2; a.iters[pair] = 0; }
+        if (a.F && t < 9) a.F[9 * (size_t)pair + t] = 0.0;
+        return;
+    }
+    const bool ransac = n >= 15, have = st.have[pair] != 0;
+    double thr2 = 9.0;
+    if (!ransac && n > 7 && have) {
+        double sigma = 2.5 * 1.4826 * (1 + 5. / (n - 7)) * sqrt(st.min_med[pair]);
+        sigma = fmax(sigma, 0.001);
+        thr2 = sigma * sigma;
+    }
+    double F[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) F[i] = st.bestF[9 * (size_t)pair + i];
+    const int32_t *g1 = a.xy1 + 2 * (size_t)o0, *g2 = a.xy2 + 2 * (size_t)o0;
+    int good = 0;
+    for (int i0 = 0; i0 < n; i0 += 256) {
+        const int i = i0 + t;
+        bool in = false;
+        if (i < n && have)
+            in = n == 7 ? true : epi_error(F, (float)g1[2 * i], (float)g1[2 * i + 1], (float)g2[2 * i], (float)g2[2 * i + 1]) <= thr2;
+        if (i < n) mask[i] = in ? 1 : 0;
+        good += (int)__popcll(__ballot(in));
+    }
+    if (lane == 0) sGood[w] = good;
+    __syncthreads();
+    good = sGood[0] + sGood[1] + sGood[2] + sGood[3];
+    int verdict = have ? good : -1;
+    if (have && !ransac && n > 7 && good < 7) verdict = -1;     // LMedS: fewer than 7 inliers is a failure
+    if (t == 0) { a.counts[pair] = verdict; a.iters[pair] = st.done[pair]; }
+    if (verdict < 0) for (int i = t; i < n; i += 256) mask[i] = 0;
+    if (a.F && t < 9) a.F[9 * (size_t)pair + t] = verdict < 0 ? 0.0 : st.bestF[9 * (size_t)pair + t];
 }
 
 }  // namespace
@@ -562,8 +593,33 @@ static int fmat_launch(rcn_ctx *ctx, int32_t n_pairs, const int32_t *off, const 
     if (n_pairs <= 0) return RCN_OK;
     FmatArgs a;
     a.off = off; a.xy1 = xy1; a.xy2 = xy2; a.n_pairs = n_pairs; a.mask = mask; a.counts = counts; a.iters = iters; a.F = F;
-    const int blocks = std::min<int>(n_pairs, ctx->prop.multiProcessorCount * 24);
-    k_fmat_filter<<<blocks, 256, 0, ctx->stream>>>(a);
+    const size_t P = (size_t)n_pairs;
+    auto al = [](size_t b) { return (b + 255) / 256 * 256; };
+    const size_t bytes = al(8 * P) + 8 * al(4 * P) + al(8 * P) + al(72 * P) + al(4 * P * FM_B * 7) + al(8 * P * FM_B * 27) +
+                         al(4 * P * FM_B) + al(4 * P * 3 * FM_B) + al(8 * P * 3 * FM_B) + 256;
+    RCN_HIP(ctx->fm_state.reserve(bytes));
+    char *base = ctx->fm_state.as<char>();
+    size_t o = 0;
+    auto take = [&](size_t b) { char *q = base + o; o += al(b); return q; };
+    FmState st;
+    st.rng = (unsigned long long *)take(8 * P);
+    st.niters = (int *)take(4 * P); st.max_good = (int *)take(4 * P); st.done = (int *)take(4 * P); st.stop = (int *)take(4 * P);
+    st.have = (int *)take(4 * P); st.drawn = (int *)take(4 * P); st.fail = (int *)take(4 * P); st.base = (int *)take(4 * P);
+    st.min_med = (double *)take(8 * P); st.bestF = (double *)take(72 * P);
+    st.idx = (int *)take(4 * P * FM_B * 7); st.F = (double *)take(8 * P * FM_B * 27); st.nm = (int *)take(4 * P * FM_B);
+    st.good = (int *)take(4 * P * 3 * FM_B); st.med = (double *)take(8 * P * 3 * FM_B);
+    st.active = (int *)take(4);
+    hipStream_t s = ctx->stream;
+    RCN_HIP(hipMemsetAsync(st.active, 0, 4, s));
+    RCN_HIP(hipMemsetAsync(st.bestF, 0, 72 * P, s));
+    const int pb = (n_pairs + 63) / 64;
+    k_fm_begin<<<pb, 64, 0, s>>>(a, st);
+    for (int round = 0; round < (FM_MAX_ITERS + FM_B - 1) / FM_B; ++round) {
+        k_fm_solve<<<(n_pairs + 64 / FM_B - 1) / (64 / FM_B), 64, 0, s>>>(a, st);
+        k_fm_score<<<n_pairs, 256, 0, s>>>(a, st);
+        k_fm_accept<<<pb, 64, 0, s>>>(a, st);
+    }
+    k_fm_finish<<<n_pairs, 256, 0, s>>>(a, st);
     RCN_HIP(hipGetLastError());
     return RCN_OK;
 }

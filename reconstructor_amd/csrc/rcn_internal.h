@@ -99,7 +99,7 @@ struct rcn_ctx {
     // ---- BA state (ba.hip)
     DevBuf ba_ws[28];
     DevBuf lm_ws;              // landmark validity sweep (validity.hip)
-    DevBuf fm_ws;              // epipolar filter (fmat.hip)
+    DevBuf fm_ws, fm_state;    // epipolar filter (fmat.hip): host-API staging, per-pair RANSAC state
     bool ba_atomics = false;   // RCN_BA_SCHUR_ATOMICS=1: atomic Schur accumulation instead of the gather form
     bool ba_trsv_fwd = false;  // RCN_BA_TRSV_FWD=1: separate forward substitution instead of the rhs row inside the factorisation
     hipStream_t aux_stream = nullptr;   // lookahead stream of the Cholesky
