@@ -102,25 +102,25 @@ __device__ int solve_cubic(const double *c, double *r)
     return n;
 }
 
-// seven correspondences (s1, s2: 7 x 2 floats, in registers) -> up to three matrices in F (27 doubles,
-// LDS).  The 7x9 design matrix lives in registers: every loop is fully unrolled and the pivot row /
-// column -- which are data dependent -- are picked with selects, never with indexed addressing.
-__device__ int run_7point(const float *s1, const float *s2, double *F)
+// seven correspondences (s1, s2: 7 x 2 floats, in registers) -> up to three matrices in F (27 doubles).
+// The 7x9 design matrix of every lane lives in LDS, element-major: element e of lane l at sA[e * 64 + l].
+// Pivot rows and columns are data dependent, i.e. different in every lane -- indexed LDS addressing
+// takes that in its stride, and with this layout lane l only ever touches banks 2l and 2l + 1
+// whatever element it asks for, so the accesses stay conflict-free.
+#define FM_AT(r, c) sA[((r) * 9 + (c)) * 64 + lane]
+__device__ int run_7point(const float *s1, const float *s2, double *sA, int lane, double *F)
 {
 #pragma clang fp contract(off)
-    double A[7][9];
 #pragma unroll
     for (int i = 0; i < 7; ++i) {
         const double x0 = s1[2 * i], y0 = s1[2 * i + 1], x1 = s2[2 * i], y1 = s2[2 * i + 1];
-        A[i][0] = x1 * x0; A[i][1] = x1 * y0; A[i][2] = x1;
-        A[i][3] = y1 * x0; A[i][4] = y1 * y0; A[i][5] = y1;
-        A[i][6] = x0; A[i][7] = y0; A[i][8] = 1;
+        FM_AT(i, 0) = x1 * x0; FM_AT(i, 1) = x1 * y0; FM_AT(i, 2) = x1;
+        FM_AT(i, 3) = y1 * x0; FM_AT(i, 4) = y1 * y0; FM_AT(i, 5) = y1;
+        FM_AT(i, 6) = x0; FM_AT(i, 7) = y0; FM_AT(i, 8) = 1;
     }
     // null space: Gauss-Jordan, complete pivoting, no row exchanges (oracle: null_space_7x9)
-    unsigned row_used = 0, col_used = 0;
-    int prk[7], pck[7];
+    unsigned row_used = 0, col_used = 0, prs = 0, pcs = 0;   // prs / pcs: 4 bits per step
     bool singular = false;
-#pragma unroll
     for (int k = 0; k < 7; ++k) {
         int pr = -1, pc = -1;
         double best = 0;
@@ -128,66 +128,45 @@ __device__ int run_7point(const float *s1, const float *s2, double *F)
         for (int r = 0; r < 7; ++r)
 #pragma unroll
             for (int c = 0; c < 9; ++c) {
-                const double v = fabs(A[r][c]);
+                const double v = fabs(FM_AT(r, c));
                 const bool ok = !(row_used >> r & 1) && !(col_used >> c & 1) && v > best;
                 best = ok ? v : best; pr = ok ? r : pr; pc = ok ? c : pc;
             }
         singular |= pr < 0;
         pr = pr < 0 ? 0 : pr; pc = pc < 0 ? 0 : pc;
         row_used |= 1u << pr; col_used |= 1u << pc;
-        prk[k] = pr; pck[k] = pc;
-        double prow[9], pval = 0;
+        prs |= (unsigned)pr << (4 * k); pcs |= (unsigned)pc << (4 * k);
+        double prow[9];
+        const double inv = 1. / FM_AT(pr, pc);
 #pragma unroll
-        for (int c = 0; c < 9; ++c) {
-            double v = 0;
-#pragma unroll
-            for (int r = 0; r < 7; ++r) v = r == pr ? A[r][c] : v;
-            prow[c] = v;
-            pval = c == pc ? v : pval;
-        }
-        const double inv = 1. / pval;
-#pragma unroll
-        for (int c = 0; c < 9; ++c) prow[c] *= inv;
-#pragma unroll
+        for (int c = 0; c < 9; ++c) { prow[c] = FM_AT(pr, c) * inv; FM_AT(pr, c) = prow[c]; }
         for (int r = 0; r < 7; ++r) {
-            double m = 0;
+            const double m = FM_AT(r, pc);
+            if (r == pr || m == 0) continue;
 #pragma unroll
-            for (int c = 0; c < 9; ++c) m = c == pc ? A[r][c] : m;
-#pragma unroll
-            for (int c = 0; c < 9; ++c) {
-                const double upd = A[r][c] - m * prow[c];
-                A[r][c] = r == pr ? prow[c] : (m == 0 ? A[r][c] : upd);
-            }
+            for (int c = 0; c < 9; ++c) FM_AT(r, c) -= m * prow[c];
         }
     }
     if (singular) return 0;
-    // the two free columns, ascending
-    int fc0 = -1, fc1 = -1;
+    int fc0 = -1, fc1 = -1;   // the two free columns, ascending
 #pragma unroll
     for (int c = 0; c < 9; ++c) {
         const bool fr = !(col_used >> c & 1);
         fc1 = fr && fc0 >= 0 && fc1 < 0 ? c : fc1;
         fc0 = fr && fc0 < 0 ? c : fc0;
     }
-    double g1[9], g2[9];   // basis vectors: free variable = 1, pivot variables = -A[piv_row][free col]
+    // basis vectors (free variable = 1, pivot variables = -A[pivot row][free column]) built in place in
+    // LDS rows 0 and 1 of a scratch area: the matrix rows are dead once their two entries are read
+    double v0[7], v1[7];
 #pragma unroll
-    for (int c = 0; c < 9; ++c) { g1[c] = c == fc0 ? 1.0 : 0.0; g2[c] = c == fc1 ? 1.0 : 0.0; }
+    for (int k = 0; k < 7; ++k) { const int pr = prs >> (4 * k) & 15; v0[k] = FM_AT(pr, fc0); v1[k] = FM_AT(pr, fc1); }
 #pragma unroll
-    for (int k = 0; k < 7; ++k) {
-        double v0 = 0, v1 = 0;
+    for (int c = 0; c < 9; ++c) { FM_AT(0, c) = c == fc0 ? 1.0 : 0.0; FM_AT(1, c) = c == fc1 ? 1.0 : 0.0; }
 #pragma unroll
-        for (int r = 0; r < 7; ++r)
-#pragma unroll
-            for (int c = 0; c < 9; ++c) {
-                v0 = r == prk[k] && c == fc0 ? A[r][c] : v0;
-                v1 = r == prk[k] && c == fc1 ? A[r][c] : v1;
-            }
-#pragma unroll
-        for (int c = 0; c < 9; ++c) { g1[c] = c == pck[k] ? -v0 : g1[c]; g2[c] = c == pck[k] ? -v1 : g2[c]; }
-    }
+    for (int k = 0; k < 7; ++k) { const int pc = pcs >> (4 * k) & 15; FM_AT(0, pc) = -v0[k]; FM_AT(1, pc) = -v1[k]; }
     double f1[9], f2[9], c[4], r[3];
 #pragma unroll
-    for (int i = 0; i < 9; ++i) { f2[i] = g2[i]; f1[i] = g1[i] - g2[i]; }
+    for (int i = 0; i < 9; ++i) { f2[i] = FM_AT(1, i); f1[i] = FM_AT(0, i) - f2[i]; }
     double t0 = f2[4] * f2[8] - f2[5] * f2[7], t1 = f2[3] * f2[8] - f2[5] * f2[6], t2 = f2[3] * f2[7] - f2[4] * f2[6];
     c[3] = f2[0] * t0 - f2[1] * t1 + f2[2] * t2;
     c[2] = f1[0] * t0 - f1[1] * t1 + f1[2] * t2 -
@@ -274,14 +253,14 @@ __device__ __forceinline__ bool last_point_collinear(const float *m, int count)
 // ---------------------------------------------------------------------------------------------
 // Round-synchronous form: every pair advances by up to FM_B hypotheses per round, and each phase of
 // a round is its own launch over ALL pairs, so that every phase runs with full lanes:
-//   k_fm_begin   per pair: RNG seed, iteration budget, first round of index sets
-//   k_fm_solve   one lane per hypothesis (FM_B lanes = one pair, two pairs per wave): collinearity
-//                test of the sample (a hit sends the pair through the reference's literal redraw
-//                loop, run by one lane), 7-point solve in registers
+//   k_fm_begin   one wave per pair: RNG seed, iteration budget, first round of samples
+//   k_fm_solve   one lane per hypothesis (FM_B lanes = one pair, two pairs per wave): 7-point solve,
+//                the design matrix of every lane in LDS (element-major: conflict-free indexed access)
 //   k_fm_score   one workgroup per pair: <= 3 FM_B matrices against the pair's points (LDS), with
 //                the exact pruning bound; LMedS pairs: one matrix per lane
-//   k_fm_accept  per pair (scalar work, one lane): the reference's sequential accept / shrink logic
-//                over the round, then the next round's index sets
+//   k_fm_accept  one wave per pair: the reference's sequential accept / shrink logic over the round
+//                (one lane), then the next round's samples, drawn exactly as the reference draws them
+//                (index stream on the scalar unit, collinearity tests of a sample on 30 lanes)
 //   k_fm_finish  per pair: mask of the winning matrix, count, iterations
 // Rounds are enqueued back to back without host round trips: FM_MAX_ITERS / FM_B of them, each
 // launch returning at once when no pair is active any more (a device counter).
@@ -307,22 +286,39 @@ struct Pts {   // the pair's points: LDS copy when it fits, else the global arra
     }
 };
 
-// index sets of the next round for one pair (one lane): draws only -- the collinearity test of the
-// samples is done by k_fm_solve with one lane per sample
-__device__ void draw_round(const FmState &st, int pair, int n)
+// The next round's samples of one pair, drawn by one WAVE exactly as the reference draws them:
+// seven distinct indices per sample (a duplicate is redrawn), the whole sample redrawn while its last
+// point is collinear with two earlier ones in either image.  The index stream runs on wave-uniform
+// values (readfirstlane: scalar unit; x % n is a multiply-high by floor((2^32-1)/n) plus at most two
+// corrections); the 2 x 15 collinearity tests of a sample run on 30 lanes at once out of a small LDS
+// line.  sp: 28 floats of LDS scratch per wave.
+__device__ void draw_round(const FmState &st, int pair, int n, const Pts &pts, int lane, float *sp)
 {
-    unsigned long long rng = st.rng[pair];
-    const int niters = st.niters[pair], base = st.base[pair];
-    const unsigned un = (unsigned)n, M = 0xFFFFFFFFu / un;
+#pragma clang fp contract(off)
+    const unsigned long long rng0 = st.rng[pair];
+    unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)rng0), hi = __builtin_amdgcn_readfirstlane((unsigned)(rng0 >> 32));
+    const unsigned un = (unsigned)__builtin_amdgcn_readfirstlane(n), M = 0xFFFFFFFFu / un;
+    const int niters = __builtin_amdgcn_readfirstlane(st.niters[pair]), base = __builtin_amdgcn_readfirstlane(st.base[pair]);
     int drawn = 0;
+    bool failed = false;
+    // lane l < 15 tests the pair (j, k), k < j < 6, number l; lanes 32..46 the same in the second image
+    int tj = 1, tk = 0;
+    {
+        int l = lane & 31, j = 1;
+        while (l >= j && j < 6) { l -= j; ++j; }
+        tj = j; tk = l;
+    }
+    const bool tester = (lane & 31) < 15;
     for (; drawn < FM_B && base + drawn < niters; ++drawn) {
         int idx[7];
 #pragma unroll
         for (int j = 0; j < 7; ++j) idx[j] = j;            // n == 7: the sample is the data set
-        if (n != 7)
+        bool ok = un == 7;
+        for (int attempt = 0; attempt < FM_MAX_ATTEMPTS && !ok; ++attempt) {
             for (int i = 0; i < 7;) {
-                const unsigned lo = rng_next(rng);
-                unsigned v = lo - __umulhi(lo, M) * un;     // lo % n: multiply-high by floor((2^32-1)/n), <= 2 corrections
+                const unsigned long long s = (unsigned long long)lo * 4164903690U + hi;
+                lo = (unsigned)s; hi = (unsigned)(s >> 32);
+                unsigned v = lo - __umulhi(lo, M) * un;
                 while (v >= un) v -= un;
                 bool dup = false;
 #pragma unroll
@@ -332,102 +328,87 @@ __device__ void draw_round(const FmState &st, int pair, int n)
                 for (int j = 0; j < 7; ++j) idx[j] = j == i ? (int)v : idx[j];
                 ++i;
             }
-        int *o = st.idx + ((size_t)pair * FM_B + drawn) * 7;
+            // the sample's points -> LDS line (lanes 0..6), then the tests
+            if (lane < 7) {
+                int mine = idx[0];
 #pragma unroll
-        for (int j = 0; j < 7; ++j) o[j] = idx[j];
+                for (int j = 1; j < 7; ++j) mine = lane == j ? idx[j] : mine;
+                float ax, ay, bx, by;
+                pts.get(mine, ax, ay, bx, by);
+                sp[2 * lane] = ax; sp[2 * lane + 1] = ay; sp[14 + 2 * lane] = bx; sp[14 + 2 * lane + 1] = by;
+            }
+            __builtin_amdgcn_wave_barrier();
+            bool coll = false;
+            if (tester) {
+                const float *m = sp + (lane >= 32 ? 14 : 0);
+                const double dx1 = m[2 * tj] - m[12], dy1 = m[2 * tj + 1] - m[13];
+                const double dx2 = m[2 * tk] - m[12], dy2 = m[2 * tk + 1] - m[13];
+                coll = fabs(dx2 * dy1 - dy2 * dx1) <= FLT_EPSILON * (fabs(dx1) + fabs(dy1) + fabs(dx2) + fabs(dy2));
+            }
+            ok = __ballot(coll) == 0;
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (!ok) { failed = true; break; }
+        if (lane < 7) {
+            int mine = idx[0];
+#pragma unroll
+            for (int j = 1; j < 7; ++j) mine = lane == j ? idx[j] : mine;
+            st.idx[((size_t)pair * FM_B + drawn) * 7 + lane] = mine;
+        }
     }
-    st.rng[pair] = rng;
-    st.drawn[pair] = drawn;
+    if (lane == 0) {
+        st.rng[pair] = (unsigned long long)hi << 32 | lo;
+        st.drawn[pair] = drawn;
+        st.fail[pair] = failed ? 1 : 0;
+    }
 }
 
-__global__ void k_fm_begin(FmatArgs a, FmState st)
+// one wave per pair
+__global__ __launch_bounds__(64) void k_fm_begin(FmatArgs a, FmState st)
 {
-    const int pair = blockIdx.x * blockDim.x + threadIdx.x;
-    if (pair >= a.n_pairs) return;
-    const int n = a.off[pair + 1] - a.off[pair];
-    st.base[pair] = 0; st.max_good[pair] = 0; st.done[pair] = 0; st.have[pair] = 0; st.fail[pair] = 0; st.drawn[pair] = 0;
-    st.min_med[pair] = DBL_MAX;
-    st.rng[pair] = ~0ull;
-    if (n < 7) { st.stop[pair] = 1; st.niters[pair] = 0; return; }
-    int ni = FM_MAX_ITERS;
-    if (n < 15) { ni = update_num_iters(0.99, 0.45, 7, FM_MAX_ITERS); if (ni < 3) ni = 3; }
-    if (n == 7) ni = 1;
-    st.niters[pair] = ni; st.stop[pair] = 0;
-    atomicAdd(st.active, 1);
-    *reinterpret_cast<unsigned long long *>(st.med + (size_t)pair * 3 * FM_B) = st.rng[pair];   // pre-round state, see k_fm_accept
-    draw_round(st, pair, n);
+    __shared__ float sp[28];
+    const int pair = blockIdx.x, lane = threadIdx.x;
+    const int o0 = a.off[pair], n = a.off[pair + 1] - o0;
+    if (lane == 0) {
+        st.base[pair] = 0; st.max_good[pair] = 0; st.done[pair] = 0; st.have[pair] = 0; st.fail[pair] = 0; st.drawn[pair] = 0;
+        st.min_med[pair] = DBL_MAX;
+        st.rng[pair] = ~0ull;
+        int ni = FM_MAX_ITERS;
+        if (n < 15) { ni = update_num_iters(0.99, 0.45, 7, FM_MAX_ITERS); if (ni < 3) ni = 3; }
+        if (n == 7) ni = 1;
+        if (n < 7) ni = 0;
+        st.niters[pair] = ni; st.stop[pair] = n < 7 ? 1 : 0;
+        if (n >= 7) atomicAdd(st.active, 1);
+    }
+    if (n < 7) return;
+    __syncthreads();
+    Pts pts;
+    pts.l1 = nullptr; pts.l2 = nullptr; pts.g1 = a.xy1 + 2 * (size_t)o0; pts.g2 = a.xy2 + 2 * (size_t)o0;
+    draw_round(st, pair, n, pts, lane, sp);
 }
 
-// FM_B lanes per pair; blockDim = 64 -> two pairs per workgroup
+// one lane per hypothesis: FM_B lanes = one pair, two pairs per workgroup
 __global__ __launch_bounds__(64) void k_fm_solve(FmatArgs a, FmState st)
 {
 #pragma clang fp contract(off)
+    __shared__ double sA[63 * 64];
     if (*st.active == 0) return;
     const int lane = threadIdx.x, h = lane & (FM_B - 1);
     const int pair = blockIdx.x * (64 / FM_B) + lane / FM_B;
     const bool live = pair < a.n_pairs && !st.stop[pair];
-    int drawn = live ? st.drawn[pair] : 0;
-    const int o0 = live ? a.off[pair] : 0, n = live ? a.off[pair + 1] - o0 : 0;
-    Pts pts;
-    pts.l1 = nullptr; pts.l2 = nullptr; pts.g1 = a.xy1 + 2 * (size_t)o0; pts.g2 = a.xy2 + 2 * (size_t)o0;
+    const int drawn = live ? st.drawn[pair] : 0;
+    if (h >= drawn) return;
+    const int o0 = a.off[pair];
+    const int32_t *g1 = a.xy1 + 2 * (size_t)o0, *g2 = a.xy2 + 2 * (size_t)o0;
+    const int *ix = st.idx + ((size_t)pair * FM_B + h) * 7;
     float s1[14], s2[14];
-    bool coll = false;
-    if (h < drawn) {
-        const int *ix = st.idx + ((size_t)pair * FM_B + h) * 7;
 #pragma unroll
-        for (int i = 0; i < 7; ++i) pts.get(ix[i], s1[2 * i], s1[2 * i + 1], s2[2 * i], s2[2 * i + 1]);
-        coll = n != 7 && (last_point_collinear(s1, 7) || last_point_collinear(s2, 7));
+    for (int i = 0; i < 7; ++i) {
+        const int v = ix[i];
+        s1[2 * i] = (float)g1[2 * v]; s1[2 * i + 1] = (float)g1[2 * v + 1];
+        s2[2 * i] = (float)g2[2 * v]; s2[2 * i + 1] = (float)g2[2 * v + 1];
     }
-    const unsigned long long cm = __ballot(coll);
-    const unsigned mine = (unsigned)(cm >> (lane & ~(FM_B - 1)));     // the collinear flags of this lane's pair
-    if (cm) {
-        // Slow path, exactly the reference's loop: one lane redoes the pair's draws of this round one by
-        // one with the collinearity test inside, starting from the RNG state before the round (parked by
-        // k_fm_begin / k_fm_accept in the pair's med[] row).  The new index sets reach the other lanes
-        // through LDS.
-        __shared__ int sIdx[64 / FM_B][FM_B][7], sDrawn[64 / FM_B];
-        const int slot = lane / FM_B;
-        if (mine && h == 0) {
-            unsigned long long rng = *reinterpret_cast<const unsigned long long *>(st.med + (size_t)pair * 3 * FM_B);
-            const int niters = st.niters[pair], base = st.base[pair];
-            int d2 = 0;
-            bool failed = false;
-            for (; d2 < FM_B && base + d2 < niters; ++d2) {
-                bool ok = false;
-                int idx[7];
-                for (int attempt = 0; attempt < FM_MAX_ATTEMPTS && !ok; ++attempt) {
-                    float q1[14], q2[14];
-                    for (int i = 0; i < 7;) {
-                        const int v = (int)(rng_next(rng) % (unsigned)n);
-                        bool dup = false;
-#pragma unroll
-                        for (int j = 0; j < 7; ++j) dup |= j < i && idx[j] == v;
-                        if (dup) continue;
-#pragma unroll
-                        for (int j = 0; j < 7; ++j)
-                            if (j == i) { idx[j] = v; pts.get(v, q1[2 * j], q1[2 * j + 1], q2[2 * j], q2[2 * j + 1]); }
-                        ++i;
-                    }
-                    ok = !last_point_collinear(q1, 7) && !last_point_collinear(q2, 7);
-                }
-                if (!ok) { failed = true; break; }
-#pragma unroll
-                for (int j = 0; j < 7; ++j) sIdx[slot][d2][j] = idx[j];
-            }
-            st.rng[pair] = rng; st.drawn[pair] = d2; st.fail[pair] = failed ? 1 : 0;
-            sDrawn[slot] = d2;
-        }
-        __syncthreads();
-        if (mine) {
-            drawn = sDrawn[slot];
-            if (h < drawn) {
-                int *ix = st.idx + ((size_t)pair * FM_B + h) * 7;
-#pragma unroll
-                for (int i = 0; i < 7; ++i) { const int v = sIdx[slot][h][i]; ix[i] = v; pts.get(v, s1[2 * i], s1[2 * i + 1], s2[2 * i], s2[2 * i + 1]); }
-            }
-        }
-    }
-    if (h < drawn) st.nm[(size_t)pair * FM_B + h] = run_7point(s1, s2, st.F + ((size_t)pair * FM_B + h) * 27);
+    st.nm[(size_t)pair * FM_B + h] = run_7point(s1, s2, sA, lane, st.F + ((size_t)pair * FM_B + h) * 27);
 }
 
 __global__ __launch_bounds__(256) void k_fm_score(FmatArgs a, FmState st)
@@ -499,47 +480,54 @@ __global__ __launch_bounds__(256) void k_fm_score(FmatArgs a, FmState st)
     }
 }
 
-// one lane per pair: the sequential accept logic over the finished round, then the next round's draws
-__global__ void k_fm_accept(FmatArgs a, FmState st)
+// one wave per pair: lane 0 replays the reference's sequential accept / shrink logic over the finished
+// round, then the wave draws the next round's samples
+__global__ __launch_bounds__(64) void k_fm_accept(FmatArgs a, FmState st)
 {
 #pragma clang fp contract(off)
+    __shared__ float sp[28];
+    __shared__ int sStop;
     if (*st.active == 0) return;
-    const int pair = blockIdx.x * blockDim.x + threadIdx.x;
-    if (pair >= a.n_pairs || st.stop[pair]) return;
-    const int n = a.off[pair + 1] - a.off[pair];
-    const bool ransac = n >= 15;
-    const int drawn = st.drawn[pair], base = st.base[pair];
-    int niters = st.niters[pair], max_good = st.max_good[pair], done = st.done[pair];
-    bool have_best = st.have[pair] != 0;
-    double min_median = st.min_med[pair];
-    bool stop = st.fail[pair] != 0 || drawn == 0;
-    const int *nm = st.nm + (size_t)pair * FM_B, *gd = st.good + (size_t)pair * 3 * FM_B;
-    const double *md = st.med + (size_t)pair * 3 * FM_B, *Fp = st.F + (size_t)pair * FM_B * 27;
-    for (int h = 0; h < drawn; ++h) {
-        if (base + h >= niters) { stop = true; break; }
-        done = base + h + 1;
-        for (int k = 0; k < nm[h]; ++k) {
-            const int m = 3 * h + k;
-            bool take = false;
-            if (n == 7) { take = !have_best; max_good = 7; }
-            else if (ransac) {
-                const int good = gd[m];
-                if (good > (max_good > 6 ? max_good : 6)) {
-                    take = true; max_good = good;
-                    niters = update_num_iters(0.99, (double)(n - good) / n, 7, niters);
-                }
-            } else if (md[m] < min_median) { take = true; min_median = md[m]; }
-            if (take) { have_best = true; for (int i = 0; i < 9; ++i) st.bestF[9 * (size_t)pair + i] = Fp[27 * h + 9 * k + i]; }
+    const int pair = blockIdx.x, lane = threadIdx.x;
+    if (st.stop[pair]) return;
+    const int o0 = a.off[pair], n = a.off[pair + 1] - o0;
+    if (lane == 0) {
+        const bool ransac = n >= 15;
+        const int drawn = st.drawn[pair], base = st.base[pair];
+        int niters = st.niters[pair], max_good = st.max_good[pair], done = st.done[pair];
+        bool have_best = st.have[pair] != 0;
+        double min_median = st.min_med[pair];
+        bool stop = st.fail[pair] != 0 || drawn == 0;
+        const int *nm = st.nm + (size_t)pair * FM_B, *gd = st.good + (size_t)pair * 3 * FM_B;
+        const double *md = st.med + (size_t)pair * 3 * FM_B, *Fp = st.F + (size_t)pair * FM_B * 27;
+        for (int h = 0; h < drawn; ++h) {
+            if (base + h >= niters) { stop = true; break; }
+            done = base + h + 1;
+            for (int k = 0; k < nm[h]; ++k) {
+                const int m = 3 * h + k;
+                bool take = false;
+                if (n == 7) { take = !have_best; max_good = 7; }
+                else if (ransac) {
+                    const int good = gd[m];
+                    if (good > (max_good > 6 ? max_good : 6)) {
+                        take = true; max_good = good;
+                        niters = update_num_iters(0.99, (double)(n - good) / n, 7, niters);
+                    }
+                } else if (md[m] < min_median) { take = true; min_median = md[m]; }
+                if (take) { have_best = true; for (int i = 0; i < 9; ++i) st.bestF[9 * (size_t)pair + i] = Fp[27 * h + 9 * k + i]; }
+            }
         }
+        if (base + drawn >= niters) stop = true;
+        st.niters[pair] = niters; st.max_good[pair] = max_good; st.done[pair] = done; st.have[pair] = have_best ? 1 : 0;
+        st.min_med[pair] = min_median; st.base[pair] = base + FM_B;
+        if (stop) { st.stop[pair] = 1; st.drawn[pair] = 0; atomicSub(st.active, 1); }
+        sStop = stop;
     }
-    if (base + drawn >= niters) stop = true;
-    st.niters[pair] = niters; st.max_good[pair] = max_good; st.done[pair] = done; st.have[pair] = have_best ? 1 : 0;
-    st.min_med[pair] = min_median; st.base[pair] = base + FM_B;
-    if (stop) { st.stop[pair] = 1; st.drawn[pair] = 0; atomicSub(st.active, 1); return; }
-    // the pre-round RNG state, for the slow path of k_fm_solve (parked in the pair's med[] row, which the
-    // scoring of RANSAC pairs does not use and LMedS pairs overwrite only after k_fm_solve has run)
-    *reinterpret_cast<unsigned long long *>(st.med + (size_t)pair * 3 * FM_B) = st.rng[pair];
-    draw_round(st, pair, n);
+    __syncthreads();
+    if (sStop) return;
+    Pts pts;
+    pts.l1 = nullptr; pts.l2 = nullptr; pts.g1 = a.xy1 + 2 * (size_t)o0; pts.g2 = a.xy2 + 2 * (size_t)o0;
+    draw_round(st, pair, n, pts, lane, sp);
 }
 
 __global__ __launch_bounds__(256) void k_fm_finish(FmatArgs a, FmState st)
@@ -612,12 +600,11 @@ static int fmat_launch(rcn_ctx *ctx, int32_t n_pairs, const int32_t *off, const 
     hipStream_t s = ctx->stream;
     RCN_HIP(hipMemsetAsync(st.active, 0, 4, s));
     RCN_HIP(hipMemsetAsync(st.bestF, 0, 72 * P, s));
-    const int pb = (n_pairs + 63) / 64;
-    k_fm_begin<<<pb, 64, 0, s>>>(a, st);
+    k_fm_begin<<<n_pairs, 64, 0, s>>>(a, st);
     for (int round = 0; round < (FM_MAX_ITERS + FM_B - 1) / FM_B; ++round) {
         k_fm_solve<<<(n_pairs + 64 / FM_B - 1) / (64 / FM_B), 64, 0, s>>>(a, st);
         k_fm_score<<<n_pairs, 256, 0, s>>>(a, st);
-        k_fm_accept<<<pb, 64, 0, s>>>(a, st);
+        k_fm_accept<<<n_pairs, 64, 0, s>>>(a, st);
     }
     k_fm_finish<<<n_pairs, 256, 0, s>>>(a, st);
     RCN_HIP(hipGetLastError());
