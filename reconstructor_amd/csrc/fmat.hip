@@ -310,36 +310,28 @@ __device__ void draw_round(const FmState &st, int pair, int n, const Pts &pts, i
     }
     const bool tester = (lane & 31) < 15;
     for (; drawn < FM_B && base + drawn < niters; ++drawn) {
-        int idx[7];
-#pragma unroll
-        for (int j = 0; j < 7; ++j) idx[j] = j;            // n == 7: the sample is the data set
-        bool ok = un == 7;
+        int myidx = lane;                                   // lanes 0..6 hold the sample (n == 7: the data set itself)
+        bool ok = false;
         for (int attempt = 0; attempt < FM_MAX_ATTEMPTS && !ok; ++attempt) {
-            for (int i = 0; i < 7;) {
-                const unsigned long long s = (unsigned long long)lo * 4164903690U + hi;
-                lo = (unsigned)s; hi = (unsigned)(s >> 32);
-                unsigned v = lo - __umulhi(lo, M) * un;
-                while (v >= un) v -= un;
-                bool dup = false;
-#pragma unroll
-                for (int j = 0; j < 7; ++j) dup |= j < i && idx[j] == (int)v;
-                if (dup) continue;
-#pragma unroll
-                for (int j = 0; j < 7; ++j) idx[j] = j == i ? (int)v : idx[j];
-                ++i;
-            }
+            if (un != 7)
+                for (int i = 0; i < 7;) {
+                    const unsigned long long s = (unsigned long long)lo * 4164903690U + hi;
+                    lo = (unsigned)s; hi = (unsigned)(s >> 32);
+                    unsigned v = lo - __umulhi(lo, M) * un;
+                    while (v >= un) v -= un;
+                    if (__ballot(lane < i && myidx == (int)v)) continue;     // a duplicate is redrawn
+                    myidx = lane == i ? (int)v : myidx;
+                    ++i;
+                }
             // the sample's points -> LDS line (lanes 0..6), then the tests
             if (lane < 7) {
-                int mine = idx[0];
-#pragma unroll
-                for (int j = 1; j < 7; ++j) mine = lane == j ? idx[j] : mine;
                 float ax, ay, bx, by;
-                pts.get(mine, ax, ay, bx, by);
+                pts.get(myidx, ax, ay, bx, by);
                 sp[2 * lane] = ax; sp[2 * lane + 1] = ay; sp[14 + 2 * lane] = bx; sp[14 + 2 * lane + 1] = by;
             }
             __builtin_amdgcn_wave_barrier();
             bool coll = false;
-            if (tester) {
+            if (tester && un != 7) {
                 const float *m = sp + (lane >= 32 ? 14 : 0);
                 const double dx1 = m[2 * tj] - m[12], dy1 = m[2 * tj + 1] - m[13];
                 const double dx2 = m[2 * tk] - m[12], dy2 = m[2 * tk + 1] - m[13];
@@ -349,12 +341,7 @@ __device__ void draw_round(const FmState &st, int pair, int n, const Pts &pts, i
             __builtin_amdgcn_wave_barrier();
         }
         if (!ok) { failed = true; break; }
-        if (lane < 7) {
-            int mine = idx[0];
-#pragma unroll
-            for (int j = 1; j < 7; ++j) mine = lane == j ? idx[j] : mine;
-            st.idx[((size_t)pair * FM_B + drawn) * 7 + lane] = mine;
-        }
+        if (lane < 7) st.idx[((size_t)pair * FM_B + drawn) * 7 + lane] = myidx;
     }
     if (lane == 0) {
         st.rng[pair] = (unsigned long long)hi << 32 | lo;
@@ -382,8 +369,17 @@ __global__ __launch_bounds__(64) void k_fm_begin(FmatArgs a, FmState st)
     }
     if (n < 7) return;
     __syncthreads();
+    __shared__ float2 P1[FM_NLDS], P2[FM_NLDS];   // the pair's points: every sample costs an LDS read, not a trip to L2
     Pts pts;
-    pts.l1 = nullptr; pts.l2 = nullptr; pts.g1 = a.xy1 + 2 * (size_t)o0; pts.g2 = a.xy2 + 2 * (size_t)o0;
+    pts.g1 = a.xy1 + 2 * (size_t)o0; pts.g2 = a.xy2 + 2 * (size_t)o0;
+    pts.l1 = n <= FM_NLDS ? P1 : nullptr; pts.l2 = n <= FM_NLDS ? P2 : nullptr;
+    if (n <= FM_NLDS) {
+        for (int i = lane; i < n; i += 64) {
+            P1[i] = make_float2((float)pts.g1[2 * i], (float)pts.g1[2 * i + 1]);
+            P2[i] = make_float2((float)pts.g2[2 * i], (float)pts.g2[2 * i + 1]);
+        }
+        __syncthreads();
+    }
     draw_round(st, pair, n, pts, lane, sp);
 }
 
@@ -439,10 +435,23 @@ __global__ __launch_bounds__(256) void k_fm_score(FmatArgs a, FmState st)
         // of the round is a lower bound of the best at this matrix's turn, so once even all remaining
         // points could not lift the count above it the matrix is dropped (its stored count stays
         // <= the bound: never accepted, exactly as if fully counted).
-        const int mg = st.max_good[pair], bound = mg > 6 ? mg : 6;
+        // ... and the same holds for the counts of EARLIER matrices of this round: whichever of them
+        // are finished when this matrix starts (sCnt, written by the four waves as they go) raise the
+        // bound.  Later matrices must not: the reference may stop before it reaches them.
+        __shared__ int sCnt[3 * FM_B];
+        for (int i = t; i < 3 * FM_B; i += 256) sCnt[i] = -1;
+        __syncthreads();
+        const int mg = st.max_good[pair], bound0 = mg > 6 ? mg : 6;
         for (int m = w; m < 3 * drawn; m += 4) {
             const int h = m / 3, k = m - 3 * h;
             if (k >= nm[h]) continue;
+            int bound = bound0;
+            {
+                int b = max(lane < m ? __atomic_load_n(&sCnt[lane], __ATOMIC_RELAXED) : -1,
+                            lane + 64 < m ? __atomic_load_n(&sCnt[(lane + 64) % (3 * FM_B)], __ATOMIC_RELAXED) : -1);
+                for (int o = 32; o; o >>= 1) b = max(b, __shfl_xor(b, o));
+                bound = max(bound, b);
+            }
             double F[9];
 #pragma unroll
             for (int i = 0; i < 9; ++i) F[i] = Fp[27 * h + 9 * k + i];
@@ -454,7 +463,7 @@ __global__ __launch_bounds__(256) void k_fm_score(FmatArgs a, FmState st)
                 good += (int)__popcll(__ballot(in));
                 if (good + (n - i0 - 64) <= bound) break;
             }
-            if (lane == 0) st.good[(size_t)pair * 3 * FM_B + m] = good;
+            if (lane == 0) { st.good[(size_t)pair * 3 * FM_B + m] = good; __atomic_store_n(&sCnt[m], good, __ATOMIC_RELAXED); }
         }
     } else {                                               // LMedS, 8 <= n <= 14: one matrix per lane
         for (int m = t; m < 3 * drawn; m += 256) {
@@ -525,8 +534,17 @@ __global__ __launch_bounds__(64) void k_fm_accept(FmatArgs a, FmState st)
     }
     __syncthreads();
     if (sStop) return;
+    __shared__ float2 P1[FM_NLDS], P2[FM_NLDS];   // the pair's points: every sample costs an LDS read, not a trip to L2
     Pts pts;
-    pts.l1 = nullptr; pts.l2 = nullptr; pts.g1 = a.xy1 + 2 * (size_t)o0; pts.g2 = a.xy2 + 2 * (size_t)o0;
+    pts.g1 = a.xy1 + 2 * (size_t)o0; pts.g2 = a.xy2 + 2 * (size_t)o0;
+    pts.l1 = n <= FM_NLDS ? P1 : nullptr; pts.l2 = n <= FM_NLDS ? P2 : nullptr;
+    if (n <= FM_NLDS) {
+        for (int i = lane; i < n; i += 64) {
+            P1[i] = make_float2((float)pts.g1[2 * i], (float)pts.g1[2 * i + 1]);
+            P2[i] = make_float2((float)pts.g2[2 * i], (float)pts.g2[2 * i + 1]);
+        }
+        __syncthreads();
+    }
     draw_round(st, pair, n, pts, lane, sp);
 }
 
