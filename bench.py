@@ -84,6 +84,56 @@ def ba_leg(ctx, with_cpu):
     return out
 
 
+def fmat_leg(ctx, with_cpu):
+    """Epipolar filter (GeometricFilter::estimateFundamental inside the pair loop, SURVEY 8f rank 1) on a
+    cfg-2-sized grid: 4950 pairs x 400..620 matches, 30 % gross outliers, inputs resident in HBM
+    (rcn_fmat_filter_grid_device), timed over 5 back-to-back grids."""
+    import ctypes as C
+    import torch
+    from reconstructor_amd import synth_fmat
+    P = 4950
+    sizes = np.random.default_rng(0).integers(400, 620, P)
+    off, a, b = synth_fmat.grid(sizes, 0.3, seed=3)
+    d = {k: torch.from_numpy(v).cuda() for k, v in (("off", off), ("a", a), ("b", b))}
+    mask = torch.zeros(int(off[-1]), dtype=torch.uint8, device="cuda")
+    cnt = torch.zeros(P, dtype=torch.int32, device="cuda")
+    it = torch.zeros(P, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+
+    def run():
+        ctx.check(ctx.lib.rcn_fmat_filter_grid_device(ctx.h, P, d["off"].data_ptr(), d["a"].data_ptr(), d["b"].data_ptr(),
+                                                      mask.data_ptr(), cnt.data_ptr(), it.data_ptr(), None))
+    run()
+    ctx.check(ctx.lib.rcn_synchronize(ctx.h))
+    t0 = time.perf_counter()
+    for _ in range(5):
+        run()
+    ctx.check(ctx.lib.rcn_synchronize(ctx.h))
+    dt = (time.perf_counter() - t0) / 5
+    its = it.cpu().numpy().astype(np.int64)
+    n = np.diff(off).astype(np.int64)
+    # the reference's own work: every executed iteration scores its (on average ~2) matrices against all n points,
+    # 44 flop per (matrix, point) -- 20 mul + 18 add + 2 div + 4 for the squares and the scale; the 7-point solves add < 2 %
+    evals = float((its * n).sum()) * 2.0
+    out = {"workload": "4950 pairs x 400..620 matches (%d points), 30%% outliers" % off[-1], "pairs_per_s": P / dt,
+           "ms_per_grid": 1e3 * dt, "mean_iterations": float(its.mean()), "inlier_share": float(mask.sum().item()) / float(off[-1]),
+           "roofline": {"bound": "fp64 valu", "achieved": evals * 44.0 / dt * 1e-12, "peak": 78.6, "unit": "TFLOP/s",
+                        "frac": evals * 44.0 / dt * 1e-12 / 78.6, "traffic": None,
+                        "note": "algorithmic flop = executed iterations x 2 matrices x n points x 44 (unfused: the reference's arithmetic has no FMA, so the usable peak is half of 78.6)"}}
+    if with_cpu:
+        from oracle import orc_fmat
+        sel = P
+        orc_fmat.filter_grid(off[:65], a[:off[64]], b[:off[64]], threads=host_threads())       # warm
+        t0 = time.perf_counter()
+        for _ in range(5):
+            m0, c0, i0 = orc_fmat.filter_grid(off[:sel + 1], a[:off[sel]], b[:off[sel]], threads=host_threads())
+        dtc = (time.perf_counter() - t0) / 5
+        out["cpu_baseline"] = {"value": sel / dtc, "unit": "pairs/s", "cores": host_threads(), "kind": "port",
+                               "sample": "the whole grid 5 times, oracle/fmat_oracle.c, OpenMP over pairs, %.2f s" % (5 * dtc)}
+        out["equal_to_cpu"] = bool((mask[:off[sel]].cpu().numpy().astype(bool) == m0).all() and (cnt[:sel].cpu().numpy() == c0).all())
+    return out
+
+
 def sweep_leg(ctx, with_cpu):
     """Landmark validity sweep (checkLandmarkValidity) on the cfg-5 observation
     graph: 1000 cameras, 100k landmarks, ragged tracks of up to 10 observations, inputs resident in
@@ -303,6 +353,7 @@ def main():
         if not args.no_ba and world == 1:
             line["ba"] = ba_leg(matcher.ctx, not args.no_cpu_baseline)
             line["ba_lm_iterations_per_s"] = line["ba"]["cfg5"]["lm_iterations_per_s"]   # 1k cams / 100k pts / 1M obs
+            line["epipolar_filter"] = fmat_leg(matcher.ctx, not args.no_cpu_baseline)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
