@@ -240,6 +240,19 @@ int rcn_fmat_filter_grid_device(rcn_ctx *ctx, int32_t n_pairs, const int32_t *pa
                                 const int32_t *xy2_dev, uint8_t *out_mask_dev, int32_t *out_counts_dev,
                                 int32_t *out_iterations_dev, double *out_F_dev);
 
+/* Fused form for a match table that is already in HBM (rcn_match_grid_device): lines :237-269 of
+ * the pair loop for every pair, no host round trip.  Needs the integer pixel coordinates of the
+ * keypoints of every image involved (Feature<int>::featCoord, K x 2), uploaded once per image. */
+int rcn_coords_upload(rcn_ctx *ctx, int32_t img_id, const int32_t *xy_host, int32_t K);
+int rcn_coords_clear(rcn_ctx *ctx);
+/* pairs_host / table_dev / stride / counts_dev exactly as given to and left by rcn_match_grid_device.
+ * The table is filtered in place: in a pair with >= 7 matches only the inliers stay (none when no
+ * model was found); pairs with fewer are left alone.  counts_dev is updated; out_status_dev (may be
+ * NULL) receives rcn_fmat_filter's out_count per pair.  Asynchronous on the ctx stream after one
+ * small host-to-device copy. */
+int rcn_match_table_filter_device(rcn_ctx *ctx, const int32_t *pairs_host, int32_t n_pairs, int32_t *table_dev,
+                                  int64_t stride, int32_t *counts_dev, int32_t *out_status_dev);
+
 #ifdef __cplusplus
 }
 #endif

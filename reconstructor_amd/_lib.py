@@ -21,6 +21,7 @@ SYMBOLS = [
     "rcn_match_last_stats", "rcn_match_profile", "rcn_ba_default_options", "rcn_ba_solve",
     "rcn_landmark_validity", "rcn_landmark_validity_device",
     "rcn_fmat_filter", "rcn_fmat_filter_grid", "rcn_fmat_filter_grid_device",
+    "rcn_coords_upload", "rcn_coords_clear", "rcn_match_table_filter_device",
 ]
 
 
@@ -136,6 +137,12 @@ def load():
     for fn in (L.rcn_fmat_filter_grid, L.rcn_fmat_filter_grid_device):
         fn.restype = C.c_int
         fn.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp]
+    L.rcn_coords_upload.restype = C.c_int
+    L.rcn_coords_upload.argtypes = [vp, i32, vp, i32]
+    L.rcn_coords_clear.restype = C.c_int
+    L.rcn_coords_clear.argtypes = [vp]
+    L.rcn_match_table_filter_device.restype = C.c_int
+    L.rcn_match_table_filter_device.argtypes = [vp, vp, i32, vp, C.c_int64, vp, vp]
     _LIB = L
     return L
 

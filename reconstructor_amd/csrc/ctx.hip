@@ -83,6 +83,8 @@ void rcn_destroy(rcn_ctx *ctx)
     ctx->lm_ws.release();
     ctx->fm_ws.release();
     ctx->fm_state.release();
+    ctx->fm_csr.release(); ctx->fm_pairs.release();
+    for (auto &kv : ctx->coords) kv.second.first.release();
     if (ctx->ev_made)
         for (auto &row : ctx->ev)
             for (auto &e : row) (void)hipEventDestroy(e);

@@ -13,6 +13,7 @@
 #include "rcn_internal.h"
 
 #include <cfloat>
+#include <string>
 
 namespace {
 
@@ -625,6 +626,175 @@ static int fmat_launch(rcn_ctx *ctx, int32_t n_pairs, const int32_t *off, const 
         k_fm_accept<<<n_pairs, 64, 0, s>>>(a, st);
     }
     k_fm_finish<<<n_pairs, 256, 0, s>>>(a, st);
+    RCN_HIP(hipGetLastError());
+    return RCN_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Fused form for a device-resident match table (what rcn_match_grid_device leaves in HBM): the
+// pair loop's lines SequentialReconstructor.cpp:237-269 for every pair without a host round trip.
+//   k_tf_scan    exclusive scan of the per-pair match counts -> CSR offsets
+//   k_tf_fill    per pair: matched features in ascending query order -> coordinates of both sides
+//   (the RANSAC / LMedS rounds above)
+//   k_tf_apply   per pair: drop the matches the filter rejected (all of them when no model was found),
+//                leave pairs with fewer than 7 matches alone; new counts
+namespace {
+
+struct PairXY { const int32_t *q, *t; int32_t Kq, pad; };
+
+__global__ __launch_bounds__(1024) void k_tf_scan(const int32_t *counts, int n, int32_t *off)
+{
+    __shared__ int sh[16];
+    __shared__ int carry_s;
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    int carry = 0;
+    if (t == 0) off[0] = 0;
+    for (int b = 0; b < n; b += 1024) {
+        const int i = b + t;
+        int v = i < n ? counts[i] : 0;
+        for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(v, o); if (lane >= o) v += u; }
+        if (lane == 63) sh[w] = v;
+        __syncthreads();
+        if (t < 16) { int s = sh[t]; for (int o = 1; o < 16; o <<= 1) { const int u = __shfl_up(s, o, 16); if (t >= o) s += u; } sh[t] = s; }
+        __syncthreads();
+        const int incl = v + (w ? sh[w - 1] : 0) + carry;
+        if (i < n) off[i + 1] = incl;
+        if (t == 1023) carry_s = incl;
+        __syncthreads();
+        carry = carry_s;
+        __syncthreads();
+    }
+}
+
+// ordered position of each flagged thread within the workgroup's 256-wide chunk; returns the chunk total
+__device__ __forceinline__ int chunk_rank(bool flag, int &rank, int *sh)
+{
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const unsigned long long m = __ballot(flag);
+    if (lane == 0) sh[w] = (int)__popcll(m);
+    __syncthreads();
+    int base = 0, total = 0;
+    for (int i = 0; i < 4; ++i) { base += i < w ? sh[i] : 0; total += sh[i]; }
+    rank = base + (int)__popcll(m & ((1ull << lane) - 1ull));
+    __syncthreads();
+    return total;
+}
+
+__global__ __launch_bounds__(256) void k_tf_fill(const PairXY *px, const int32_t *table, int64_t stride, const int32_t *off,
+                                                 int32_t *xy1, int32_t *xy2)
+{
+    __shared__ int sh[4];
+    const int pair = blockIdx.x, t = threadIdx.x;
+    const PairXY p = px[pair];
+    const int32_t *row = table + (size_t)pair * stride;
+    int pos = off[pair];
+    for (int q0 = 0; q0 < p.Kq; q0 += 256) {
+        const int q = q0 + t;
+        const int tr = q < p.Kq ? row[q] : -1;
+        int rank;
+        const int total = chunk_rank(tr >= 0, rank, sh);
+        if (tr >= 0) {
+            const size_t o = 2 * (size_t)(pos + rank);
+            xy1[o] = p.q[2 * q]; xy1[o + 1] = p.q[2 * q + 1];
+            xy2[o] = p.t[2 * tr]; xy2[o + 1] = p.t[2 * tr + 1];
+        }
+        pos += total;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_tf_apply(const PairXY *px, int32_t *table, int64_t stride, const int32_t *off,
+                                                  const uint8_t *mask, const int32_t *verdict, int32_t *counts)
+{
+    __shared__ int sh[4];
+    const int pair = blockIdx.x, t = threadIdx.x;
+    const PairXY p = px[pair];
+    const int v = verdict[pair];
+    if (v == -2) return;                                   // fewer than 7 matches: left as they are (:271-277)
+    int32_t *row = table + (size_t)pair * stride;
+    int pos = off[pair];
+    for (int q0 = 0; q0 < p.Kq; q0 += 256) {
+        const int q = q0 + t;
+        const int tr = q < p.Kq ? row[q] : -1;
+        int rank;
+        const int total = chunk_rank(tr >= 0, rank, sh);
+        if (tr >= 0 && (v < 0 || !mask[pos + rank])) row[q] = -1;
+        pos += total;
+    }
+    if (t == 0) counts[pair] = v < 0 ? 0 : v;
+}
+
+}  // namespace
+
+extern "C" int rcn_coords_upload(rcn_ctx *ctx, int32_t img_id, const int32_t *xy_host, int32_t K)
+{
+    if (!ctx) return RCN_ERR_ARG;
+    if (K < 0 || (K > 0 && !xy_host)) { ctx->set_error("rcn_coords_upload: bad argument"); return RCN_ERR_ARG; }
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    RCN_HIP(hipSetDevice(ctx->device));
+    auto &e = ctx->coords[img_id];
+    RCN_HIP(e.first.reserve(std::max<size_t>(8 * (size_t)K, 8)));
+    if (K > 0) {
+        RCN_HIP(hipMemcpyAsync(e.first.p, xy_host, 8 * (size_t)K, hipMemcpyHostToDevice, ctx->stream));
+        RCN_HIP(hipStreamSynchronize(ctx->stream));        // the host rows are borrowed
+    }
+    e.second = K;
+    return RCN_OK;
+}
+
+extern "C" int rcn_coords_clear(rcn_ctx *ctx)
+{
+    if (!ctx) return RCN_ERR_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    RCN_HIP(hipSetDevice(ctx->device));
+    RCN_HIP(hipStreamSynchronize(ctx->stream));
+    for (auto &kv : ctx->coords) kv.second.first.release();
+    ctx->coords.clear();
+    return RCN_OK;
+}
+
+extern "C" int rcn_match_table_filter_device(rcn_ctx *ctx, const int32_t *pairs_host, int32_t n_pairs, int32_t *table_dev,
+                                             int64_t stride, int32_t *counts_dev, int32_t *out_status_dev)
+{
+    if (!ctx) return RCN_ERR_ARG;
+    if (n_pairs < 0 || (n_pairs > 0 && (!pairs_host || !table_dev || !counts_dev)) || stride < 0) {
+        ctx->set_error("rcn_match_table_filter_device: bad argument");
+        return RCN_ERR_ARG;
+    }
+    if (n_pairs == 0) return RCN_OK;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    RCN_HIP(hipSetDevice(ctx->device));
+    std::vector<PairXY> px((size_t)n_pairs);
+    size_t cap = 0;
+    for (int p = 0; p < n_pairs; ++p) {
+        auto q = ctx->coords.find(pairs_host[2 * p]), t = ctx->coords.find(pairs_host[2 * p + 1]);
+        if (q == ctx->coords.end() || t == ctx->coords.end()) {
+            ctx->set_error("rcn_match_table_filter_device: coordinates of image " + std::to_string(pairs_host[2 * p + (q == ctx->coords.end() ? 0 : 1)]) + " are not resident");
+            return RCN_ERR_NOT_FOUND;
+        }
+        if (q->second.second > stride) { ctx->set_error("rcn_match_table_filter_device: stride smaller than a query image's keypoint count"); return RCN_ERR_ARG; }
+        px[p].q = q->second.first.as<int32_t>(); px[p].t = t->second.first.as<int32_t>(); px[p].Kq = q->second.second; px[p].pad = 0;
+        cap += (size_t)q->second.second;                   // a pair has at most Kq matches
+    }
+    hipStream_t st = ctx->stream;
+    auto al = [](size_t b) { return (b + 255) / 256 * 256; };
+    const size_t P = (size_t)n_pairs;
+    RCN_HIP(ctx->fm_pairs.reserve(al(sizeof(PairXY) * P)));
+    RCN_HIP(ctx->fm_csr.reserve(al(4 * (P + 1)) + 2 * al(8 * cap) + al(cap) + 2 * al(4 * P) + 256));
+    char *base = ctx->fm_csr.as<char>();
+    size_t o = 0;
+    auto take = [&](size_t b) { char *q = base + o; o += al(b); return q; };
+    int32_t *d_off = (int32_t *)take(4 * (P + 1)), *d_1 = (int32_t *)take(8 * cap), *d_2 = (int32_t *)take(8 * cap);
+    uint8_t *d_mask = (uint8_t *)take(cap);
+    int32_t *d_ver = out_status_dev ? out_status_dev : (int32_t *)take(4 * P), *d_it = (int32_t *)take(4 * P);
+    RCN_HIP(hipMemcpyAsync(ctx->fm_pairs.p, px.data(), sizeof(PairXY) * P, hipMemcpyHostToDevice, st));
+    RCN_HIP(hipStreamSynchronize(st));                      // px is a local vector
+    const PairXY *d_px = ctx->fm_pairs.as<PairXY>();
+    k_tf_scan<<<1, 1024, 0, st>>>(counts_dev, n_pairs, d_off);
+    k_tf_fill<<<n_pairs, 256, 0, st>>>(d_px, table_dev, stride, d_off, d_1, d_2);
+    RCN_HIP(hipGetLastError());
+    int rc = fmat_launch(ctx, n_pairs, d_off, d_1, d_2, d_mask, d_ver, d_it, nullptr);
+    if (rc) return rc;
+    k_tf_apply<<<n_pairs, 256, 0, st>>>(d_px, table_dev, stride, d_off, d_mask, d_ver, counts_dev);
     RCN_HIP(hipGetLastError());
     return RCN_OK;
 }

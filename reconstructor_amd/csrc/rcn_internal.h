@@ -100,6 +100,8 @@ struct rcn_ctx {
     DevBuf ba_ws[28];
     DevBuf lm_ws;              // landmark validity sweep (validity.hip)
     DevBuf fm_ws, fm_state;    // epipolar filter (fmat.hip): host-API staging, per-pair RANSAC state
+    DevBuf fm_csr, fm_pairs;   // fused table filter: CSR of the matched points, per-pair coordinate pointers
+    std::map<int32_t, std::pair<DevBuf, int32_t>> coords;   // image id -> (K x 2 int32 pixel coordinates in HBM, K)
     bool ba_atomics = false;   // RCN_BA_SCHUR_ATOMICS=1: atomic Schur accumulation instead of the gather form
     bool ba_trsv_fwd = false;  // RCN_BA_TRSV_FWD=1: separate forward substitution instead of the rhs row inside the factorisation
     hipStream_t aux_stream = nullptr;   // lookahead stream of the Cholesky

@@ -97,6 +97,7 @@ class HipL2Matcher(FeatureMatcher):
 
     def clear(self):
         self.ctx.check(self.ctx.lib.rcn_desc_clear(self.ctx.h))
+        self.ctx.check(self.ctx.lib.rcn_coords_clear(self.ctx.h))
 
     def match_grid(self, pairs, out_stride):
         """pairs: (P,2) (query image id, train image id).  Returns (out[P,out_stride], counts[P])."""
@@ -114,6 +115,19 @@ class HipL2Matcher(FeatureMatcher):
         self.ctx.check(self.ctx.lib.rcn_match_grid_device(
             self.ctx.h, pairs.ctypes.data, pairs.shape[0], self.ratio,
             C.c_void_p(out_dev_ptr), out_stride, C.c_void_p(counts_dev_ptr)))
+
+    def upload_coords(self, img_id, xy):
+        """Integer pixel coordinates of the image's keypoints (K x 2), for filter_table_device."""
+        xy = np.ascontiguousarray(xy, np.int32).reshape(-1, 2)
+        self.ctx.check(self.ctx.lib.rcn_coords_upload(self.ctx.h, int(img_id), xy.ctypes.data, len(xy)))
+
+    def filter_table_device(self, pairs, table_dev_ptr, out_stride, counts_dev_ptr, status_dev_ptr=None):
+        """Epipolar filter of a device match table in place (SequentialReconstructor.cpp:237-269 for every
+        pair); asynchronous on the ctx stream."""
+        pairs = np.ascontiguousarray(pairs, np.int32).reshape(-1, 2)
+        self.ctx.check(self.ctx.lib.rcn_match_table_filter_device(
+            self.ctx.h, pairs.ctypes.data, pairs.shape[0], C.c_void_p(table_dev_ptr), out_stride,
+            C.c_void_p(counts_dev_ptr), C.c_void_p(status_dev_ptr) if status_dev_ptr else None))
 
     def profile(self, enable=True):
         self.ctx.check(self.ctx.lib.rcn_match_profile(self.ctx.h, 1 if enable else 0))

@@ -108,3 +108,41 @@ def test_full_size_grid_properties_and_device_entry(gpu_ctx):
     assert (mask_d.cpu().numpy().astype(bool) == want[0]).all()
     sums = np.add.reduceat(want[0].astype(np.int64), off[:-1])
     assert (sums == want[1]).all() and (want[1] <= np.diff(off)).all()
+
+
+def test_device_table_filter_equals_host_composition(gpu_ctx):
+    """rcn_match_grid_device -> rcn_match_table_filter_device (everything stays in HBM) against the host
+    composition of the same steps, itself checked against the oracles above; ragged image sizes, a pair
+    with fewer than 7 matches, and a pair whose matches admit no model."""
+    import torch
+    from reconstructor_amd import synth
+    from reconstructor_amd.matcher import HipL2Matcher, all_pairs
+    Ks = [260, 300, 180, 40, 230]
+    ims = synth.descriptor_set("superpoint", 5, Ks, n_world=420, seed=12)
+    rng = np.random.default_rng(12)
+    coords = [rng.integers(0, 500, (k, 2)).astype(np.int32) for k in Ks]
+    coords[4][:] = 77                                       # every sample of pairs (i, 4) is collinear on the train side: no model
+    m = HipL2Matcher(ctx=gpu_ctx)
+    m.clear()
+    for i, im in enumerate(ims):
+        m.upload(i, im)
+        m.upload_coords(i, coords[i])
+    pairs = all_pairs(5)
+    stride = max(Ks)
+    table, counts = m.match_grid(pairs, stride)
+    want, status = fmat.apply_geometric_filter(gpu_ctx, coords, pairs, table)
+    t_d = torch.full((len(pairs), stride), -7, dtype=torch.int32, device="cuda")
+    c_d = torch.zeros(len(pairs), dtype=torch.int32, device="cuda")
+    s_d = torch.zeros(len(pairs), dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    m.match_grid_device(pairs, t_d.data_ptr(), stride, c_d.data_ptr())
+    m.filter_table_device(pairs, t_d.data_ptr(), stride, c_d.data_ptr(), s_d.data_ptr())
+    gpu_ctx.check(gpu_ctx.lib.rcn_synchronize(gpu_ctx.h))
+    got = t_d.cpu().numpy()
+    assert np.array_equal(got, want) and np.array_equal(s_d.cpu().numpy(), status)
+    assert np.array_equal(c_d.cpu().numpy(), (want >= 0).sum(1))
+    assert (status == -1).any() and (status >= 7).any() and ((counts >= 7) | (status == -2)).all()
+    with pytest.raises(_lib.RcnError) as e:                 # coordinates of an image missing
+        m.filter_table_device(np.array([[0, 9]], np.int32), t_d.data_ptr(), stride, c_d.data_ptr())
+    assert e.value.code == -5
+    m.clear()
