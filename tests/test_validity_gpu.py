@@ -80,3 +80,12 @@ def test_full_size_properties_and_device_entry(gpu_ctx):
     gpu_ctx.check(gpu_ctx.lib.rcn_synchronize(gpu_ctx.h))
     assert (inl_d.cpu().numpy().astype(bool) == want[0]).all() and (keep_d.cpu().numpy().astype(bool) == want[1]).all()
     assert int(n_d.item()) == int(want[0].sum())
+
+
+def test_long_tracks(gpu_ctx):
+    """Tracks of up to 80 observations (quadratic angle loop, long erase walks)."""
+    c = synth_ba.make_validity_case(90, 300, obs_per_point=80, seed=4, defect_rate=0.2)
+    assert np.diff(c["pt_off"]).max() > 64
+    want = ov.landmark_validity(**c)
+    got = validity.check_landmark_validity(gpu_ctx, *_args(c))
+    assert (got[0] == want[0]).all() and (got[1] == want[1]).all()
