@@ -625,7 +625,7 @@ __global__ __launch_bounds__(64) void k_ba_cam_rhs(BaDev d)
 //      per lane, kept in the otherwise unused upper triangle of the block), then the six
 //      off-diagonal 32x32 blocks left to right, in place:
 //          X[i][j] = -Dinv_i * sum_{m=j}^{i-1} L[i][m] X[m][j],   X[j][j] = Dinv_j.
-// Writes L into S and L^-1 into Linv[kb] (used by the panel GEMM and the triangular solves).
+// Writes L^-1 into Linv[kb] (used by the panel GEMM and the triangular solves) and, on request, L into S.
 #define DL 129   // LDS row stride of the diagonal block (doubles): row walks are conflict-free
 #define LB 16    // leaf size
 #define NBL (NB / LB)
@@ -690,7 +690,7 @@ __device__ unsigned long long g_stamps[32];
 #else
 #define STAMP(i)
 #endif
-__global__ __launch_bounds__(256) void k_chol_diag(double *S, int ld, int kb, double *Linv, int *flag)
+__global__ __launch_bounds__(256) void k_chol_diag(double *S, int ld, int kb, double *Linv, int *flag, int store_L)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     double *L = reinterpret_cast<double *>(smem_raw);  // [128][DL]
@@ -814,10 +814,13 @@ __global__ __launch_bounds__(256) void k_chol_diag(double *S, int ld, int kb, do
         STAMP(3);
     }
     STAMP(13);
-    for (int i = t; i < NB * NB; i += 256) {
-        const int r = i / NB, c = i % NB;
-        if (c <= r) A[(size_t)r * ld + c] = L[r * DL + c];
-    }
+    // The factor of the diagonal tile itself is read by nobody (panels and triangular solves use its
+    // inverse) except for the right-hand-side row inside the LAST tile (k_ba_y_from_row): stored on request.
+    if (store_L)
+        for (int i = t; i < NB * NB; i += 256) {
+            const int r = i / NB, c = i % NB;
+            if (c <= r) A[(size_t)r * ld + c] = L[r * DL + c];
+        }
     STAMP(14);
     // 2a. (leaf inverses were produced by wave 0 right after each leaf factorization)
     __syncthreads();
@@ -1466,7 +1469,7 @@ int rcn_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_options *o
             RCN_HIP(hipStreamWaitEvent(sb, ctx->ba_ev[0], 0));      // aux starts behind everything queued so far
             int have_rest = 0;
             for (int kb = 0; kb < nblk; ++kb) {
-                k_chol_diag<<<1, 256, NB * DL * 8, st>>>(d.S, npad, kb, d.Linv, d.flag);
+                k_chol_diag<<<1, 256, NB * DL * 8, st>>>(d.S, npad, kb, d.Linv, d.flag, kb == nblk - 1);
                 const int m = nblk - kb - 1;
                 if (m <= 0) break;
                 k_gemm_q<0><<<32 * ((4 * m + 7) / 8), 256, 0, st>>>(d.S, d.L, npad, kb, m, d.Linv);
