@@ -842,6 +842,42 @@ __global__ void k_unique_emit(const ImgDev *__restrict__ imgs, const int32_t *__
     if ((threadIdx.x & 63) == 0 && m) atomicAdd(counts + pair, (int)__popcll(m));
 }
 
+// K3, one launch: a workgroup per pair with the owner table of the pair's train rows in LDS
+// (K2 <= 8192): claim with ds_min, emit, count -- the match table is read once and only the
+// entries that change are rewritten.
+#define RCN_UNIQ_LDS 8192
+__global__ __launch_bounds__(256) void k_unique_pair(const ImgDev *__restrict__ imgs, const int32_t *__restrict__ pairs,
+                                                     int32_t *__restrict__ out, int64_t out_stride,
+                                                     int32_t *__restrict__ counts, int pair_base)
+{
+    __shared__ int owner[RCN_UNIQ_LDS];
+    __shared__ int wsum[4];
+    const int pair = pair_base + blockIdx.x, t = threadIdx.x;
+    const int Kq = imgs[pairs[2 * pair]].K, Kt = imgs[pairs[2 * pair + 1]].K;
+    for (int i = t; i < Kt; i += 256) owner[i] = 0x7fffffff;
+    __syncthreads();
+    int32_t *row = out + (size_t)pair * out_stride;
+    for (int q = t; q < Kq; q += 256) {
+        const int tr = row[q];
+        if (tr >= 0) atomicMin(&owner[tr], q);
+    }
+    __syncthreads();
+    int kept = 0;
+    for (int q0 = 0; q0 < out_stride; q0 += 256) {
+        const int q = q0 + t;
+        bool keep = false;
+        if (q < out_stride) {
+            const int tr = q < Kq ? row[q] : -1;
+            keep = tr >= 0 && owner[tr] == q;
+            if (!keep && (q >= Kq || tr >= 0)) row[q] = -1;      // the tail beyond Kq is defined as -1
+        }
+        kept += (int)__popcll(__ballot(keep));
+    }
+    if ((t & 63) == 0) wsum[t >> 6] = kept;
+    __syncthreads();
+    if (t == 0) counts[pair] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
 // =========================================================================================
 // host side
 // =========================================================================================
@@ -1177,12 +1213,13 @@ static int match_grid_impl(rcn_ctx *ctx, const int32_t *pairs_host, int32_t n_pa
 
     RCN_HIP(ctx->pairs_dev.reserve(slots.size() * sizeof(int32_t)));
     RCN_HIP(ctx->cand.reserve((size_t)n_pairs * kq_stride * sizeof(uint2)));
-    RCN_HIP(ctx->owner.reserve((size_t)n_pairs * owner_stride * sizeof(int32_t)));
+    const bool uniq_lds = kt_max <= RCN_UNIQ_LDS;     // owner table of a pair fits LDS: one fused launch
+    if (!uniq_lds) RCN_HIP(ctx->owner.reserve((size_t)n_pairs * owner_stride * sizeof(int32_t)));
     RCN_HIP(ctx->fb_list.reserve(std::max<int64_t>(1, rows) * sizeof(unsigned long long)));
     RCN_HIP(ctx->sv_list.reserve(std::max<int64_t>(1, rows) * sizeof(unsigned long long)));
     RCN_HIP(hipMemcpyAsync(ctx->pairs_dev.p, slots.data(), slots.size() * sizeof(int32_t),
                            hipMemcpyHostToDevice, ctx->stream));
-    RCN_HIP(hipMemsetAsync(ctx->owner.p, 0x7f, (size_t)n_pairs * owner_stride * sizeof(int32_t), ctx->stream));
+    if (!uniq_lds) RCN_HIP(hipMemsetAsync(ctx->owner.p, 0x7f, (size_t)n_pairs * owner_stride * sizeof(int32_t), ctx->stream));
     RCN_HIP(hipMemsetAsync(counts_dev, 0, (size_t)n_pairs * sizeof(int32_t), ctx->stream));
 
     const ImgDev *imgs = ctx->img_table.as<ImgDev>();
@@ -1289,15 +1326,16 @@ static int match_grid_impl(rcn_ctx *ctx, const int32_t *pairs_host, int32_t n_pa
             else k_exact_rows<false><<<fb_blocks, 256, 0, sb>>>(imgs, pairs, ra.fb_list, ra.fb_count, ctx->D, ratio, out_dev, out_stride);
             RCN_HIP(hipGetLastError());
             if (prof && c == n_chunks - 1) RCN_HIP(hipEventRecord(ctx->ev[evi][2], sb));
-            k_unique_claim<<<g, 256, 0, sb>>>(imgs, pairs, out_dev, out_stride, ctx->owner.as<int32_t>(), owner_stride, qblocks, p0);
+            if (!uniq_lds) k_unique_claim<<<g, 256, 0, sb>>>(imgs, pairs, out_dev, out_stride, ctx->owner.as<int32_t>(), owner_stride, qblocks, p0);
             RCN_HIP(hipGetLastError());
         }
-        {
+        if (uniq_lds) k_unique_pair<<<np_c, 256, 0, sb>>>(imgs, pairs, out_dev, out_stride, counts_dev, p0);
+        else {
             const int eblocks = (int)((out_stride + 255) / 256);
             dim3 g((unsigned)eblocks * (unsigned)np_c);
             k_unique_emit<<<g, 256, 0, sb>>>(imgs, pairs, out_dev, out_stride, ctx->owner.as<int32_t>(), owner_stride, counts_dev, eblocks, p0);
-            RCN_HIP(hipGetLastError());
         }
+        RCN_HIP(hipGetLastError());
     }
     if (prof && kq_max > 0) {
         RCN_HIP(hipEventRecord(ctx->ev[evi][3], sb));
