@@ -735,16 +735,17 @@ __global__ __launch_bounds__(256) void k_exact_rows(const ImgDev *__restrict__ i
 // carrying the fp64 accumulator across chunks -- the row-per-lane global access pattern of the
 // simple kernel is latency-bound (0.22 ms for 351 rows at cfg 2).
 #define EX_LD 36   // floats per staged row: 32 + 4 pad
-__global__ __launch_bounds__(256) void k_exact_rows_lds(const ImgDev *__restrict__ imgs,
+#define EX_WAVES 8
+__global__ __launch_bounds__(64 * EX_WAVES) void k_exact_rows_lds(const ImgDev *__restrict__ imgs,
                                                          const int32_t *__restrict__ pairs,
                                                          const unsigned long long *__restrict__ list,
                                                          const unsigned *__restrict__ count, int D,
                                                          float ratio, int32_t *__restrict__ out,
                                                          int64_t out_stride)
 {
-    __shared__ __attribute__((aligned(16))) float tile[4][65 * EX_LD];
-    __shared__ double sb[4][2];
-    __shared__ int si[4][2];
+    __shared__ __attribute__((aligned(16))) float tile[EX_WAVES][65 * EX_LD];
+    __shared__ double sb[EX_WAVES][2];
+    __shared__ int si[EX_WAVES][2];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const unsigned n = *count;
     const int nchunk = (D + 31) / 32;
@@ -757,7 +758,7 @@ __global__ __launch_bounds__(256) void k_exact_rows_lds(const ImgDev *__restrict
         const float *qrow = qi.f32 + (size_t)q * D;
         double b0 = INFINITY, b1 = INFINITY;
         int i0 = 0x7FFFFFFF, i1 = 0x7FFFFFFF;
-        for (int base0 = 0; base0 < ti.K; base0 += 256) {      // uniform trip count over the waves
+        for (int base0 = 0; base0 < ti.K; base0 += 64 * EX_WAVES) {      // uniform trip count over the waves
             const int base = base0 + w * 64;
             const int j = base + lane;
             double acc = 0.0;
@@ -804,7 +805,7 @@ __global__ __launch_bounds__(256) void k_exact_rows_lds(const ImgDev *__restrict
         if (lane == 0) { sb[w][0] = b0; sb[w][1] = b1; si[w][0] = i0; si[w][1] = i1; }
         __syncthreads();
         if (threadIdx.x == 0) {
-            for (int k = 1; k < 4; ++k) merge_top2(b0, i0, b1, i1, sb[k][0], si[k][0], sb[k][1], si[k][1]);
+            for (int k = 1; k < EX_WAVES; ++k) merge_top2(b0, i0, b1, i1, sb[k][0], si[k][0], sb[k][1], si[k][1]);
             out[(size_t)pair * out_stride + q] = ratio_pass(b0, b1, ratio) ? i0 : -1;
         }
     }
@@ -1322,7 +1323,7 @@ static int match_grid_impl(rcn_ctx *ctx, const int32_t *pairs_host, int32_t n_pa
                 RCN_HIP(hipGetLastError());
             }
             const int fb_blocks = ctx->prop.multiProcessorCount * 8;
-            if (vec4) k_exact_rows_lds<<<fb_blocks, 256, 0, sb>>>(imgs, pairs, ra.fb_list, ra.fb_count, ctx->D, ratio, out_dev, out_stride);
+            if (vec4) k_exact_rows_lds<<<fb_blocks, 64 * EX_WAVES, 0, sb>>>(imgs, pairs, ra.fb_list, ra.fb_count, ctx->D, ratio, out_dev, out_stride);
             else k_exact_rows<false><<<fb_blocks, 256, 0, sb>>>(imgs, pairs, ra.fb_list, ra.fb_count, ctx->D, ratio, out_dev, out_stride);
             RCN_HIP(hipGetLastError());
             if (prof && c == n_chunks - 1) RCN_HIP(hipEventRecord(ctx->ev[evi][2], sb));
