@@ -594,8 +594,11 @@ __global__ __launch_bounds__(256) void k_fm_finish(FmatArgs a, FmState st)
 
 }  // namespace
 
+// host_poll: the caller synchronises with the host anyway (host-pointer API), so the number of pairs
+// still running is read back every four rounds and the remaining launches are skipped once it is 0;
+// the device-pointer API enqueues all rounds and never blocks.
 static int fmat_launch(rcn_ctx *ctx, int32_t n_pairs, const int32_t *off, const int32_t *xy1, const int32_t *xy2,
-                       uint8_t *mask, int32_t *counts, int32_t *iters, double *F)
+                       uint8_t *mask, int32_t *counts, int32_t *iters, double *F, bool host_poll = false)
 {
     if (n_pairs <= 0) return RCN_OK;
     FmatArgs a;
@@ -624,6 +627,12 @@ static int fmat_launch(rcn_ctx *ctx, int32_t n_pairs, const int32_t *off, const 
         k_fm_solve<<<(n_pairs + 64 / FM_B - 1) / (64 / FM_B), 64, 0, s>>>(a, st);
         k_fm_score<<<n_pairs, 256, 0, s>>>(a, st);
         k_fm_accept<<<n_pairs, 64, 0, s>>>(a, st);
+        if (host_poll && (round & 3) == 3) {
+            int active = 0;
+            RCN_HIP(hipMemcpyAsync(&active, st.active, 4, hipMemcpyDeviceToHost, s));
+            RCN_HIP(hipStreamSynchronize(s));
+            if (active == 0) break;
+        }
     }
     k_fm_finish<<<n_pairs, 256, 0, s>>>(a, st);
     RCN_HIP(hipGetLastError());
@@ -830,7 +839,7 @@ extern "C" int rcn_fmat_filter_grid(rcn_ctx *ctx, int32_t n_pairs, const int32_t
         RCN_HIP(hipMemcpyAsync(d_1, xy1, b_xy, hipMemcpyHostToDevice, st));
         RCN_HIP(hipMemcpyAsync(d_2, xy2, b_xy, hipMemcpyHostToDevice, st));
     }
-    int rc = fmat_launch(ctx, n_pairs, d_off, d_1, d_2, d_mask, d_cnt, d_it, d_F);
+    int rc = fmat_launch(ctx, n_pairs, d_off, d_1, d_2, d_mask, d_cnt, d_it, d_F, true);
     if (rc) return rc;
     if (N > 0) RCN_HIP(hipMemcpyAsync(out_mask, d_mask, b_mask, hipMemcpyDeviceToHost, st));
     RCN_HIP(hipMemcpyAsync(out_counts, d_cnt, b_cnt, hipMemcpyDeviceToHost, st));

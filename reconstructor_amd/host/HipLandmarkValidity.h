@@ -76,17 +76,22 @@ public:
         return inlierLandmarks;
     }
 
-    // SequentialReconstructor.cpp:956-976
+    // SequentialReconstructor.cpp:956-976: keep the inlier landmarks in order; the observations still
+    // attached to a dropped landmark become free again (landmarkId = -1).
     static void removeOutlierLandmarks(std::unordered_map<int, std::vector<FeaturePtr<>>> &features,
                                        std::vector<Landmark> &landmarks, const std::vector<bool> &inlierIds)
     {
-        std::vector<Landmark> updatedLandmarks;
-        for (size_t i = 0; i < inlierIds.size(); ++i) {
-            if (inlierIds[i]) updatedLandmarks.push_back(landmarks[i]);
-            else
-                for (const auto &tf : landmarks[i].triangulatedFeatures) features[tf.imgIdx][tf.featIdx]->landmarkId = -1;
+        size_t w = 0;
+        for (size_t j = 0; j < landmarks.size() && j < inlierIds.size(); ++j) {
+            if (!inlierIds[j]) {
+                for (const TriangulatedFeature &tf : landmarks[j].triangulatedFeatures)
+                    features.at(tf.imgIdx).at(tf.featIdx)->landmarkId = -1;
+                continue;
+            }
+            if (w != j) landmarks[w] = std::move(landmarks[j]);
+            ++w;
         }
-        landmarks = updatedLandmarks;
+        landmarks.resize(w);
     }
 
 private:
