@@ -885,9 +885,8 @@ __global__ __launch_bounds__(256) void k_chol_diag(double *S, int ld, int kb, do
     double *out = Linv + (size_t)kb * NB * NB;
     for (int idx = t; idx < NB * NB; idx += 256) {
         const int r = idx / NB, c = idx % NB;
-        double v = 0.0;
-        if (c <= r) v = (r / LB == c / LB) ? dinv_at(L, rd, r / LB, r % LB, c % LB) : L[r * DL + c];   // all off-diagonal entries are in place
-        out[idx] = v;
+        // (the strict upper triangle of every Linv tile is zeroed once per solve and never written)
+        if (c <= r) out[idx] = (r / LB == c / LB) ? dinv_at(L, rd, r / LB, r % LB, c % LB) : L[r * DL + c];   // all off-diagonal entries are in place
     }
     STAMP(17);
 }
@@ -1371,6 +1370,7 @@ int rcn_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_options *o
     RCN_HIP(H2D(p_cols, cols.data(), sizeof(int) * 10 * nc));
     RCN_HIP(hipMemsetAsync(vecs, 0, sizeof(double) * 12 * nvec, st));
     RCN_HIP(hipMemsetAsync(d.S, 0, sizeof(double) * (size_t)npad * npad, st));   // upper part / padding never rewritten
+    RCN_HIP(hipMemsetAsync(d.Linv, 0, sizeof(double) * (size_t)nblk * NB * NB, st));   // upper triangles of the tile inverses stay zero
     RCN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_chol_diag), hipFuncAttributeMaxDynamicSharedMemorySize, NB * DL * 8));
     RCN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_nt_ring<0>), hipFuncAttributeMaxDynamicSharedMemorySize, GST * GSTAGE_BYTES));
     if (gather && np > 0) {

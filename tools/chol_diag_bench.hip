@@ -16,7 +16,7 @@ int main()
         }
     double *dA, *dLinv; int *dflag;
     (void)hipMalloc(&dA, n * n * 8); (void)hipMalloc(&dLinv, n * n * 8); (void)hipMalloc(&dflag, 4);
-    (void)hipMemset(dflag, 0, 4);
+    (void)hipMemset(dflag, 0, 4); (void)hipMemset(dLinv, 0, n * n * 8);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_chol_diag), hipFuncAttributeMaxDynamicSharedMemorySize, NB * DL * 8);
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     for (int rep = 0; rep < 3; ++rep) {
