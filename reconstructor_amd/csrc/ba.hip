@@ -706,11 +706,10 @@ __global__ __launch_bounds__(256) void k_chol_diag(double *S, int ld, int kb, do
     }
     __syncthreads();
     STAMP(0);
-    for (int c0 = 0; c0 < NB; c0 += LB) {
-        // 1a. 16x16 leaf by wave 0 alone: lane l holds row l in registers; the pivot column is
-        //     broadcast through a small LDS line (one ds_write + uniform-address reads per pivot;
-        //     LDS operations of one wave are ordered, so no workgroup barrier inside)
-        if (w == 0) {
+    // 1a. 16x16 leaf by wave 0 alone: lane l holds row l in registers; the pivot column is
+    //     broadcast through a small LDS line (one ds_write + uniform-address reads per pivot;
+    //     LDS operations of one wave are ordered, so no workgroup barrier inside)
+    auto leaf_factor = [&](int c0) {
             const int row = lane & (LB - 1);
             double a[LB];
 #pragma unroll
@@ -761,9 +760,11 @@ __global__ __launch_bounds__(256) void k_chol_diag(double *S, int ld, int kb, do
                         if (r > row) L[(c0 + row) * DL + c0 + r] = x[r];   // transposed, strictly upper
                 }
             }
-        }
-        __syncthreads();
-        STAMP(1);
+            };
+    if (w == 0) leaf_factor(0);
+    __syncthreads();
+    STAMP(1);
+    for (int c0 = 0; c0 < NB; c0 += LB) {
         if (misc[0] != 0.0) { if (t == 0) *flag = 1; return; }
         const int r0 = c0 + LB;
         if (r0 >= NB) break;
@@ -788,10 +789,12 @@ __global__ __launch_bounds__(256) void k_chol_diag(double *S, int ld, int kb, do
         __syncthreads();
         STAMP(2);
         // 1c. trailing square -= panel panel^T, lower 16x16 tiles on MFMA: the accumulator starts
-        //     as the C tile and the A operand is negated
+        //     as the C tile and the A operand is negated.  LOOKAHEAD: wave 0 takes tile (0,0) -- the next
+        //     leaf's diagonal block -- and goes straight on to factor and invert that leaf while waves
+        //     1..3 update the rest of the square, so the serial leaf work hides behind the MFMA work.
         {
             const int nt = (NB - r0) / 16, ntile = nt * (nt + 1) / 2;
-            for (int tile = w; tile < ntile; tile += 4) {
+            for (int tile = w == 0 ? 0 : w; tile < ntile; tile += (w == 0 ? ntile : 3)) {
                 int tr = (int)((sqrtf(8.f * tile + 1.f) - 1.f) * 0.5f);
                 while ((tr + 1) * (tr + 2) / 2 <= tile) ++tr;
                 while (tr * (tr + 1) / 2 > tile) --tr;
@@ -809,6 +812,7 @@ __global__ __launch_bounds__(256) void k_chol_diag(double *S, int ld, int kb, do
 #pragma unroll
                 for (int reg = 0; reg < 4; ++reg) Ct[((lane >> 4) + 4 * reg) * DL + (lane & 15)] = acc[reg];
             }
+            if (w == 0) leaf_factor(r0);
         }
         __syncthreads();
         STAMP(3);
@@ -883,10 +887,16 @@ __global__ __launch_bounds__(256) void k_chol_diag(double *S, int ld, int kb, do
     }
     STAMP(16);
     double *out = Linv + (size_t)kb * NB * NB;
-    for (int idx = t; idx < NB * NB; idx += 256) {
-        const int r = idx / NB, c = idx % NB;
-        // (the strict upper triangle of every Linv tile is zeroed once per solve and never written)
-        if (c <= r) out[idx] = (r / LB == c / LB) ? dinv_at(L, rd, r / LB, r % LB, c % LB) : L[r * DL + c];   // all off-diagonal entries are in place
+    // (the strict upper triangle of every Linv tile is zeroed once per solve and never written, except
+    // for the zero beside an odd diagonal entry.)  A thread moves two neighbouring columns of four rows apart.
+    {
+        const int c = 2 * (t & 63);
+        auto at = [&](int r, int cc) -> double {
+            return cc > r ? 0.0 : (r / LB == cc / LB) ? dinv_at(L, rd, r / LB, r % LB, cc % LB) : L[r * DL + cc];   // all off-diagonal entries are in place
+        };
+#pragma unroll 8
+        for (int r = t >> 6; r < NB; r += 4)
+            if (c <= r) *reinterpret_cast<f64x2 *>(out + (size_t)r * NB + c) = (f64x2){at(r, c), at(r, c + 1)};
     }
     STAMP(17);
 }
