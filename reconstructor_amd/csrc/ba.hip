@@ -723,7 +723,6 @@ __global__ __launch_bounds__(256) void k_chol_diag(double *S, int ld, int kb, do
                 // 1/sqrt and sqrt from v_rsq_f64 + Newton steps
                 double inv = __builtin_amdgcn_rsq(djj);
                 inv = inv * (1.5 - 0.5 * djj * inv * inv);
-                inv = inv * (1.5 - 0.5 * djj * inv * inv);
                 double dj = djj * inv;
                 dj = fma(0.5 * inv, fma(-dj, dj, djj), dj);
                 inv = fma(inv, fma(-dj, inv, 1.0), inv);
