@@ -617,14 +617,16 @@ __global__ __launch_bounds__(64) void k_ba_cam_rhs(BaDev d)
 
 // ---------------------------------------------------------------------------------------
 // K7: dense Cholesky of the padded reduced system (npad multiple of 128), lower triangle.
-// Diagonal block (one workgroup, block resident in LDS, ~40 workgroup barriers in total):
-//   1. blocked factorization with 32-wide leaves: the 32x32 leaf is factored by ONE wave (LDS
-//      operations of a wave are ordered, so no workgroup barrier inside), rows below by a
-//      row-wise triangular solve, trailing square by 16x16 thread tiles;
-//   2. blocked inverse of the factor: the four leaf inverses in parallel (one wave each, column
-//      per lane, kept in the otherwise unused upper triangle of the block), then the six
-//      off-diagonal 32x32 blocks left to right, in place:
-//          X[i][j] = -Dinv_i * sum_{m=j}^{i-1} L[i][m] X[m][j],   X[j][j] = Dinv_j.
+// Diagonal block (one workgroup, block resident in LDS, ~30 workgroup barriers in total):
+//   1. blocked factorisation with 16-wide leaves: a leaf is factored AND inverted by wave 0 alone (LDS
+//      operations of a wave are ordered, so no workgroup barrier inside; the leaf inverse lives
+//      transposed in the otherwise unused upper triangle of the leaf's diagonal block), rows below
+//      become A Dinv^T and the trailing square is updated as 16x16 v_mfma_f64_16x16x4_f64 tiles.
+//      Lookahead: wave 0 updates the next leaf's diagonal tile first and factors it while waves 1..3
+//      finish the trailing square, so the serial leaf work hides behind the MFMA work;
+//   2. blocked inverse of the factor by doubling, 16 -> 32 -> 64 -> 128, in place:
+//          X_hi,lo = -Dinv_hi * (L_hi,lo * Dinv_lo)
+//      (row strips per wave in the first product, column strips in the second: three barriers a step).
 // Writes L^-1 into Linv[kb] (used by the panel GEMM and the triangular solves) and, on request, L into S.
 #define DL 129   // LDS row stride of the diagonal block (doubles): row walks are conflict-free
 #define LB 16    // leaf size
@@ -646,12 +648,6 @@ __device__ __forceinline__ double rdlane(double v, int src)
 __device__ __forceinline__ double dinv_at(const double *L, const double *rd, int i, int r, int c)
 {
     return r == c ? rd[LB * i + r] : L[(LB * i + c) * DL + LB * i + r];
-}
-
-__device__ __forceinline__ double dinv32_at(const double *L, const double *rd, int i32, int r, int c)
-{
-    const int gr = 32 * i32 + r, gc = 32 * i32 + c;
-    return (gr / LB == gc / LB) ? dinv_at(L, rd, gr / LB, gr % LB, gc % LB) : L[gr * DL + gc];
 }
 
 template <int NT> __device__ __forceinline__ void trail_update(double *L, int r0, int c0, int t)
@@ -853,36 +849,77 @@ __global__ __launch_bounds__(256) void k_chol_diag(double *S, int ld, int kb, do
         for (int reg = 0; reg < 4; ++reg) Bt[((lane >> 4) + 4 * reg) * DL + (lane & 15)] = acc[reg];
     }
     __syncthreads();
-    // 2c. off-diagonal 32x32 blocks, left to right, in place:
-    //         X[i][j] = -Dinv32_i * sum_{m=j}^{i-1} L[i][m] X[m][j],   X[j][j] = Dinv32_j.
-    //     Wave w owns the 16x16 quadrant (w>>1, w&1) of the block; two MFMA passes per block.
-    {
-        const int qr = (w >> 1) * 16, qc = (w & 1) * 16;
-        for (int j = 0; j < 3; ++j)
-            for (int i = j + 1; i < 4; ++i) {
-                f64x4 acc = {0.0, 0.0, 0.0, 0.0};
-                for (int m = j; m < i; ++m)
-                    for (int kk = 0; kk < 32; kk += 4) {
-                        const int k = kk + (lane >> 4), c = qc + (lane & 15);
-                        const double a = L[(32 * i + qr + (lane & 15)) * DL + 32 * m + k];
-                        const double b = m == j ? (c <= k ? dinv32_at(L, rd, j, k, c) : 0.0) : L[(32 * m + k) * DL + 32 * j + c];
-                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
-                    }
-                __syncthreads();   // every read of the original L[i][j] is done
+    // 2c. two more doubling steps, 32 -> 64 -> 128, each  X_hi,lo = -Dinv_hi * (L_hi,lo * Dinv_lo)  in place:
+    //     pass 1 gives every wave whole ROW strips of L_hi,lo (all their columns are read before the strip
+    //     is overwritten by T), pass 2 whole COLUMN strips of T; three workgroup barriers per step.
+    //     An entry of an already inverted diagonal part is dinv_at inside a 16-leaf and in place otherwise.
+    auto inv_at = [&](int r, int c) -> double {   // c <= r, both inside an inverted diagonal part
+        return (r / LB == c / LB) ? dinv_at(L, rd, r / LB, r % LB, c % LB) : L[r * DL + c];
+    };
 #pragma unroll
-                for (int reg = 0; reg < 4; ++reg) L[(32 * i + qr + (lane >> 4) + 4 * reg) * DL + 32 * j + qc + (lane & 15)] = acc[reg];
-                __syncthreads();
-                acc = (f64x4){0.0, 0.0, 0.0, 0.0};
-                for (int kk = 0; kk < 32; kk += 4) {
-                    const int k = kk + (lane >> 4), r = qr + (lane & 15);
-                    const double a = k <= r ? -dinv32_at(L, rd, i, r, k) : 0.0;
-                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, L[(32 * i + k) * DL + 32 * j + qc + (lane & 15)], acc, 0, 0, 0);
+    for (int half = 32; half <= 64; half *= 2) {
+        const int nblk2 = NB / (2 * half);                 // off-diagonal blocks at this level: 2, then 1
+        const int strips = half / 16, wpb = 4 / nblk2;     // 16-wide strips per block; waves per block: 2, then 4
+        const int blk = w / wpb, wl = w % wpb;
+        const int lo0 = 2 * half * blk, hi0 = lo0 + half;  // the block is rows hi0.., columns lo0..
+        f64x4 acc[4][4];                                   // [own strip][tile across]; at most 2 x 2 or 1 x 4 used
+        const int own = strips / wpb;                      // strips per wave: 1
+        // pass 1: T = B * Dinv_lo, row strips
+#pragma unroll
+        for (int s0 = 0; s0 < own; ++s0) {
+            const int rs = hi0 + 16 * (wl * own + s0);
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) {
+                if (ct >= strips) break;
+                f64x4 a4 = {0.0, 0.0, 0.0, 0.0};
+                for (int kk = 16 * ct; kk < half; kk += 4) {      // Dinv_lo is lower triangular: k >= column
+                    const int k = kk + (lane >> 4), c = 16 * ct + (lane & 15);
+                    const double bb = c <= k ? inv_at(lo0 + k, lo0 + c) : 0.0;
+                    a4 = __builtin_amdgcn_mfma_f64_16x16x4f64(L[(rs + (lane & 15)) * DL + lo0 + k], bb, a4, 0, 0, 0);
                 }
-                __syncthreads();
-#pragma unroll
-                for (int reg = 0; reg < 4; ++reg) L[(32 * i + qr + (lane >> 4) + 4 * reg) * DL + 32 * j + qc + (lane & 15)] = acc[reg];
-                __syncthreads();
+                acc[s0][ct] = a4;
             }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int s0 = 0; s0 < own; ++s0) {
+            const int rs = hi0 + 16 * (wl * own + s0);
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) {
+                if (ct >= strips) break;
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) L[(rs + (lane >> 4) + 4 * reg) * DL + lo0 + 16 * ct + (lane & 15)] = acc[s0][ct][reg];
+            }
+        }
+        __syncthreads();
+        // pass 2: X = -Dinv_hi * T, column strips
+#pragma unroll
+        for (int s0 = 0; s0 < own; ++s0) {
+            const int cs = lo0 + 16 * (wl * own + s0);
+#pragma unroll
+            for (int rt = 0; rt < 4; ++rt) {
+                if (rt >= strips) break;
+                f64x4 a4 = {0.0, 0.0, 0.0, 0.0};
+                for (int kk = 0; kk < 16 * (rt + 1); kk += 4) {   // Dinv_hi is lower triangular: k <= row
+                    const int k = kk + (lane >> 4), r = 16 * rt + (lane & 15);
+                    const double aa = k <= r ? -inv_at(hi0 + r, hi0 + k) : 0.0;
+                    a4 = __builtin_amdgcn_mfma_f64_16x16x4f64(aa, L[(hi0 + k) * DL + cs + (lane & 15)], a4, 0, 0, 0);
+                }
+                acc[s0][rt] = a4;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int s0 = 0; s0 < own; ++s0) {
+            const int cs = lo0 + 16 * (wl * own + s0);
+#pragma unroll
+            for (int rt = 0; rt < 4; ++rt) {
+                if (rt >= strips) break;
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) L[(hi0 + 16 * rt + (lane >> 4) + 4 * reg) * DL + cs + (lane & 15)] = acc[s0][rt][reg];
+            }
+        }
+        __syncthreads();
     }
     STAMP(16);
     double *out = Linv + (size_t)kb * NB * NB;
