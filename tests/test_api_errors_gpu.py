@@ -59,3 +59,30 @@ def test_ba_errors(gpu_ctx):
     P, I, X, s = ba.solve_flat(gpu_ctx, sc["poses"], sc["intrinsics"], sc["points"],
                                np.zeros((0, 2)), np.zeros(0, np.int32), np.zeros(0, np.int32))
     assert s["iterations"] == 0 and np.array_equal(P, sc["poses"])
+
+
+def test_plugin_calls_from_four_threads(gpu_ctx):
+    """The reference calls matchFeatures / estimateFundamental from 4 OpenMP threads on one shared
+    plugin object (SequentialReconstructor.cpp:202): the per-pair entry points must be re-entrant."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import orc, orc_fmat
+    from reconstructor_amd import fmat, synth, synth_fmat
+    from reconstructor_amd.matcher import HipL2Matcher
+    m = HipL2Matcher(ctx=gpu_ctx)
+    m.clear()
+    ims = synth.descriptor_set("sift", 6, [180, 220, 150, 260, 200, 170], n_world=500, seed=31)
+    jobs = [(i, j) for i in range(6) for j in range(i + 1, 6)]
+    two = [synth_fmat.two_view(120 + 10 * k, 0.3, seed=k) for k in range(len(jobs))]
+
+    def work(k):
+        i, j = jobs[k]
+        got = m.match_pair(ims[i], ims[j])
+        mask, cnt = fmat.estimate_fundamental_inliers(gpu_ctx, two[k][0], two[k][1])
+        return got, mask, cnt
+    with ThreadPoolExecutor(4) as ex:
+        res = list(ex.map(work, range(len(jobs))))
+    for k, (i, j) in enumerate(jobs):
+        exp, cnt = orc.match_pair(ims[i], ims[j])
+        assert np.array_equal(res[k][0], exp) and (res[k][0] >= 0).sum() == cnt
+        m0, c0, _ = orc_fmat.filter_pair(two[k][0], two[k][1])
+        assert np.array_equal(res[k][1], m0) and res[k][2] == c0
