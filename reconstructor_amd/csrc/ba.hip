@@ -188,35 +188,46 @@ __global__ void k_ba_point_raw(BaDev d)
     for (int a = 0; a < 3; ++a) d.gpraw[3 * (size_t)j + a] = g[a];
 }
 
-// K5: per camera  Uraw = sum Jc'Jc (10x10), gcraw = sum Jc'r ; one workgroup per camera
-__global__ __launch_bounds__(128) void k_ba_cam_raw(BaDev d)
+// K5: per camera  Uraw = sum Jc'Jc (10x10), gcraw = sum Jc'r ; one workgroup per camera, eight groups of
+// 128 threads: group g stages and sums the 32-observation chunks g, g+8, ... (a camera of the reference's own
+// regime sees thousands of observations), the eight partial sums are added in group order.
+#define CR_GROUPS 8
+__global__ __launch_bounds__(128 * CR_GROUPS) void k_ba_cam_raw(BaDev d)
 {
-    __shared__ double sh[32 * 22];
-    const int c = blockIdx.x, t = threadIdx.x;
-    // thread t < 110 owns one entry: 0..99 of U (a = t/10, b = t%10), 100..109 of g
+    __shared__ double sh[CR_GROUPS][32 * 22];
+    __shared__ double part[CR_GROUPS][110];
+    const int c = blockIdx.x, g = threadIdx.x >> 7, t = threadIdx.x & 127;
+    // thread t < 110 of a group owns one entry: 0..99 of U (a = t/10, b = t%10), 100..109 of g
     double acc = 0.0;
     const int e0 = d.cam_obs_off[c], e1 = d.cam_obs_off[c + 1];
-    for (int base = e0; base < e1; base += 32) {
+    for (int base0 = e0; base0 < e1; base0 += 32 * CR_GROUPS) {      // uniform trip count over the groups
+        const int base = base0 + 32 * g;
         // stage 32 observations' (Jc 20 + r 2) rows in LDS
         __syncthreads();
         for (int i = t; i < 32 * 22; i += 128) {
             const int oi = i / 22, k = i % 22, e = base + oi;
             double v = 0.0;
             if (e < e1) { const int o = d.cam_obs[e]; v = k < 20 ? d.Jc[20 * (size_t)o + k] : d.r[2 * o + (k - 20)]; }
-            sh[i] = v;
+            sh[g][i] = v;
         }
         __syncthreads();
         if (t < 110) {
             const int a = t < 100 ? t / 10 : t - 100, b = t % 10;
             for (int oi = 0; oi < 32; ++oi) {
-                const double *row = sh + oi * 22;
+                const double *row = sh[g] + oi * 22;
                 if (t < 100) acc += row[a] * row[b] + row[10 + a] * row[10 + b];
                 else acc += row[a] * row[20] + row[10 + a] * row[21];
             }
         }
     }
-    if (t < 100) d.Uraw[100 * (size_t)c + t] = acc;
-    else if (t < 110) d.gcraw[10 * (size_t)c + (t - 100)] = acc;
+    if (t < 110) part[g][t] = acc;
+    __syncthreads();
+    if (g == 0 && t < 110) {
+        double s = 0.0;
+        for (int k = 0; k < CR_GROUPS; ++k) s += part[k][t];
+        if (t < 100) d.Uraw[100 * (size_t)c + t] = s;
+        else d.gcraw[10 * (size_t)c + (t - 100)] = s;
+    }
 }
 
 // Jacobi scaling (initial point) or clamped LM diagonal (scaled Jacobian) from the raw diagonals
@@ -404,18 +415,53 @@ __global__ __launch_bounds__(256) void k_pair_fill(BaDev d, const int *off, int 
 }
 
 // fixed order inside every block: ascending (o, o2); segments are short except the diagonal blocks
+#define PAIR_SORT_SHORT 32
 __global__ void k_pair_sort(const int *off, unsigned long long *list, int nkeys)
 {
     const int key = blockIdx.x * blockDim.x + threadIdx.x;
     if (key >= nkeys) return;
     unsigned long long *a = list + off[key];
     const int n = off[key + 1] - off[key];
+    if (n > PAIR_SORT_SHORT) return;           // long segments: k_pair_sort_long
     for (int i = 1; i < n; ++i) {
         const unsigned long long v = a[i];
         int p = i - 1;
         while (p >= 0 && a[p] > v) { a[p + 1] = a[p]; --p; }
         a[p + 1] = v;
     }
+}
+
+// Long segments (few cameras sharing thousands of landmarks: the reference's own regime, 3..25 views):
+// one workgroup per segment, bitonic sort -- in LDS up to 4096 entries, in global memory beyond.
+__global__ __launch_bounds__(256) void k_pair_sort_long(const int *off, unsigned long long *list)
+{
+    __shared__ unsigned long long sh[4096];
+    const int key = blockIdx.x, t = threadIdx.x;
+    const int n = off[key + 1] - off[key];
+    if (n <= PAIR_SORT_SHORT) return;
+    unsigned long long *g = list + off[key];
+    int P = 64;
+    while (P < n) P <<= 1;
+    const bool in_lds = n <= 4096;
+    if (in_lds) {
+        for (int i = t; i < n; i += 256) sh[i] = g[i];
+        __syncthreads();
+    }
+    unsigned long long *a = in_lds ? sh : g;
+    // normalised bitonic network: every comparator ascending, the first step of a merge pairs i with its
+    // mirror image i ^ (k - 1); entries beyond n count as +infinity and therefore never move
+    for (int k = 2; k <= P; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = t; i < n; i += 256) {
+                const int l = j == (k >> 1) ? (i ^ (k - 1)) : (i ^ j);
+                if (l > i && l < n) {
+                    const unsigned long long x = a[i], y = a[l];
+                    if (x > y) { a[i] = y; a[l] = x; }
+                }
+            }
+            __syncthreads();
+        }
+    if (in_lds) for (int i = t; i < n; i += 256) g[i] = sh[i];
 }
 
 // ---- MFMA form of the gather (default).  k_ba_wy tabulates, per observation, the scaled
@@ -496,6 +542,38 @@ __global__ __launch_bounds__(256) void k_ba_schur_mfma(BaDev d, const int *off, 
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg)
             if (r0 + 4 * reg < dc) out[(size_t)(r0 + 4 * reg) * d.npad + col] = acc[reg];
+}
+
+// The same for long pair lists (few cameras sharing thousands of landmarks): one 8-wave workgroup per block,
+// wave w takes the 64-pair chunks w, w+8, ...; the eight partial blocks are added in wave order.
+__global__ __launch_bounds__(512) void k_ba_schur_mfma_wg(BaDev d, const int *off, const unsigned long long *list)
+{
+    __shared__ double part[8][256];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, blk = blockIdx.x;
+    int c = (int)((sqrt(8.0 * blk + 1.0) + 1.0) * 0.5);
+    while (c * (c + 1) / 2 <= blk) ++c;
+    while (c * (c - 1) / 2 > blk) --c;
+    const int c2 = blk - c * (c - 1) / 2, key = c * d.nc + c2;
+    const int dc = d.cam_dim[c], dc2 = d.cam_dim[c2];
+    if (dc == 0 || dc2 == 0) return;
+    f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+    const int e0 = off[key], e1 = off[key + 1];
+    for (int base = e0 + 64 * w; base < e1; base += 64 * 8) {
+        const int cnt = min(64, e1 - base);
+        const unsigned long long pr = lane < cnt ? list[base + lane] : 0ull;
+        acc = schur_mfma_chunk<false>(d.WY, pr, cnt, lane, acc);
+    }
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) part[w][((lane >> 4) + 4 * reg) * 16 + (lane & 15)] = acc[reg];
+    __syncthreads();
+    if (threadIdx.x < 256) {
+        const int a = threadIdx.x >> 4, b = threadIdx.x & 15;
+        if (a < dc && b < dc2) {
+            double v = 0.0;
+            for (int k = 0; k < 8; ++k) v += part[k][threadIdx.x];
+            d.S[(size_t)(d.cam_off[c] + a) * d.npad + d.cam_off[c2] + b] = v;
+        }
+    }
 }
 
 // diagonal blocks: one 16-wave workgroup per camera; wave w takes the observations w, w+16, ... of
@@ -1429,6 +1507,7 @@ int rcn_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_options *o
         k_scan_apply<<<nchunks, 1024, 0, st>>>(pk_cnt, pk_sums, pk_off, nkeys);
         k_pair_fill<<<np, thr, 0, st>>>(d, pk_off, pk_fill, pk_list);
         k_pair_sort<<<(nkeys + 127) / 128, 128, 0, st>>>(pk_off, pk_list, nkeys);
+        k_pair_sort_long<<<nkeys, 256, 0, st>>>(pk_off, pk_list);
         RCN_HIP(hipGetLastError());
     }
     RCN_HIP(hipStreamSynchronize(st));   // host vectors go out of use; timing starts with inputs resident
@@ -1448,7 +1527,7 @@ int rcn_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_options *o
         k_finish_sum<<<1, 256, 0, st>>>(d.partial, no > 0 ? eb : 0, d.scal + slot, 0.5);
         if (jac) {
             if (np > 0) k_ba_point_raw<<<(np + 127) / 128, 128, 0, st>>>(d);
-            k_ba_cam_raw<<<nc, 128, 0, st>>>(d);
+            k_ba_cam_raw<<<nc, 128 * CR_GROUPS, 0, st>>>(d);
         }
         return hipGetLastError();
     };
@@ -1494,7 +1573,11 @@ int rcn_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_options *o
         if (np > 0) k_ba_point_solve<<<(np + 127) / 128, 128, 0, st>>>(d, ir);
         if (gather) {
             if (no > 0) k_ba_wy<<<(unsigned)((10 * (size_t)no + 255) / 256), 256, 0, st>>>(d);
-            if (nc > 1) k_ba_schur_mfma<<<(nc * (nc - 1) / 2 + 3) / 4, 256, 0, st>>>(d, pk_off, pk_list);
+            if (nc > 1) {
+                const int nlow = nc * (nc - 1) / 2;
+                if (npairs_lower / (size_t)nlow > 128) k_ba_schur_mfma_wg<<<nlow, 512, 0, st>>>(d, pk_off, pk_list);   // long lists: a workgroup per block
+                else k_ba_schur_mfma<<<(nlow + 3) / 4, 256, 0, st>>>(d, pk_off, pk_list);
+            }
             k_ba_schur_diag_mfma<<<nc, 1024, 0, st>>>(d, pk_off, pk_list, ir);
             if (npad > n) k_ba_S_pad<<<(npad - n + 127) / 128, 128, 0, st>>>(d);
         } else {
