@@ -204,11 +204,21 @@ __global__ __launch_bounds__(128 * CR_GROUPS) void k_ba_cam_raw(BaDev d)
         const int base = base0 + 32 * g;
         // stage 32 observations' (Jc 20 + r 2) rows in LDS
         __syncthreads();
-        for (int i = t; i < 32 * 22; i += 128) {
-            const int oi = i / 22, k = i % 22, e = base + oi;
-            double v = 0.0;
-            if (e < e1) { const int o = d.cam_obs[e]; v = k < 20 ? d.Jc[20 * (size_t)o + k] : d.r[2 * o + (k - 20)]; }
-            sh[g][i] = v;
+        {   // 704 elements over 128 threads: six per thread, the index loads and then the value loads issued together
+            int oo[6];
+#pragma unroll
+            for (int q = 0; q < 6; ++q) {
+                const int i = t + 128 * q, e = base + i / 22;
+                oo[q] = (i < 32 * 22 && e < e1) ? d.cam_obs[e] : -1;
+            }
+            double vv[6];
+#pragma unroll
+            for (int q = 0; q < 6; ++q) {
+                const int k = (t + 128 * q) % 22;
+                vv[q] = oo[q] < 0 ? 0.0 : (k < 20 ? d.Jc[20 * (size_t)oo[q] + k] : d.r[2 * (size_t)oo[q] + (k - 20)]);
+            }
+#pragma unroll
+            for (int q = 0; q < 6; ++q) if (t + 128 * q < 32 * 22) sh[g][t + 128 * q] = vv[q];
         }
         __syncthreads();
         if (t < 110) {
@@ -491,15 +501,16 @@ __global__ __launch_bounds__(256) void k_ba_wy(BaDev d)
 // (<= 64) pairs held one per lane in `pr` (o << 32 | o2)
 // RHS: column 10 of the B operand carries the scaled point gradient of the pair's landmark, so
 // column 10 of the block comes out as  - sum Y_o gp_j(o)  -- the camera's reduced right-hand side.
+#define SMB 12   // MFMA steps (of 4 k) per trip of the gather loop: 36 pair-components, i.e. 12 pairs
 template <bool RHS>
 __device__ __forceinline__ f64x4 schur_mfma_chunk(const double *__restrict__ WY, unsigned long long pr, int cnt, int lane, f64x4 acc,
                                                   const int *__restrict__ opt = nullptr, const double *__restrict__ gps = nullptr)
 {
     const int i = lane & 15, kk = lane >> 4, K = 3 * cnt;
-    for (int k0 = 0; k0 < K; k0 += 16) {   // four MFMA steps per trip: eight gathers in flight per lane
-        double a[4], b[4];
+    for (int k0 = 0; k0 < K; k0 += 4 * SMB) {   // SMB MFMA steps per trip: 2 SMB gathers in flight per lane
+        double a[SMB], b[SMB];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < SMB; ++u) {
             const int k = k0 + 4 * u + kk, p = k / 3, m = k - 3 * p;
             const unsigned long long e = __shfl(pr, p & 63);
             a[u] = 0.0; b[u] = 0.0;
@@ -510,7 +521,8 @@ __device__ __forceinline__ f64x4 schur_mfma_chunk(const double *__restrict__ WY,
             if (RHS && k < K && i == 10) b[u] = gps[3 * (size_t)opt[(unsigned)(e & 0xFFFFFFFFu)] + m];
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-a[u], b[u], acc, 0, 0, 0);
+        for (int u = 0; u < SMB; ++u)
+            if (k0 + 4 * u < K) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-a[u], b[u], acc, 0, 0, 0);
     }
     return acc;
 }
