@@ -501,8 +501,9 @@ __global__ __launch_bounds__(256) void k_ba_wy(BaDev d)
 // (<= 64) pairs held one per lane in `pr` (o << 32 | o2)
 // RHS: column 10 of the B operand carries the scaled point gradient of the pair's landmark, so
 // column 10 of the block comes out as  - sum Y_o gp_j(o)  -- the camera's reduced right-hand side.
-#define SMB 12   // MFMA steps (of 4 k) per trip of the gather loop: 36 pair-components, i.e. 12 pairs
-template <bool RHS>
+// SMB: MFMA steps (of 4 k) per trip of the gather loop -- 4 for the short lists of the one-wave kernel,
+// 12 (16 pairs' worth of gathers in flight) where a wave walks hundreds of pairs
+template <bool RHS, int SMB>
 __device__ __forceinline__ f64x4 schur_mfma_chunk(const double *__restrict__ WY, unsigned long long pr, int cnt, int lane, f64x4 acc,
                                                   const int *__restrict__ opt = nullptr, const double *__restrict__ gps = nullptr)
 {
@@ -545,7 +546,7 @@ __global__ __launch_bounds__(256) void k_ba_schur_mfma(BaDev d, const int *off, 
     for (int base = e0; base < e1; base += 64) {
         const int cnt = min(64, e1 - base);
         const unsigned long long pr = lane < cnt ? list[base + lane] : 0ull;
-        acc = schur_mfma_chunk<false>(d.WY, pr, cnt, lane, acc);
+        acc = schur_mfma_chunk<false, 4>(d.WY, pr, cnt, lane, acc);
     }
     // C/D layout: column = lane & 15, row = (lane >> 4) + 4 * reg
     const int col = lane & 15, r0 = lane >> 4;
@@ -573,7 +574,7 @@ __global__ __launch_bounds__(512) void k_ba_schur_mfma_wg(BaDev d, const int *of
     for (int base = e0 + 64 * w; base < e1; base += 64 * 8) {
         const int cnt = min(64, e1 - base);
         const unsigned long long pr = lane < cnt ? list[base + lane] : 0ull;
-        acc = schur_mfma_chunk<false>(d.WY, pr, cnt, lane, acc);
+        acc = schur_mfma_chunk<false, 12>(d.WY, pr, cnt, lane, acc);
     }
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) part[w][((lane >> 4) + 4 * reg) * 16 + (lane & 15)] = acc[reg];
@@ -604,12 +605,12 @@ __global__ __launch_bounds__(1024) void k_ba_schur_diag_mfma(BaDev d, const int 
         const int cnt = min(64, (o1 - base + 15) / 16);
         unsigned long long pr = 0ull;
         if (lane < cnt) { const unsigned o = (unsigned)d.cam_obs[base + 16 * lane]; pr = ((unsigned long long)o << 32) | o; }
-        acc = schur_mfma_chunk<true>(d.WY, pr, cnt, lane, acc, d.opt, d.gps);
+        acc = schur_mfma_chunk<true, 12>(d.WY, pr, cnt, lane, acc, d.opt, d.gps);
     }
     for (int base = off[key] + w; base < off[key + 1]; base += 16 * 64) {   // the same camera seen twice by one landmark
         const int cnt = min(64, (off[key + 1] - base + 15) / 16);
         const unsigned long long pr = lane < cnt ? list[base + 16 * lane] : 0ull;
-        acc = schur_mfma_chunk<false>(d.WY, pr, cnt, lane, acc);
+        acc = schur_mfma_chunk<false, 12>(d.WY, pr, cnt, lane, acc);
     }
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) part[w][((lane >> 4) + 4 * reg) * 16 + (lane & 15)] = acc[reg];
