@@ -10,7 +10,10 @@ pytestmark = pytest.mark.gpu
 RMS_TOL_PX = 1e-5
 
 
-@pytest.mark.parametrize("nc,npts,k", [(3, 20, 3), (9, 150, 6), (12, 300, 10), (40, 3000, 10)])
+# (3, 6000, 3): pair segments of 6000 entries (bitonic sort in global memory); (6, 3000, 5) and (25, 2500, 8):
+# segments of hundreds (LDS bitonic sort, workgroup-per-block Schur kernel) -- the reference's own regime
+@pytest.mark.parametrize("nc,npts,k", [(3, 20, 3), (9, 150, 6), (12, 300, 10), (40, 3000, 10),
+                                       (3, 6000, 3), (6, 3000, 5), (25, 2500, 8)])
 def test_small_scenes_match_oracle(gpu_ctx, nc, npts, k):
     from reconstructor_amd import ba
     sc = synth_ba.make_scene(nc, npts, obs_per_point=k, seed=5)
