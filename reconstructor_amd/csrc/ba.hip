@@ -39,6 +39,7 @@ struct BaDev {
     double *sc, *sp, *dgc, *dgp;       // Jacobi scale, clamped diag(Js'Js)
     double *Vinv, *gps, *rhs, *S, *L, *Linv, *yc, *stc, *stp, *dlc, *dlp;   // S: reduced system, L: its sub-diagonal Cholesky tiles
     double *partial, *scal;            // reduction scratch, scalars
+    double *csplit;                    // [n_cams][split][256] partial per-camera sums when a camera is split over workgroups
     double *WY;                        // per observation [2][3][10]: scaled W_o = Jc'Jp and Y_o = W_o Vinv, camera index fastest
     int *flag;
 };
@@ -191,16 +192,18 @@ __global__ void k_ba_point_raw(BaDev d)
 // K5: per camera  Uraw = sum Jc'Jc (10x10), gcraw = sum Jc'r ; one workgroup per camera, eight groups of
 // 128 threads: group g stages and sums the 32-observation chunks g, g+8, ... (a camera of the reference's own
 // regime sees thousands of observations), the eight partial sums are added in group order.
+// With few cameras (the reference's regime) a camera is further split over `split` workgroups so that
+// the launch fills the chip; their partial sums go to d.csplit and are added in order by k_ba_cam_fin.
 #define CR_GROUPS 8
-__global__ __launch_bounds__(128 * CR_GROUPS) void k_ba_cam_raw(BaDev d)
+__global__ __launch_bounds__(128 * CR_GROUPS) void k_ba_cam_raw(BaDev d, int split)
 {
     __shared__ double sh[CR_GROUPS][32 * 22];
     __shared__ double part[CR_GROUPS][110];
-    const int c = blockIdx.x, g = threadIdx.x >> 7, t = threadIdx.x & 127;
+    const int c = blockIdx.x / split, sidx = blockIdx.x - c * split, g = threadIdx.x >> 7, t = threadIdx.x & 127;
     // thread t < 110 of a group owns one entry: 0..99 of U (a = t/10, b = t%10), 100..109 of g
     double acc = 0.0;
     const int e0 = d.cam_obs_off[c], e1 = d.cam_obs_off[c + 1];
-    for (int base0 = e0; base0 < e1; base0 += 32 * CR_GROUPS) {      // uniform trip count over the groups
+    for (int base0 = e0 + 32 * CR_GROUPS * sidx; base0 < e1; base0 += 32 * CR_GROUPS * split) {      // uniform trip count over the groups
         const int base = base0 + 32 * g;
         // stage 32 observations' (Jc 20 + r 2) rows in LDS
         __syncthreads();
@@ -235,9 +238,19 @@ __global__ __launch_bounds__(128 * CR_GROUPS) void k_ba_cam_raw(BaDev d)
     if (g == 0 && t < 110) {
         double s = 0.0;
         for (int k = 0; k < CR_GROUPS; ++k) s += part[k][t];
-        if (t < 100) d.Uraw[100 * (size_t)c + t] = s;
+        if (split > 1) d.csplit[((size_t)c * split + sidx) * 256 + t] = s;
+        else if (t < 100) d.Uraw[100 * (size_t)c + t] = s;
         else d.gcraw[10 * (size_t)c + (t - 100)] = s;
     }
+}
+__global__ __launch_bounds__(128) void k_ba_cam_fin(BaDev d, int split)
+{
+    const int c = blockIdx.x, t = threadIdx.x;
+    if (t >= 110) return;
+    double s = 0.0;
+    for (int k = 0; k < split; ++k) s += d.csplit[((size_t)c * split + k) * 256 + t];
+    if (t < 100) d.Uraw[100 * (size_t)c + t] = s;
+    else d.gcraw[10 * (size_t)c + (t - 100)] = s;
 }
 
 // Jacobi scaling (initial point) or clamped LM diagonal (scaled Jacobian) from the raw diagonals
@@ -593,42 +606,55 @@ __global__ __launch_bounds__(512) void k_ba_schur_mfma_wg(BaDev d, const int *of
 // the camera (a pair (o, o)) and the listed pairs of the key (c, c); the 16 partial blocks are
 // summed in wave order and  scaled U + D/radius  is added before the store into S; column 10 of
 // the same product is the camera's reduced right-hand side.
-__global__ __launch_bounds__(1024) void k_ba_schur_diag_mfma(BaDev d, const int *off, const unsigned long long *list, double inv_radius)
+__device__ __forceinline__ void schur_diag_finish(const BaDev &d, int c, int idx, double v, double inv_radius)
+{
+    const int a = idx >> 4, b = idx & 15, dc = d.cam_dim[c], offc = d.cam_off[c];
+    if (a < dc && b < dc) {
+        v += d.Uraw[100 * (size_t)c + 10 * a + b] * d.sc[offc + a] * d.sc[offc + b];
+        if (a == b) v += d.dgc[offc + a] * inv_radius;
+        d.S[(size_t)(offc + a) * d.npad + offc + b] = v;
+    } else if (a < dc && b == 10) {   // reduced right-hand side: scaled gc - sum_o Y_o gp
+        d.rhs[offc + a] = d.gcraw[10 * (size_t)c + a] * d.sc[offc + a] + v;
+    }
+}
+// (`split` > 1: a camera's observations are spread over that many workgroups, see k_ba_cam_raw)
+__global__ __launch_bounds__(1024) void k_ba_schur_diag_mfma(BaDev d, const int *off, const unsigned long long *list, double inv_radius, int split)
 {
     __shared__ double part[16][256];
-    const int c = blockIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int dc = d.cam_dim[c], offc = d.cam_off[c], key = c * d.nc + c;
+    const int c = blockIdx.x / split, sidx = blockIdx.x - c * split, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int dc = d.cam_dim[c], key = c * d.nc + c;
     if (dc == 0) return;
+    const int W = 16 * split, ww = 16 * sidx + w;          // this wave's rank among all the camera's waves
     f64x4 acc = {0.0, 0.0, 0.0, 0.0};
     const int o0 = d.cam_obs_off[c], o1 = d.cam_obs_off[c + 1];
-    for (int base = o0 + w; base < o1; base += 16 * 64) {
-        const int cnt = min(64, (o1 - base + 15) / 16);
+    for (int base = o0 + ww; base < o1; base += W * 64) {
+        const int cnt = min(64, (o1 - base + W - 1) / W);
         unsigned long long pr = 0ull;
-        if (lane < cnt) { const unsigned o = (unsigned)d.cam_obs[base + 16 * lane]; pr = ((unsigned long long)o << 32) | o; }
+        if (lane < cnt) { const unsigned o = (unsigned)d.cam_obs[base + W * lane]; pr = ((unsigned long long)o << 32) | o; }
         acc = schur_mfma_chunk<true, 12>(d.WY, pr, cnt, lane, acc, d.opt, d.gps);
     }
-    for (int base = off[key] + w; base < off[key + 1]; base += 16 * 64) {   // the same camera seen twice by one landmark
-        const int cnt = min(64, (off[key + 1] - base + 15) / 16);
-        const unsigned long long pr = lane < cnt ? list[base + 16 * lane] : 0ull;
+    for (int base = off[key] + ww; base < off[key + 1]; base += W * 64) {   // the same camera seen twice by one landmark
+        const int cnt = min(64, (off[key + 1] - base + W - 1) / W);
+        const unsigned long long pr = lane < cnt ? list[base + W * lane] : 0ull;
         acc = schur_mfma_chunk<false, 12>(d.WY, pr, cnt, lane, acc);
     }
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) part[w][((lane >> 4) + 4 * reg) * 16 + (lane & 15)] = acc[reg];
     __syncthreads();
     if (threadIdx.x < 256) {
-        const int a = threadIdx.x >> 4, b = threadIdx.x & 15;
-        if (a < dc && b < dc) {
-            double v = 0.0;
-            for (int k = 0; k < 16; ++k) v += part[k][threadIdx.x];
-            v += d.Uraw[100 * (size_t)c + 10 * a + b] * d.sc[offc + a] * d.sc[offc + b];
-            if (a == b) v += d.dgc[offc + a] * inv_radius;
-            d.S[(size_t)(offc + a) * d.npad + offc + b] = v;
-        } else if (a < dc && b == 10) {   // reduced right-hand side: scaled gc - sum_o Y_o gp
-            double v = 0.0;
-            for (int k = 0; k < 16; ++k) v += part[k][threadIdx.x];
-            d.rhs[offc + a] = d.gcraw[10 * (size_t)c + a] * d.sc[offc + a] + v;
-        }
+        double v = 0.0;
+        for (int k = 0; k < 16; ++k) v += part[k][threadIdx.x];
+        if (split > 1) d.csplit[((size_t)c * split + sidx) * 256 + threadIdx.x] = v;
+        else schur_diag_finish(d, c, threadIdx.x, v, inv_radius);
     }
+}
+__global__ __launch_bounds__(256) void k_ba_schur_diag_fin(BaDev d, double inv_radius, int split)
+{
+    const int c = blockIdx.x;
+    if (d.cam_dim[c] == 0) return;
+    double v = 0.0;
+    for (int k = 0; k < split; ++k) v += d.csplit[((size_t)c * split + k) * 256 + threadIdx.x];
+    schur_diag_finish(d, c, threadIdx.x, v, inv_radius);
 }
 
 // padded rows of the dense system: identity (the gather form writes every other lower block itself)
@@ -1359,6 +1385,7 @@ struct Ws {   // growable device workspace out of ctx->ba_ws
     hipError_t err = hipSuccess;
     template <class T> T *get(size_t count)
     {
+        if (next >= (int)(sizeof(ctx->ba_ws) / sizeof(ctx->ba_ws[0]))) { err = hipErrorOutOfMemory; return nullptr; }
         DevBuf &b = ctx->ba_ws[next++];
         hipError_t e = b.reserve(std::max<size_t>(count, 1) * sizeof(T));
         if (e != hipSuccess) err = e;
@@ -1479,6 +1506,9 @@ int rcn_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_options *o
     int *pk_cnt = pk, *pk_off = pk + nkeys + 1, *pk_fill = pk + 2 * nkeys + 2, *pk_sums = pk + 3 * (size_t)nkeys + 4;
     unsigned long long *pk_list = ws.get<unsigned long long>(gather ? std::max<size_t>(npairs_lower, 1) : 1);
     d.WY = ws.get<double>(gather ? 60 * (size_t)std::max(no, 1) : 1);
+    // few cameras: split every camera over several workgroups so that the per-camera kernels fill the chip
+    const int csplit = nc >= 128 ? 1 : std::max(1, std::min(16, 512 / std::max(nc, 1)));
+    d.csplit = ws.get<double>((size_t)std::max(nc, 1) * csplit * 256);
     const int eb = (no + 255) / 256, pbk = (std::max(nc, np) + 255) / 256;
     d.partial = ws.get<double>(4 * (size_t)std::max(std::max(eb, pbk), 1) + 16);
     d.scal = ws.get<double>(32);
@@ -1540,7 +1570,8 @@ int rcn_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_options *o
         k_finish_sum<<<1, 256, 0, st>>>(d.partial, no > 0 ? eb : 0, d.scal + slot, 0.5);
         if (jac) {
             if (np > 0) k_ba_point_raw<<<(np + 127) / 128, 128, 0, st>>>(d);
-            k_ba_cam_raw<<<nc, 128 * CR_GROUPS, 0, st>>>(d);
+            k_ba_cam_raw<<<nc * csplit, 128 * CR_GROUPS, 0, st>>>(d, csplit);
+            if (csplit > 1) k_ba_cam_fin<<<nc, 128, 0, st>>>(d, csplit);
         }
         return hipGetLastError();
     };
@@ -1591,7 +1622,8 @@ int rcn_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_options *o
                 if (npairs_lower / (size_t)nlow > 128) k_ba_schur_mfma_wg<<<nlow, 512, 0, st>>>(d, pk_off, pk_list);   // long lists: a workgroup per block
                 else k_ba_schur_mfma<<<(nlow + 3) / 4, 256, 0, st>>>(d, pk_off, pk_list);
             }
-            k_ba_schur_diag_mfma<<<nc, 1024, 0, st>>>(d, pk_off, pk_list, ir);
+            k_ba_schur_diag_mfma<<<nc * csplit, 1024, 0, st>>>(d, pk_off, pk_list, ir, csplit);
+            if (csplit > 1) k_ba_schur_diag_fin<<<nc, 256, 0, st>>>(d, ir, csplit);
             if (npad > n) k_ba_S_pad<<<(npad - n + 127) / 128, 128, 0, st>>>(d);
         } else {
             if (np > 0) k_ba_schur<<<np, std::min(256, std::max(64, 64 * ((kmax * kmax + 7) / 8))), 0, st>>>(d, Sb);

@@ -97,7 +97,7 @@ struct rcn_ctx {
     bool force_exact = false;  // RCN_FORCE_EXACT=1: skip the MFMA coarse pass (diagnostics)
 
     // ---- BA state (ba.hip)
-    DevBuf ba_ws[28];
+    DevBuf ba_ws[40];
     DevBuf lm_ws;              // landmark validity sweep (validity.hip)
     DevBuf fm_ws, fm_state;    // epipolar filter (fmat.hip): host-API staging, per-pair RANSAC state
     DevBuf fm_csr, fm_pairs;   // fused table filter: CSR of the matched points, per-pair coordinate pointers
