@@ -617,7 +617,9 @@ __device__ __forceinline__ void schur_diag_finish(const BaDev &d, int c, int idx
         d.rhs[offc + a] = d.gcraw[10 * (size_t)c + a] * d.sc[offc + a] + v;
     }
 }
-// (`split` > 1: a camera's observations are spread over that many workgroups, see k_ba_cam_raw)
+// (`split` > 1: a camera's observations are spread over that many workgroups, see k_ba_cam_raw; SMB: gather
+// depth, 12 in that latency-bound regime, 4 when a thousand cameras keep the chip full anyway)
+template <int SMB>
 __global__ __launch_bounds__(1024) void k_ba_schur_diag_mfma(BaDev d, const int *off, const unsigned long long *list, double inv_radius, int split)
 {
     __shared__ double part[16][256];
@@ -631,12 +633,12 @@ __global__ __launch_bounds__(1024) void k_ba_schur_diag_mfma(BaDev d, const int 
         const int cnt = min(64, (o1 - base + W - 1) / W);
         unsigned long long pr = 0ull;
         if (lane < cnt) { const unsigned o = (unsigned)d.cam_obs[base + W * lane]; pr = ((unsigned long long)o << 32) | o; }
-        acc = schur_mfma_chunk<true, 12>(d.WY, pr, cnt, lane, acc, d.opt, d.gps);
+        acc = schur_mfma_chunk<true, SMB>(d.WY, pr, cnt, lane, acc, d.opt, d.gps);
     }
     for (int base = off[key] + ww; base < off[key + 1]; base += W * 64) {   // the same camera seen twice by one landmark
         const int cnt = min(64, (off[key + 1] - base + W - 1) / W);
         const unsigned long long pr = lane < cnt ? list[base + W * lane] : 0ull;
-        acc = schur_mfma_chunk<false, 12>(d.WY, pr, cnt, lane, acc);
+        acc = schur_mfma_chunk<false, SMB>(d.WY, pr, cnt, lane, acc);
     }
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) part[w][((lane >> 4) + 4 * reg) * 16 + (lane & 15)] = acc[reg];
@@ -1622,7 +1624,8 @@ int rcn_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_options *o
                 if (npairs_lower / (size_t)nlow > 128) k_ba_schur_mfma_wg<<<nlow, 512, 0, st>>>(d, pk_off, pk_list);   // long lists: a workgroup per block
                 else k_ba_schur_mfma<<<(nlow + 3) / 4, 256, 0, st>>>(d, pk_off, pk_list);
             }
-            k_ba_schur_diag_mfma<<<nc * csplit, 1024, 0, st>>>(d, pk_off, pk_list, ir, csplit);
+            if (csplit > 1) k_ba_schur_diag_mfma<12><<<nc * csplit, 1024, 0, st>>>(d, pk_off, pk_list, ir, csplit);
+            else k_ba_schur_diag_mfma<4><<<nc, 1024, 0, st>>>(d, pk_off, pk_list, ir, 1);
             if (csplit > 1) k_ba_schur_diag_fin<<<nc, 256, 0, st>>>(d, ir, csplit);
             if (npad > n) k_ba_S_pad<<<(npad - n + 127) / 128, 128, 0, st>>>(d);
         } else {
