@@ -192,3 +192,23 @@ def test_power_of_two_scale_invariance(matcher, kind):
     for k in (-40, -7, 9, 33):
         f = np.float32(2.0 ** k)
         assert np.array_equal(matcher.match_pair(ims[0] * f, ims[1] * f), base), k
+
+
+def test_more_than_8192_train_rows_takes_the_generic_path(matcher):
+    """K2 > 8192: the row index no longer fits the 13 packed bits of the coarse pass and the owner table
+    of the uniqueness step no longer fits LDS -- exact kernel + global owner table, same answers."""
+    rng = np.random.default_rng(17)
+    t = rng.standard_normal((9000, 32)).astype(np.float32)
+    q = np.concatenate([t[rng.choice(9000, 200, replace=False)] + 0.05 * rng.standard_normal((200, 32)).astype(np.float32),
+                        rng.standard_normal((150, 32)).astype(np.float32)])
+    q[5] = q[4]                                            # two queries claiming one train row
+    got = matcher.match_pair(q, t)
+    exp, cnt = orc.match_pair(q, t)
+    assert np.array_equal(got, exp) and cnt > 100
+    matcher.clear()
+    matcher.upload(0, q); matcher.upload(1, t)
+    out, counts = matcher.match_grid(np.array([[0, 1], [1, 0]], np.int32), 9000)
+    exp2, c2 = orc.match_grid([q, t], np.array([[0, 1], [1, 0]]), threads=4)
+    assert np.array_equal(out, exp2) and np.array_equal(counts, c2)
+    assert matcher.stats()["used_mfma_path"] == 0
+    matcher.clear()
