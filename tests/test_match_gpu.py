@@ -212,3 +212,11 @@ def test_more_than_8192_train_rows_takes_the_generic_path(matcher):
     assert np.array_equal(out, exp2) and np.array_equal(counts, c2)
     assert matcher.stats()["used_mfma_path"] == 0
     matcher.clear()
+
+
+def test_exactly_8192_rows_still_on_the_mfma_path(matcher):
+    """K = 8192 is the largest image the packed 13-bit row index supports."""
+    ims = synth.descriptor_set("orb", 2, 8192, n_world=20000, seed=23)
+    exp, cnt = orc.match_pair(ims[0], ims[1])
+    assert np.array_equal(matcher.match_pair(ims[0], ims[1]), exp) and cnt > 500
+    assert matcher.stats()["used_mfma_path"] == 1
