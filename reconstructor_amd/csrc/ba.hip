@@ -9,10 +9,13 @@
 //   K4 k_ba_eval          residual (+ analytic 2x(10+3) tangent Jacobian) per observation   [HBM]
 //   K5 k_ba_point_raw / k_ba_cam_raw   J'J blocks and J'r per point / per camera             [HBM]
 //      k_ba_point_solve   V = Vs + D^2/radius, V^-1, per point                               [HBM]
-//   K6 k_ba_schur         S -= (W V^-1)(W')^T over camera pairs of each point (f64 atomics) [atomics]
-//      k_ba_cam_rhs       reduced right-hand side, per camera
-//   K7 k_chol_diag / k_gemm_nt  blocked right-looking Cholesky, v_mfma_f64_16x16x4_f64       [f64 MFMA]
-//      k_trsv_fwd / k_trsv_bwd  blocked triangular solves
+//   K6 k_ba_wy + k_ba_schur_mfma[_wg] + k_ba_schur_diag_mfma   point Schur complement as f64-MFMA
+//      gathers over per-block observation-pair lists built once per solve (k_pair_*), written
+//      straight into the dense reduced system; bit-reproducible                      [L2 gathers / f64 MFMA]
+//      (k_ba_schur + k_ba_S_assemble + k_ba_cam_rhs: the atomic form, RCN_BA_SCHUR_ATOMICS=1)
+//   K7 k_chol_diag -> k_gemm_q<0> -> k_gemm_q<1> (latency chain) beside k_gemm_nt_ring (bulk, second
+//      stream): blocked right-looking Cholesky with lookahead, v_mfma_f64_16x16x4_f64       [f64 MFMA]
+//      k_trsv_bwd (k_trsv_fwd only when the rhs does not ride through the factorisation)
 //   K8 k_ba_backsub, k_ba_model, k_ba_plus, reductions                                       [HBM]
 // The LM control flow on the host follows Ceres' TrustRegionMinimizer / LevenbergMarquardt
 // strategy step by step (same order of tests as the CPU restatement used for parity).
@@ -364,7 +367,7 @@ __global__ __launch_bounds__(256) void k_ba_schur(BaDev d, double *Sb)
 // -- hence the whole solve -- is bit-reproducible from run to run.
 __device__ __forceinline__ bool pair_key(const BaDev &d, int o, int o2, int &key)
 {
-    if (o == o2) return false;   // an observation with itself: walked from the per-camera list (k_ba_schur_diag)
+    if (o == o2) return false;   // an observation with itself: walked from the per-camera list (k_ba_schur_diag_mfma)
     const int c = d.ocam[o], c2 = d.ocam[o2];
     if (c2 > c || d.cam_dim[c] == 0 || d.cam_dim[c2] == 0) return false;
     key = c * d.nc + c2;
