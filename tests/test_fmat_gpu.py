@@ -146,3 +146,32 @@ def test_device_table_filter_equals_host_composition(gpu_ctx):
         m.filter_table_device(np.array([[0, 9]], np.int32), t_d.data_ptr(), stride, c_d.data_ptr())
     assert e.value.code == -5
     m.clear()
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_redraw_heavy_and_degenerate_inputs(gpu_ctx, seed):
+    """Inputs that push the sampler through its rejection paths: points on a coarse integer lattice (most
+    samples have a collinear last point and are redrawn), heavy duplication (few distinct points),
+    large coordinates, and pairs that are exact copies of each other."""
+    rng = np.random.default_rng(seed)
+    off, a, b = [0], [], []
+
+    def add(x, y):
+        a.append(np.asarray(x, np.int32)); b.append(np.asarray(y, np.int32)); off.append(off[-1] + len(x))
+    for n in (15, 40, 90, 300):
+        lat1 = rng.integers(0, 6, (n, 2)) * 40                       # 6 x 6 lattice
+        lat2 = lat1 + rng.integers(-2, 3, (n, 2))
+        add(lat1, lat2)
+    for n in (16, 60, 200):
+        base1, base2, _ = synth_fmat.two_view(8, 0.0, seed=seed * 10 + n)
+        pick = rng.integers(0, 8, n)                                   # only 8 distinct correspondences
+        add(base1[pick], base2[pick])
+    x, y, _ = synth_fmat.two_view(120, 0.3, seed=seed + 50)
+    add(x * 37 + 5000, y * 37 + 5000)                                   # coordinates up to ~25 000
+    add(x, x)                                                          # identical images: F is not unique
+    add(x[:25] * 0, y[:25])                                            # every point of image 1 at the origin
+    off = np.asarray(off, np.int32); A = np.concatenate(a); B = np.concatenate(b)
+    want = of.filter_grid(off, A, B, threads=8)
+    got = fmat.filter_grid(gpu_ctx, off, A, B)
+    assert (got[1] == want[1]).all() and (got[2] == want[2]).all() and (got[0] == want[0]).all()
+    assert (want[1] == -1).any()                                       # some of these admit no model at all
