@@ -80,6 +80,10 @@ def ba_leg(ctx, with_cpu):
                                "sample": "cfg4 full solve (%d iterations, %.2f s), oracle/ba_oracle.c" % (s["iterations"], time.perf_counter() - t0),
                                "final_rms_px": s["final_rms_px"]}
         out["cfg4"]["rms_diff_vs_cpu_px"] = abs(out["cfg4"]["final_rms_px"] - s["final_rms_px"])
+        t0 = time.perf_counter()
+        P, I, X, s4 = orc_ba.solve(sc4, threads=4)      # options.num_threads = 4 in the reference (BundleAdjuster.cpp:134)
+        out["cpu_baseline"]["at_reference_thread_count"] = {"value": s4["iterations"] / s4["solve_seconds"], "cores": 4,
+                                                            "sample": "cfg4 full solve, %.2f s" % (time.perf_counter() - t0)}
     out["landmark_sweep"] = sweep_leg(ctx, with_cpu)
     return out
 
