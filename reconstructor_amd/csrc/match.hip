@@ -26,6 +26,7 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 #define RCN_QT 512          // query rows per workgroup (8 waves x 64)
 #define RCN_GROUP 4         // consecutive pairs (same query image) swept by one workgroup
+#define RCN_TBL_BYTES ((RCN_GROUP * 24 + 127) / 128 * 128)   // LDS table of the group's train-image records
 #define RCN_NBUF 4          // LDS ring depth (train tiles)
 #define RCN_PD 2            // prefetch distance, tiles
 #define RCN_CHUNKS 4        // pair-list chunks: coarse(c+1) overlaps re-rank(c)
@@ -237,6 +238,7 @@ __global__ __launch_bounds__(512, 2) void k_coarse_top2(CoarseArgs a)
     // per-pair train image records, read once with ordinary loads and parked in LDS: inside the
     // tile loop nothing but LDS-DMA may sit on the vector-memory queue (counted vmcnt)
     struct TrainRec { const char *f16; const float *hn; int nT; int pad; };
+    static_assert(sizeof(TrainRec) * RCN_GROUP <= RCN_TBL_BYTES, "train-record table does not fit its LDS slot");
     TrainRec *tbl = reinterpret_cast<TrainRec *>(smem + RCN_NBUF * BUFB);
     if (tid < R) {
         const ImgDev ti = a.imgs[a.pairs[2 * (p0 + tid) + 1]];
@@ -1168,7 +1170,7 @@ static int prepare_all(rcn_ctx *ctx)
 
 template <int DP, int ABL = 0> static hipError_t launch_coarse(rcn_ctx *ctx, const CoarseArgs &ca, int blocks)
 {
-    const size_t lds = (size_t)RCN_NBUF * (RCN_BT * DP * 2 + 8 * 256) + 128;
+    const size_t lds = (size_t)RCN_NBUF * (RCN_BT * DP * 2 + 8 * 256) + RCN_TBL_BYTES;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_coarse_top2<DP, ABL>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
