@@ -57,6 +57,8 @@ int rcn_create(int device_id, rcn_ctx **out)
     ctx->ba_ev_made = true;
     const char *fe = std::getenv("RCN_FORCE_EXACT");
     ctx->force_exact = fe && fe[0] == '1';
+    const char *nio = getenv("RCN_MATCH_NO_ORDER");
+    ctx->no_item_order = nio && nio[0] == '1';
     const char *ab = std::getenv("RCN_COARSE_ABL");
     ctx->ablate = ab ? std::atoi(ab) : 0;
     const char *bat = std::getenv("RCN_BA_SCHUR_ATOMICS");

@@ -211,6 +211,7 @@ __global__ __launch_bounds__(512, 2) void k_coarse_top2(CoarseArgs a)
     const int grp = item / a.tiles_per_pair, qt = item - grp * a.tiles_per_pair;
     const int2 g = a.groups[grp];
     const int p0 = g.x, R = g.y;
+    if (R == 0) return;                                      // padding slot of the item order
     const ImgDev qi = a.imgs[a.pairs[2 * p0]];
     if (qt * RCN_QT >= qi.K) return;
 
@@ -1265,13 +1266,33 @@ static int match_grid_impl(rcn_ctx *ctx, const int32_t *pairs_host, int32_t n_pa
         groups.push_back(make_int2(p, cnt));
         p += cnt;
     }
-    RCN_HIP(ctx->groups_dev.reserve(groups.size() * sizeof(int2)));
-    RCN_HIP(hipMemcpyAsync(ctx->groups_dev.p, groups.data(), groups.size() * sizeof(int2), hipMemcpyHostToDevice, ctx->stream));
-
     // Chunks of the pair list: the MFMA-bound coarse kernel of chunk c+1 (main stream) runs
     // beside the memory-bound filter / exact re-rank / uniqueness of chunk c (auxiliary stream).
     const int n_groups = (int)groups.size();
     const int n_chunks = (mfma && n_groups >= 64 && kq_max > 0) ? std::max(1, std::min(RCN_CHUNKS, ctx->chunks)) : 1;
+    // Order of the work items (single-chunk launches): every XCD walks its own contiguous range of the
+    // group list, heaviest groups first, so that the last items to start are the short ones (the tail
+    // of a launch is one item long: 5 % of a cfg-2 grid for a four-pair group, 1 % for a one-pair group).
+    // Groups are dealt to the XCD ranges round-robin in descending weight; unused slots hold empty groups.
+    int n_groups_dev = n_groups;
+    {
+        std::vector<int2> &arr = ctx->groups_arranged;
+        if (n_chunks == 1 && mfma && n_groups >= 64 && !ctx->no_item_order) {
+            std::vector<std::pair<int64_t, int>> order((size_t)n_groups);
+            for (int g = 0; g < n_groups; ++g) {
+                int64_t wgt = 0;
+                for (int r = 0; r < groups[g].y; ++r) wgt += ctx->images.find(pairs_host[2 * (groups[g].x + r) + 1])->second.K;
+                order[g] = std::make_pair(-wgt, g);
+            }
+            std::stable_sort(order.begin(), order.end());
+            const int gpx = (n_groups + 7) / 8;
+            arr.assign((size_t)8 * gpx, make_int2(0, 0));
+            for (int k = 0; k < n_groups; ++k) arr[(size_t)(k % 8) * gpx + k / 8] = groups[order[k].second];
+            n_groups_dev = 8 * gpx;
+        } else arr = groups;
+        RCN_HIP(ctx->groups_dev.reserve(arr.size() * sizeof(int2)));
+        RCN_HIP(hipMemcpyAsync(ctx->groups_dev.p, arr.data(), arr.size() * sizeof(int2), hipMemcpyHostToDevice, ctx->stream));
+    }
     hipStream_t sa = ctx->stream, sb = n_chunks > 1 ? ctx->aux_stream : ctx->stream;
     unsigned *ccnt = ctx->counters.as<unsigned>() + 8;     // per chunk: [2c] fallback count, [2c+1] survivor count
     RCN_HIP(hipMemsetAsync(ccnt, 0, 2 * RCN_CHUNKS * sizeof(unsigned), sa));
@@ -1288,9 +1309,10 @@ static int match_grid_impl(rcn_ctx *ctx, const int32_t *pairs_host, int32_t n_pa
         if (mfma) {
             CoarseArgs ca;
             ca.imgs = imgs; ca.pairs = pairs; ca.cand = ctx->cand.as<uint2>();
+            const int ng_c = n_chunks == 1 ? n_groups_dev : g1 - g0;
             ca.groups = ctx->groups_dev.as<int2>() + g0;
-            ca.n_groups = g1 - g0; ca.tiles_per_pair = tiles; ca.kq_stride = kq_stride;
-            const int64_t items = (int64_t)(g1 - g0) * tiles;
+            ca.n_groups = ng_c; ca.tiles_per_pair = tiles; ca.kq_stride = kq_stride;
+            const int64_t items = (int64_t)ng_c * tiles;
             ca.items_per_xcd = (int)((items + 7) / 8);
             ca.idx_mask = idx_mask;
             const int blocks = ca.items_per_xcd * 8;

@@ -81,7 +81,7 @@ struct rcn_ctx {
     int32_t D = 0, DP = 0;
     std::map<int32_t, ImgHost> images;
     std::vector<Slab> slabs;
-    std::vector<int2> groups_host;   // kept alive: uploaded asynchronously
+    std::vector<int2> groups_host, groups_arranged;   // kept alive: uploaded asynchronously
     bool prepared = false;
     double scale = 0.0;      // s, power of two (0 = nothing prepared yet)
     double bias = 0.0;       // BIAS in accumulator units
@@ -95,6 +95,7 @@ struct rcn_ctx {
     int ablate = 0;            // RCN_COARSE_ABL (diagnostics)
     int chunks = 1;            // RCN_MATCH_CHUNKS: >1 overlaps re-rank(c) with coarse(c+1) on two streams
     bool force_exact = false;  // RCN_FORCE_EXACT=1: skip the MFMA coarse pass (diagnostics)
+    bool no_item_order = false;   // RCN_MATCH_NO_ORDER=1: work items in pair order instead of heaviest-first per XCD (diagnostics)
 
     // ---- BA state (ba.hip)
     DevBuf ba_ws[40];
