@@ -168,3 +168,18 @@ def test_alternative_device_paths_agree(gpu_ctx, env, monkeypatch):
     assert s1["iterations"] == s0["iterations"]
     assert abs(s1["final_rms_px"] - s0["final_rms_px"]) < 1e-9
     assert np.allclose(P1, P0, rtol=0, atol=1e-8) and np.allclose(X1, X0, rtol=0, atol=1e-7)
+
+
+def test_rejected_steps_follow_the_oracle(gpu_ctx):
+    """A badly initialised, noisy scene: the trust region shrinks through unsuccessful steps; the GPU loop
+    must take the same accept / reject decisions as the CPU restatement (same iteration trace)."""
+    from reconstructor_amd import ba
+    sc = synth_ba.make_scene(10, 200, obs_per_point=5, seed=40, noise_px=2.0, perturb=(0.8, 3.0, 2.5))   # 47 accepted, 3 rejected, hits the 50-iteration cap
+    P0, I0, X0, s0 = orc_ba.solve(sc, threads=4)
+    P1, I1, X1, s1 = ba.solve_scene(gpu_ctx, sc)
+    assert s0["unsuccessful_steps"] + s0["invalid_steps"] > 0, "the scene is meant to produce rejected steps"
+    assert s1["iterations"] == s0["iterations"] and s1["successful_steps"] == s0["successful_steps"]
+    assert s1["unsuccessful_steps"] == s0["unsuccessful_steps"] and s1["termination"] == s0["termination"]
+    n = min(len(s0["cost_trace"]), len(s1["cost_trace"]), 12)
+    assert np.allclose(s1["cost_trace"][:n], s0["cost_trace"][:n], rtol=1e-6)       # the early trace; 50 chaotic iterations amplify rounding
+    assert abs(s1["final_rms_px"] - s0["final_rms_px"]) <= 1e-3 * s0["final_rms_px"]
