@@ -78,7 +78,8 @@ int rcn_match_pair(rcn_ctx *ctx, const float *q_host, int32_t K1,
 /* Pair grid over resident images (SequentialReconstructor.cpp:199-279).  pairs = n_pairs x
  * (query image id, train image id) on the HOST.  out = n_pairs rows of out_stride int32 on
  * the HOST (out_stride >= K of every query image; tail of each row is set to -1),
- * counts[p] = matches of pair p.                                                          */
+ * counts[p] = matches of pair p.  pairs_host == NULL: the reference's canonical grid, every
+ * i < j over the resident image ids in ascending order; n_pairs must then be n (n - 1) / 2.  */
 int rcn_match_grid(rcn_ctx *ctx, const int32_t *pairs_host, int32_t n_pairs, float ratio,
                    int32_t *out_host, int64_t out_stride, int32_t *counts_host);
 

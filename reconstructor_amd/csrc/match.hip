@@ -1182,6 +1182,20 @@ template <int DP, int ABL = 0> static hipError_t launch_coarse(rcn_ctx *ctx, con
 static int match_grid_impl(rcn_ctx *ctx, const int32_t *pairs_host, int32_t n_pairs, float ratio,
                            int32_t *out_dev, int64_t out_stride, int32_t *counts_dev)
 {
+    // pairs == NULL: the canonical grid of the reference's pair loop (SequentialReconstructor.cpp:202-227
+    // with FakeImgMatcher, ImageMatcher.cpp:6-23): every i < j over the resident image ids in ascending order
+    if (!pairs_host && n_pairs > 0) {
+        std::vector<int32_t> ids;
+        for (const auto &kv : ctx->images)
+            if (kv.first != INT32_MIN && kv.first != INT32_MIN + 1) ids.push_back(kv.first);
+        const int64_t want = (int64_t)ids.size() * ((int64_t)ids.size() - 1) / 2;
+        if (want != n_pairs) { ctx->set_error("rcn_match_grid: pairs == NULL needs n_pairs = n (n - 1) / 2 over the resident images"); return RCN_ERR_ARG; }
+        std::vector<int32_t> &all = ctx->all_pairs_host;
+        all.clear();
+        for (size_t i = 0; i < ids.size(); ++i)
+            for (size_t j = i + 1; j < ids.size(); ++j) { all.push_back(ids[i]); all.push_back(ids[j]); }
+        pairs_host = all.data();
+    }
     if (n_pairs < 0 || (n_pairs > 0 && (!pairs_host || !out_dev || !counts_dev))) {
         ctx->set_error("rcn_match_grid: bad argument");
         return RCN_ERR_ARG;
@@ -1448,7 +1462,7 @@ int rcn_match_grid(rcn_ctx *ctx, const int32_t *pairs_host, int32_t n_pairs, flo
 {
     if (!ctx) return RCN_ERR_ARG;
     std::lock_guard<std::mutex> lk(ctx->mu);
-    if (n_pairs < 0 || (n_pairs > 0 && (!pairs_host || !out_host || !counts_host)) || out_stride < 0) {
+    if (n_pairs < 0 || (n_pairs > 0 && (!out_host || !counts_host)) || out_stride < 0) {
         ctx->set_error("rcn_match_grid: bad argument");
         return RCN_ERR_ARG;
     }

@@ -82,6 +82,7 @@ struct rcn_ctx {
     std::map<int32_t, ImgHost> images;
     std::vector<Slab> slabs;
     std::vector<int2> groups_host, groups_arranged;   // kept alive: uploaded asynchronously
+    std::vector<int32_t> all_pairs_host;              // the canonical i < j grid when the caller passes pairs == NULL
     bool prepared = false;
     double scale = 0.0;      // s, power of two (0 = nothing prepared yet)
     double bias = 0.0;       // BIAS in accumulator units

@@ -109,6 +109,14 @@ class HipL2Matcher(FeatureMatcher):
                                                    out.ctypes.data, out.shape[1], counts.ctypes.data))
         return out, counts[:P]
 
+    def match_all_pairs(self, n_images, out_stride):
+        """The reference's canonical grid (every i < j over the resident images, ascending ids): pairs = NULL."""
+        P = n_images * (n_images - 1) // 2
+        out = np.full((max(P, 1), max(1, out_stride)), -1, np.int32)
+        counts = np.zeros(max(P, 1), np.int32)
+        self.ctx.check(self.ctx.lib.rcn_match_grid(self.ctx.h, None, P, self.ratio, out.ctypes.data, out.shape[1], counts.ctypes.data))
+        return out[:P], counts[:P]
+
     def match_grid_device(self, pairs, out_dev_ptr, out_stride, counts_dev_ptr):
         """Asynchronous on the ctx stream; results stay in HBM."""
         pairs = np.ascontiguousarray(pairs, np.int32).reshape(-1, 2)

@@ -220,3 +220,20 @@ def test_exactly_8192_rows_still_on_the_mfma_path(matcher):
     exp, cnt = orc.match_pair(ims[0], ims[1])
     assert np.array_equal(matcher.match_pair(ims[0], ims[1]), exp) and cnt > 500
     assert matcher.stats()["used_mfma_path"] == 1
+
+
+def test_null_pair_list_is_the_canonical_grid(matcher):
+    """pairs == NULL: every i < j over the resident ids in ascending order (the reference's pair loop)."""
+    ims = synth.descriptor_set("superpoint", 5, [90, 130, 70, 110, 60], n_world=300, seed=3)
+    matcher.clear()
+    ids = [7, 2, 11, 5, 3]
+    for i, im in zip(ids, ims):
+        matcher.upload(i, im)
+    out, counts = matcher.match_all_pairs(5, 130)
+    order = sorted(range(5), key=lambda k: ids[k])
+    pairs = [(order[a], order[b]) for a in range(5) for b in range(a + 1, 5)]
+    exp, ec = orc.match_grid(ims, np.array(pairs), threads=2)
+    assert np.array_equal(out[:, :exp.shape[1]], exp) and np.array_equal(counts, ec)
+    with pytest.raises(Exception):
+        matcher.ctx.check(matcher.ctx.lib.rcn_match_grid(matcher.ctx.h, None, 7, 0.7, out.ctypes.data, 130, counts.ctypes.data))
+    matcher.clear()
