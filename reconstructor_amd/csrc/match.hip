@@ -120,11 +120,18 @@ __global__ void k_prepare(const float *__restrict__ x, const double *__restrict_
     int row = gid / CPR, c = gid % CPR;
     if (row >= Kp) return;
     half8 v;
+    if (row < K && c * 8 + 8 <= D && (D & 3) == 0) {      // whole chunk inside the row, 16-B aligned: two float4 loads
+        const float4 lo = *reinterpret_cast<const float4 *>(x + (size_t)row * D + c * 8);
+        const float4 hi = *reinterpret_cast<const float4 *>(x + (size_t)row * D + c * 8 + 4);
+        v[0] = (_Float16)(lo.x * scale); v[1] = (_Float16)(lo.y * scale); v[2] = (_Float16)(lo.z * scale); v[3] = (_Float16)(lo.w * scale);
+        v[4] = (_Float16)(hi.x * scale); v[5] = (_Float16)(hi.y * scale); v[6] = (_Float16)(hi.z * scale); v[7] = (_Float16)(hi.w * scale);
+    } else {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        int k = c * 8 + e;
-        float f = (row < K && k < D) ? x[(size_t)row * D + k] * scale : 0.f;
-        v[e] = (_Float16)f;  // round to nearest even
+        for (int e = 0; e < 8; ++e) {
+            int k = c * 8 + e;
+            float f = (row < K && k < D) ? x[(size_t)row * D + k] * scale : 0.f;
+            v[e] = (_Float16)f;  // round to nearest even
+        }
     }
     *reinterpret_cast<half8 *>(f16 + (size_t)row * DP + ((c ^ swz<DP>(row)) * 8)) = v;
     if (c == 0) hn[row] = row < K ? (float)(half_s2 * nrm2[row] + bias) : RCN_PAD_HN;
