@@ -1,20 +1,25 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark: descriptor pair-distances/s of the all-pairs matcher.
 
-Workload (BASELINE.json configs[1]): synthetic 100 images x 2048 SuperPoint-like 256-d
-keypoints, exact brute-force L2 2-NN + ratio + uniqueness over all 4950 image pairs.
-One "step" = one pass of the hot path over the whole pair grid, descriptors resident in HBM,
-match tables left in HBM.
+Workload at EVERY N (strong scaling): BASELINE.json configs[2], the configuration the metric's
+"@1/2/4/8 GPU" is quoted on and which fits one GPU -- synthetic 1000 images x 4096 SuperPoint-like
+256-d keypoints, exact brute-force L2 2-NN + ratio + uniqueness over all 499 500 image pairs.
+One "step" = one pass of the hot path over the whole grid, through the sharded-grid C ABI
+(rcn_shard_*, csrc/shard.hip) at every N including 1:
+    exchange   each rank's block of fp32 descriptors is resident in HBM when the step starts; row
+               statistics, RCCL all-reduce of the scale statistics, fp16 conversion of the local
+               block, in-place RCCL all-gather of the fp16 payload (+ fp32 rows on a side stream)
+    match      this rank's share of the canonical grid (pair number p -> rank p % N)
+    materialise  (query, train) lists compacted on the GPU and copied to pinned host memory
+               ("incl. result materialisation on host"); the copy of step k overlaps step k+1
+The N = 1 line also carries configs[1] (100 x 2048 x 256, 4950 pairs) under "cfg2", the CPU baseline,
+the BA legs (cfg 4 / cfg 5; BA does not shard: "replicas only") and the two widened rows.
 
   python bench.py [--gpus N] [--steps K] [--warmup W]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-N > 1 (weak scaling): the image count grows as 100*sqrt(N) so every rank keeps ~4950 pairs.
-Each rank owns n/N images ("detected locally"), one RCCL all-gather over xGMI replicates
-the descriptors, then the pair list is dealt round-robin to ranks; no other exchange.  Every
-timed step gathers, ingests and matches one whole batch; the all-gather of batch k+1 runs on a
-side stream into a second landing buffer while batch k is matched (double buffering).
-Prints ONE JSON line on rank 0.
+Control plane (rendezvous id, barriers, max-over-ranks time): torch.distributed / gloo.  Data plane:
+RCCL called directly from librcn.so.  Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
@@ -28,26 +33,70 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-K_PER_IMAGE = 2048
 D = 256
-N_IMAGES_1GPU = 100
+WORKLOADS = {"cfg3": (1000, 4096), "cfg2": (100, 2048)}     # BASELINE.json configs[2] / configs[1]: images, keypoints per image
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 MFMA_F16_PEAK_TFLOPS = 2500.0  # dense bf16/f16 MFMA peak (same guide)
 
 
 def host_threads():
     """Threads for the CPU baselines: the GPU box's CPU share for one GPU is 16 cores even though
-    the affinity mask lists every core of the host."""
+    the affinity mask lists every core of the host (a cap, not nproc: both are in the line)."""
     return max(1, min(16, len(os.sched_getaffinity(0))))
 
 
+def host_info():
+    model = "?"
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                model = ln.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return {"cpu_model": model, "nproc": os.cpu_count(), "affinity": len(os.sched_getaffinity(0)), "threads_used_cap": 16}
+
+
+def source_hash():
+    """Identity of the binary: sha256 over the sources librcn.so is built from.  Profile summaries under
+    profiles/ carry the hash they were taken at; a counter-derived figure is quoted only when it matches."""
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(os.listdir(os.path.join(ROOT, "reconstructor_amd", "csrc")))
+    for f in files:
+        if f.endswith((".hip", ".h")):
+            h.update(f.encode())
+            h.update(open(os.path.join(ROOT, "reconstructor_amd", "csrc", f), "rb").read())
+    h.update(open(os.path.join(ROOT, "include", "rcn.h"), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def measured_traffic(kernel_key):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes -- only if that
+    profile was taken on THIS source (else None: a stale file is not a measurement of this run)."""
+    path = os.path.join(ROOT, "profiles", "r02_match_traffic.json")
+    if not os.path.exists(path):
+        return None, "no PMC profile committed for this round"
+    d = json.load(open(path))
+    if d.get("source_hash") != source_hash():
+        return None, "profiles/r02_match_traffic.json was taken at source %s, this binary is %s: not quoted" % (d.get("source_hash"), source_hash())
+    e = d.get(kernel_key)
+    if not e:
+        return None, "no entry for " + kernel_key
+    return e["traffic_bytes_per_launch"], e.get("note", "")
+
+
 def cpu_baseline(images, n_threads):
-    """Oracle (CPU restatement, kind "port") on a bounded sample of the same workload: about ten
-    seconds at all of the box's cores for this GPU, plus the reference's own thread count
-    (MAX_NUM_THREADS = 4, SequentialReconstructor.h:17) on a smaller sample."""
+    """Oracle (CPU restatement, kind "port"; rebuilt -march=native on this box) on a bounded sample of the
+    same workload: about ten seconds at the box's cores for this GPU, plus the reference's own thread
+    count (MAX_NUM_THREADS = 4, SequentialReconstructor.h:17) on a smaller sample."""
     from oracle import orc
-    allp = orc.all_pairs(len(images))
+    orc.build(native=True)
+    n = len(images)
+    allp = np.array([(i, j) for i in range(n) for j in range(i + 1, n)], np.int32)
     rng = np.random.default_rng(0)
+    K = images[0].shape[0]
+    scale = (2048 * 2048) / float(K * K)        # pairs of the sample shrink with the pair size
 
     def timed(n_pairs, threads):
         pick = allp[rng.choice(len(allp), size=min(n_pairs, len(allp)), replace=False)]
@@ -57,11 +106,12 @@ def cpu_baseline(images, n_threads):
         return sum(images[a].shape[0] * images[b].shape[0] for a, b in pick) / dt, len(pick), dt
 
     orc.match_grid(images, allp[:n_threads], threads=n_threads)  # warm (page-in, transposes)
-    v, n, dt = timed(100 * n_threads, n_threads)
-    v4, n4, dt4 = timed(96, 4)
+    v, n, dt = timed(max(n_threads, int(100 * n_threads * scale)), n_threads)
+    v4, n4, dt4 = timed(max(4, int(96 * scale)), 4)
     return {"value": v, "unit": "pair-distances/s", "cores": n_threads, "kind": "port",
-            "sample": "%d of %d image pairs (2048x2048x256 each), oracle/match_oracle.c, OpenMP over pairs, %.1f s"
-                      % (n, len(allp), dt),
+            "sample": "%d image pairs (%dx%dx256 each) among the first %d images of the workload, oracle/match_oracle.c (-O3 -march=native), OpenMP over pairs, %.1f s"
+                      % (n, K, K, len(images), dt),
+            "host": host_info(),
             "at_reference_thread_count": {"value": v4, "cores": 4, "sample": "%d pairs, %.1f s" % (n4, dt4)}}
 
 
@@ -185,20 +235,126 @@ def sweep_leg(ctx, with_cpu):
     return out
 
 
+class PinnedLists:
+    """Pinned host buffers (rcn_host_alloc) for the materialised match lists; two alternate so that the host
+    could still read step k's lists while step k+1's copy is in flight."""
+
+    def __init__(self, ctx, n_pairs, capacity):
+        import ctypes as C
+        self.ctx, self.C = ctx, C
+        self.capacity = int(capacity)
+        self.offs = [np.zeros(n_pairs + 1, np.int64) for _ in range(2)]
+        self.ptr = []
+        for _ in range(2):
+            p = C.c_void_p()
+            ctx.check(ctx.lib.rcn_host_alloc(C.byref(p), 8 * max(1, self.capacity)))
+            self.ptr.append(p)
+        self.k = 0
+        self.total = C.c_int64(0)
+
+    def begin(self, table_ptr, stride, counts_ptr, n_pairs):
+        C = self.C
+        b = self.k & 1
+        self.k += 1
+        self.ctx.check(self.ctx.lib.rcn_match_compact_begin(self.ctx.h, C.c_void_p(table_ptr), stride, C.c_void_p(counts_ptr), n_pairs,
+                                                            self.offs[b].ctypes.data, self.ptr[b], self.capacity, C.byref(self.total)))
+        return self.total.value
+
+    def wait(self):
+        self.ctx.check(self.ctx.lib.rcn_match_compact_wait(self.ctx.h))
+
+    def close(self):
+        for p in self.ptr:
+            self.ctx.lib.rcn_host_free(p)
+
+
+def run_grid(torch, dist, dev, shard, n_img, K, local_dev, steps, warmup, world, materialise=True):
+    """warmup + `steps` timed steps of exchange -> match -> materialise through the sharded-grid ABI.
+    Returns (seconds of the timed region on this rank, stats of the timed steps, matches found, lists bytes)."""
+    ctx = shard.ctx
+    shard.reserve(n_img, K, D)
+    info0 = shard.info()
+    P = info0["n_pairs"]
+    out = torch.empty((max(P, 1), K), dtype=torch.int32, device=dev)
+    counts = torch.zeros((max(P, 1),), dtype=torch.int32, device=dev)
+    torch.cuda.synchronize(dev)
+    lists = None
+
+    def fence():
+        ctx.check(ctx.lib.rcn_synchronize(ctx.h))
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    def step():
+        nonlocal lists
+        shard.exchange(local_dev.data_ptr())
+        shard.match(0.7, out.data_ptr(), K, counts.data_ptr())
+        if materialise and P > 0:
+            if lists is None:          # first step sizes the pinned buffers (same data every step: same total)
+                ctx.check(ctx.lib.rcn_synchronize(ctx.h))
+                lists = PinnedLists(ctx, P, int(counts[:P].sum().item()))
+            lists.begin(out.data_ptr(), K, counts.data_ptr(), P)
+
+    for _ in range(warmup):
+        step()
+    if lists is None and materialise and P > 0:      # warmup 0: size the buffers outside the timed region
+        step()
+    if lists is not None:
+        lists.wait()
+    fence()
+    from reconstructor_amd.matcher import HipL2Matcher
+    m = HipL2Matcher(ctx=ctx)
+    m.stats()                 # clears counters
+    m.profile(True)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    if lists is not None:
+        lists.wait()          # the last step's lists have landed in host memory
+    fence()
+    dt = time.perf_counter() - t0
+    st = m.stats()
+    m.profile(False)
+    n_matches = int(counts[:P].sum().item()) if P else 0
+    list_bytes = 8 * (lists.total.value if lists is not None else 0)
+    if lists is not None:
+        lists.close()
+    return dt, st, n_matches, list_bytes, shard.info()
+
+
+def grid_line(K, n_img, n_pairs_total, dt, steps, st, world, my_pairs):
+    """value / roofline of one measured grid (pair-distances of the whole job per second; K1 against the f16 MFMA peak)."""
+    pd_job = float(n_pairs_total) * K * K
+    calls = max(1, st["profiled_calls"])
+    coarse_ms = st["coarse_ms"] / calls
+    flops = 2.0 * D * float(st["pair_distances"])      # SURVEY 8(d): 2*D flop per pair-distance, this rank's launch
+    achieved = flops / (coarse_ms * 1e-3) / 1e12 if coarse_ms > 0 else 0.0
+    traffic, tnote = measured_traffic("k_coarse_top2<256>@%dx%d" % (n_img, K)) if world == 1 else (None, "PMC passes are single-GPU")
+    roof = {"bound": "mfma", "kernel": "k_coarse_top2<256>", "achieved": achieved, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": achieved / MFMA_F16_PEAK_TFLOPS, "traffic": traffic,
+            "traffic_note": "HBM bytes per launch from rocprofv3 --pmc passes on this exact source (profiles/r02_match_traffic.json); " + str(tnote),
+            "algorithmic_hbm_bytes_per_launch": float(n_img) * K * D * 2 + 8.0 * float(st["rows_total"]),
+            "launch_ms": coarse_ms, "rerank_ms": st["rerank_ms"] / calls, "unique_ms": st["unique_ms"] / calls,
+            "source_hash": source_hash()}
+    return pd_job * steps / dt, dt / steps * 1e3, roof
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
     ap.add_argument("--images", type=int, default=0, help="override image count (debug)")
-    ap.add_argument("--kpts", type=int, default=0, help="override keypoints per image (debug, e.g. 4096 = cfg3 shape)")
+    ap.add_argument("--kpts", type=int, default=0, help="override keypoints per image (debug)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-ba", action="store_true", help="skip the BA leg (cfg 4 + cfg 5 LM iterations/s)")
+    ap.add_argument("--no-ba", action="store_true", help="skip the BA / epipolar / sweep legs")
+    ap.add_argument("--no-cfg2", action="store_true", help="skip the configs[1] sub-measurement of the N = 1 line")
     args = ap.parse_args()
 
-    global K_PER_IMAGE
-    if args.kpts:
-        K_PER_IMAGE = args.kpts
     import torch
     import torch.distributed as dist
 
@@ -207,158 +363,94 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit("--gpus must equal WORLD_SIZE")
-    # REHEARSAL ONLY (one-GPU box): RCN_BENCH_REHEARSE=1 maps every rank to device 0 and moves the
-    # all-gather through the host with gloo, so the rest of the N>1 path can be exercised.
-    rehearse = os.environ.get("RCN_BENCH_REHEARSE") == "1"
-    if rehearse:
-        local_rank = 0
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if rehearse:
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=dev)
+        dist.init_process_group("gloo")        # control plane only; the data plane is RCCL inside librcn.so
 
-    from reconstructor_amd import synth
-    from reconstructor_amd.matcher import HipL2Matcher, all_pairs
-    from reconstructor_amd import pairgrid
+    from reconstructor_amd import _lib, pairgrid, synth
 
-    n_img = args.images or int(round(N_IMAGES_1GPU * math.sqrt(world)))
-    n_img = (n_img + world - 1) // world * world if world > 1 else n_img
-    matcher = HipL2Matcher(device=local_rank)
-    stream = torch.cuda.current_stream(dev)
-    matcher.ctx.check(matcher.ctx.lib.rcn_set_stream(matcher.ctx.h, stream.cuda_stream))
+    n_img, K = WORKLOADS[args.workload]
+    n_img, K = args.images or n_img, args.kpts or K
+    ctx = _lib.Context(local_rank)
+    # rendezvous: rank 0 draws the RCCL id, the control plane hands it round
+    uid = [pairgrid.unique_id() if rank == 0 else None]
+    if world > 1:
+        dist.broadcast_object_list(uid, src=0)
+    shard = pairgrid.Shard(ctx, rank, world, uid[0])
 
     # ---- inputs: every rank generates only the images it "detected"
     lo, hi = pairgrid.owned_images(n_img, world, rank)
-    pool = synth.world_pool("superpoint", 4 * K_PER_IMAGE, seed=1234)
-    local = np.stack([synth.image_descriptors("superpoint", i, K_PER_IMAGE, pool, seed=1234)
-                      for i in range(lo, hi)])
-    local_dev = torch.from_numpy(local).to(dev)
-    pairs = all_pairs(n_img)
-    my_pairs = pairgrid.shard_pairs(pairs, world, rank)
-    out = torch.empty((len(my_pairs), K_PER_IMAGE), dtype=torch.int32, device=dev)
-    counts = torch.empty((len(my_pairs),), dtype=torch.int32, device=dev)
-    # N > 1: two landing buffers; the all-gather of batch k+1 runs on a side stream (RCCL over
-    # xGMI) while batch k is being matched -- every step still gathers, ingests and matches
-    # one whole batch inside the timed region.
-    gathered = [torch.empty((n_img, K_PER_IMAGE, D), dtype=torch.float32, device=dev) for _ in range(2)] if world > 1 else None
-    comm_stream = torch.cuda.Stream(device=dev) if world > 1 else None
-    pending = [None, None]
-    state = {"k": 0, "overlap": world > 1 and not rehearse}
+    pool = synth.world_pool("superpoint", 4 * K, seed=1234)
+    local = np.stack([synth.image_descriptors("superpoint", i, K, pool, seed=1234) for i in range(lo, hi)]) if hi > lo \
+        else np.zeros((0, K, D), np.float32)
+    local_dev = torch.from_numpy(local).to(dev) if hi > lo else torch.zeros((1, K, D), dtype=torch.float32, device=dev)
+    n_pairs_total = n_img * (n_img - 1) // 2
 
-    def launch_gather(slot):
-        """Start the all-gather of the next batch into gathered[slot] (asynchronous)."""
-        if rehearse:
-            host = torch.empty(gathered[slot].shape, dtype=torch.float32)
-            dist.all_gather_into_tensor(host.view(-1), local_dev.cpu().view(-1))
-            gathered[slot].copy_(host)
-            pending[slot] = None
-            return
-        if state["overlap"]:
-            try:
-                comm_stream.wait_stream(torch.cuda.current_stream(dev))   # slot's previous readers are queued before this point
-                with torch.cuda.stream(comm_stream):
-                    pending[slot] = dist.all_gather_into_tensor(gathered[slot].view(-1), local_dev.view(-1), async_op=True)
-                return
-            except Exception as exc:   # fall back to the in-line collective
-                state["overlap"] = False
-                sys.stderr.write("bench: async all-gather unavailable (%s); using the in-line collective\n" % exc)
-        dist.all_gather_into_tensor(gathered[slot].view(-1), local_dev.view(-1))
-        pending[slot] = None
-
-    if world == 1:
-        matcher.upload_batch_device(0, n_img, local_dev.data_ptr(), K_PER_IMAGE, D)
-    else:
-        launch_gather(0)
-
-    def step():
-        if world > 1:
-            slot = state["k"] & 1
-            if pending[slot] is not None:
-                pending[slot].wait()                      # main stream waits for the collective
-                pending[slot] = None
-            matcher.upload_batch_device(0, n_img, gathered[slot].data_ptr(), K_PER_IMAGE, D)
-            launch_gather(slot ^ 1)                       # next batch travels while this one is matched
-            state["k"] += 1
-        matcher.match_grid_device(my_pairs, out.data_ptr(), K_PER_IMAGE, counts.data_ptr())
-
-    def fence():
-        torch.cuda.synchronize(dev)
-        if world > 1:
-            dist.barrier()
-            torch.cuda.synchronize(dev)
-
-    for _ in range(args.warmup):
-        step()
-    fence()
-    matcher.stats()                 # clears counters
-    matcher.profile(True)
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    dt = time.perf_counter() - t0
-    st = matcher.stats()
-    matcher.profile(False)
+    dt, st, n_matches, list_bytes, info = run_grid(torch, dist, dev, shard, n_img, K, local_dev, args.steps, args.warmup, world)
 
     if world > 1:
-        rdev = torch.device("cpu") if rehearse else dev
-        tmax = torch.tensor([dt], dtype=torch.float64, device=rdev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
-        tot = torch.tensor([float(st["pair_distances"]), float(counts.sum().item())], dtype=torch.float64, device=rdev)
+        t = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        tot = torch.tensor([float(n_matches), float(list_bytes), float(st["rows_reranked"]), float(st["rows_exact_fallback"]), float(st["rows_total"])], dtype=torch.float64)
         dist.all_reduce(tot)
-        pd_step, n_matches = float(tot[0].item()), int(tot[1].item())
+        n_matches, list_bytes = int(tot[0].item()), int(tot[1].item())
+        rows = [int(x) for x in tot[2:].tolist()]
     else:
-        pd_step, n_matches = float(st["pair_distances"]), int(counts.sum().item())
+        rows = [int(st["rows_reranked"]), int(st["rows_exact_fallback"]), int(st["rows_total"])]
 
     if rank == 0:
-        ms_step = dt / args.steps * 1e3
-        value = pd_step * args.steps / dt
-        calls = max(1, st["profiled_calls"])
-        coarse_ms = st["coarse_ms"] / calls
-        my_pd = float(st["pair_distances"])
-        flops = 2.0 * D * my_pd                      # SURVEY 8(d): 2*D flop per pair-distance
-        achieved = flops / (coarse_ms * 1e-3) / 1e12 if coarse_ms > 0 else 0.0
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_match_traffic.json")
-        if world == 1 and n_img == N_IMAGES_1GPU and os.path.exists(tpath):
-            traffic = json.load(open(tpath))["traffic_bytes_per_launch"]   # PMC passes, see the file
+        value, ms_step, roof = grid_line(K, n_img, n_pairs_total, dt, args.steps, st, world, info["n_pairs"])
+        name = args.workload if (n_img, K) == WORKLOADS[args.workload] else "custom"
         line = {
             "metric": "descriptor pair-distances/s + BA LM-iterations/s (1k cams, 100k pts)",
-            "metric_note": "value = 256-d L2 pair-distances/s of the whole step (exact 2-NN + ratio + uniqueness over all image pairs); BA LM-iterations/s are in `ba` (single GPU: BA does not shard)",
+            "metric_note": "value = 256-d L2 pair-distances/s of the whole step: descriptor exchange (RCCL) + exact 2-NN + ratio + uniqueness over all image pairs + (query, train) lists materialised in host memory; BA LM-iterations/s are in `ba` (single GPU: BA does not shard)",
             "value": value, "unit": "pair-distances/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f16+f64",
+            "scaling": "strong", "vs_baseline": None, "dtype": "f16+f64",
             "dtype_note": "f16 MFMA (f32 accumulate) coarse pass, f64 exact re-rank; indices bit-exact vs the f64 oracle",
             "data": "synthetic",
-            "config": {"workload": ("cfg2" if K_PER_IMAGE == 2048 else "custom") + ": %d images x %d keypoints x %d-d, %d image pairs%s"
-                                   % (n_img, K_PER_IMAGE, D, len(pairs),
-                                      "" if world == 1 else " (weak scaling of cfg2: ~4950 pairs per rank, RCCL all-gather (double-buffered, overlapped with the previous batch's matching) + ingest inside the step)"),
-                       "pairs_per_rank": int(len(my_pairs)), "pair_matches_per_s": len(pairs) * args.steps / dt,
-                       "matches_found": n_matches,
-                       "rows_reranked": int(st["rows_reranked"]), "rows_exact_fallback": int(st["rows_exact_fallback"]), "rows_total": int(st["rows_total"])},
-            "roofline": {"bound": "mfma", "kernel": "k_coarse_top2<256>", "achieved": achieved,
-                         "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / MFMA_F16_PEAK_TFLOPS, "traffic": traffic,
-                         "traffic_note": "bytes per launch from rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes (profiles/r01_match_traffic.json); kernel is MFMA-bound, algorithmic HBM bytes per launch = 1.86e8",
-                         "launch_ms": coarse_ms, "rerank_ms": st["rerank_ms"] / calls,
-                         "unique_ms": st["unique_ms"] / calls},
+            "config": {"workload": "%s: %d images x %d keypoints x %d-d, %d image pairs, the same grid at every N (pair number p -> rank p %% N)"
+                                   % (name, n_img, K, D, n_pairs_total),
+                       "pairs_per_rank": int(info["n_pairs"]), "pair_matches_per_s": n_pairs_total * args.steps / dt,
+                       "matches_found": n_matches, "host_list_bytes_per_step": list_bytes,
+                       "exchange_bytes_f16_payload": int(info["exchange_bytes_f16"]), "exchange_bytes_f32_side_stream": int(info["exchange_bytes_f32"]),
+                       "rows_reranked": rows[0], "rows_exact_fallback": rows[1], "rows_total": rows[2]},
+            "roofline": roof,
         }
-        if not args.no_cpu_baseline and world == 1:
-            images = [local[i] for i in range(local.shape[0])]
-            line["cpu_baseline"] = cpu_baseline(images, host_threads())
-        elif world == 1:
-            line["cpu_baseline"] = None
-        if not args.no_ba and world == 1:
-            line["ba"] = ba_leg(matcher.ctx, not args.no_cpu_baseline)
-            line["ba_lm_iterations_per_s"] = line["ba"]["cfg5"]["lm_iterations_per_s"]   # 1k cams / 100k pts / 1M obs
-            line["epipolar_filter"] = fmat_leg(matcher.ctx, not args.no_cpu_baseline)
+        if world == 1:
+            if not args.no_cfg2 and args.workload != "cfg2":
+                # BASELINE configs[1] on the same GPU, same path (exchange + match + materialise)
+                n2, K2 = WORKLOADS["cfg2"]
+                pool2 = synth.world_pool("superpoint", 4 * K2, seed=1234)
+                loc2 = np.stack([synth.image_descriptors("superpoint", i, K2, pool2, seed=1234) for i in range(n2)])
+                loc2_dev = torch.from_numpy(loc2).to(dev)
+                dt2, st2, nm2, lb2, info2 = run_grid(torch, dist, dev, shard, n2, K2, loc2_dev, 20, 3, 1)
+                v2, ms2, roof2 = grid_line(K2, n2, n2 * (n2 - 1) // 2, dt2, 20, st2, 1, info2["n_pairs"])
+                # and with the tables left in HBM (round 1's definition of the step), for comparison
+                dt2b, st2b, _, _, _ = run_grid(torch, dist, dev, shard, n2, K2, loc2_dev, 20, 3, 1, materialise=False)
+                line["cfg2"] = {"workload": "cfg2: %d images x %d keypoints x %d-d, %d image pairs" % (n2, K2, D, n2 * (n2 - 1) // 2),
+                                "value": v2, "unit": "pair-distances/s", "steps": 20, "warmup": 3, "ms_per_step": ms2, "matches_found": nm2,
+                                "host_list_bytes_per_step": lb2, "roofline": roof2,
+                                "value_tables_left_in_hbm": float(n2 * (n2 - 1) // 2) * K2 * K2 * 20 / dt2b,
+                                "rows_reranked": int(st2["rows_reranked"]), "rows_exact_fallback": int(st2["rows_exact_fallback"]), "rows_total": int(st2["rows_total"])}
+                del loc2_dev
+            if not args.no_cpu_baseline:
+                images = [local[i] for i in range(min(local.shape[0], 64))]
+                line["cpu_baseline"] = cpu_baseline(images, host_threads())
+            else:
+                line["cpu_baseline"] = None
+            if not args.no_ba:
+                shard.close()
+                shard = None
+                line["ba"] = ba_leg(ctx, not args.no_cpu_baseline)
+                line["ba_lm_iterations_per_s"] = line["ba"]["cfg5"]["lm_iterations_per_s"]   # 1k cams / 100k pts / 1M obs
+                line["epipolar_filter"] = fmat_leg(ctx, not args.no_cpu_baseline)
         print(json.dumps(line), flush=True)
+    if shard is not None:
+        shard.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

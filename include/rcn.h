@@ -19,6 +19,7 @@
 #ifndef RCN_H
 #define RCN_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -32,6 +33,8 @@ extern "C" {
 #define RCN_ERR_UNSUPPORTED -4   /* shape outside what the kernels cover */
 #define RCN_ERR_NOT_FOUND   -5   /* image id not resident */
 #define RCN_ERR_NUMERIC     -6   /* BA: non-finite cost / Cholesky breakdown that LM could not recover */
+#define RCN_ERR_COMM        -7   /* RCCL error (sharded grid); text in rcn_last_error */
+#define RCN_ERR_IO          -8   /* store file: cannot open / short read / bad magic, version or checksum */
 
 typedef struct rcn_ctx rcn_ctx;
 
@@ -88,6 +91,26 @@ int rcn_match_grid(rcn_ctx *ctx, const int32_t *pairs_host, int32_t n_pairs, flo
 int rcn_match_grid_device(rcn_ctx *ctx, const int32_t *pairs_host, int32_t n_pairs, float ratio,
                           int32_t *out_dev, int64_t out_stride, int32_t *counts_dev);
 
+/* ---- host materialisation of a match table ------------------------------------------------
+ * The (query feature, train feature) lists the pair loop keeps in featureMatches
+ * (SequentialReconstructor.cpp:260-267, :272-275), for a table rcn_match_grid_device (or
+ * rcn_shard_match, rcn_match_table_filter_device) left in HBM: compacted on the GPU, then copied to
+ * host memory.  Pair p owns entries offsets[p] .. offsets[p+1]-1 of qt, each two int32 (query row,
+ * train row), ascending query row -- the iteration order of the reference's std::map<int,int>.
+ *
+ * rcn_match_compact_begin: compacts on the ctx stream, waits until the device knows the total,
+ * fills offsets_host (n_pairs + 1 entries) and *total_out, starts the copy of the lists into qt_host
+ * on the ctx's copy stream and returns; the copy overlaps whatever is enqueued on the ctx stream
+ * next (two device staging buffers alternate).  qt_host should be pinned (rcn_host_alloc) for a true
+ * DMA; capacity = entries qt_host can hold (RCN_ERR_ARG with *total_out set when it is too small).
+ * rcn_match_compact_wait: the lists of the last begin have landed.                              */
+int  rcn_host_alloc(void **out, size_t bytes);      /* pinned host memory; usable without a ctx once a device exists */
+void rcn_host_free(void *p);
+int  rcn_match_compact_begin(rcn_ctx *ctx, const int32_t *table_dev, int64_t stride, const int32_t *counts_dev,
+                             int32_t n_pairs, int64_t *offsets_host, int32_t *qt_host, int64_t capacity,
+                             int64_t *total_out);
+int  rcn_match_compact_wait(rcn_ctx *ctx);
+
 /* Statistics of the last grid call (diagnostics; rows_total = sum of K1 over pairs). */
 typedef struct {
     int64_t rows_total;
@@ -105,6 +128,52 @@ int rcn_match_last_stats(const rcn_ctx *ctx, rcn_match_stats *out);
 /* enable != 0: bracket the kernels of every following grid call with HIP events on the ctx
  * stream (up to 64 calls are kept); rcn_match_last_stats sums and clears them. */
 int rcn_match_profile(rcn_ctx *ctx, int enable);
+
+/* ---- pair grid sharded over the GPUs of one node -----------------------------------------
+ * The N x N loop of SequentialReconstructor::matchFeatures (SequentialReconstructor.cpp:202-279) runs
+ * its pairs as independent units (OpenMP collapse(2)); here they are spread over several GPUs, one
+ * rcn_shard (= one rcn_ctx + RCCL communicators, called directly over xGMI) per GPU, in one process
+ * per GPU or in one process with a host thread per GPU (reconstructor_amd/host/HipPairGridDriver.h).
+ *   images  equal contiguous blocks: rank r owns ids [r*per, min(n, (r+1)*per)), per = ceil(n / world)
+ *   pairs   the canonical i < j list (row-major) dealt round-robin: pair number p belongs to rank p % world
+ *   exchange  local row statistics -> ncclAllReduce(max) of the two scale statistics -> fp16 conversion of
+ *             the LOCAL block -> in-place ncclAllGather of fp16 rows + half-norms + norms (ctx stream);
+ *             ncclAllGather of the fp32 rows on a side stream (read only by the exact re-rank stages)
+ * Every rank converts with the same global scale: tables are bit-identical to a one-GPU run.     */
+typedef struct rcn_shard rcn_shard;
+#define RCN_SHARD_ID_BYTES 128            /* sizeof(ncclUniqueId) */
+
+/* Partition: pure host functions (no GPU, no communicator). */
+int     rcn_shard_owned_images(int32_t n_images, int32_t world, int32_t rank, int32_t *first, int32_t *count);
+int64_t rcn_shard_pair_count(int32_t n_images, int32_t world, int32_t rank);
+int     rcn_shard_pairs(int32_t n_images, int32_t world, int32_t rank, int32_t *pairs_out /* 2 x count */);
+
+/* Rendezvous: ONE rank (or the single process) draws the id, the host hands it to every rank
+ * (environment, file, MPI, torch store ...); rcn_shard_create is collective over the world. */
+int      rcn_shard_unique_id(uint8_t id[RCN_SHARD_ID_BYTES]);
+int      rcn_shard_create(rcn_ctx *ctx, int32_t rank, int32_t world, const uint8_t id[RCN_SHARD_ID_BYTES],
+                          rcn_shard **out);
+void     rcn_shard_destroy(rcn_shard *sh);   /* also drops the ctx's resident descriptors (views into the landing buffer) */
+rcn_ctx *rcn_shard_ctx(rcn_shard *sh);
+
+/* Shape of the next exchanges: n_images over all ranks, each K x D fp32.  *local_slot_dev (may be NULL)
+ * receives this rank's block of the landing buffer, [count][K][D] fp32 in HBM: a detector can write its
+ * rows straight there (the producer contract, see rcn_desc_upload_batch_device) and pass NULL to
+ * rcn_shard_exchange.  The pointer stays valid until a reserve with another shape. */
+int rcn_shard_reserve(rcn_shard *sh, int32_t n_images, int32_t K, int32_t D, float **local_slot_dev);
+/* Collective.  local_desc_dev: this rank's [count][K][D] fp32 block in HBM (copied), or NULL when the rows
+ * are already in the slot.  Afterwards ids 0 .. n_images-1 are resident in the shard's ctx. */
+int rcn_shard_exchange(rcn_shard *sh, const float *local_desc_dev);
+/* This rank's share of the canonical grid (rcn_shard_pairs order); out_dev / counts_dev as rcn_match_grid_device. */
+int rcn_shard_match(rcn_shard *sh, float ratio, int32_t *out_dev, int64_t out_stride, int32_t *counts_dev);
+
+typedef struct {
+    int32_t rank, world, n_images, images_per_rank;
+    int64_t n_pairs;              /* this rank's share */
+    int64_t exchange_bytes_f16;   /* whole all-gather (all ranks' blocks): fp16 rows + half-norms + norms */
+    int64_t exchange_bytes_f32;   /* whole all-gather of the fp32 rows (side stream) */
+} rcn_shard_stats;
+int rcn_shard_info(const rcn_shard *sh, rcn_shard_stats *out);
 
 /* ---- bundle adjustment -----------------------------------------------------------------
  * Flat form of what BundleAdjuster::adjust packs (BundleAdjuster.cpp:17-97):
@@ -253,6 +322,31 @@ int rcn_coords_clear(rcn_ctx *ctx);
  * small host-to-device copy. */
 int rcn_match_table_filter_device(rcn_ctx *ctx, const int32_t *pairs_host, int32_t n_pairs, int32_t *table_dev,
                                   int64_t stride, int32_t *counts_dev, int32_t *out_status_dev);
+
+/* ---- store: features + matches on disk -------------------------------------------------------
+ * The cache of features / matches the reference lists as a TODO (README.md:39): one versioned binary
+ * file (format in reconstructor_amd/csrc/store.hip; FNV-1a checksum; written to <path>.tmp, then
+ * renamed) holding per image the K x D fp32 descriptor rows -- the Feature::featDesc.desc vectors,
+ * datatypes.h:48-72 -- and optionally the K x 2 integer keypoint coordinates (Feature<int>::featCoord),
+ * and per matched pair the (query feature, train feature) lists of featureMatches in the layout
+ * rcn_match_compact_begin produces.  Pure host code; a matching stage can be resumed from the file. */
+typedef struct {
+    int32_t n_images, D, has_coords, n_pairs;
+    const int32_t        *img_ids;    /* n_images */
+    const int32_t        *img_K;      /* n_images */
+    const float  *const  *desc;       /* n_images pointers to K x D fp32 */
+    const int32_t *const *coords;     /* n_images pointers to K x 2 int32, or NULL when !has_coords */
+    const int32_t        *pairs;      /* n_pairs x (query image id, train image id) */
+    const int64_t        *offsets;    /* n_pairs + 1 */
+    const int32_t        *qt;         /* offsets[n_pairs] x (query row, train row) */
+} rcn_store_contents;
+typedef struct rcn_store rcn_store;
+int  rcn_store_save(const char *path, const rcn_store_contents *contents);
+int  rcn_store_open(const char *path, rcn_store **out);      /* reads and verifies the whole file */
+int  rcn_store_contents_of(const rcn_store *store, rcn_store_contents *out);   /* pointers live until rcn_store_close */
+void rcn_store_close(rcn_store *store);
+/* descriptors (and coordinates) of every stored image into the ctx: rcn_desc_upload / rcn_coords_upload per image */
+int  rcn_store_upload(rcn_ctx *ctx, const rcn_store *store);
 
 #ifdef __cplusplus
 }

@@ -12,14 +12,25 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 
 
-def build(force=False):
-    so = os.path.join(_HERE, "liborc.so")
+def build(force=False, native=False):
+    """liborc.so: -march=x86-64-v3 (travels from the build container to the GPU box).  native=True builds
+    liborc_native.so with -march=native ON THE BOX IT RUNS ON and makes it the library every later call
+    uses -- bench.py's cpu_baseline legs do so (SURVEY 8d: the CPU baseline is compiled -march=native);
+    the arithmetic is the same either way (-ffp-contract=off, explicit fma() calls)."""
+    global _LIB
+    name = "liborc_native.so" if native else "liborc.so"
+    so = os.path.join(_HERE, name)
     srcs = [os.path.join(_HERE, f) for f in ("match_oracle.c", "ba_oracle.c", "validity_oracle.c", "fmat_oracle.c", "Makefile")]
     stale = (not os.path.exists(so)) or any(
         os.path.getmtime(s) > os.path.getmtime(so) for s in srcs)
-    if force or stale:
-        subprocess.check_call(["make", "-B", "-C", _HERE, "liborc.so"],
-                              stdout=subprocess.DEVNULL)
+    if native and getattr(build, "_native_done", False):
+        return so
+    if force or stale or native:          # a native build is never trusted from another machine
+        subprocess.check_call(["make", "-B", "-C", _HERE, name], stdout=subprocess.DEVNULL)
+    if native:
+        build._native_done = True
+        _LIB = C.CDLL(so)
+        _sig()
     return so
 
 

@@ -11,7 +11,8 @@ SO_PATH = os.environ.get("RCN_LIB", os.path.join(_HERE, "librcn.so"))   # RCN_LI
 
 RCN_OK = 0
 ERRORS = {-1: "RCN_ERR_ARG", -2: "RCN_ERR_HIP", -3: "RCN_ERR_NO_DEVICE",
-          -4: "RCN_ERR_UNSUPPORTED", -5: "RCN_ERR_NOT_FOUND", -6: "RCN_ERR_NUMERIC"}
+          -4: "RCN_ERR_UNSUPPORTED", -5: "RCN_ERR_NOT_FOUND", -6: "RCN_ERR_NUMERIC",
+          -7: "RCN_ERR_COMM", -8: "RCN_ERR_IO"}
 
 # every symbol include/rcn.h declares (tests check the library exports exactly these)
 SYMBOLS = [
@@ -22,7 +23,13 @@ SYMBOLS = [
     "rcn_landmark_validity", "rcn_landmark_validity_device",
     "rcn_fmat_filter", "rcn_fmat_filter_grid", "rcn_fmat_filter_grid_device",
     "rcn_coords_upload", "rcn_coords_clear", "rcn_match_table_filter_device",
+    "rcn_host_alloc", "rcn_host_free", "rcn_match_compact_begin", "rcn_match_compact_wait",
+    "rcn_shard_owned_images", "rcn_shard_pair_count", "rcn_shard_pairs", "rcn_shard_unique_id",
+    "rcn_shard_create", "rcn_shard_destroy", "rcn_shard_ctx", "rcn_shard_reserve", "rcn_shard_exchange",
+    "rcn_shard_match", "rcn_shard_info",
+    "rcn_store_save", "rcn_store_open", "rcn_store_contents_of", "rcn_store_close", "rcn_store_upload",
 ]
+SHARD_ID_BYTES = 128
 
 
 class RcnError(RuntimeError):
@@ -36,6 +43,17 @@ class MatchStats(C.Structure):
                 ("pair_distances", C.c_int64), ("err_bound_d2", C.c_double),
                 ("used_mfma_path", C.c_int32), ("profiled_calls", C.c_int32),
                 ("coarse_ms", C.c_double), ("rerank_ms", C.c_double), ("unique_ms", C.c_double)]
+
+
+class ShardStats(C.Structure):
+    _fields_ = [("rank", C.c_int32), ("world", C.c_int32), ("n_images", C.c_int32), ("images_per_rank", C.c_int32),
+                ("n_pairs", C.c_int64), ("exchange_bytes_f16", C.c_int64), ("exchange_bytes_f32", C.c_int64)]
+
+
+class StoreContents(C.Structure):
+    _fields_ = [("n_images", C.c_int32), ("D", C.c_int32), ("has_coords", C.c_int32), ("n_pairs", C.c_int32),
+                ("img_ids", C.c_void_p), ("img_K", C.c_void_p), ("desc", C.c_void_p), ("coords", C.c_void_p),
+                ("pairs", C.c_void_p), ("offsets", C.c_void_p), ("qt", C.c_void_p)]
 
 
 class BaProblem(C.Structure):
@@ -91,6 +109,10 @@ def load():
         raise ImportError(
             "reconstructor_amd/librcn.so is missing: run `python -c 'import __graft_entry__ as g; "
             "g.build()'` (hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+    try:
+        import torch  # noqa: F401  -- FIRST: torch ships its own ROCm runtime + RCCL under the same SONAMEs; whichever
+    except ImportError:             # copy is mapped first serves both, and two copies in one process corrupt the heap at exit
+        pass
     L = C.CDLL(SO_PATH, mode=C.RTLD_GLOBAL)
     vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
     L.rcn_create.restype = C.c_int
@@ -143,6 +165,46 @@ def load():
     L.rcn_coords_clear.argtypes = [vp]
     L.rcn_match_table_filter_device.restype = C.c_int
     L.rcn_match_table_filter_device.argtypes = [vp, vp, i32, vp, C.c_int64, vp, vp]
+    L.rcn_host_alloc.restype = C.c_int
+    L.rcn_host_alloc.argtypes = [C.POINTER(vp), C.c_size_t]
+    L.rcn_host_free.restype = None
+    L.rcn_host_free.argtypes = [vp]
+    L.rcn_match_compact_begin.restype = C.c_int
+    L.rcn_match_compact_begin.argtypes = [vp, vp, i64, vp, i32, vp, vp, i64, C.POINTER(i64)]
+    L.rcn_match_compact_wait.restype = C.c_int
+    L.rcn_match_compact_wait.argtypes = [vp]
+    L.rcn_shard_owned_images.restype = C.c_int
+    L.rcn_shard_owned_images.argtypes = [i32, i32, i32, C.POINTER(i32), C.POINTER(i32)]
+    L.rcn_shard_pair_count.restype = i64
+    L.rcn_shard_pair_count.argtypes = [i32, i32, i32]
+    L.rcn_shard_pairs.restype = C.c_int
+    L.rcn_shard_pairs.argtypes = [i32, i32, i32, vp]
+    L.rcn_shard_unique_id.restype = C.c_int
+    L.rcn_shard_unique_id.argtypes = [vp]
+    L.rcn_shard_create.restype = C.c_int
+    L.rcn_shard_create.argtypes = [vp, i32, i32, vp, C.POINTER(vp)]
+    L.rcn_shard_destroy.restype = None
+    L.rcn_shard_destroy.argtypes = [vp]
+    L.rcn_shard_ctx.restype = vp
+    L.rcn_shard_ctx.argtypes = [vp]
+    L.rcn_shard_reserve.restype = C.c_int
+    L.rcn_shard_reserve.argtypes = [vp, i32, i32, i32, C.POINTER(vp)]
+    L.rcn_shard_exchange.restype = C.c_int
+    L.rcn_shard_exchange.argtypes = [vp, vp]
+    L.rcn_shard_match.restype = C.c_int
+    L.rcn_shard_match.argtypes = [vp, f32, vp, i64, vp]
+    L.rcn_shard_info.restype = C.c_int
+    L.rcn_shard_info.argtypes = [vp, C.POINTER(ShardStats)]
+    L.rcn_store_save.restype = C.c_int
+    L.rcn_store_save.argtypes = [C.c_char_p, C.POINTER(StoreContents)]
+    L.rcn_store_open.restype = C.c_int
+    L.rcn_store_open.argtypes = [C.c_char_p, C.POINTER(vp)]
+    L.rcn_store_contents_of.restype = C.c_int
+    L.rcn_store_contents_of.argtypes = [vp, C.POINTER(StoreContents)]
+    L.rcn_store_close.restype = None
+    L.rcn_store_close.argtypes = [vp]
+    L.rcn_store_upload.restype = C.c_int
+    L.rcn_store_upload.argtypes = [vp, vp]
     _LIB = L
     return L
 

@@ -6,7 +6,14 @@
 
 extern "C" {
 
-const char *rcn_version(void) { return "reconstructor_amd 0.1 (gfx950)"; }
+const char *rcn_version(void)
+{
+#ifdef RCN_DIAG
+    return "reconstructor_amd 0.2 (gfx950) DIAGNOSTIC BUILD";
+#else
+    return "reconstructor_amd 0.2 (gfx950)";
+#endif
+}
 
 int rcn_create(int device_id, rcn_ctx **out)
 {
@@ -40,7 +47,11 @@ int rcn_create(int device_id, rcn_ctx **out)
         const int ncu = ctx->prop.multiProcessorCount;
         std::vector<uint32_t> mask((ncu + 31) / 32, 0xFFFFFFFFu);
         if (ncu % 32) mask.back() = (1u << (ncu % 32)) - 1u;
-        if (ncu >= 64 && !getenv("RCN_NO_CU_MASK")) mask[0] &= ~0xFFu;
+        bool carve = ncu >= 64;
+#ifdef RCN_DIAG
+        if (getenv("RCN_NO_CU_MASK")) carve = false;
+#endif
+        if (carve) mask[0] &= ~0xFFu;
         if (hipExtStreamCreateWithCUMask(&ctx->aux_stream, (uint32_t)mask.size(), mask.data()) != hipSuccess) {
             (void)hipGetLastError();
             ctx->aux_stream = nullptr;
@@ -55,6 +66,9 @@ int rcn_create(int device_id, rcn_ctx **out)
     for (auto &e : ctx->ba_tev)
         if (hipEventCreate(&e) != hipSuccess) { delete ctx; return RCN_ERR_HIP; }
     ctx->ba_ev_made = true;
+#ifdef RCN_DIAG
+    // Diagnostic build only (tools/librcn_diag.so, -DRCN_DIAG): ablations and alternative device paths.
+    // The shipping library reads no environment variable.
     const char *fe = std::getenv("RCN_FORCE_EXACT");
     ctx->force_exact = fe && fe[0] == '1';
     const char *nio = getenv("RCN_MATCH_NO_ORDER");
@@ -67,6 +81,7 @@ int rcn_create(int device_id, rcn_ctx **out)
     ctx->ba_trsv_fwd = btf && btf[0] == '1';
     const char *ch = std::getenv("RCN_MATCH_CHUNKS");
     ctx->chunks = ch ? std::atoi(ch) : 1;
+#endif
     memset(&ctx->last_stats, 0, sizeof(ctx->last_stats));
     *out = ctx;
     return RCN_OK;
@@ -92,6 +107,13 @@ void rcn_destroy(rcn_ctx *ctx)
             for (auto &e : row) (void)hipEventDestroy(e);
     if (ctx->ba_ev_made)
         { for (auto &e : ctx->ba_ev) (void)hipEventDestroy(e); for (auto &e : ctx->ba_tev) (void)hipEventDestroy(e); }
+    if (ctx->copy_stream) {
+        (void)hipStreamSynchronize(ctx->copy_stream);
+        (void)hipStreamDestroy(ctx->copy_stream);
+        for (auto &e : ctx->cmp_ev) (void)hipEventDestroy(e);
+        (void)hipEventDestroy(ctx->cmp_filled);
+    }
+    ctx->cmp_off.release(); ctx->cmp_qt[0].release(); ctx->cmp_qt[1].release();
     if (ctx->aux_stream) (void)hipStreamDestroy(ctx->aux_stream);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;

@@ -649,8 +649,6 @@ static int fmat_launch(rcn_ctx *ctx, int32_t n_pairs, const int32_t *off, const 
 //                leave pairs with fewer than 7 matches alone; new counts
 namespace {
 
-struct PairXY { const int32_t *q, *t; int32_t Kq, pad; };
-
 __global__ __launch_bounds__(1024) void k_tf_scan(const int32_t *counts, int n, int32_t *off)
 {
     __shared__ int sh[16];
@@ -772,13 +770,21 @@ extern "C" int rcn_match_table_filter_device(rcn_ctx *ctx, const int32_t *pairs_
     if (n_pairs == 0) return RCN_OK;
     std::lock_guard<std::mutex> lk(ctx->mu);
     RCN_HIP(hipSetDevice(ctx->device));
-    std::vector<PairXY> px((size_t)n_pairs);
+    std::vector<PairXY> &px = ctx->fm_pairs_host;          // kept in the ctx: uploaded asynchronously
+    px.resize((size_t)n_pairs);
     size_t cap = 0;
     for (int p = 0; p < n_pairs; ++p) {
         auto q = ctx->coords.find(pairs_host[2 * p]), t = ctx->coords.find(pairs_host[2 * p + 1]);
         if (q == ctx->coords.end() || t == ctx->coords.end()) {
             ctx->set_error("rcn_match_table_filter_device: coordinates of image " + std::to_string(pairs_host[2 * p + (q == ctx->coords.end() ? 0 : 1)]) + " are not resident");
             return RCN_ERR_NOT_FOUND;
+        }
+        // the table indexes descriptor rows: the coordinate lists must cover exactly those rows
+        // (k_tf_fill reads p.t[2 * train row] for any train row the table names)
+        auto dq = ctx->images.find(pairs_host[2 * p]), dt = ctx->images.find(pairs_host[2 * p + 1]);
+        if ((dq != ctx->images.end() && dq->second.K != q->second.second) || (dt != ctx->images.end() && dt->second.K != t->second.second)) {
+            ctx->set_error("rcn_match_table_filter_device: an image's coordinate count differs from its descriptor count");
+            return RCN_ERR_ARG;
         }
         if (q->second.second > stride) { ctx->set_error("rcn_match_table_filter_device: stride smaller than a query image's keypoint count"); return RCN_ERR_ARG; }
         px[p].q = q->second.first.as<int32_t>(); px[p].t = t->second.first.as<int32_t>(); px[p].Kq = q->second.second; px[p].pad = 0;
@@ -796,7 +802,6 @@ extern "C" int rcn_match_table_filter_device(rcn_ctx *ctx, const int32_t *pairs_
     uint8_t *d_mask = (uint8_t *)take(cap);
     int32_t *d_ver = out_status_dev ? out_status_dev : (int32_t *)take(4 * P), *d_it = (int32_t *)take(4 * P);
     RCN_HIP(hipMemcpyAsync(ctx->fm_pairs.p, px.data(), sizeof(PairXY) * P, hipMemcpyHostToDevice, st));
-    RCN_HIP(hipStreamSynchronize(st));                      // px is a local vector
     const PairXY *d_px = ctx->fm_pairs.as<PairXY>();
     k_tf_scan<<<1, 1024, 0, st>>>(counts_dev, n_pairs, d_off);
     k_tf_fill<<<n_pairs, 256, 0, st>>>(d_px, table_dev, stride, d_off, d_1, d_2);

@@ -936,6 +936,17 @@ static void free_slab(Slab &sl)
     sl = Slab();
 }
 
+// Slabs that no resident image refers to any more (their ids were re-uploaded with another shape).
+// The caller has synchronised the stream.
+static void retire_unreferenced_slabs(rcn_ctx *ctx)
+{
+    std::vector<char> used(ctx->slabs.size(), 0);
+    for (const auto &kv : ctx->images)
+        if (kv.second.slab >= 0) used[kv.second.slab] = 1;
+    for (size_t i = 0; i < ctx->slabs.size(); ++i)
+        if (ctx->slabs[i].live && !used[i]) free_slab(ctx->slabs[i]);   // the index stays: images refer to slabs by position
+}
+
 int rcn_match_release(rcn_ctx *ctx)
 {
     for (auto &kv : ctx->images) free_image(kv.second);
@@ -1028,13 +1039,22 @@ static int upload_common(rcn_ctx *ctx, int32_t img_id, const float *src, bool sr
     return RCN_OK;
 }
 
-static int upload_batch(rcn_ctx *ctx, int32_t first_id, int32_t n, const float *src, int32_t K, int32_t D)
+// Attach a block of equally shaped images ([n_slots][K][D] fp32 in HBM, borrowed) as ids
+// first_id .. first_id + n_images - 1.  n_slots >= n_images: the block may carry unused slots at
+// its end (the landing buffer of an all-gather whose image count is not a multiple of the rank
+// count).  [conv_first, conv_first + conv_n) are the slots THIS ctx converts to fp16 itself; the
+// other slots' fp16 rows / half-norms / norms are filled by the caller (RCCL all-gather, shard.hip).
+// Same shape again reuses every allocation.
+int rcn_int_slab_attach(rcn_ctx *ctx, int32_t first_id, int32_t n_images, int32_t n_slots, const float *src,
+                        int32_t K, int32_t D, int32_t conv_first, int32_t conv_n, int *slab_out)
 {
-    if (n < 0 || K <= 0 || D <= 0 || (n > 0 && !src) || (int64_t)n * K > 0x7fffffffLL) {
+    if (n_images < 0 || n_slots < n_images || K <= 0 || D <= 0 || (n_slots > 0 && !src) || (int64_t)n_slots * K > 0x7fffffffLL ||
+        conv_first < 0 || conv_n < 0 || conv_first + conv_n > n_slots) {
         ctx->set_error("rcn_desc_upload_batch_device: bad argument");
         return RCN_ERR_ARG;
     }
-    if (n == 0) return RCN_OK;
+    if (slab_out) *slab_out = -1;
+    if (n_slots == 0) return RCN_OK;
     if (D % 4 == 0 && (reinterpret_cast<uintptr_t>(src) & 15) != 0) {
         ctx->set_error("rcn_desc_upload_batch_device: the borrowed block must be 16-byte aligned when D % 4 == 0");
         return RCN_ERR_ARG;
@@ -1054,26 +1074,36 @@ static int upload_batch(rcn_ctx *ctx, int32_t first_id, int32_t n, const float *
     int si = -1;
     for (size_t i = 0; i < ctx->slabs.size(); ++i) {
         const Slab &sl = ctx->slabs[i];
-        if (sl.live && sl.first_id == first_id && sl.n == n && sl.K == K && sl.D == D) si = (int)i;
+        if (sl.live && sl.first_id == first_id && sl.n == n_slots && sl.K == K && sl.D == D) si = (int)i;
     }
     if (si < 0) {
         // new shape: drop whatever these ids held, then allocate once
         RCN_HIP(hipStreamSynchronize(ctx->stream));
-        for (int i = 0; i < n; ++i) {
+        for (int i = 0; i < n_images; ++i) {
             auto it = ctx->images.find(first_id + i);
             if (it != ctx->images.end()) { free_image(it->second); ctx->images.erase(it); }
         }
+        retire_unreferenced_slabs(ctx);      // a slab none of whose images is left gives its HBM back
         Slab sl;
-        sl.first_id = first_id; sl.n = n; sl.K = K; sl.Kp = Kp; sl.D = D; sl.live = true;
-        RCN_HIP(hipMalloc(&sl.f16, (size_t)n * Kp * DPa * sizeof(_Float16)));
-        RCN_HIP(hipMalloc(&sl.hn, (size_t)n * Kp * sizeof(float)));
-        RCN_HIP(hipMalloc(&sl.nrm2, (size_t)n * K * sizeof(double)));
-        ctx->slabs.push_back(sl);
-        si = (int)ctx->slabs.size() - 1;
+        sl.first_id = first_id; sl.n = n_slots; sl.K = K; sl.Kp = Kp; sl.D = D; sl.live = true;
+        RCN_HIP(hipMalloc(&sl.f16, (size_t)n_slots * Kp * DPa * sizeof(_Float16)));
+        RCN_HIP(hipMalloc(&sl.hn, (size_t)n_slots * Kp * sizeof(float)));
+        RCN_HIP(hipMalloc(&sl.nrm2, (size_t)n_slots * K * sizeof(double)));
+        for (size_t i = 0; i < ctx->slabs.size() && si < 0; ++i)
+            if (!ctx->slabs[i].live) { ctx->slabs[i] = sl; si = (int)i; }      // reuse a retired position
+        if (si < 0) { ctx->slabs.push_back(sl); si = (int)ctx->slabs.size() - 1; }
     }
     Slab &sl = ctx->slabs[si];
     sl.f32 = src;
-    for (int i = 0; i < n; ++i) {
+    sl.n_images = n_images;
+    sl.conv_first = conv_first; sl.conv_n = conv_n;
+    for (int i = 0; i < n_images; ++i) {
+        auto old = ctx->images.find(first_id + i);
+        if (old != ctx->images.end() && old->second.slab != si) {
+            // the id was re-uploaded on its own (or through another slab) in between: release what it owns
+            if (old->second.slab < 0) { RCN_HIP(hipStreamSynchronize(ctx->stream)); free_image(old->second); }
+            ctx->images.erase(old);
+        }
         ImgHost im;
         im.K = K; im.Kp = Kp; im.slab = si; im.dirty = true;
         im.f32 = const_cast<float *>(src) + (size_t)i * K * D;
@@ -1084,18 +1114,44 @@ static int upload_batch(rcn_ctx *ctx, int32_t first_id, int32_t n, const float *
         if (it != ctx->images.end()) im.slot = it->second.slot;
         ctx->images[first_id + i] = im;
     }
-    unsigned *cnt = ctx->counters.as<unsigned>();
-    const int rows = n * K;
-    RCN_HIP(launch_rowstats(ctx, src, rows, D, sl.nrm2, cnt));
+    // images of a previous, larger attach of the same slab that are no longer part of it
+    for (auto it = ctx->images.begin(); it != ctx->images.end();) {
+        if (it->second.slab == si && (it->first < first_id || it->first >= first_id + n_images)) it = ctx->images.erase(it);
+        else ++it;
+    }
     ctx->prepared = false;
+    if (slab_out) *slab_out = si;
     return RCN_OK;
+}
+
+// Row statistics (|x|^2 per row into the slab's norm array, running maxima into the ctx counters) of
+// slots [first, first + n) of an attached slab.
+int rcn_int_slab_rowstats(rcn_ctx *ctx, int si, int32_t first, int32_t n)
+{
+    if (si < 0 || n <= 0) return RCN_OK;
+    const Slab &sl = ctx->slabs[si];
+    unsigned *cnt = ctx->counters.as<unsigned>();
+    RCN_HIP(launch_rowstats(ctx, sl.f32 + (size_t)first * sl.K * sl.D, n * sl.K, sl.D, sl.nrm2 + (size_t)first * sl.K, cnt));
+    return RCN_OK;
+}
+
+static int upload_batch(rcn_ctx *ctx, int32_t first_id, int32_t n, const float *src, int32_t K, int32_t D)
+{
+    int si = -1;
+    int rc = rcn_int_slab_attach(ctx, first_id, n, n, src, K, D, 0, n, &si);
+    if (rc || si < 0) return rc;
+    return rcn_int_slab_rowstats(ctx, si, 0, n);
 }
 
 template <int DP> static void launch_prepare_batch(rcn_ctx *ctx, const Slab &sl, float s, double hs2, double bias)
 {
-    const long nthr = (long)sl.n * sl.Kp * (DP / 8);
+    // only the slots this ctx converts itself (all of them unless the slab is an all-gather landing buffer)
+    if (sl.conv_n <= 0) return;
+    const long nthr = (long)sl.conv_n * sl.Kp * (DP / 8);
+    const size_t f = sl.conv_first;
     k_prepare_batch<DP><<<(unsigned)((nthr + 255) / 256), 256, 0, ctx->stream>>>(
-        sl.f32, sl.nrm2, sl.n, sl.K, sl.Kp, sl.D, s, hs2, bias, sl.f16, sl.hn);
+        sl.f32 + f * sl.K * sl.D, sl.nrm2 + f * sl.K, sl.conv_n, sl.K, sl.Kp, sl.D, s, hs2, bias,
+        sl.f16 + f * sl.Kp * DP, sl.hn + f * sl.Kp);
 }
 
 template <int DP> static void launch_prepare(rcn_ctx *ctx, const ImgHost &im, float s, double hs2, double bias)
@@ -1106,7 +1162,7 @@ template <int DP> static void launch_prepare(rcn_ctx *ctx, const ImgHost &im, fl
 }
 
 // Fix the global scale / bias, (re)build every image's fp16 copy and the device image table.
-static int prepare_all(rcn_ctx *ctx)
+int rcn_int_prepare_all(rcn_ctx *ctx)
 {
     if (ctx->prepared) return RCN_OK;
     unsigned hc[4] = {0, 0, 0, 0};
@@ -1186,7 +1242,7 @@ template <int DP, int ABL = 0> static hipError_t launch_coarse(rcn_ctx *ctx, con
     return hipGetLastError();
 }
 
-static int match_grid_impl(rcn_ctx *ctx, const int32_t *pairs_host, int32_t n_pairs, float ratio,
+int rcn_int_match_grid(rcn_ctx *ctx, const int32_t *pairs_host, int32_t n_pairs, float ratio,
                            int32_t *out_dev, int64_t out_stride, int32_t *counts_dev)
 {
     // pairs == NULL: the canonical grid of the reference's pair loop (SequentialReconstructor.cpp:202-227
@@ -1210,11 +1266,12 @@ static int match_grid_impl(rcn_ctx *ctx, const int32_t *pairs_host, int32_t n_pa
     memset(&ctx->last_stats, 0, sizeof(ctx->last_stats));
     if (n_pairs == 0) return RCN_OK;
     RCN_HIP(hipSetDevice(ctx->device));
-    int rc = prepare_all(ctx);
+    int rc = rcn_int_prepare_all(ctx);
     if (rc) return rc;
 
     // image ids -> table slots; shape bookkeeping
-    std::vector<int32_t> slots(2 * (size_t)n_pairs);
+    std::vector<int32_t> &slots = ctx->slots_host;     // kept in the ctx: uploaded asynchronously
+    slots.assign(2 * (size_t)n_pairs, 0);
     int kq_max = 0, kt_max = 0, ktp_max = 0;
     int64_t rows = 0, pd = 0;
     for (int p = 0; p < n_pairs; ++p) {
@@ -1343,11 +1400,15 @@ static int match_grid_impl(rcn_ctx *ctx, const int32_t *pairs_host, int32_t n_pa
             case 64: e = launch_coarse<64>(ctx, ca, blocks); break;
             case 128: e = launch_coarse<128>(ctx, ca, blocks); break;
             default:
-                switch (ctx->ablate) {   // RCN_COARSE_ABL: timing experiments only
+#ifdef RCN_DIAG
+                switch (ctx->ablate) {   // RCN_COARSE_ABL: timing experiments only (diagnostic build)
                 case 1: e = launch_coarse<256, 1>(ctx, ca, blocks); break;
                 case 9: e = launch_coarse<256, 9>(ctx, ca, blocks); break;
                 default: e = launch_coarse<256>(ctx, ca, blocks); break;
                 }
+#else
+                e = launch_coarse<256>(ctx, ca, blocks);
+#endif
                 break;
             }
             RCN_HIP(e);
@@ -1369,6 +1430,9 @@ static int match_grid_impl(rcn_ctx *ctx, const int32_t *pairs_host, int32_t n_pa
             ra.qblocks = (kq_max + RCN_FB - 1) / RCN_FB;
             k_filter<<<(unsigned)ra.qblocks * (unsigned)np_c, RCN_FB, 0, sb>>>(ra);
             RCN_HIP(hipGetLastError());
+            // sharded grid: the fp32 rows of the other ranks' images travel on a side stream while the
+            // coarse pass runs on the fp16 payload; the exact stages are the first to read them
+            if (ctx->f32_ready) RCN_HIP(hipStreamWaitEvent(sb, ctx->f32_ready, 0));
             if (mfma) {
                 if (vec4) k_rerank_lds<<<ctx->prop.multiProcessorCount * 16, 64, 0, sb>>>(ra);
                 else k_rerank_generic<<<ctx->prop.multiProcessorCount * 8, 256, 0, sb>>>(ra);
@@ -1461,7 +1525,7 @@ int rcn_match_grid_device(rcn_ctx *ctx, const int32_t *pairs_host, int32_t n_pai
 {
     if (!ctx) return RCN_ERR_ARG;
     std::lock_guard<std::mutex> lk(ctx->mu);
-    return match_grid_impl(ctx, pairs_host, n_pairs, ratio, out_dev, out_stride, counts_dev);
+    return rcn_int_match_grid(ctx, pairs_host, n_pairs, ratio, out_dev, out_stride, counts_dev);
 }
 
 int rcn_match_grid(rcn_ctx *ctx, const int32_t *pairs_host, int32_t n_pairs, float ratio,
@@ -1474,14 +1538,17 @@ int rcn_match_grid(rcn_ctx *ctx, const int32_t *pairs_host, int32_t n_pairs, flo
         return RCN_ERR_ARG;
     }
     if (n_pairs == 0) return RCN_OK;
+    // out_stride == 0 is legal when every query image is empty: the device table still gets one
+    // column, but nothing is copied into the caller's zero-width rows
     const int64_t stride = std::max<int64_t>(out_stride, 1);
     RCN_HIP(ctx->out_tmp.reserve((size_t)n_pairs * stride * sizeof(int32_t)));
     RCN_HIP(ctx->cnt_tmp.reserve((size_t)n_pairs * sizeof(int32_t)));
-    int rc = match_grid_impl(ctx, pairs_host, n_pairs, ratio, ctx->out_tmp.as<int32_t>(), stride,
+    int rc = rcn_int_match_grid(ctx, pairs_host, n_pairs, ratio, ctx->out_tmp.as<int32_t>(), stride,
                              ctx->cnt_tmp.as<int32_t>());
     if (rc) return rc;
-    RCN_HIP(hipMemcpyAsync(out_host, ctx->out_tmp.p, (size_t)n_pairs * stride * sizeof(int32_t),
-                           hipMemcpyDeviceToHost, ctx->stream));
+    if (out_stride > 0)
+        RCN_HIP(hipMemcpyAsync(out_host, ctx->out_tmp.p, (size_t)n_pairs * out_stride * sizeof(int32_t),
+                               hipMemcpyDeviceToHost, ctx->stream));
     RCN_HIP(hipMemcpyAsync(counts_host, ctx->cnt_tmp.p, (size_t)n_pairs * sizeof(int32_t),
                            hipMemcpyDeviceToHost, ctx->stream));
     RCN_HIP(hipStreamSynchronize(ctx->stream));
@@ -1515,7 +1582,7 @@ int rcn_match_pair(rcn_ctx *ctx, const float *q_host, int32_t K1, const float *t
     const int64_t stride = std::max(K1, 1);
     RCN_HIP(ctx->out_tmp.reserve((size_t)stride * sizeof(int32_t)));
     RCN_HIP(ctx->cnt_tmp.reserve(sizeof(int32_t)));
-    rc = match_grid_impl(ctx, pr, 1, ratio, ctx->out_tmp.as<int32_t>(), stride, ctx->cnt_tmp.as<int32_t>());
+    rc = rcn_int_match_grid(ctx, pr, 1, ratio, ctx->out_tmp.as<int32_t>(), stride, ctx->cnt_tmp.as<int32_t>());
     if (rc == RCN_OK) {
         if (K1 > 0)
             RCN_HIP(hipMemcpyAsync(out_train_for_query, ctx->out_tmp.p, (size_t)K1 * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));

@@ -61,13 +61,18 @@ struct ImgHost {
 
 // One batch of equally shaped images (rcn_desc_upload_batch_device): one allocation per array.
 struct Slab {
-    int32_t first_id = 0, n = 0, K = 0, Kp = 0, D = 0;
+    int32_t first_id = 0, n = 0, K = 0, Kp = 0, D = 0;   // n = slots of the block (>= n_images)
+    int32_t n_images = 0;                 // ids first_id .. first_id + n_images - 1 live in slots 0 .. n_images - 1
+    int32_t conv_first = 0, conv_n = 0;   // slots this ctx converts to fp16 itself (the rest arrives by all-gather)
     const float *f32 = nullptr;   // borrowed from the caller
     _Float16 *f16 = nullptr;
     float *hn = nullptr;
     double *nrm2 = nullptr;
     bool live = false;
 };
+
+// fused table filter (fmat.hip): per-pair keypoint coordinate lists
+struct PairXY { const int32_t *q, *t; int32_t Kq, pad; };
 
 struct rcn_ctx {
     int device = 0;
@@ -82,30 +87,47 @@ struct rcn_ctx {
     std::map<int32_t, ImgHost> images;
     std::vector<Slab> slabs;
     std::vector<int2> groups_host, groups_arranged;   // kept alive: uploaded asynchronously
+    std::vector<int32_t> slots_host;                  // pair list as table slots (same reason)
     std::vector<int32_t> all_pairs_host;              // the canonical i < j grid when the caller passes pairs == NULL
     bool prepared = false;
     double scale = 0.0;      // s, power of two (0 = nothing prepared yet)
     double bias = 0.0;       // BIAS in accumulator units
     double max_norm = 0.0;   // max |x| over resident rows
     DevBuf img_table, pairs_dev, groups_dev, cand, owner, fb_list, sv_list, counters, out_tmp, cnt_tmp;
+    hipEvent_t f32_ready = nullptr;   // shard.hip: set while an all-gather of fp32 rows may be in flight on a side stream
+    // host materialisation (store.hip): offsets, two alternating staging buffers, copy stream
+    DevBuf cmp_off, cmp_qt[2];
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t cmp_ev[2] = {nullptr, nullptr}, cmp_filled = nullptr;
+    bool cmp_busy[2] = {false, false};
+    int cmp_next = 0, cmp_last = -1;
     rcn_match_stats last_stats;
     bool profile = false;
     hipEvent_t ev[64][4];
     bool ev_made = false;
     int ev_n = 0;          // recorded calls since the last stats read (<= 64)
-    int ablate = 0;            // RCN_COARSE_ABL (diagnostics)
+    // Ablations / alternative device paths exist only in the diagnostic build (-DRCN_DIAG,
+    // tools/librcn_diag.so), where rcn_create reads them from the environment; in the shipping
+    // library they are compile-time constants and the alternative code is dead.
+#ifdef RCN_DIAG
+    int ablate = 0;            // RCN_COARSE_ABL
     int chunks = 1;            // RCN_MATCH_CHUNKS: >1 overlaps re-rank(c) with coarse(c+1) on two streams
-    bool force_exact = false;  // RCN_FORCE_EXACT=1: skip the MFMA coarse pass (diagnostics)
-    bool no_item_order = false;   // RCN_MATCH_NO_ORDER=1: work items in pair order instead of heaviest-first per XCD (diagnostics)
+    bool force_exact = false;  // RCN_FORCE_EXACT=1: skip the MFMA coarse pass
+    bool no_item_order = false;   // RCN_MATCH_NO_ORDER=1: work items in pair order instead of heaviest-first per XCD
+    bool ba_atomics = false;   // RCN_BA_SCHUR_ATOMICS=1: atomic Schur accumulation instead of the gather form
+    bool ba_trsv_fwd = false;  // RCN_BA_TRSV_FWD=1: separate forward substitution instead of the rhs row inside the factorisation
+#else
+    static constexpr int ablate = 0, chunks = 1;
+    static constexpr bool force_exact = false, no_item_order = false, ba_atomics = false, ba_trsv_fwd = false;
+#endif
 
     // ---- BA state (ba.hip)
     DevBuf ba_ws[40];
     DevBuf lm_ws;              // landmark validity sweep (validity.hip)
     DevBuf fm_ws, fm_state;    // epipolar filter (fmat.hip): host-API staging, per-pair RANSAC state
+    std::vector<PairXY> fm_pairs_host;   // staging of fm_pairs (uploaded asynchronously)
     DevBuf fm_csr, fm_pairs;   // fused table filter: CSR of the matched points, per-pair coordinate pointers
     std::map<int32_t, std::pair<DevBuf, int32_t>> coords;   // image id -> (K x 2 int32 pixel coordinates in HBM, K)
-    bool ba_atomics = false;   // RCN_BA_SCHUR_ATOMICS=1: atomic Schur accumulation instead of the gather form
-    bool ba_trsv_fwd = false;  // RCN_BA_TRSV_FWD=1: separate forward substitution instead of the rhs row inside the factorisation
     hipStream_t aux_stream = nullptr;   // lookahead stream of the Cholesky
     hipEvent_t ba_ev[9];
     hipEvent_t ba_tev[4];            // phase timing of rcn_ba_solve
@@ -115,3 +137,10 @@ struct rcn_ctx {
 };
 
 int rcn_match_release(rcn_ctx *ctx);
+// match.hip internals shared with shard.hip (all expect ctx->mu held)
+int rcn_int_slab_attach(rcn_ctx *ctx, int32_t first_id, int32_t n_images, int32_t n_slots, const float *src,
+                        int32_t K, int32_t D, int32_t conv_first, int32_t conv_n, int *slab_out);
+int rcn_int_slab_rowstats(rcn_ctx *ctx, int slab, int32_t first, int32_t n);
+int rcn_int_prepare_all(rcn_ctx *ctx);
+int rcn_int_match_grid(rcn_ctx *ctx, const int32_t *pairs_host, int32_t n_pairs, float ratio,
+                       int32_t *out_dev, int64_t out_stride, int32_t *counts_dev);

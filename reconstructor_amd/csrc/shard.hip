@@ -1,0 +1,270 @@
+// shard.hip -- the image-pair grid sharded over the GPUs of one node: one rcn_shard per GPU,
+// RCCL collectives over xGMI called directly (no torch, no MPI).  C ABI: include/rcn.h.
+//
+// Replaces the pair loop of SequentialReconstructor::matchFeatures (SequentialReconstructor.cpp:202-279)
+// when its N x N iterations -- independent units, the reference already runs them under OpenMP
+// collapse(2) -- are spread over several GPUs:
+//   * every rank owns an equal contiguous block of images ("detected locally");
+//   * one exchange replicates the descriptors: row statistics of the local block, an 16-byte
+//     ncclAllReduce(max) that fixes the global fp16 scale, fp16 conversion of the LOCAL block only,
+//     then in-place ncclAllGather of the converted payload (fp16 rows + half-norms + fp64 norms: what
+//     the MFMA coarse pass and its error bound read -- half the bytes of the fp32 rows) on the ctx
+//     stream, and an ncclAllGather of the fp32 rows on a side stream: only the exact re-rank of the few
+//     uncertified rows reads those, so that transfer hides behind the coarse kernel;
+//   * the canonical i < j pair list is dealt round-robin to the ranks; match tables stay on the rank
+//     that computed them.  No other exchange.
+// Every rank converts with the same global scale, so the tables are bit-identical to a one-GPU run.
+#include "rcn_internal.h"
+
+#include <rccl/rccl.h>
+
+#include <algorithm>
+
+static_assert(sizeof(ncclUniqueId) == RCN_SHARD_ID_BYTES, "rcn.h: RCN_SHARD_ID_BYTES must be sizeof(ncclUniqueId)");
+
+struct rcn_shard {
+    rcn_ctx *ctx = nullptr;
+    ncclComm_t comm = nullptr;         // ctx stream: scale statistics + fp16 payload (the critical path)
+    ncclComm_t comm32 = nullptr;       // side stream: fp32 rows.  A communicator of its own -- RCCL serialises the
+                                       // operations of ONE communicator in issue order whatever stream they are on
+    int rank = 0, world = 1;
+    hipStream_t side = nullptr;        // carries the fp32 all-gather beside the coarse kernel
+    hipEvent_t ev_local = nullptr;     // ctx stream: the local fp32 block is in place / previous readers are queued
+    hipEvent_t ev_f32 = nullptr;       // side stream: fp32 rows of every rank have landed
+    DevBuf landing;                    // [world * per][K][D] fp32
+    int32_t n_images = 0, per = 0, K = 0, D = 0;
+    int slab = -1;
+    std::vector<int32_t> pairs;        // this rank's share of the canonical grid
+    int64_t bytes_f16 = 0, bytes_f32 = 0;   // payload sizes of the last exchange (whole gather, all ranks)
+};
+
+#define RCN_NCCL(call)                                                                   \
+    do {                                                                                 \
+        ncclResult_t r_ = (call);                                                        \
+        if (r_ != ncclSuccess) {                                                         \
+            ctx->set_error(std::string(#call) + ": " + ncclGetErrorString(r_));          \
+            return RCN_ERR_COMM;                                                         \
+        }                                                                                \
+    } while (0)
+
+// ---- partition: pure functions -------------------------------------------------------------
+static int32_t per_rank(int32_t n_images, int32_t world) { return (n_images + world - 1) / world; }
+
+// rank r's pairs are numbers r, r + world, r + 2 world, ... of the canonical row-major i < j list
+static int64_t pairs_of(int32_t n, int32_t world, int32_t rank)
+{
+    const int64_t total = (int64_t)n * (n - 1) / 2;
+    return total > rank ? (total - rank + world - 1) / world : 0;
+}
+
+extern "C" {
+
+int rcn_shard_owned_images(int32_t n_images, int32_t world, int32_t rank, int32_t *first, int32_t *count)
+{
+    if (n_images < 0 || world < 1 || rank < 0 || rank >= world || !first || !count) return RCN_ERR_ARG;
+    const int32_t per = per_rank(n_images, world);
+    const int32_t lo = std::min<int64_t>(n_images, (int64_t)rank * per);
+    *first = lo;
+    *count = std::min(n_images, lo + per) - lo;
+    return RCN_OK;
+}
+
+int64_t rcn_shard_pair_count(int32_t n_images, int32_t world, int32_t rank)
+{
+    if (n_images < 0 || world < 1 || rank < 0 || rank >= world) return RCN_ERR_ARG;
+    return pairs_of(n_images, world, rank);
+}
+
+int rcn_shard_pairs(int32_t n_images, int32_t world, int32_t rank, int32_t *pairs_out)
+{
+    if (n_images < 0 || world < 1 || rank < 0 || rank >= world || (!pairs_out && pairs_of(n_images, world, rank) > 0)) return RCN_ERR_ARG;
+    int64_t p = 0, k = 0;
+    for (int32_t i = 0; i < n_images; ++i) {
+        // pairs (i, i+1 .. n-1) are numbers p .. p + (n-1-i) - 1; the first one of this rank is the
+        // smallest number >= p congruent to rank
+        const int64_t row = n_images - 1 - i;
+        int64_t q = p + ((rank - p) % world + world) % world;
+        for (; q < p + row; q += world) {
+            pairs_out[2 * k] = i;
+            pairs_out[2 * k + 1] = (int32_t)(i + 1 + (q - p));
+            ++k;
+        }
+        p += row;
+    }
+    return RCN_OK;
+}
+
+int rcn_shard_unique_id(uint8_t id[RCN_SHARD_ID_BYTES])
+{
+    if (!id) return RCN_ERR_ARG;
+    ncclUniqueId u;
+    if (ncclGetUniqueId(&u) != ncclSuccess) return RCN_ERR_COMM;
+    memcpy(id, &u, RCN_SHARD_ID_BYTES);
+    return RCN_OK;
+}
+
+int rcn_shard_create(rcn_ctx *ctx, int32_t rank, int32_t world, const uint8_t id[RCN_SHARD_ID_BYTES], rcn_shard **out)
+{
+    if (!ctx || !out) return RCN_ERR_ARG;
+    *out = nullptr;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    if (world < 1 || rank < 0 || rank >= world || !id) { ctx->set_error("rcn_shard_create: bad argument"); return RCN_ERR_ARG; }
+    RCN_HIP(hipSetDevice(ctx->device));
+    rcn_shard *sh = new rcn_shard();
+    sh->ctx = ctx; sh->rank = rank; sh->world = world;
+    ncclUniqueId u;
+    memcpy(&u, id, RCN_SHARD_ID_BYTES);
+    ncclResult_t r = ncclCommInitRank(&sh->comm, world, u, rank);
+    if (r != ncclSuccess) {
+        ctx->set_error(std::string("ncclCommInitRank: ") + ncclGetErrorString(r));
+        delete sh;
+        return RCN_ERR_COMM;
+    }
+    r = ncclCommSplit(sh->comm, 0, rank, &sh->comm32, nullptr);
+    if (r != ncclSuccess) {
+        ctx->set_error(std::string("ncclCommSplit: ") + ncclGetErrorString(r));
+        (void)ncclCommDestroy(sh->comm);
+        delete sh;
+        return RCN_ERR_COMM;
+    }
+    hipError_t e = hipStreamCreateWithFlags(&sh->side, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&sh->ev_local, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&sh->ev_f32, hipEventDisableTiming);
+    if (e != hipSuccess) {
+        ctx->set_error(std::string("rcn_shard_create: ") + hipGetErrorString(e));
+        (void)ncclCommDestroy(sh->comm32);
+        (void)ncclCommDestroy(sh->comm);
+        if (sh->side) (void)hipStreamDestroy(sh->side);
+        if (sh->ev_local) (void)hipEventDestroy(sh->ev_local);
+        delete sh;
+        return RCN_ERR_HIP;
+    }
+    *out = sh;
+    return RCN_OK;
+}
+
+void rcn_shard_destroy(rcn_shard *sh)
+{
+    if (!sh) return;
+    rcn_ctx *ctx = sh->ctx;
+    {
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        (void)hipSetDevice(ctx->device);
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipStreamSynchronize(sh->side);
+        if (ctx->f32_ready == sh->ev_f32) ctx->f32_ready = nullptr;
+        // the images of the landing buffer are borrowed views: they must not outlive it
+        if (sh->slab >= 0) rcn_match_release(ctx);
+        (void)ncclCommDestroy(sh->comm32);
+        (void)ncclCommDestroy(sh->comm);
+        (void)hipStreamDestroy(sh->side);
+        (void)hipEventDestroy(sh->ev_local);
+        (void)hipEventDestroy(sh->ev_f32);
+        sh->landing.release();
+    }
+    delete sh;
+}
+
+rcn_ctx *rcn_shard_ctx(rcn_shard *sh) { return sh ? sh->ctx : nullptr; }
+
+int rcn_shard_reserve(rcn_shard *sh, int32_t n_images, int32_t K, int32_t D, float **local_slot_dev)
+{
+    if (!sh) return RCN_ERR_ARG;
+    rcn_ctx *ctx = sh->ctx;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    if (n_images < 1 || K < 1 || D < 1 || (int64_t)per_rank(n_images, sh->world) * sh->world * K > 0x7fffffffLL) {
+        ctx->set_error("rcn_shard_reserve: bad shape");
+        return RCN_ERR_ARG;
+    }
+    RCN_HIP(hipSetDevice(ctx->device));
+    const int32_t per = per_rank(n_images, sh->world);
+    if (n_images != sh->n_images || K != sh->K || D != sh->D) {
+        // another shape: nothing may still read or fill the old buffer
+        RCN_HIP(hipStreamSynchronize(ctx->stream));
+        RCN_HIP(hipStreamSynchronize(sh->side));
+        if (sh->slab >= 0) { rcn_match_release(ctx); sh->slab = -1; }
+        RCN_HIP(sh->landing.reserve((size_t)sh->world * per * K * D * sizeof(float)));
+        sh->n_images = n_images; sh->per = per; sh->K = K; sh->D = D;
+        sh->pairs.assign(2 * (size_t)pairs_of(n_images, sh->world, sh->rank), 0);
+        rcn_shard_pairs(n_images, sh->world, sh->rank, sh->pairs.data());
+    }
+    if (local_slot_dev) *local_slot_dev = sh->landing.as<float>() + (size_t)sh->rank * per * K * D;
+    return RCN_OK;
+}
+
+int rcn_shard_exchange(rcn_shard *sh, const float *local_desc_dev)
+{
+    if (!sh) return RCN_ERR_ARG;
+    rcn_ctx *ctx = sh->ctx;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    if (sh->n_images < 1) { ctx->set_error("rcn_shard_exchange: call rcn_shard_reserve first"); return RCN_ERR_ARG; }
+    RCN_HIP(hipSetDevice(ctx->device));
+    const int32_t per = sh->per, K = sh->K, D = sh->D, world = sh->world;
+    int32_t lo = 0, cnt = 0;
+    rcn_shard_owned_images(sh->n_images, world, sh->rank, &lo, &cnt);
+    float *landing = sh->landing.as<float>();
+    float *mine = landing + (size_t)sh->rank * per * K * D;
+    hipStream_t st = ctx->stream;
+    if (local_desc_dev && local_desc_dev != mine && cnt > 0)
+        RCN_HIP(hipMemcpyAsync(mine, local_desc_dev, (size_t)cnt * K * D * sizeof(float), hipMemcpyDeviceToDevice, st));
+    // every image of the grid becomes a view into the landing buffer; this rank converts its own block
+    int rc = rcn_int_slab_attach(ctx, 0, sh->n_images, world * per, landing, K, D, sh->rank * per, cnt, &sh->slab);
+    if (rc) return rc;
+    rc = rcn_int_slab_rowstats(ctx, sh->slab, sh->rank * per, cnt);
+    if (rc) return rc;
+    // global scale statistics: max |x| (fp32 bits) and max |x|^2 (fp64 bits); non-negative floats order like
+    // their bit patterns, so an unsigned max is the floating-point max
+    unsigned *cw = ctx->counters.as<unsigned>();
+    RCN_NCCL(ncclGroupStart());
+    RCN_NCCL(ncclAllReduce(cw, cw, 1, ncclUint32, ncclMax, sh->comm, st));
+    RCN_NCCL(ncclAllReduce(cw + 2, cw + 2, 1, ncclUint64, ncclMax, sh->comm, st));
+    RCN_NCCL(ncclGroupEnd());
+    rc = rcn_int_prepare_all(ctx);          // reads the statistics, converts the local block, builds the image table
+    if (rc) return rc;
+    const Slab &sl = ctx->slabs[sh->slab];
+    const int DPa = ctx->DP ? ctx->DP : 32;
+    const size_t blk16 = (size_t)per * sl.Kp * DPa * sizeof(_Float16), blkhn = (size_t)per * sl.Kp * sizeof(float),
+                 blkn2 = (size_t)per * K * sizeof(double);
+    char *f16 = reinterpret_cast<char *>(sl.f16), *hn = reinterpret_cast<char *>(sl.hn), *n2 = reinterpret_cast<char *>(sl.nrm2);
+    RCN_NCCL(ncclGroupStart());
+    RCN_NCCL(ncclAllGather(f16 + sh->rank * blk16, f16, blk16, ncclChar, sh->comm, st));
+    RCN_NCCL(ncclAllGather(hn + sh->rank * blkhn, hn, blkhn, ncclChar, sh->comm, st));
+    RCN_NCCL(ncclAllGather(n2 + sh->rank * blkn2, n2, blkn2, ncclChar, sh->comm, st));
+    RCN_NCCL(ncclGroupEnd());
+    // fp32 rows: on the side stream with their own communicator, behind the fp16 payload (so the two do
+    // not share the links while the coarse kernel is waiting) and hence behind (a) the local block being
+    // in place and (b) every reader of the previous batch -- all earlier work of the ctx stream.  The
+    // exact stages of the next grid call wait for ev_f32 (ctx->f32_ready).
+    const size_t blk32 = (size_t)per * K * D * sizeof(float);
+    RCN_HIP(hipEventRecord(sh->ev_local, st));
+    RCN_HIP(hipStreamWaitEvent(sh->side, sh->ev_local, 0));
+    RCN_NCCL(ncclAllGather(mine, landing, blk32, ncclChar, sh->comm32, sh->side));
+    RCN_HIP(hipEventRecord(sh->ev_f32, sh->side));
+    ctx->f32_ready = sh->ev_f32;
+    sh->bytes_f16 = (int64_t)world * (blk16 + blkhn + blkn2);
+    sh->bytes_f32 = (int64_t)world * blk32;
+    return RCN_OK;
+}
+
+int rcn_shard_match(rcn_shard *sh, float ratio, int32_t *out_dev, int64_t out_stride, int32_t *counts_dev)
+{
+    if (!sh) return RCN_ERR_ARG;
+    rcn_ctx *ctx = sh->ctx;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    if (sh->slab < 0) { ctx->set_error("rcn_shard_match: call rcn_shard_exchange first"); return RCN_ERR_ARG; }
+    return rcn_int_match_grid(ctx, sh->pairs.data(), (int32_t)(sh->pairs.size() / 2), ratio, out_dev, out_stride, counts_dev);
+}
+
+int rcn_shard_info(const rcn_shard *sh, rcn_shard_stats *out)
+{
+    if (!sh || !out) return RCN_ERR_ARG;
+    memset(out, 0, sizeof(*out));
+    out->rank = sh->rank; out->world = sh->world;
+    out->n_images = sh->n_images; out->images_per_rank = sh->per;
+    out->n_pairs = (int64_t)(sh->pairs.size() / 2);
+    out->exchange_bytes_f16 = sh->bytes_f16;
+    out->exchange_bytes_f32 = sh->bytes_f32;
+    return RCN_OK;
+}
+
+}  // extern "C"

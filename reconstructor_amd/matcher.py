@@ -50,6 +50,7 @@ class HipL2Matcher(FeatureMatcher):
         super().__init__()
         self.ctx = ctx if ctx is not None else _lib.Context(device)
         self.ratio = float(np.float32(ratio))
+        self._D = 0     # descriptor length of the resident images (0 = nothing uploaded yet)
 
     # -- per-pair plugin boundary -------------------------------------------------------
     def match_features(self, features1, features2, matches, img_shape1=None, img_shape2=None):
@@ -80,6 +81,8 @@ class HipL2Matcher(FeatureMatcher):
         desc = _as_desc(desc)
         K = desc.shape[0]
         D = desc.shape[1] if desc.ndim == 2 and desc.shape[1] else self._D
+        if D <= 0:
+            raise ValueError("the first upload must have a descriptor length (an empty set before any other image has no D)")
         self._D = D
         self.ctx.check(self.ctx.lib.rcn_desc_upload(self.ctx.h, int(img_id),
                                                     desc.ctypes.data if K else None, K, D))

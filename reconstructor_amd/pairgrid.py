@@ -1,35 +1,87 @@
-"""Sharding of the image-pair grid over the GPUs of one node (one process per GPU).
+"""Host-side mirror (Python) of the sharded pair grid: include/rcn.h `rcn_shard_*`.
 
 The reference treats image pairs as independent units (OpenMP collapse(2) over the N x N loop,
-SequentialReconstructor.cpp:202-205).  Here: every rank owns a contiguous block of images
-(the ones it "detected"), one RCCL all-gather replicates the descriptor blocks over xGMI,
-and the canonical pair list is dealt round-robin to the ranks.  No other exchange: match
-tables stay on the rank that computed them (or are gathered by the caller; they are small).
-Pure functions here; the collective itself is torch.distributed (backend "nccl" == RCCL).
+SequentialReconstructor.cpp:202-205).  The partition, the RCCL exchange and the per-rank grid call
+all live in librcn.so (csrc/shard.hip); this module only marshals.  One `Shard` per GPU / process:
+the 128-byte rendezvous id is drawn by one rank (`unique_id`) and handed to the others by whatever
+the host has (bench.py: a torch.distributed broadcast over its control-plane process group).
 """
+import ctypes as C
+
 import numpy as np
+
+from . import _lib
 
 
 def owned_images(n_images, world, rank):
-    """[lo, hi) of the images rank `rank` holds before the all-gather (equal blocks; the bench
-    rounds n_images up to a multiple of world so one all_gather_into_tensor suffices)."""
-    per = (n_images + world - 1) // world
-    lo = min(n_images, rank * per)
-    return lo, min(n_images, lo + per)
+    """[lo, hi) of the image ids rank `rank` holds before the exchange (rcn_shard_owned_images)."""
+    lo, cnt = C.c_int32(), C.c_int32()
+    rc = _lib.load().rcn_shard_owned_images(n_images, world, rank, C.byref(lo), C.byref(cnt))
+    if rc:
+        raise _lib.RcnError(rc, "rcn_shard_owned_images")
+    return lo.value, lo.value + cnt.value
 
 
-def shard_pairs(pairs, world, rank):
-    """Round-robin deal of the canonical (i<j, row-major) pair list: balanced to within one
-    pair, and consecutive pairs of a rank still share their query image (L2 reuse)."""
-    pairs = np.asarray(pairs, np.int32).reshape(-1, 2)
-    return np.ascontiguousarray(pairs[rank::world])
+def shard_pairs(n_images, world, rank):
+    """This rank's share of the canonical i < j list (rcn_shard_pairs): pair number p -> rank p % world."""
+    L = _lib.load()
+    n = L.rcn_shard_pair_count(n_images, world, rank)
+    if n < 0:
+        raise _lib.RcnError(int(n), "rcn_shard_pair_count")
+    out = np.zeros((int(n), 2), np.int32)
+    rc = L.rcn_shard_pairs(n_images, world, rank, out.ctypes.data if n else None)
+    if rc:
+        raise _lib.RcnError(rc, "rcn_shard_pairs")
+    return out
 
 
 def merge_shards(shards, world):
-    """Inverse of shard_pairs for per-pair result rows: shards[r] = rows of rank r."""
+    """Inverse of the round-robin deal for per-pair result rows: shards[r] = rows of rank r."""
     n = sum(len(s) for s in shards)
     first = next(s for s in shards if len(s))
     out = np.empty((n,) + first.shape[1:], first.dtype)
     for r, s in enumerate(shards):
         out[r::world] = s
     return out
+
+
+def unique_id():
+    """ncclGetUniqueId as 128 bytes (one rank draws it, every rank passes it to Shard)."""
+    buf = (C.c_uint8 * _lib.SHARD_ID_BYTES)()
+    rc = _lib.load().rcn_shard_unique_id(buf)
+    if rc:
+        raise _lib.RcnError(rc, "rcn_shard_unique_id")
+    return bytes(buf)
+
+
+class Shard:
+    """One rank of the sharded grid (rcn_shard): a ctx plus its RCCL communicators."""
+
+    def __init__(self, ctx, rank, world, uid):
+        self.ctx, self.rank, self.world = ctx, rank, world
+        h = C.c_void_p()
+        buf = (C.c_uint8 * _lib.SHARD_ID_BYTES).from_buffer_copy(uid)
+        ctx.check(ctx.lib.rcn_shard_create(ctx.h, rank, world, buf, C.byref(h)))
+        self.h = h
+
+    def reserve(self, n_images, K, D):
+        """Returns the device address of this rank's [count][K][D] fp32 block of the landing buffer."""
+        slot = C.c_void_p()
+        self.ctx.check(self.ctx.lib.rcn_shard_reserve(self.h, n_images, K, D, C.byref(slot)))
+        return slot.value
+
+    def exchange(self, local_dev_ptr=None):
+        self.ctx.check(self.ctx.lib.rcn_shard_exchange(self.h, C.c_void_p(local_dev_ptr) if local_dev_ptr else None))
+
+    def match(self, ratio, out_dev_ptr, out_stride, counts_dev_ptr):
+        self.ctx.check(self.ctx.lib.rcn_shard_match(self.h, float(ratio), C.c_void_p(out_dev_ptr), out_stride, C.c_void_p(counts_dev_ptr)))
+
+    def info(self):
+        s = _lib.ShardStats()
+        self.ctx.check(self.ctx.lib.rcn_shard_info(self.h, C.byref(s)))
+        return {k: getattr(s, k) for k, _ in s._fields_}
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.ctx.lib.rcn_shard_destroy(self.h)
+            self.h = None

@@ -59,3 +59,32 @@ def test_product_never_imports_oracle():
         for f in files:
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 assert not bad.search(open(os.path.join(d, f)).read()), f
+
+
+def test_shipping_library_reads_no_environment_switch(lib):
+    """Ablations and alternative device paths are compiled out of the product (-DRCN_DIAG builds tools/librcn_diag.so
+    only): the shipping binary does not even contain the names of the switches."""
+    from reconstructor_amd import _lib
+    blob = open(_lib.SO_PATH, "rb").read()
+    for name in (b"RCN_COARSE_ABL", b"RCN_BA_SCHUR_ATOMICS", b"RCN_BA_TRSV_FWD", b"RCN_MATCH_CHUNKS", b"RCN_FORCE_EXACT",
+                 b"RCN_MATCH_NO_ORDER", b"RCN_NO_CU_MASK"):
+        assert name not in blob, name
+    assert b"DIAGNOSTIC" not in lib.rcn_version()
+
+
+def test_partition_functions_need_no_gpu(lib):
+    """rcn_shard_owned_images / rcn_shard_pairs are pure host code: callable without a device."""
+    import ctypes as C
+    import numpy as np
+    n, world = 11, 4
+    seen = []
+    for r in range(world):
+        cnt = lib.rcn_shard_pair_count(n, world, r)
+        buf = np.zeros((cnt, 2), np.int32)
+        assert lib.rcn_shard_pairs(n, world, r, buf.ctypes.data) == 0
+        seen.append(buf)
+        lo, c = C.c_int32(), C.c_int32()
+        assert lib.rcn_shard_owned_images(n, world, r, C.byref(lo), C.byref(c)) == 0 and lo.value == min(n, 3 * r)
+    allp = np.concatenate(seen)
+    assert len(allp) == n * (n - 1) // 2 and len({tuple(p) for p in allp}) == len(allp) and (allp[:, 0] < allp[:, 1]).all()
+    assert lib.rcn_shard_pairs(n, 0, 0, None) == -1 and lib.rcn_shard_pair_count(n, 4, 4) == -1

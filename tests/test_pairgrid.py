@@ -1,4 +1,5 @@
-"""CPU suite: sharding of the pair grid (pure functions + a world_size-2 gloo run)."""
+"""CPU suite: sharding of the pair grid -- the partition functions of the C ABI (rcn_shard_owned_images /
+rcn_shard_pairs: pure host code, no GPU) and a world_size-2 gloo run that deals the grid with them."""
 import os
 import subprocess
 import sys
@@ -12,11 +13,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_shards_partition_the_grid():
-    for n in (2, 5, 100, 141):
+    for n in (2, 5, 100, 141, 1000):
         pairs = all_pairs(n)
         assert len(pairs) == n * (n - 1) // 2 and (pairs[:, 0] < pairs[:, 1]).all()
         for world in (1, 2, 4, 8):
-            shards = [pairgrid.shard_pairs(pairs, world, r) for r in range(world)]
+            shards = [pairgrid.shard_pairs(n, world, r) for r in range(world)]
+            assert all(np.array_equal(shards[r], pairs[r::world]) for r in range(world))      # pair number p -> rank p % world
             sizes = [len(s) for s in shards]
             assert max(sizes) - min(sizes) <= 1
             merged = pairgrid.merge_shards(shards, world)
@@ -42,7 +44,7 @@ local = np.stack([synth.image_descriptors("orb", i, K, pool, seed=7) for i in ra
 gathered = torch.empty((n, K, D), dtype=torch.float32)
 dist.all_gather_into_tensor(gathered.view(-1), torch.from_numpy(local).view(-1))      # the one collective
 ims = [gathered[i].numpy() for i in range(n)]
-mine = pairgrid.shard_pairs(all_pairs(n), world, rank)
+mine = pairgrid.shard_pairs(n, world, rank)            # the C partition (rcn_shard_pairs)
 out, counts = orc.match_grid(ims, mine, threads=1)          # stand-in for the per-rank GPU grid call
 rows = [None] * world
 dist.all_gather_object(rows, out)

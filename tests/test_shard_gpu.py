@@ -1,0 +1,115 @@
+"""GPU suite: the sharded pair grid (rcn_shard_*, csrc/shard.hip) through the C ABI at world_size 1 -- the
+exact code path every rank runs at N > 1 (RCCL communicators, all-reduce of the scale statistics, in-place
+all-gathers, side-stream fp32 gather) -- and the host materialisation of a device match table."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from oracle import orc
+from reconstructor_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def shard(gpu_ctx):
+    from reconstructor_amd import pairgrid
+    sh = pairgrid.Shard(gpu_ctx, 0, 1, pairgrid.unique_id())
+    yield sh
+    sh.close()
+
+
+def _hip():
+    return C.CDLL("libamdhip64.so")
+
+
+def _run(shard, ims, via_slot):
+    import torch
+    n, (K, D) = len(ims), ims[0].shape
+    shard.ctx.check(shard.ctx.lib.rcn_desc_clear(shard.ctx.h))      # whatever earlier tests left resident (another D)
+    slot = shard.reserve(n, K, D)
+    block = np.ascontiguousarray(np.stack(ims), np.float32)
+    if via_slot:        # a producer writing its rows straight into the landing buffer
+        assert _hip().hipMemcpy(C.c_void_p(slot), C.c_void_p(block.ctypes.data), C.c_size_t(block.nbytes), 1) == 0
+        shard.exchange(None)
+    else:
+        dev = torch.from_numpy(block).cuda()
+        torch.cuda.synchronize()
+        shard.exchange(dev.data_ptr())
+    P = n * (n - 1) // 2
+    out = torch.full((P, K), -7, dtype=torch.int32, device="cuda")
+    cnt = torch.full((P,), -7, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    shard.match(0.7, out.data_ptr(), K, cnt.data_ptr())
+    shard.ctx.check(shard.ctx.lib.rcn_synchronize(shard.ctx.h))
+    return out, cnt
+
+
+@pytest.mark.parametrize("kind,K", [("superpoint", 300), ("sift", 700), ("orb", 130)])
+def test_world1_equals_oracle(shard, kind, K):
+    from reconstructor_amd.matcher import all_pairs
+    ims = synth.descriptor_set(kind, 6, K, n_world=2 * K, seed=41)
+    exp, ec = orc.match_grid(ims, all_pairs(6), threads=4)
+    for via_slot in (False, True):
+        out, cnt = _run(shard, ims, via_slot)
+        assert np.array_equal(out.cpu().numpy(), exp) and np.array_equal(cnt.cpu().numpy(), ec)
+    info = shard.info()
+    assert info["n_pairs"] == 15 and info["world"] == 1 and info["exchange_bytes_f32"] == 6 * K * ims[0].shape[1] * 4
+
+
+def test_every_exchange_sees_fresh_data(shard):
+    """Back-to-back exchange + match steps on DIFFERENT data without a host synchronisation in between: the
+    stream/event ordering between the gathers, the conversion and the readers of the previous batch is what
+    keeps step k from reading rows of step k+1 (or the reverse)."""
+    import torch
+    from reconstructor_amd.matcher import all_pairs
+    n, K, D = 5, 512, 256
+    sets = [synth.descriptor_set("superpoint", n, K, n_world=1024, seed=100 + s) for s in range(4)]
+    devs = [torch.from_numpy(np.stack(s)).cuda() for s in sets]
+    P = n * (n - 1) // 2
+    outs = [torch.empty((P, K), dtype=torch.int32, device="cuda") for _ in sets]
+    cnts = [torch.empty((P,), dtype=torch.int32, device="cuda") for _ in sets]
+    shard.ctx.check(shard.ctx.lib.rcn_desc_clear(shard.ctx.h))
+    shard.reserve(n, K, D)
+    torch.cuda.synchronize()
+    for d, o, c in zip(devs, outs, cnts):
+        shard.exchange(d.data_ptr())
+        shard.match(0.7, o.data_ptr(), K, c.data_ptr())
+    shard.ctx.check(shard.ctx.lib.rcn_synchronize(shard.ctx.h))
+    for s, o, c in zip(sets, outs, cnts):
+        exp, ec = orc.match_grid(s, all_pairs(n), threads=4)
+        assert np.array_equal(o.cpu().numpy(), exp) and np.array_equal(c.cpu().numpy(), ec)
+
+
+def test_compact_to_host_lists(shard):
+    """rcn_match_compact_*: per pair the (query, train) lists in ascending query order, offsets from the counts."""
+    import torch
+    lib, ctx = shard.ctx.lib, shard.ctx
+    ims = synth.descriptor_set("superpoint", 7, 900, n_world=1500, seed=77)
+    out, cnt = _run(shard, ims, False)
+    P, K = out.shape
+    table = out.cpu().numpy()
+    for pinned in (True, False):
+        cap = int(cnt.sum().item())
+        offs = np.zeros(P + 1, np.int64)
+        total = C.c_int64(0)
+        if pinned:
+            hp = C.c_void_p()
+            assert lib.rcn_host_alloc(C.byref(hp), 8 * max(cap, 1)) == 0
+            qt = np.ctypeslib.as_array(C.cast(hp, C.POINTER(C.c_int32)), shape=(max(cap, 1), 2))
+        else:
+            qt = np.zeros((max(cap, 1), 2), np.int32)
+        qt[:] = -5
+        ctx.check(lib.rcn_match_compact_begin(ctx.h, out.data_ptr(), K, cnt.data_ptr(), P, offs.ctypes.data, qt.ctypes.data, cap, C.byref(total)))
+        ctx.check(lib.rcn_match_compact_wait(ctx.h))
+        assert total.value == cap and offs[-1] == cap and np.array_equal(np.diff(offs), cnt.cpu().numpy())
+        for p in range(P):
+            q = np.nonzero(table[p] >= 0)[0]
+            got = qt[offs[p]:offs[p + 1]]
+            assert np.array_equal(got[:, 0], q) and np.array_equal(got[:, 1], table[p][q])
+        if pinned:
+            # too small a buffer is an argument error that still reports the total
+            rc = lib.rcn_match_compact_begin(ctx.h, out.data_ptr(), K, cnt.data_ptr(), P, offs.ctypes.data, qt.ctypes.data, cap - 1, C.byref(total))
+            assert rc == -1 and total.value == cap
+            lib.rcn_host_free(hp)
