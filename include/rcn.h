@@ -39,6 +39,7 @@ extern "C" {
 typedef struct rcn_ctx rcn_ctx;
 
 /* ---- context ------------------------------------------------------------------------- */
+int         rcn_device_count(void);                  /* HIP devices visible to this process (0 without a GPU) */
 int         rcn_create(int device_id, rcn_ctx **out);
 void        rcn_destroy(rcn_ctx *ctx);
 const char *rcn_last_error(const rcn_ctx *ctx);      /* never NULL */
@@ -161,11 +162,20 @@ rcn_ctx *rcn_shard_ctx(rcn_shard *sh);
  * rows straight there (the producer contract, see rcn_desc_upload_batch_device) and pass NULL to
  * rcn_shard_exchange.  The pointer stays valid until a reserve with another shape. */
 int rcn_shard_reserve(rcn_shard *sh, int32_t n_images, int32_t K, int32_t D, float **local_slot_dev);
-/* Collective.  local_desc_dev: this rank's [count][K][D] fp32 block in HBM (copied), or NULL when the rows
- * are already in the slot.  Afterwards ids 0 .. n_images-1 are resident in the shard's ctx. */
-int rcn_shard_exchange(rcn_shard *sh, const float *local_desc_dev);
-/* This rank's share of the canonical grid (rcn_shard_pairs order); out_dev / counts_dev as rcn_match_grid_device. */
+/* Host rows of ONE owned image into its slot (featDescToCV's gather, FeatureMatcher.cpp:11-25, done once per
+ * image): K_img <= K rows are copied, the rest of the slot is zero-filled, K_img is remembered for the exchange. */
+int rcn_shard_put_image(rcn_shard *sh, int32_t img_id, const float *desc_host, int32_t K_img);
+/* Collective.  local_desc_dev: this rank's [count][K][D] fp32 block in HBM (copied), or NULL when the rows are
+ * already in the slot.  local_K: rows in use per owned image (count entries, each <= K; tails are zeroed), or
+ * NULL = what rcn_shard_put_image recorded, K for untouched slots.  Afterwards ids 0 .. n_images-1 are resident
+ * in the shard's ctx, image i with its own row count. */
+int rcn_shard_exchange(rcn_shard *sh, const float *local_desc_dev, const int32_t *local_K);
+/* This rank's share of the canonical grid (rcn_shard_pairs order); out_dev / counts_dev as rcn_match_grid_device
+ * (out_stride >= K).  Both NULL: the tables stay in buffers owned by the ctx, for rcn_shard_lists. */
 int rcn_shard_match(rcn_shard *sh, float ratio, int32_t *out_dev, int64_t out_stride, int32_t *counts_dev);
+/* Host lists of the last rcn_shard_match(sh, ratio, NULL, 0, NULL): rcn_match_compact_begin + _wait on the ctx's
+ * own tables (same arguments and the same behaviour when capacity is too small: *total_out tells how many). */
+int rcn_shard_lists(rcn_shard *sh, int64_t *offsets_host, int32_t *qt_host, int64_t capacity, int64_t *total_out);
 
 typedef struct {
     int32_t rank, world, n_images, images_per_rank;

@@ -25,8 +25,8 @@ SYMBOLS = [
     "rcn_coords_upload", "rcn_coords_clear", "rcn_match_table_filter_device",
     "rcn_host_alloc", "rcn_host_free", "rcn_match_compact_begin", "rcn_match_compact_wait",
     "rcn_shard_owned_images", "rcn_shard_pair_count", "rcn_shard_pairs", "rcn_shard_unique_id",
-    "rcn_shard_create", "rcn_shard_destroy", "rcn_shard_ctx", "rcn_shard_reserve", "rcn_shard_exchange",
-    "rcn_shard_match", "rcn_shard_info",
+    "rcn_shard_create", "rcn_shard_destroy", "rcn_shard_ctx", "rcn_shard_reserve", "rcn_shard_put_image", "rcn_shard_exchange",
+    "rcn_shard_match", "rcn_shard_lists", "rcn_shard_info", "rcn_device_count",
     "rcn_store_save", "rcn_store_open", "rcn_store_contents_of", "rcn_store_close", "rcn_store_upload",
 ]
 SHARD_ID_BYTES = 128
@@ -190,7 +190,13 @@ def load():
     L.rcn_shard_reserve.restype = C.c_int
     L.rcn_shard_reserve.argtypes = [vp, i32, i32, i32, C.POINTER(vp)]
     L.rcn_shard_exchange.restype = C.c_int
-    L.rcn_shard_exchange.argtypes = [vp, vp]
+    L.rcn_shard_exchange.argtypes = [vp, vp, vp]
+    L.rcn_shard_put_image.restype = C.c_int
+    L.rcn_shard_put_image.argtypes = [vp, i32, vp, i32]
+    L.rcn_shard_lists.restype = C.c_int
+    L.rcn_shard_lists.argtypes = [vp, vp, vp, i64, C.POINTER(i64)]
+    L.rcn_device_count.restype = C.c_int
+    L.rcn_device_count.argtypes = []
     L.rcn_shard_match.restype = C.c_int
     L.rcn_shard_match.argtypes = [vp, f32, vp, i64, vp]
     L.rcn_shard_info.restype = C.c_int

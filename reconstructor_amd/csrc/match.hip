@@ -140,16 +140,19 @@ __global__ void k_prepare(const float *__restrict__ x, const double *__restrict_
 // Same for a batch of n equally shaped images ([n][K][D] fp32 -> [n][Kp][DP] fp16).
 template <int DP>
 __global__ void k_prepare_batch(const float *__restrict__ x, const double *__restrict__ nrm2,
-                                int n, int K, int Kp, int D, float scale, double half_s2,
-                                double bias, _Float16 *__restrict__ f16, float *__restrict__ hn)
+                                int n, int Kslot, int Kp, int D, float scale, double half_s2,
+                                double bias, _Float16 *__restrict__ f16, float *__restrict__ hn,
+                                const int32_t *__restrict__ Ks)
 {
+    // every image owns a slot of Kslot fp32 rows; Ks (may be NULL = Kslot everywhere) holds the rows in use
     constexpr int CPR = DP / 8;
     const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const long grow = gid / CPR;
     const int c = (int)(gid % CPR);
     if (grow >= (long)n * Kp) return;
     const int img = (int)(grow / Kp), row = (int)(grow % Kp);
-    const float *xi = x + (size_t)img * K * D;
+    const float *xi = x + (size_t)img * Kslot * D;
+    const int K = Ks ? Ks[img] : Kslot;
     half8 v;
     if (row < K && c * 8 + 8 <= D && (D & 3) == 0) {      // whole chunk inside the row, 16-B aligned: two float4 loads
         const float4 lo = *reinterpret_cast<const float4 *>(xi + (size_t)row * D + c * 8);
@@ -165,7 +168,7 @@ __global__ void k_prepare_batch(const float *__restrict__ x, const double *__res
         }
     }
     *reinterpret_cast<half8 *>(f16 + (size_t)grow * DP + ((c ^ swz<DP>(row)) * 8)) = v;
-    if (c == 0) hn[grow] = row < K ? (float)(half_s2 * nrm2[(size_t)img * K + row] + bias) : RCN_PAD_HN;
+    if (c == 0) hn[grow] = row < K ? (float)(half_s2 * nrm2[(size_t)img * Kslot + row] + bias) : RCN_PAD_HN;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1045,8 +1048,11 @@ static int upload_common(rcn_ctx *ctx, int32_t img_id, const float *src, bool sr
 // count).  [conv_first, conv_first + conv_n) are the slots THIS ctx converts to fp16 itself; the
 // other slots' fp16 rows / half-norms / norms are filled by the caller (RCCL all-gather, shard.hip).
 // Same shape again reuses every allocation.
+// Ks_host / Ks_dev (both or neither): rows in use per slot (<= K) when the images are ragged; the unused
+// tail rows of a slot must hold zeros (they take part in the row statistics) and are never matched.
 int rcn_int_slab_attach(rcn_ctx *ctx, int32_t first_id, int32_t n_images, int32_t n_slots, const float *src,
-                        int32_t K, int32_t D, int32_t conv_first, int32_t conv_n, int *slab_out)
+                        int32_t K, int32_t D, int32_t conv_first, int32_t conv_n, int *slab_out,
+                        const int32_t *Ks_host, const int32_t *Ks_dev)
 {
     if (n_images < 0 || n_slots < n_images || K <= 0 || D <= 0 || (n_slots > 0 && !src) || (int64_t)n_slots * K > 0x7fffffffLL ||
         conv_first < 0 || conv_n < 0 || conv_first + conv_n > n_slots) {
@@ -1097,7 +1103,9 @@ int rcn_int_slab_attach(rcn_ctx *ctx, int32_t first_id, int32_t n_images, int32_
     sl.f32 = src;
     sl.n_images = n_images;
     sl.conv_first = conv_first; sl.conv_n = conv_n;
+    sl.Ks_dev = Ks_dev;
     for (int i = 0; i < n_images; ++i) {
+        if (Ks_host && (Ks_host[i] < 0 || Ks_host[i] > K)) { ctx->set_error("slab attach: an image's row count exceeds its slot"); return RCN_ERR_ARG; }
         auto old = ctx->images.find(first_id + i);
         if (old != ctx->images.end() && old->second.slab != si) {
             // the id was re-uploaded on its own (or through another slab) in between: release what it owns
@@ -1105,7 +1113,7 @@ int rcn_int_slab_attach(rcn_ctx *ctx, int32_t first_id, int32_t n_images, int32_
             ctx->images.erase(old);
         }
         ImgHost im;
-        im.K = K; im.Kp = Kp; im.slab = si; im.dirty = true;
+        im.K = Ks_host ? Ks_host[i] : K; im.Kp = Kp; im.slab = si; im.dirty = true;
         im.f32 = const_cast<float *>(src) + (size_t)i * K * D;
         im.f16 = sl.f16 + (size_t)i * Kp * DPa;
         im.hn = sl.hn + (size_t)i * Kp;
@@ -1138,7 +1146,7 @@ int rcn_int_slab_rowstats(rcn_ctx *ctx, int si, int32_t first, int32_t n)
 static int upload_batch(rcn_ctx *ctx, int32_t first_id, int32_t n, const float *src, int32_t K, int32_t D)
 {
     int si = -1;
-    int rc = rcn_int_slab_attach(ctx, first_id, n, n, src, K, D, 0, n, &si);
+    int rc = rcn_int_slab_attach(ctx, first_id, n, n, src, K, D, 0, n, &si, nullptr, nullptr);
     if (rc || si < 0) return rc;
     return rcn_int_slab_rowstats(ctx, si, 0, n);
 }
@@ -1151,7 +1159,7 @@ template <int DP> static void launch_prepare_batch(rcn_ctx *ctx, const Slab &sl,
     const size_t f = sl.conv_first;
     k_prepare_batch<DP><<<(unsigned)((nthr + 255) / 256), 256, 0, ctx->stream>>>(
         sl.f32 + f * sl.K * sl.D, sl.nrm2 + f * sl.K, sl.conv_n, sl.K, sl.Kp, sl.D, s, hs2, bias,
-        sl.f16 + f * sl.Kp * DP, sl.hn + f * sl.Kp);
+        sl.f16 + f * sl.Kp * DP, sl.hn + f * sl.Kp, sl.Ks_dev ? sl.Ks_dev + f : nullptr);
 }
 
 template <int DP> static void launch_prepare(rcn_ctx *ctx, const ImgHost &im, float s, double hs2, double bias)

@@ -65,6 +65,7 @@ struct Slab {
     int32_t n_images = 0;                 // ids first_id .. first_id + n_images - 1 live in slots 0 .. n_images - 1
     int32_t conv_first = 0, conv_n = 0;   // slots this ctx converts to fp16 itself (the rest arrives by all-gather)
     const float *f32 = nullptr;   // borrowed from the caller
+    const int32_t *Ks_dev = nullptr;   // borrowed: rows in use per slot when the images are ragged (NULL = K everywhere)
     _Float16 *f16 = nullptr;
     float *hn = nullptr;
     double *nrm2 = nullptr;
@@ -139,7 +140,8 @@ struct rcn_ctx {
 int rcn_match_release(rcn_ctx *ctx);
 // match.hip internals shared with shard.hip (all expect ctx->mu held)
 int rcn_int_slab_attach(rcn_ctx *ctx, int32_t first_id, int32_t n_images, int32_t n_slots, const float *src,
-                        int32_t K, int32_t D, int32_t conv_first, int32_t conv_n, int *slab_out);
+                        int32_t K, int32_t D, int32_t conv_first, int32_t conv_n, int *slab_out,
+                        const int32_t *Ks_host, const int32_t *Ks_dev);
 int rcn_int_slab_rowstats(rcn_ctx *ctx, int slab, int32_t first, int32_t n);
 int rcn_int_prepare_all(rcn_ctx *ctx);
 int rcn_int_match_grid(rcn_ctx *ctx, const int32_t *pairs_host, int32_t n_pairs, float ratio,

@@ -31,9 +31,13 @@ struct rcn_shard {
     hipStream_t side = nullptr;        // carries the fp32 all-gather beside the coarse kernel
     hipEvent_t ev_local = nullptr;     // ctx stream: the local fp32 block is in place / previous readers are queued
     hipEvent_t ev_f32 = nullptr;       // side stream: fp32 rows of every rank have landed
-    DevBuf landing;                    // [world * per][K][D] fp32
+    DevBuf landing;                    // [world * per][K][D] fp32: one K-row slot per image
+    DevBuf counts;                     // [world * per] int32: rows in use per slot (all-gathered every exchange)
+    std::vector<int32_t> local_K;      // this rank's block of `counts` (rcn_shard_put_image / exchange argument)
+    std::vector<int32_t> all_K;        // host copy of `counts` after the gather
     int32_t n_images = 0, per = 0, K = 0, D = 0;
     int slab = -1;
+    bool own_table = false;            // the last rcn_shard_match wrote into the ctx's own tables
     std::vector<int32_t> pairs;        // this rank's share of the canonical grid
     int64_t bytes_f16 = 0, bytes_f32 = 0;   // payload sizes of the last exchange (whole gather, all ranks)
 };
@@ -57,7 +61,23 @@ static int64_t pairs_of(int32_t n, int32_t world, int32_t rank)
     return total > rank ? (total - rank + world - 1) / world : 0;
 }
 
+// rows K_i .. K-1 of every local slot <- 0 (ragged images: the tail takes part in the row statistics)
+__global__ void k_zero_tails(float *__restrict__ block, const int32_t *__restrict__ Ks, int K, int D)
+{
+    const int img = blockIdx.y, k = Ks[img];
+    float *base = block + ((size_t)img * K + k) * D;
+    const size_t n = (size_t)(K - k) * D;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) base[i] = 0.f;
+}
+
 extern "C" {
+
+int rcn_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return n;
+}
 
 int rcn_shard_owned_images(int32_t n_images, int32_t world, int32_t rank, int32_t *first, int32_t *count)
 {
@@ -161,6 +181,7 @@ void rcn_shard_destroy(rcn_shard *sh)
         (void)hipEventDestroy(sh->ev_local);
         (void)hipEventDestroy(sh->ev_f32);
         sh->landing.release();
+        sh->counts.release();
     }
     delete sh;
 }
@@ -184,6 +205,14 @@ int rcn_shard_reserve(rcn_shard *sh, int32_t n_images, int32_t K, int32_t D, flo
         RCN_HIP(hipStreamSynchronize(sh->side));
         if (sh->slab >= 0) { rcn_match_release(ctx); sh->slab = -1; }
         RCN_HIP(sh->landing.reserve((size_t)sh->world * per * K * D * sizeof(float)));
+        RCN_HIP(sh->counts.reserve((size_t)sh->world * per * sizeof(int32_t)));
+        sh->local_K.assign((size_t)per, 0);
+        sh->all_K.assign((size_t)sh->world * per, 0);
+        {
+            int32_t lo = 0, cnt = 0;
+            rcn_shard_owned_images(n_images, sh->world, sh->rank, &lo, &cnt);
+            for (int i = 0; i < cnt; ++i) sh->local_K[i] = K;        // full slots until told otherwise
+        }
         sh->n_images = n_images; sh->per = per; sh->K = K; sh->D = D;
         sh->pairs.assign(2 * (size_t)pairs_of(n_images, sh->world, sh->rank), 0);
         rcn_shard_pairs(n_images, sh->world, sh->rank, sh->pairs.data());
@@ -192,7 +221,29 @@ int rcn_shard_reserve(rcn_shard *sh, int32_t n_images, int32_t K, int32_t D, flo
     return RCN_OK;
 }
 
-int rcn_shard_exchange(rcn_shard *sh, const float *local_desc_dev)
+int rcn_shard_put_image(rcn_shard *sh, int32_t img_id, const float *desc_host, int32_t K_img)
+{
+    if (!sh) return RCN_ERR_ARG;
+    rcn_ctx *ctx = sh->ctx;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    int32_t lo = 0, cnt = 0;
+    rcn_shard_owned_images(sh->n_images, sh->world, sh->rank, &lo, &cnt);
+    if (sh->n_images < 1 || img_id < lo || img_id >= lo + cnt || K_img < 0 || K_img > sh->K || (K_img > 0 && !desc_host)) {
+        ctx->set_error("rcn_shard_put_image: the image is not owned by this rank, or its rows do not fit the reserved slot");
+        return RCN_ERR_ARG;
+    }
+    RCN_HIP(hipSetDevice(ctx->device));
+    float *slot = sh->landing.as<float>() + ((size_t)sh->rank * sh->per + (img_id - lo)) * sh->K * sh->D;
+    if (K_img > 0)
+        RCN_HIP(hipMemcpyAsync(slot, desc_host, (size_t)K_img * sh->D * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    if (K_img < sh->K)
+        RCN_HIP(hipMemsetAsync(slot + (size_t)K_img * sh->D, 0, (size_t)(sh->K - K_img) * sh->D * sizeof(float), ctx->stream));
+    RCN_HIP(hipStreamSynchronize(ctx->stream));                 // the host rows are borrowed
+    sh->local_K[img_id - lo] = K_img;
+    return RCN_OK;
+}
+
+int rcn_shard_exchange(rcn_shard *sh, const float *local_desc_dev, const int32_t *local_K)
 {
     if (!sh) return RCN_ERR_ARG;
     rcn_ctx *ctx = sh->ctx;
@@ -205,10 +256,31 @@ int rcn_shard_exchange(rcn_shard *sh, const float *local_desc_dev)
     float *landing = sh->landing.as<float>();
     float *mine = landing + (size_t)sh->rank * per * K * D;
     hipStream_t st = ctx->stream;
+    if (local_K)
+        for (int i = 0; i < cnt; ++i) {
+            if (local_K[i] < 0 || local_K[i] > K) { ctx->set_error("rcn_shard_exchange: a row count exceeds the reserved slot"); return RCN_ERR_ARG; }
+            sh->local_K[i] = local_K[i];
+        }
     if (local_desc_dev && local_desc_dev != mine && cnt > 0)
         RCN_HIP(hipMemcpyAsync(mine, local_desc_dev, (size_t)cnt * K * D * sizeof(float), hipMemcpyDeviceToDevice, st));
+    // rows in use per slot: every rank's block of counts, all-gathered (always: whether the images are
+    // ragged must not be a per-rank decision), then read back -- the image table needs them on the host
+    int32_t *counts = sh->counts.as<int32_t>();
+    RCN_HIP(hipMemcpyAsync(counts + (size_t)sh->rank * per, sh->local_K.data(), (size_t)per * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    RCN_NCCL(ncclAllGather(counts + (size_t)sh->rank * per, counts, (size_t)per, ncclInt32, sh->comm, st));
+    RCN_HIP(hipMemcpyAsync(sh->all_K.data(), counts, (size_t)world * per * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    bool ragged_local = false;
+    for (int i = 0; i < cnt; ++i) ragged_local |= sh->local_K[i] < K;
+    if (ragged_local && local_desc_dev)       // rcn_shard_put_image zero-fills on its own
+        k_zero_tails<<<dim3(64, (unsigned)cnt), 256, 0, st>>>(mine, counts + (size_t)sh->rank * per, K, D);
+    RCN_HIP(hipGetLastError());
+    RCN_HIP(hipStreamSynchronize(st));
+    bool ragged = false;
+    for (int i = 0; i < sh->n_images; ++i) ragged |= sh->all_K[i] != K;
+
     // every image of the grid becomes a view into the landing buffer; this rank converts its own block
-    int rc = rcn_int_slab_attach(ctx, 0, sh->n_images, world * per, landing, K, D, sh->rank * per, cnt, &sh->slab);
+    int rc = rcn_int_slab_attach(ctx, 0, sh->n_images, world * per, landing, K, D, sh->rank * per, cnt, &sh->slab,
+                                 ragged ? sh->all_K.data() : nullptr, ragged ? counts : nullptr);
     if (rc) return rc;
     rc = rcn_int_slab_rowstats(ctx, sh->slab, sh->rank * per, cnt);
     if (rc) return rc;
@@ -252,7 +324,32 @@ int rcn_shard_match(rcn_shard *sh, float ratio, int32_t *out_dev, int64_t out_st
     rcn_ctx *ctx = sh->ctx;
     std::lock_guard<std::mutex> lk(ctx->mu);
     if (sh->slab < 0) { ctx->set_error("rcn_shard_match: call rcn_shard_exchange first"); return RCN_ERR_ARG; }
-    return rcn_int_match_grid(ctx, sh->pairs.data(), (int32_t)(sh->pairs.size() / 2), ratio, out_dev, out_stride, counts_dev);
+    const int32_t P = (int32_t)(sh->pairs.size() / 2);
+    if (!out_dev && !counts_dev) {
+        // tables owned by the ctx (host callers that only want the lists: rcn_shard_lists)
+        RCN_HIP(hipSetDevice(ctx->device));
+        out_stride = sh->K;
+        RCN_HIP(ctx->out_tmp.reserve(std::max<size_t>(1, (size_t)P) * out_stride * sizeof(int32_t)));
+        RCN_HIP(ctx->cnt_tmp.reserve(std::max<size_t>(1, (size_t)P) * sizeof(int32_t)));
+        out_dev = ctx->out_tmp.as<int32_t>();
+        counts_dev = ctx->cnt_tmp.as<int32_t>();
+        sh->own_table = true;
+    } else sh->own_table = false;
+    return rcn_int_match_grid(ctx, sh->pairs.data(), P, ratio, out_dev, out_stride, counts_dev);
+}
+
+int rcn_shard_lists(rcn_shard *sh, int64_t *offsets_host, int32_t *qt_host, int64_t capacity, int64_t *total_out)
+{
+    if (!sh) return RCN_ERR_ARG;
+    rcn_ctx *ctx = sh->ctx;
+    {
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        if (!sh->own_table) { ctx->set_error("rcn_shard_lists: call rcn_shard_match with NULL tables first"); return RCN_ERR_ARG; }
+    }
+    int rc = rcn_match_compact_begin(ctx, ctx->out_tmp.as<int32_t>(), sh->K, ctx->cnt_tmp.as<int32_t>(), (int32_t)(sh->pairs.size() / 2),
+                                     offsets_host, qt_host, capacity, total_out);
+    if (rc) return rc;
+    return rcn_match_compact_wait(ctx);
 }
 
 int rcn_shard_info(const rcn_shard *sh, rcn_shard_stats *out)

@@ -1,0 +1,178 @@
+// HipPairGridDriver.h -- the reference's pair loop on every GPU of the node, from C++.
+//
+// Takes the place of the body of SequentialReconstructor::matchFeatures
+// (SequentialReconstructor.cpp:199-279) for the FakeImgMatcher grid (every i != j, ImageMatcher.cpp:6-23):
+// one host thread per GPU, each owning one rcn_ctx + one rcn_shard (RCCL communicators over xGMI);
+// nothing here touches HIP or RCCL directly -- only include/rcn.h.
+//
+//   images   0 .. n-1 (the loop indexes `features` by position, :204-214), rank r packs and uploads the
+//            block it owns (featDescToCV's gather, FeatureMatcher.cpp:11-25, once per image, ragged K)
+//   exchange rcn_shard_exchange: RCCL all-reduce of the scale statistics, all-gather of the fp16 payload
+//   match    rcn_shard_match: pair number p of the canonical i < j list runs on rank p % world
+//   results  featureMatches[(i,j)][query feature] = train feature and the inverted map under (j,i), exactly
+//            what the loop stores when it meets (j,i) after (i,j) (:219-227).  A pair whose forward
+//            matching stored NOTHING has no entry to invert: the loop then matches (j,i) in its own right
+//            (query = j), and so does this driver, in a second pass over those pairs.
+// The geometric filter (:237-269) is not applied here; HipGeometricFilter.h / rcn_match_table_filter_device do that.
+#pragma once
+#include <atomic>
+#include <stdexcept>
+#include <string>
+#include <thread>
+
+#include "../../include/rcn.h"
+#include "rcn_types.h"
+
+namespace reconstructor::Core {
+
+// key hash of featureMatches (the reference declares its own pair_hash, SequentialReconstructor.h:51-63;
+// any hash of the pair serves -- the container's contents do not depend on it)
+struct pair_hash {
+    std::size_t operator()(const std::pair<int, int> &p) const
+    {
+        return std::hash<long long>()(((long long)p.first << 32) ^ (unsigned)p.second);
+    }
+};
+using FeatureMatches = std::unordered_map<std::pair<int, int>, std::unordered_map<int, int>, pair_hash>;
+
+class HipPairGridDriver {
+public:
+    // nDevices = 0: every visible GPU
+    explicit HipPairGridDriver(int nDevices = 0)
+    {
+        const int have = rcn_device_count();
+        world_ = nDevices > 0 ? nDevices : have;
+        if (world_ < 1 || world_ > have) throw std::runtime_error("HipPairGridDriver: no usable gfx950 device");
+        uint8_t id[RCN_SHARD_ID_BYTES];
+        if (rcn_shard_unique_id(id) != RCN_OK) throw std::runtime_error("HipPairGridDriver: rcn_shard_unique_id failed");
+        ctx_.assign(world_, nullptr);
+        shard_.assign(world_, nullptr);
+        // rcn_shard_create is collective: one thread per rank
+        std::vector<std::string> err(world_);
+        run([&](int r) {
+            if (rcn_create(r, &ctx_[r]) != RCN_OK) { err[r] = "rcn_create failed"; return; }
+            if (rcn_shard_create(ctx_[r], r, world_, id, &shard_[r]) != RCN_OK) err[r] = std::string("rcn_shard_create: ") + rcn_last_error(ctx_[r]);
+        });
+        for (const auto &e : err)
+            if (!e.empty()) { release(); throw std::runtime_error("HipPairGridDriver: " + e); }
+    }
+    ~HipPairGridDriver() { release(); }
+    HipPairGridDriver(const HipPairGridDriver &) = delete;
+    HipPairGridDriver &operator=(const HipPairGridDriver &) = delete;
+
+    int world() const { return world_; }
+    rcn_ctx *context(int rank = 0) { return ctx_[rank]; }
+
+    // features[imgId] for imgId = 0 .. n-1 (SequentialReconstructor.h:205); fills featureMatches (:226)
+    void matchFeatures(std::unordered_map<int, std::vector<FeaturePtr<>>> &features, FeatureMatches &featureMatches)
+    {
+        const int n = (int)features.size();
+        if (n < 2) return;
+        int Kmax = 0, D = 0;
+        for (int i = 0; i < n; ++i) {
+            auto it = features.find(i);
+            if (it == features.end()) throw std::runtime_error("HipPairGridDriver: image ids must be 0 .. n-1");
+            Kmax = std::max(Kmax, (int)it->second.size());
+            if (!it->second.empty()) {
+                const int d = (int)it->second[0]->featDesc.desc.size();
+                if (D && d != D) throw std::runtime_error("descriptor lengths differ");
+                D = d;
+            }
+        }
+        if (Kmax == 0 || D == 0) return;
+        struct RankOut {
+            std::vector<int32_t> pairs, qt, rev_pairs, rev_out, rev_cnt;
+            std::vector<int64_t> offs;
+            std::string err;
+        };
+        std::vector<RankOut> out(world_);
+        run([&](int r) {
+            RankOut &o = out[r];
+            rcn_shard *sh = shard_[r];
+            auto fail = [&](const char *what) { o.err = std::string(what) + ": " + rcn_last_error(ctx_[r]); };
+            // NB every rank walks the same sequence of collectives even after a local failure would be
+            // unrecoverable anyway: errors are reported after the join
+            if (rcn_shard_reserve(sh, n, Kmax, D, nullptr) != RCN_OK) { fail("rcn_shard_reserve"); return; }
+            int32_t lo = 0, cnt = 0;
+            rcn_shard_owned_images(n, world_, r, &lo, &cnt);
+            std::vector<float> dense;
+            for (int img = lo; img < lo + cnt; ++img) {
+                const auto &f = features[img];
+                dense.resize(f.size() * (size_t)D);
+                for (size_t k = 0; k < f.size(); ++k) {
+                    const std::vector<float> &d = f[k]->featDesc.desc;
+                    if ((int)d.size() != D) { o.err = "descriptor lengths differ"; return; }
+                    std::copy(d.begin(), d.end(), dense.begin() + k * D);
+                }
+                if (rcn_shard_put_image(sh, img, dense.data(), (int32_t)f.size()) != RCN_OK) { fail("rcn_shard_put_image"); return; }
+            }
+            if (rcn_shard_exchange(sh, nullptr, nullptr) != RCN_OK) { fail("rcn_shard_exchange"); return; }
+            if (rcn_shard_match(sh, ratioThresh, nullptr, 0, nullptr) != RCN_OK) { fail("rcn_shard_match"); return; }
+            const int64_t P = rcn_shard_pair_count(n, world_, r);
+            o.pairs.resize(2 * (size_t)P);
+            rcn_shard_pairs(n, world_, r, o.pairs.data());
+            o.offs.assign((size_t)P + 1, 0);
+            int64_t total = 0;
+            int rc = rcn_shard_lists(sh, o.offs.data(), nullptr, 0, &total);
+            if (rc != RCN_OK && total == 0) { fail("rcn_shard_lists"); return; }
+            o.qt.resize(2 * (size_t)total);
+            if (total > 0 && rcn_shard_lists(sh, o.offs.data(), o.qt.data(), total, &total) != RCN_OK) { fail("rcn_shard_lists"); return; }
+            // second pass: pairs that stored nothing are matched again the other way round (:219-232)
+            for (int64_t p = 0; p < P; ++p)
+                if (o.offs[p + 1] == o.offs[p]) { o.rev_pairs.push_back(o.pairs[2 * p + 1]); o.rev_pairs.push_back(o.pairs[2 * p]); }
+            const int32_t R = (int32_t)(o.rev_pairs.size() / 2);
+            if (R > 0) {
+                o.rev_out.assign((size_t)R * Kmax, -1);
+                o.rev_cnt.assign(R, 0);
+                if (rcn_match_grid(ctx_[r], o.rev_pairs.data(), R, ratioThresh, o.rev_out.data(), Kmax, o.rev_cnt.data()) != RCN_OK) { fail("rcn_match_grid"); return; }
+            }
+        });
+        for (const auto &o : out)
+            if (!o.err.empty()) throw std::runtime_error("HipPairGridDriver: " + o.err);
+        for (const RankOut &o : out) {
+            const size_t P = o.pairs.size() / 2;
+            for (size_t p = 0; p < P; ++p) {
+                if (o.offs[p + 1] == o.offs[p]) continue;
+                const std::pair<int, int> cur(o.pairs[2 * p], o.pairs[2 * p + 1]), inv(cur.second, cur.first);
+                auto &fwd = featureMatches[cur];
+                auto &bwd = featureMatches[inv];
+                for (int64_t e = o.offs[p]; e < o.offs[p + 1]; ++e) {
+                    fwd[o.qt[2 * e]] = o.qt[2 * e + 1];
+                    bwd[o.qt[2 * e + 1]] = o.qt[2 * e];
+                }
+            }
+            const size_t R = o.rev_pairs.size() / 2;
+            for (size_t p = 0; p < R; ++p) {
+                if (o.rev_cnt[p] == 0) continue;
+                auto &m = featureMatches[{o.rev_pairs[2 * p], o.rev_pairs[2 * p + 1]}];
+                const int32_t *row = o.rev_out.data() + p * (size_t)Kmax;
+                for (int q = 0; q < Kmax; ++q)
+                    if (row[q] >= 0) m[q] = row[q];
+            }
+        }
+    }
+
+private:
+    template <class F> void run(F &&body)
+    {
+        if (world_ == 1) { body(0); return; }
+        std::vector<std::thread> th;
+        for (int r = 0; r < world_; ++r) th.emplace_back([&, r] { body(r); });
+        for (auto &t : th) t.join();
+    }
+    void release()
+    {
+        // communicator teardown is collective as well
+        run([&](int r) {
+            if (shard_[r]) rcn_shard_destroy(shard_[r]);
+            if (ctx_[r]) rcn_destroy(ctx_[r]);
+            shard_[r] = nullptr; ctx_[r] = nullptr;
+        });
+    }
+    int world_ = 0;
+    std::vector<rcn_ctx *> ctx_;
+    std::vector<rcn_shard *> shard_;
+    const float ratioThresh = 0.7;   // FeatureMatcher.h:45
+};
+
+}  // namespace reconstructor::Core

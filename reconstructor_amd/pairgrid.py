@@ -70,11 +70,33 @@ class Shard:
         self.ctx.check(self.ctx.lib.rcn_shard_reserve(self.h, n_images, K, D, C.byref(slot)))
         return slot.value
 
-    def exchange(self, local_dev_ptr=None):
-        self.ctx.check(self.ctx.lib.rcn_shard_exchange(self.h, C.c_void_p(local_dev_ptr) if local_dev_ptr else None))
+    def put_image(self, img_id, desc):
+        """Host rows of one owned image into its slot (ragged K allowed: K_img <= reserved K)."""
+        desc = np.ascontiguousarray(desc, np.float32)
+        self.ctx.check(self.ctx.lib.rcn_shard_put_image(self.h, int(img_id), desc.ctypes.data if len(desc) else None, len(desc)))
 
-    def match(self, ratio, out_dev_ptr, out_stride, counts_dev_ptr):
-        self.ctx.check(self.ctx.lib.rcn_shard_match(self.h, float(ratio), C.c_void_p(out_dev_ptr), out_stride, C.c_void_p(counts_dev_ptr)))
+    def exchange(self, local_dev_ptr=None, local_K=None):
+        k = None if local_K is None else np.ascontiguousarray(local_K, np.int32)
+        self.ctx.check(self.ctx.lib.rcn_shard_exchange(self.h, C.c_void_p(local_dev_ptr) if local_dev_ptr else None,
+                                                       k.ctypes.data if k is not None else None))
+
+    def match(self, ratio, out_dev_ptr=None, out_stride=0, counts_dev_ptr=None):
+        """Both pointers None: the tables stay in the ctx's own buffers (then `lists()`)."""
+        self.ctx.check(self.ctx.lib.rcn_shard_match(self.h, float(ratio), C.c_void_p(out_dev_ptr) if out_dev_ptr else None, out_stride,
+                                                    C.c_void_p(counts_dev_ptr) if counts_dev_ptr else None))
+
+    def lists(self):
+        """(offsets[P+1] int64, qt[total, 2] int32) of the last match() into the ctx's own tables."""
+        P = self.info()["n_pairs"]
+        offs = np.zeros(P + 1, np.int64)
+        total = C.c_int64(0)
+        rc = self.ctx.lib.rcn_shard_lists(self.h, offs.ctypes.data, None, 0, C.byref(total))
+        if rc not in (0, -1):
+            self.ctx.check(rc)
+        qt = np.zeros((max(1, total.value), 2), np.int32)
+        if total.value:
+            self.ctx.check(self.ctx.lib.rcn_shard_lists(self.h, offs.ctypes.data, qt.ctypes.data, total.value, C.byref(total)))
+        return offs, qt[:total.value]
 
     def info(self):
         s = _lib.ShardStats()

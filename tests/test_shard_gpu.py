@@ -113,3 +113,43 @@ def test_compact_to_host_lists(shard):
             rc = lib.rcn_match_compact_begin(ctx.h, out.data_ptr(), K, cnt.data_ptr(), P, offs.ctypes.data, qt.ctypes.data, cap - 1, C.byref(total))
             assert rc == -1 and total.value == cap
             lib.rcn_host_free(hp)
+
+
+def test_ragged_images_through_the_slots(shard):
+    """Images of different sizes (the reference's SIFT keypoint counts vary per image): every image owns a slot of
+    Kmax rows; rows past its own count are zero-filled and never matched.  Both ways in: host rows per image
+    (rcn_shard_put_image) and a device block with the per-image counts."""
+    import torch
+    from reconstructor_amd.matcher import all_pairs
+    Ks = [300, 64, 0, 513, 2, 97, 1]
+    ims = synth.descriptor_set("sift", len(Ks), Ks, n_world=800, seed=5)
+    n, Kmax, D = len(Ks), max(Ks), 128
+    exp, ec = orc.match_grid(ims, all_pairs(n), threads=4)
+    P = n * (n - 1) // 2
+    for via_host in (True, False):
+        shard.ctx.check(shard.ctx.lib.rcn_desc_clear(shard.ctx.h))
+        shard.reserve(n, Kmax, D)
+        if via_host:
+            for i, im in enumerate(ims):
+                shard.put_image(i, im)
+            shard.exchange(None, None)
+        else:
+            block = np.full((n, Kmax, D), 7.0, np.float32)        # garbage in the tails: the exchange zeroes them
+            for i, im in enumerate(ims):
+                block[i, :len(im)] = im
+            dev = torch.from_numpy(block).cuda()
+            torch.cuda.synchronize()
+            shard.exchange(dev.data_ptr(), Ks)
+        out = torch.full((P, Kmax), -7, dtype=torch.int32, device="cuda")
+        cnt = torch.full((P,), -7, dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        shard.match(0.7, out.data_ptr(), Kmax, cnt.data_ptr())
+        shard.ctx.check(shard.ctx.lib.rcn_synchronize(shard.ctx.h))
+        assert np.array_equal(out.cpu().numpy(), exp) and np.array_equal(cnt.cpu().numpy(), ec)
+    # the ctx-owned tables + host lists
+    shard.match(0.7)
+    offs, qt = shard.lists()
+    assert np.array_equal(np.diff(offs), ec)
+    for p in range(P):
+        q = np.nonzero(exp[p] >= 0)[0]
+        assert np.array_equal(qt[offs[p]:offs[p + 1], 0], q) and np.array_equal(qt[offs[p]:offs[p + 1], 1], exp[p][q])
