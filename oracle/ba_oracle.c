@@ -575,13 +575,26 @@ int orc_ba_solve(int n_cams, int n_points, int n_obs, double *poses, double *int
         if (!isfinite(cand_cost)) cand_cost = DBL_MAX;
 
         /* parameter tolerance (on x - candidate) and function tolerance, before the accept test */
+        /* |x| is the norm of the REDUCED program's state, in ambient coordinates, as Ceres' trust-region
+         * minimizer takes it (x_norm_ = x_.norm()): parameter blocks that are constant (camera 0's pose;
+         * every intrinsics block when there are < 10 cameras, BundleAdjuster.cpp:100-101,112-115) or that no
+         * residual uses have been removed from the program and do not count; a block with a SubsetManifold
+         * (camera 1's pose, the intrinsics otherwise) stays, with all six of its coordinates. */
         double dn = 0.0, xn = 0.0;
-        for (int c = 0; c < n_cams; ++c)
+        for (int c = 0; c < n_cams; ++c) {
+            const int used = P.cam_obs_off[c + 1] > P.cam_obs_off[c];
+            const int pose_in = used && P.cam_dim[c] > 0 && P.cols[c][0] < 6, intr_in = used && P.mode == 1;
             for (int k = 0; k < 6; ++k) {
-                double d = poses2[6 * c + k] - poses[6 * c + k]; dn += d * d; xn += poses[6 * c + k] * poses[6 * c + k];
-                d = intr2[6 * c + k] - intr[6 * c + k]; dn += d * d; xn += intr[6 * c + k] * intr[6 * c + k];
+                double d = poses2[6 * c + k] - poses[6 * c + k]; dn += d * d;
+                if (pose_in) xn += poses[6 * c + k] * poses[6 * c + k];
+                d = intr2[6 * c + k] - intr[6 * c + k]; dn += d * d;
+                if (intr_in) xn += intr[6 * c + k] * intr[6 * c + k];
             }
-        for (int i = 0; i < 3 * n_points; ++i) { double d = pts2[i] - pts[i]; dn += d * d; xn += pts[i] * pts[i]; }
+        }
+        for (int j = 0; j < n_points; ++j) {
+            const int used = P.pt_off[j + 1] > P.pt_off[j];
+            for (int k = 0; k < 3; ++k) { double d = pts2[3 * j + k] - pts[3 * j + k]; dn += d * d; if (used) xn += pts[3 * j + k] * pts[3 * j + k]; }
+        }
         if (sqrt(dn) <= opt->parameter_tolerance * (sqrt(xn) + opt->parameter_tolerance)) {
             termination = RCN_BA_CONVERGENCE_PARAMETER;
             if (iter < 160) sum->cost_trace[iter] = cost;

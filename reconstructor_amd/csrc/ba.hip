@@ -1309,7 +1309,16 @@ __global__ __launch_bounds__(256) void k_ba_plus(BaDev d, double alpha, double *
     if (i < d.nc) {   // one thread per camera: 12 ambient parameters
         const int c = i, off = d.cam_off[c], dc = d.cam_dim[c];
         double ps[6], in[6];
-        for (int k = 0; k < 6; ++k) { ps[k] = d.poses[6 * c + k]; in[k] = d.intr[6 * c + k]; xn += ps[k] * ps[k] + in[k] * in[k]; }
+        // |x| over the reduced program only, as Ceres' minimizer (x_norm_): a constant block (camera 0's pose, the
+        // intrinsics when they are all held) or one no residual uses is not part of the state; a block with a
+        // subset manifold counts with all six coordinates
+        const bool used = d.cam_obs_off[c + 1] > d.cam_obs_off[c];
+        const bool pose_in = used && dc > 0 && d.cols[10 * c] < 6, intr_in = used && d.mode == 1;
+        for (int k = 0; k < 6; ++k) {
+            ps[k] = d.poses[6 * c + k]; in[k] = d.intr[6 * c + k];
+            if (pose_in) xn += ps[k] * ps[k];
+            if (intr_in) xn += in[k] * in[k];
+        }
         double ps2[6], in2[6];
         for (int k = 0; k < 6; ++k) { ps2[k] = ps[k]; in2[k] = in[k]; }
         for (int k = 0; k < dc; ++k) {
@@ -1331,6 +1340,7 @@ __global__ __launch_bounds__(256) void k_ba_plus(BaDev d, double alpha, double *
         }
     }
     if (i < d.np) {
+        const bool used = d.pt_off[i + 1] > d.pt_off[i];
         for (int k = 0; k < 3; ++k) {
             const size_t e = 3 * (size_t)i + k;
             const double dl = alpha * d.stp[e] * d.sp[e];
@@ -1339,7 +1349,8 @@ __global__ __launch_bounds__(256) void k_ba_plus(BaDev d, double alpha, double *
             const double x = d.pts[e];
             g0 += d.gpraw[e] * dl;
             d.pts2[e] = x + dl;
-            dn += dl * dl; xn += x * x;
+            dn += dl * dl;
+            if (used) xn += x * x;
         }
     }
     double s;

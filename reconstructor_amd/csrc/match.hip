@@ -1470,6 +1470,7 @@ int rcn_int_match_grid(rcn_ctx *ctx, const int32_t *pairs_host, int32_t n_pairs,
         RCN_HIP(hipEventRecord(ctx->ba_ev[5], sb));
         RCN_HIP(hipStreamWaitEvent(sa, ctx->ba_ev[5], 0));
     }
+    ctx->last_kq_stride = kq_stride; ctx->last_idx_mask = idx_mask; ctx->last_n_pairs = n_pairs;
     // stats: the fallback count is read back lazily in rcn_match_last_stats
     ctx->last_stats.rows_total = rows;
     ctx->last_stats.pair_distances = pd;
@@ -1633,6 +1634,28 @@ int rcn_match_last_stats(const rcn_ctx *cctx, rcn_match_stats *out)
     *out = ctx->last_stats;
     return RCN_OK;
 }
+
+#ifdef RCN_DIAG
+// Diagnostic build only (tools/librcn_diag.so; not declared in include/rcn.h): the packed (best, second)
+// table the coarse pass left for the LAST grid call and the constants of its error model, so that a test can
+// measure |MFMA accumulator - exact value| on the hardware against the bound the certificates rely on.
+// cand_host: n_pairs x kq_stride x 2 words; model[8] = {s, BIAS, Nmax, idx_mask, kq_stride, DP, hn_max, n_pairs}.
+int rcn_diag_coarse_table(rcn_ctx *ctx, uint32_t *cand_host, int64_t capacity_words, double *model)
+{
+    if (!ctx || !model) return RCN_ERR_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    const int64_t words = 2 * (int64_t)ctx->last_n_pairs * ctx->last_kq_stride;
+    model[0] = ctx->scale; model[1] = ctx->bias; model[2] = ctx->max_norm; model[3] = (double)ctx->last_idx_mask;
+    model[4] = (double)ctx->last_kq_stride; model[5] = (double)ctx->DP;
+    model[6] = 0.5 * ctx->scale * ctx->scale * ctx->max_norm * ctx->max_norm + ctx->bias; model[7] = (double)ctx->last_n_pairs;
+    if (!cand_host) return RCN_OK;
+    if (capacity_words < words || !ctx->cand.p) { ctx->set_error("rcn_diag_coarse_table: buffer too small / no grid call yet"); return RCN_ERR_ARG; }
+    RCN_HIP(hipSetDevice(ctx->device));
+    RCN_HIP(hipMemcpyAsync(cand_host, ctx->cand.p, (size_t)words * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    RCN_HIP(hipStreamSynchronize(ctx->stream));
+    return RCN_OK;
+}
+#endif
 
 int rcn_match_profile(rcn_ctx *ctx, int enable)
 {

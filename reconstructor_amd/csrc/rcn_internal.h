@@ -102,6 +102,8 @@ struct rcn_ctx {
     hipEvent_t cmp_ev[2] = {nullptr, nullptr}, cmp_filled = nullptr;
     bool cmp_busy[2] = {false, false};
     int cmp_next = 0, cmp_last = -1;
+    int32_t last_kq_stride = 0, last_n_pairs = 0;   // shape of the candidate table of the last grid call
+    uint32_t last_idx_mask = 0;
     rcn_match_stats last_stats;
     bool profile = false;
     hipEvent_t ev[64][4];

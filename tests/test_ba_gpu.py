@@ -107,6 +107,41 @@ def test_cfg5_properties(gpu_ctx):
     assert np.array_equal(P[0], sc["poses"][0]) and np.array_equal(P[1, 3:], sc["poses"][1, 3:])
     assert np.array_equal(I[:, 2:4], sc["intrinsics"][:, 2:4])
     assert np.abs(X - sc["points_gt"]).mean() < 0.05
+    # ---- and against the CPU oracle's own solve of this scene (tests/golden/ba_cfg5.npz, written once in the
+    #      build container by tests/golden/make_ba_cfg5_golden.py: the oracle needs ~3e11 flop per iteration here)
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ba_cfg5.npz"))
+    assert list(g["args"]) == [1000, 100000, 10, 2024]
+    assert s["iterations"] == int(g["iterations"]) and s["termination"] == int(g["termination"])
+    assert s["successful_steps"] == int(g["successful_steps"]) and s["unsuccessful_steps"] == int(g["unsuccessful_steps"])
+    assert abs(s["initial_cost"] - float(g["initial_cost"])) <= 1e-10 * float(g["initial_cost"])
+    assert np.allclose(tr, g["cost_trace"], rtol=1e-7)
+    assert abs(s["final_rms_px"] - float(g["final_rms_px"])) <= RMS_TOL_PX
+    assert np.allclose(P[::10], g["poses_sample"], atol=1e-6) and np.allclose(X[::500], g["points_sample"], atol=1e-5)
+    assert np.allclose(I[::10], g["intrinsics_sample"], rtol=1e-6, atol=1e-6)
+
+
+def test_parameter_tolerance_is_taken_over_the_reduced_program(gpu_ctx):
+    """|x| of the parameter-tolerance test counts only blocks of the reduced program (Ceres' x_norm_): shifting the
+    principal point -- a constant block below 10 cameras -- together with the observations must not move the
+    termination; GPU and oracle stop at the same iteration either way."""
+    from reconstructor_amd import ba
+    import os, sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_oracle_ba import shifted_principal_point
+    sc = synth_ba.make_scene(6, 120, obs_per_point=5, seed=11)
+    o0, o1 = orc_ba.default_options(6), ba.default_options(gpu_ctx, 6)
+    for o in (o0, o1):
+        o.parameter_tolerance = 1e-7
+        o.function_tolerance = 0.0
+    its = []
+    for shift in (0.0, 1.0e6):
+        scs = shifted_principal_point(sc, shift)
+        P0, I0, X0, s0 = orc_ba.solve(scs, o0)
+        P1, I1, X1, s1 = ba.solve_scene(gpu_ctx, scs, o1)
+        assert s1["termination"] == s0["termination"] == 3 and s1["iterations"] == s0["iterations"]
+        its.append(s1["iterations"])
+    assert its[0] == its[1] >= 3
 
 
 def test_edge_cases_match_oracle(gpu_ctx):

@@ -63,3 +63,28 @@ def test_noise_free_converges_to_zero():
     P, I, X, s = orc_ba.solve(sc)
     assert s["final_rms_px"] < 1e-6
     assert np.allclose(X, sc["points_gt"], atol=1e-5)
+
+
+def shifted_principal_point(sc, shift):
+    """The same optimisation problem with cx, cy and every observation moved by `shift`: residuals and Jacobians
+    are unchanged, only the value of a parameter block that is CONSTANT for < 10 cameras differs."""
+    sc2 = {k: np.array(v, copy=True) for k, v in sc.items()}
+    sc2["intrinsics"][:, 2:4] += shift
+    sc2["obs_uv"] = sc2["obs_uv"] + shift
+    return sc2
+
+
+def test_parameter_tolerance_ignores_blocks_outside_the_reduced_program():
+    """Ceres takes |x| of the parameter-tolerance test over the reduced program: constant blocks (all intrinsics
+    when there are < 10 cameras, camera 0's pose) have been removed from it.  Moving the principal point by 1e6 px
+    together with the observations leaves the problem unchanged -- so it must leave the termination unchanged; with
+    |x| taken over everything the shifted problem stops after its first iteration."""
+    sc = synth_ba.make_scene(6, 120, obs_per_point=5, seed=11)
+    o = orc_ba.default_options(6)
+    o.parameter_tolerance = 1e-7
+    o.function_tolerance = 0.0            # let the parameter test decide
+    P0, I0, X0, s0 = orc_ba.solve(sc, o)
+    P1, I1, X1, s1 = orc_ba.solve(shifted_principal_point(sc, 1.0e6), o)
+    assert s0["termination"] == 3 == s1["termination"]                       # RCN_BA_CONVERGENCE_PARAMETER
+    assert s0["iterations"] == s1["iterations"] and s0["iterations"] >= 3
+    assert np.allclose(s0["cost_trace"], s1["cost_trace"], rtol=1e-6)
