@@ -134,6 +134,17 @@ def ba_leg(ctx, with_cpu):
         P, I, X, s4 = orc_ba.solve(sc4, threads=4)      # options.num_threads = 4 in the reference (BundleAdjuster.cpp:134)
         out["cpu_baseline"]["at_reference_thread_count"] = {"value": s4["iterations"] / s4["solve_seconds"], "cores": 4,
                                                             "sample": "cfg4 full solve, %.2f s" % (time.perf_counter() - t0)}
+    # cfg 5 against the CPU oracle's own solve of the same scene (fixture written once in the build container:
+    # tests/golden/make_ba_cfg5_golden.py; the oracle needs minutes for it, too long for the bench run)
+    gpath = os.path.join(ROOT, "tests", "golden", "ba_cfg5.npz")
+    if "cfg5" in out and os.path.exists(gpath):
+        g = np.load(gpath)
+        out["cfg5"]["rms_diff_vs_cpu_px"] = abs(out["cfg5"]["final_rms_px"] - float(g["final_rms_px"]))
+        out["cfg5"]["iterations_equal_to_cpu"] = bool(out["cfg5"]["lm_iterations"] == int(g["iterations"]))
+        out["cfg5"]["cpu_oracle"] = {"final_rms_px": float(g["final_rms_px"]), "iterations": int(g["iterations"]),
+                                     "seconds": float(g["oracle_seconds"]), "threads": int(g["oracle_threads"]),
+                                     "lm_iterations_per_s": int(g["iterations"]) / float(g["oracle_seconds"]),
+                                     "source": "tests/golden/ba_cfg5.npz (oracle/ba_oracle.c in the build container)"}
     out["landmark_sweep"] = sweep_leg(ctx, with_cpu)
     return out
 

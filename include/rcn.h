@@ -64,6 +64,17 @@ int rcn_desc_upload_device(rcn_ctx *ctx, int32_t img_id, const float *desc_dev, 
  * (RCN_ERR_ARG otherwise; hipMalloc / torch allocations are). */
 int rcn_desc_upload_batch_device(rcn_ctx *ctx, int32_t first_img_id, int32_t n_images,
                                  const float *desc_dev, int32_t K, int32_t D);
+/* Producer contract.  The layout above -- [n][K][D] fp32 row-major in HBM, D = 256 unit-norm rows for SuperPoint
+ * (FeatureSuperPoint.cpp:183-211), 128 for SIFT, 32 for ORB-as-float -- is what a detector running on the GPU
+ * writes straight into: either its own buffer handed to rcn_desc_upload_batch_device (borrowed, zero copy), or
+ * the slot rcn_shard_reserve returns.  Rows past an image's keypoint count must be zero (rcn_shard_exchange's
+ * local_K) or the images are uploaded one by one.  rcn_desc_sample_device is the last step of such a detector:
+ * processDescriptors of the reference (cell = keypoint / 8 in integers, the first D <= 256 channels of that cell
+ * of the dense descriptor map, divided by FeatDesc::norm(): fp32 squares summed in fp64 in ascending order),
+ * bit-exact, writing K rows of D floats to out_rows_dev.  The map is addressed by element strides: the network's
+ * own [C][Hc][Wc] output is (Hc*Wc, Wc, 1), a channel-last copy is (1, Wc*C, C).  Asynchronous on the ctx stream. */
+int rcn_desc_sample_device(rcn_ctx *ctx, const float *desc_map_dev, int64_t stride_c, int64_t stride_y, int64_t stride_x,
+                           int32_t Hc, int32_t Wc, const int32_t *kp_xy_dev, int32_t K, int32_t D, float *out_rows_dev);
 int rcn_desc_clear(rcn_ctx *ctx);
 int rcn_desc_count(const rcn_ctx *ctx);
 

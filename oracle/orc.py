@@ -20,7 +20,7 @@ def build(force=False, native=False):
     global _LIB
     name = "liborc_native.so" if native else "liborc.so"
     so = os.path.join(_HERE, name)
-    srcs = [os.path.join(_HERE, f) for f in ("match_oracle.c", "ba_oracle.c", "validity_oracle.c", "fmat_oracle.c", "Makefile")]
+    srcs = [os.path.join(_HERE, f) for f in ("match_oracle.c", "ba_oracle.c", "validity_oracle.c", "fmat_oracle.c", "desc_oracle.c", "Makefile")]
     stale = (not os.path.exists(so)) or any(
         os.path.getmtime(s) > os.path.getmtime(so) for s in srcs)
     if native and getattr(build, "_native_done", False):
@@ -59,6 +59,8 @@ def _sig():
     L.orc_match_grid.restype = None
     L.orc_match_grid.argtypes = [_f32p, _i64p, C.c_int, C.c_int, _i32p, C.c_int, C.c_float,
                                  _i32p, C.c_int64, _i32p, C.c_int]
+    L.orc_desc_sample.restype = None
+    L.orc_desc_sample.argtypes = [_f32p, C.c_int64, C.c_int64, C.c_int64, _i32p, C.c_int, C.c_int, _f32p]
     from . import orc_ba, orc_fmat, orc_validity
     orc_ba.register(L)
     orc_validity.register(L)
@@ -114,6 +116,22 @@ def match_grid(images, pairs, ratio=RATIO, threads=0):
     lib().orc_match_grid(desc.reshape(-1), rows, len(images), D, pairs.reshape(-1), P,
                          float(ratio), out.reshape(-1), kmax, counts, threads)
     return out, counts
+
+
+def desc_sample(desc_map, kp_xy, D=256, channel_last=False):
+    """FeatureSuperPoint::processDescriptors: desc_map [C][Hc][Wc] (the network's layout) or [Hc][Wc][C];
+    kp_xy (K, 2) integer image coordinates (x, y).  Returns (K, D) fp32 unit-norm rows."""
+    m = np.ascontiguousarray(desc_map, np.float32)
+    kp = np.ascontiguousarray(kp_xy, np.int32).reshape(-1, 2)
+    if channel_last:
+        Hc, Wc, Cn = m.shape
+        sc, sy, sx = 1, Wc * Cn, Cn
+    else:
+        Cn, Hc, Wc = m.shape
+        sc, sy, sx = Hc * Wc, Wc, 1
+    out = np.zeros((len(kp), D), np.float32)
+    lib().orc_desc_sample(m.reshape(-1), sc, sy, sx, kp.reshape(-1), len(kp), D, out.reshape(-1))
+    return out
 
 
 def all_pairs(n):
