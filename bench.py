@@ -389,7 +389,17 @@ def main():
     uid = [pairgrid.unique_id() if rank == 0 else None]
     if world > 1:
         dist.broadcast_object_list(uid, src=0)
-    shard = pairgrid.Shard(ctx, rank, world, uid[0])
+    # RCCL prints its version banner to STDOUT when the first communicator comes up; this process's stdout carries ONE
+    # JSON line: send fd 1 to stderr meanwhile
+    sys.stdout.flush()
+    saved = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        shard = pairgrid.Shard(ctx, rank, world, uid[0])
+    finally:
+        sys.stdout.flush()
+        os.dup2(saved, 1)
+        os.close(saved)
 
     # ---- inputs: every rank generates only the images it "detected"
     lo, hi = pairgrid.owned_images(n_img, world, rank)

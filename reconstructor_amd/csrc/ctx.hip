@@ -69,6 +69,8 @@ int rcn_create(int device_id, rcn_ctx **out)
 #ifdef RCN_DIAG
     // Diagnostic build only (tools/librcn_diag.so, -DRCN_DIAG): ablations and alternative device paths.
     // The shipping library reads no environment variable.
+    const char *w4 = std::getenv("RCN_COARSE_W4");
+    ctx->coarse_w4 = w4 && w4[0] == '1';
     const char *fe = std::getenv("RCN_FORCE_EXACT");
     ctx->force_exact = fe && fe[0] == '1';
     const char *nio = getenv("RCN_MATCH_NO_ORDER");

@@ -188,6 +188,8 @@ struct CoarseArgs {
     uint32_t idx_mask;      // low bits that carry the train row
 };
 
+#include "coarse_w4.h"
+
 // K1: one workgroup (8 waves, 2 per SIMD) = 512 query rows of one image against every train row
 //   of up to RCN_GROUP consecutive pairs that share that query image; query fragments are
 //   loaded once per work item.
@@ -1240,6 +1242,15 @@ int rcn_int_prepare_all(rcn_ctx *ctx)
     return RCN_OK;
 }
 
+template <int DP> static hipError_t launch_coarse_w4(rcn_ctx *ctx, const CoarseArgs &ca, int blocks)
+{
+    const size_t lds = (size_t)RCN_NBUF * (RCN_BT * DP * 2 + 4 * 256) + RCN_TBL_BYTES;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_coarse_w4<DP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    k_coarse_w4<DP><<<blocks, 256, lds, ctx->stream>>>(ca);
+    return hipGetLastError();
+}
+
 template <int DP, int ABL = 0> static hipError_t launch_coarse(rcn_ctx *ctx, const CoarseArgs &ca, int blocks)
 {
     const size_t lds = (size_t)RCN_NBUF * (RCN_BT * DP * 2 + 8 * 256) + RCN_TBL_BYTES;
@@ -1360,6 +1371,9 @@ int rcn_int_match_grid(rcn_ctx *ctx, const int32_t *pairs_host, int32_t n_pairs,
     // group list, heaviest groups first, so that the last items to start are the short ones (the tail
     // of a launch is one item long: 5 % of a cfg-2 grid for a four-pair group, 1 % for a one-pair group).
     // Groups are dealt to the XCD ranges round-robin in descending weight; unused slots hold empty groups.
+    // (Measured and dropped in round 2: a train-block-major order -- every XCD runs the query tiles of ~8 query
+    // images against the SAME four train images at a time, so that all but one of them hit in its L2 -- is 0.5-1.5 %
+    // slower: the kernel is power-limited, not fabric-limited, and the order above has the shorter tail.)
     int n_groups_dev = n_groups;
     {
         std::vector<int2> &arr = ctx->groups_arranged;
@@ -1403,6 +1417,13 @@ int rcn_int_match_grid(rcn_ctx *ctx, const int32_t *pairs_host, int32_t n_pairs,
             ca.idx_mask = idx_mask;
             const int blocks = ca.items_per_xcd * 8;
             hipError_t e;
+            if (ctx->coarse_w4 && ctx->DP >= 64) {
+                switch (ctx->DP) {
+                case 64: e = launch_coarse_w4<64>(ctx, ca, blocks); break;
+                case 128: e = launch_coarse_w4<128>(ctx, ca, blocks); break;
+                default: e = launch_coarse_w4<256>(ctx, ca, blocks); break;
+                }
+            } else
             switch (ctx->DP) {
             case 32: e = launch_coarse<32>(ctx, ca, blocks); break;
             case 64: e = launch_coarse<64>(ctx, ca, blocks); break;
