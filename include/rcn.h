@@ -257,7 +257,9 @@ typedef struct {
     int32_t line_search_backtracks;
     int32_t bound_projections;
     int32_t reduced_dim;        /* rows of the reduced camera system */
-    double  solve_seconds;      /* wall time of the LM loop, inputs resident */
+    int32_t pair_lists_reused;  /* 1: the Schur build's observation-pair lists were still valid (rcn_ba_session_solve on an unchanged graph) */
+    int32_t reserved;
+    double  solve_seconds;      /* wall time of the solve, inputs resident: pair lists of the Schur build + the LM loop */
     double  schur_seconds;      /* HIP-event time, summed over iterations: point blocks + Schur build */
     double  cholesky_seconds;   /* dense factorisation of the reduced system */
     double  trisolve_seconds;   /* triangular solves + back-substitution + model/candidate evaluation */
@@ -266,6 +268,41 @@ typedef struct {
 
 int rcn_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *problem, const rcn_ba_options *options,
                  rcn_ba_summary *summary);
+
+/* ---- device-resident bundle adjustment across the incremental loop ----------------------------
+ * SequentialReconstructor::reconstruct (SequentialReconstructor.cpp:1040-1094) runs, after every registered view,
+ * checkLandmarkValidity -> BundleAdjuster().adjust(all views so far) -> checkLandmarkValidity -> removeOutlierLandmarks:
+ * N - 2 global solves on a problem that grows by one camera, its new landmarks and their observations each time.
+ * A session keeps that problem in HBM between the solves -- landmark coordinates, landmark-major observation arrays,
+ * the observation-pair lists of the Schur build, the solver workspace -- with the graph (tracks in
+ * triangulatedFeatures order; additions append like push_back) and the 12 numbers per camera mirrored on the host.
+ * A session solve is rcn_ba_solve's arithmetic on the same problem: identical results, bit for bit.
+ *   cameras       index = position in imgIdxOrder; pose6 / intr6 as rcn_ba_problem
+ *   observations  (landmark, camera, integer pixel x, y), appended to the END of the landmark's track            */
+typedef struct rcn_ba_session rcn_ba_session;
+int  rcn_ba_session_create(rcn_ctx *ctx, rcn_ba_session **out);
+void rcn_ba_session_destroy(rcn_ba_session *s);
+int  rcn_ba_session_add_camera(rcn_ba_session *s, const double *pose6, const double *intr6, int32_t *index_out);
+/* read (…_out) and / or overwrite (…_in) every camera's pose6 / intr6; any pointer may be NULL.  Adapters that keep
+ * the reference's 4x4 pose matrices between solves (unpack :157-185, re-pack :46-59) round-trip the poses here. */
+int  rcn_ba_session_cameras(rcn_ba_session *s, double *poses_out, double *intr_out, const double *poses_in, const double *intr_in);
+int  rcn_ba_session_add_points(rcn_ba_session *s, int32_t n, const double *xyz_host, int32_t *first_index_out);
+int  rcn_ba_session_add_observations(rcn_ba_session *s, int32_t n, const int32_t *pt, const int32_t *cam, const int32_t *xy);
+int  rcn_ba_session_counts(const rcn_ba_session *s, int32_t *n_cams, int32_t *n_points, int64_t *n_obs);
+/* the graph, flattened landmark-major in track order: n_obs entries each (xy_out: 2 per entry); any pointer may be NULL */
+int  rcn_ba_session_graph(rcn_ba_session *s, int32_t *pt_out, int32_t *cam_out, int32_t *xy_out);
+/* options == NULL: rcn_ba_default_options for the current camera count (the reference's choice, BundleAdjuster.cpp:99-142) */
+int  rcn_ba_session_solve(rcn_ba_session *s, const rcn_ba_options *options, rcn_ba_summary *summary);
+int  rcn_ba_session_read_points(rcn_ba_session *s, double *xyz_host);
+const double *rcn_ba_session_points_device(rcn_ba_session *s);      /* n_points x 3 in HBM; valid until the next add / remove */
+/* checkLandmarkValidity (SequentialReconstructor.cpp:869-954) on the session's arrays, on the device.  poses34_host:
+ * n_cams x 12, rows of [R | t] of imgIdx2camPose as the pipeline holds them.  Observations the sweep erases are erased
+ * from the tracks; inlier_out (n_points bytes), n_inliers_out, n_erased_out may be NULL. */
+int  rcn_ba_session_validity(rcn_ba_session *s, const double *poses34_host, double max_projection_error, double min_triangulation_angle,
+                             uint8_t *inlier_out, int32_t *n_inliers_out, int32_t *n_erased_out);
+/* removeOutlierLandmarks (:956-976) for the flags of the last sweep: landmarks compacted on the device.
+ * new_index_out (may be NULL): n_points entries before the call, -1 = removed. */
+int  rcn_ba_session_remove_outliers(rcn_ba_session *s, int32_t *new_index_out, int32_t *n_removed_out);
 
 /* ---- landmark validity sweep -------------------------------------------------------------
  * SequentialReconstructor::checkLandmarkValidity (SequentialReconstructor.cpp:869-954), the check

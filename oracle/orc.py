@@ -20,7 +20,8 @@ def build(force=False, native=False):
     global _LIB
     name = "liborc_native.so" if native else "liborc.so"
     so = os.path.join(_HERE, name)
-    srcs = [os.path.join(_HERE, f) for f in ("match_oracle.c", "ba_oracle.c", "validity_oracle.c", "fmat_oracle.c", "desc_oracle.c", "Makefile")]
+    srcs = [os.path.join(_HERE, f) for f in ("match_oracle.c", "ba_oracle.c", "validity_oracle.c", "fmat_oracle.c", "desc_oracle.c", "Makefile")] + \
+           [os.path.join(os.path.dirname(_HERE), "include", "rcn.h")]      # ba_oracle.c shares the option / summary struct layouts
     stale = (not os.path.exists(so)) or any(
         os.path.getmtime(s) > os.path.getmtime(so) for s in srcs)
     if native and getattr(build, "_native_done", False):

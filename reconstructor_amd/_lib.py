@@ -27,6 +27,10 @@ SYMBOLS = [
     "rcn_shard_owned_images", "rcn_shard_pair_count", "rcn_shard_pairs", "rcn_shard_unique_id",
     "rcn_shard_create", "rcn_shard_destroy", "rcn_shard_ctx", "rcn_shard_reserve", "rcn_shard_put_image", "rcn_shard_exchange",
     "rcn_shard_match", "rcn_shard_lists", "rcn_shard_info", "rcn_device_count",
+    "rcn_ba_session_create", "rcn_ba_session_destroy", "rcn_ba_session_add_camera", "rcn_ba_session_cameras",
+    "rcn_ba_session_add_points", "rcn_ba_session_add_observations", "rcn_ba_session_counts", "rcn_ba_session_graph",
+    "rcn_ba_session_solve", "rcn_ba_session_read_points", "rcn_ba_session_points_device", "rcn_ba_session_validity",
+    "rcn_ba_session_remove_outliers",
     "rcn_store_save", "rcn_store_open", "rcn_store_contents_of", "rcn_store_close", "rcn_store_upload",
 ]
 SHARD_ID_BYTES = 128
@@ -91,6 +95,7 @@ class BaSummary(C.Structure):
                 ("unsuccessful_steps", C.c_int32), ("invalid_steps", C.c_int32),
                 ("termination", C.c_int32), ("line_search_backtracks", C.c_int32),
                 ("bound_projections", C.c_int32), ("reduced_dim", C.c_int32),
+                ("pair_lists_reused", C.c_int32), ("reserved", C.c_int32),
                 ("solve_seconds", C.c_double), ("schur_seconds", C.c_double),
                 ("cholesky_seconds", C.c_double), ("trisolve_seconds", C.c_double),
                 ("cost_trace", C.c_double * 160)]
@@ -203,6 +208,32 @@ def load():
     L.rcn_shard_match.argtypes = [vp, f32, vp, i64, vp]
     L.rcn_shard_info.restype = C.c_int
     L.rcn_shard_info.argtypes = [vp, C.POINTER(ShardStats)]
+    L.rcn_ba_session_create.restype = C.c_int
+    L.rcn_ba_session_create.argtypes = [vp, C.POINTER(vp)]
+    L.rcn_ba_session_destroy.restype = None
+    L.rcn_ba_session_destroy.argtypes = [vp]
+    L.rcn_ba_session_add_camera.restype = C.c_int
+    L.rcn_ba_session_add_camera.argtypes = [vp, vp, vp, C.POINTER(i32)]
+    L.rcn_ba_session_cameras.restype = C.c_int
+    L.rcn_ba_session_cameras.argtypes = [vp, vp, vp, vp, vp]
+    L.rcn_ba_session_add_points.restype = C.c_int
+    L.rcn_ba_session_add_points.argtypes = [vp, i32, vp, C.POINTER(i32)]
+    L.rcn_ba_session_add_observations.restype = C.c_int
+    L.rcn_ba_session_add_observations.argtypes = [vp, i32, vp, vp, vp]
+    L.rcn_ba_session_counts.restype = C.c_int
+    L.rcn_ba_session_counts.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i64)]
+    L.rcn_ba_session_graph.restype = C.c_int
+    L.rcn_ba_session_graph.argtypes = [vp, vp, vp, vp]
+    L.rcn_ba_session_solve.restype = C.c_int
+    L.rcn_ba_session_solve.argtypes = [vp, C.POINTER(BaOptions), C.POINTER(BaSummary)]
+    L.rcn_ba_session_read_points.restype = C.c_int
+    L.rcn_ba_session_read_points.argtypes = [vp, vp]
+    L.rcn_ba_session_points_device.restype = vp
+    L.rcn_ba_session_points_device.argtypes = [vp]
+    L.rcn_ba_session_validity.restype = C.c_int
+    L.rcn_ba_session_validity.argtypes = [vp, vp, C.c_double, C.c_double, vp, C.POINTER(i32), C.POINTER(i32)]
+    L.rcn_ba_session_remove_outliers.restype = C.c_int
+    L.rcn_ba_session_remove_outliers.argtypes = [vp, vp, C.POINTER(i32)]
     L.rcn_store_save.restype = C.c_int
     L.rcn_store_save.argtypes = [C.c_char_p, C.POINTER(StoreContents)]
     L.rcn_store_open.restype = C.c_int

@@ -120,6 +120,101 @@ class BundleAdjuster:
         return g2l
 
 
+def poses34_from_angle_axis(poses):
+    """[R | t] rows as the reference's pipeline holds them after adjust(): the unpack of BundleAdjuster.cpp:157-185,
+    non-unit axis w / (angle + 1e-6) included."""
+    poses = np.asarray(poses, np.float64).reshape(-1, 6)
+    out = np.zeros((len(poses), 12))
+    for l, p in enumerate(poses):
+        ang = float(np.sqrt((p[:3] ** 2).sum()))
+        R = _angle_axis_to_rot(ang, p[:3] / (ang + 1e-6))
+        out[l] = np.concatenate([R, p[3:, None]], 1).reshape(-1)
+    return out
+
+
+class BaSession:
+    """rcn_ba_session: the incremental loop's problem resident in HBM across its N - 2 global solves
+    (SequentialReconstructor.cpp:1040-1094).  Cameras / landmarks / observations are appended; solve(), validity()
+    and remove_outliers() work on the device arrays."""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+        h = C.c_void_p()
+        ctx.check(ctx.lib.rcn_ba_session_create(ctx.h, C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.ctx.lib.rcn_ba_session_destroy(self.h)
+            self.h = None
+
+    def add_camera(self, pose6, intr6):
+        p, k = np.ascontiguousarray(pose6, np.float64), np.ascontiguousarray(intr6, np.float64)
+        idx = C.c_int32()
+        self.ctx.check(self.ctx.lib.rcn_ba_session_add_camera(self.h, p.ctypes.data, k.ctypes.data, C.byref(idx)))
+        return idx.value
+
+    def add_points(self, xyz):
+        xyz = np.ascontiguousarray(xyz, np.float64).reshape(-1, 3)
+        first = C.c_int32()
+        self.ctx.check(self.ctx.lib.rcn_ba_session_add_points(self.h, len(xyz), xyz.ctypes.data if len(xyz) else None, C.byref(first)))
+        return first.value
+
+    def add_observations(self, pt, cam, xy):
+        pt, cam = np.ascontiguousarray(pt, np.int32), np.ascontiguousarray(cam, np.int32)
+        xy = np.ascontiguousarray(xy, np.int32).reshape(-1, 2)
+        self.ctx.check(self.ctx.lib.rcn_ba_session_add_observations(self.h, len(pt), pt.ctypes.data if len(pt) else None,
+                                                                    cam.ctypes.data if len(pt) else None, xy.ctypes.data if len(pt) else None))
+
+    def counts(self):
+        nc, npts, no = C.c_int32(), C.c_int32(), C.c_int64()
+        self.ctx.check(self.ctx.lib.rcn_ba_session_counts(self.h, C.byref(nc), C.byref(npts), C.byref(no)))
+        return nc.value, npts.value, no.value
+
+    def cameras(self, poses=None, intr=None):
+        """Returns (poses, intrinsics); arrays given are written into the session first."""
+        nc = self.counts()[0]
+        pi = None if poses is None else np.ascontiguousarray(poses, np.float64)
+        ki = None if intr is None else np.ascontiguousarray(intr, np.float64)
+        po, ko = np.zeros((nc, 6)), np.zeros((nc, 6))
+        self.ctx.check(self.ctx.lib.rcn_ba_session_cameras(self.h, po.ctypes.data, ko.ctypes.data,
+                                                           pi.ctypes.data if pi is not None else None, ki.ctypes.data if ki is not None else None))
+        return po, ko
+
+    def graph(self):
+        no = self.counts()[2]
+        pt, cam, xy = np.zeros(no, np.int32), np.zeros(no, np.int32), np.zeros((no, 2), np.int32)
+        self.ctx.check(self.ctx.lib.rcn_ba_session_graph(self.h, pt.ctypes.data, cam.ctypes.data, xy.ctypes.data))
+        return pt, cam, xy
+
+    def points(self):
+        x = np.zeros((self.counts()[1], 3))
+        self.ctx.check(self.ctx.lib.rcn_ba_session_read_points(self.h, x.ctypes.data))
+        return x
+
+    def solve(self, options=None):
+        s = _lib.BaSummary()
+        self.ctx.check(self.ctx.lib.rcn_ba_session_solve(self.h, C.byref(options) if options is not None else None, C.byref(s)))
+        return summary_dict(s)
+
+    def validity(self, poses34=None, max_err=4.0, min_angle=1.0):
+        """checkLandmarkValidity on the device arrays; returns (inlier flags, observations erased)."""
+        if poses34 is None:
+            poses34 = poses34_from_angle_axis(self.cameras()[0])
+        p = np.ascontiguousarray(poses34, np.float64)
+        inl = np.zeros(max(1, self.counts()[1]), np.uint8)
+        n_in, n_er = C.c_int32(), C.c_int32()
+        self.ctx.check(self.ctx.lib.rcn_ba_session_validity(self.h, p.ctypes.data, float(max_err), float(min_angle), inl.ctypes.data, C.byref(n_in), C.byref(n_er)))
+        return inl[:self.counts()[1]].astype(bool), n_er.value
+
+    def remove_outliers(self):
+        npts = self.counts()[1]
+        new_idx = np.zeros(max(1, npts), np.int32)
+        n = C.c_int32()
+        self.ctx.check(self.ctx.lib.rcn_ba_session_remove_outliers(self.h, new_idx.ctypes.data, C.byref(n)))
+        return new_idx[:npts], n.value
+
+
 def smoke(ctx):
     """Small solve on the GPU checked against nothing but itself converging (used by
     __graft_entry__.smoke together with the oracle comparison there)."""

@@ -1443,8 +1443,19 @@ int rcn_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_options *o
 {
     if (!ctx) return RCN_ERR_ARG;
     std::lock_guard<std::mutex> lk(ctx->mu);
+    return rcn_int_ba_solve(ctx, pb, opt, sum, nullptr);
+}
+
+}  // extern "C"
+
+// The solve proper (ctx->mu held).  res == nullptr: everything comes from / goes back to the host arrays of the
+// problem.  res != nullptr (rcn_ba_session, ba_session.hip): the points and the observation arrays are already in HBM
+// and stay there -- pb->points may be NULL, pb->obs_* are the session's host mirror (structure only) -- and the pair
+// lists of the Schur build are reused when the token says the graph has not changed since they were built.
+int rcn_int_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_options *opt, rcn_ba_summary *sum, const BaResident *res)
+{
     if (!pb || !opt || !sum || pb->n_cams <= 0 || pb->n_points < 0 || pb->n_obs < 0 || !pb->poses ||
-        !pb->intrinsics || (pb->n_points > 0 && !pb->points) ||
+        !pb->intrinsics || (pb->n_points > 0 && !pb->points && !res) ||
         (pb->n_obs > 0 && (!pb->obs_uv || !pb->obs_cam || !pb->obs_pt))) {
         ctx->set_error("rcn_ba_solve: bad argument");
         return RCN_ERR_ARG;
@@ -1541,10 +1552,16 @@ int rcn_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_options *o
             for (int k = 0; k < 2; ++k)
                 if (intr0[6 * c + k] > opt->focal_upper_bound) { intr0[6 * c + k] = opt->focal_upper_bound; sum->bound_projections++; }
     RCN_HIP(H2D(d.intr, intr0.data(), sizeof(double) * 6 * nc));
-    RCN_HIP(H2D(d.pts, pb->points, sizeof(double) * 3 * np));
-    RCN_HIP(H2D(uv, pb->obs_uv, sizeof(double) * 2 * no));
-    RCN_HIP(H2D(p_ocam, pb->obs_cam, sizeof(int) * no));
-    RCN_HIP(H2D(p_opt, pb->obs_pt, sizeof(int) * no));
+    if (res) {
+        if (np > 0) RCN_HIP(hipMemcpyAsync(d.pts, res->pts, sizeof(double) * 3 * np, hipMemcpyDeviceToDevice, st));
+        uv = const_cast<double *>(res->uv); p_ocam = const_cast<int *>(res->ocam); p_opt = const_cast<int *>(res->opt);
+        d.uv = uv; d.ocam = p_ocam; d.opt = p_opt;
+    } else {
+        RCN_HIP(H2D(d.pts, pb->points, sizeof(double) * 3 * np));
+        RCN_HIP(H2D(uv, pb->obs_uv, sizeof(double) * 2 * no));
+        RCN_HIP(H2D(p_ocam, pb->obs_cam, sizeof(int) * no));
+        RCN_HIP(H2D(p_opt, pb->obs_pt, sizeof(int) * no));
+    }
     RCN_HIP(H2D(p_camobs, cam_obs.data(), sizeof(int) * no));
     RCN_HIP(H2D(p_ptoff, pt_off.data(), sizeof(int) * (np + 1)));
     RCN_HIP(H2D(p_camobsoff, cam_obs_off.data(), sizeof(int) * (nc + 1)));
@@ -1556,7 +1573,10 @@ int rcn_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_options *o
     RCN_HIP(hipMemsetAsync(d.Linv, 0, sizeof(double) * (size_t)nblk * NB * NB, st));   // upper triangles of the tile inverses stay zero
     RCN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_chol_diag), hipFuncAttributeMaxDynamicSharedMemorySize, NB * DL * 8));
     RCN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_nt_ring<0>), hipFuncAttributeMaxDynamicSharedMemorySize, GST * GSTAGE_BYTES));
-    if (gather && np > 0) {
+    RCN_HIP(hipStreamSynchronize(st));   // host vectors go out of use; timing starts with inputs resident
+    const double t_start = now_s();        // the pair lists of the Schur build are part of the solve (only the pack is not)
+    const bool pairs_cached = res && res->pair_token != 0 && ctx->ba_pair_token == res->pair_token;
+    if (gather && np > 0 && !pairs_cached) {
         RCN_HIP(hipMemsetAsync(pk, 0, sizeof(int) * (3 * (size_t)nkeys + 4 + (nkeys + 1023) / 1024), st));
         const int thr = std::min(256, std::max(64, (kmax * kmax + 63) / 64 * 64));
         k_pair_count<<<np, thr, 0, st>>>(d, pk_cnt);
@@ -1569,7 +1589,8 @@ int rcn_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_options *o
         k_pair_sort_long<<<nkeys, 256, 0, st>>>(pk_off, pk_list);
         RCN_HIP(hipGetLastError());
     }
-    RCN_HIP(hipStreamSynchronize(st));   // host vectors go out of use; timing starts with inputs resident
+    ctx->ba_pair_token = (gather && np > 0 && res) ? res->pair_token : 0;
+    sum->pair_lists_reused = pairs_cached ? 1 : 0;
 
     double hs[32];
     auto read_scal = [&](int cnt) -> hipError_t {
@@ -1592,7 +1613,6 @@ int rcn_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_options *o
         return hipGetLastError();
     };
 
-    const double t_start = now_s();
     RCN_HIP(eval(true, d.poses, d.intr, d.pts, 0));
     const int dgrid = (std::max(n, 3 * np) + 255) / 256;
     k_ba_diag<<<std::max(dgrid, 1), 256, 0, st>>>(d, 0, 0.0, 0.0, opt->jacobi_scaling);
@@ -1781,9 +1801,10 @@ int rcn_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_options *o
     sum->final_rms_px = std::sqrt(2.0 * cost / std::max(no, 1));
     RCN_HIP(hipMemcpyAsync(pb->poses, d.poses, sizeof(double) * 6 * nc, hipMemcpyDeviceToHost, st));
     RCN_HIP(hipMemcpyAsync(pb->intrinsics, d.intr, sizeof(double) * 6 * nc, hipMemcpyDeviceToHost, st));
-    if (np > 0) RCN_HIP(hipMemcpyAsync(pb->points, d.pts, sizeof(double) * 3 * np, hipMemcpyDeviceToHost, st));
+    if (np > 0) {
+        if (res) RCN_HIP(hipMemcpyAsync(res->pts, d.pts, sizeof(double) * 3 * np, hipMemcpyDeviceToDevice, st));
+        else RCN_HIP(hipMemcpyAsync(pb->points, d.pts, sizeof(double) * 3 * np, hipMemcpyDeviceToHost, st));
+    }
     RCN_HIP(hipStreamSynchronize(st));
     return termination == RCN_BA_FAILURE ? RCN_ERR_NUMERIC : RCN_OK;
 }
-
-}  // extern "C"

@@ -133,6 +133,7 @@ struct rcn_ctx {
     std::vector<PairXY> fm_pairs_host;   // staging of fm_pairs (uploaded asynchronously)
     DevBuf fm_csr, fm_pairs;   // fused table filter: CSR of the matched points, per-pair coordinate pointers
     std::map<int32_t, std::pair<DevBuf, int32_t>> coords;   // image id -> (K x 2 int32 pixel coordinates in HBM, K)
+    uint64_t ba_pair_token = 0;         // whose pair lists the Schur-build workspace holds (0 = nobody's)
     hipStream_t aux_stream = nullptr;   // lookahead stream of the Cholesky
     hipEvent_t ba_ev[9];
     hipEvent_t ba_tev[4];            // phase timing of rcn_ba_solve
@@ -141,6 +142,14 @@ struct rcn_ctx {
     void set_error(const std::string &s) { err = s; }
 };
 
+// Device-resident part of a bundle-adjustment problem (rcn_ba_session, ba_session.hip -> rcn_int_ba_solve, ba.hip)
+struct BaResident {
+    double *pts;                  // n_points x 3, in and out
+    const double *uv;             // n_obs x 2
+    const int *ocam, *opt;        // n_obs each, landmark-major
+    uint64_t pair_token;          // identifies (session, graph version): pair lists built under the same token are reused
+};
+int rcn_int_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_options *opt, rcn_ba_summary *sum, const BaResident *res);
 int rcn_match_release(rcn_ctx *ctx);
 // match.hip internals shared with shard.hip (all expect ctx->mu held)
 int rcn_int_slab_attach(rcn_ctx *ctx, int32_t first_id, int32_t n_images, int32_t n_slots, const float *src,
