@@ -41,11 +41,18 @@ inline std::vector<float> featDescToDense(const std::vector<FeaturePtr<>> &featu
 
 class HipL2Matcher : public FeatureMatcher {
 public:
-    explicit HipL2Matcher(int device = 0)
+    explicit HipL2Matcher(int device = 0) : owned_(true)
     {
         if (rcn_create(device, &ctx_) != RCN_OK) throw std::runtime_error("HipL2Matcher: no usable gfx950 device");
     }
-    ~HipL2Matcher() override { rcn_destroy(ctx_); }
+    // The documented binding: ONE rcn_ctx per GPU shared by every plugin of the pipeline (matcher, geometric filter,
+    // bundle adjuster, validity sweep) -- workspaces, streams and resident descriptors are per ctx, so nothing is
+    // allocated or torn down per plugin call.  The ctx outlives the plugin.
+    explicit HipL2Matcher(rcn_ctx *shared) : ctx_(shared), owned_(false)
+    {
+        if (!ctx_) throw std::runtime_error("HipL2Matcher: null ctx");
+    }
+    ~HipL2Matcher() override { if (owned_) rcn_destroy(ctx_); }
     HipL2Matcher(const HipL2Matcher &) = delete;
     HipL2Matcher &operator=(const HipL2Matcher &) = delete;
 
@@ -69,6 +76,7 @@ public:
 
 private:
     rcn_ctx *ctx_ = nullptr;
+    bool owned_ = true;
     const float ratioThresh = 0.7;   // FeatureMatcher.h:45
 };
 
