@@ -1293,19 +1293,37 @@ int rcn_int_match_grid(rcn_ctx *ctx, const int32_t *pairs_host, int32_t n_pairs,
     slots.assign(2 * (size_t)n_pairs, 0);
     int kq_max = 0, kt_max = 0, ktp_max = 0;
     int64_t rows = 0, pd = 0;
+    // id -> image record through a flat table when the ids are small non-negative integers (they are image indices):
+    // a 500 000-pair list costs three million std::map walks otherwise, with the GPU idle behind the host
+    std::vector<const ImgHost *> flat;
+    {
+        int32_t lo = INT32_MAX, hi = INT32_MIN;
+        for (const auto &kv : ctx->images)
+            if (kv.first != INT32_MIN && kv.first != INT32_MIN + 1) { lo = std::min(lo, kv.first); hi = std::max(hi, kv.first); }
+        if (lo >= 0 && hi >= lo && hi < (1 << 24)) {
+            flat.assign((size_t)hi + 1, nullptr);
+            for (const auto &kv : ctx->images)
+                if (kv.first >= 0) flat[kv.first] = &kv.second;
+        }
+    }
+    auto lookup = [&](int32_t id) -> const ImgHost * {
+        if (!flat.empty() && id >= 0 && (size_t)id < flat.size()) return flat[id];
+        auto it = ctx->images.find(id);
+        return it == ctx->images.end() ? nullptr : &it->second;
+    };
     for (int p = 0; p < n_pairs; ++p) {
-        auto a = ctx->images.find(pairs_host[2 * p]), b = ctx->images.find(pairs_host[2 * p + 1]);
-        if (a == ctx->images.end() || b == ctx->images.end()) {
+        const ImgHost *a = lookup(pairs_host[2 * p]), *b = lookup(pairs_host[2 * p + 1]);
+        if (!a || !b) {
             ctx->set_error("rcn_match_grid: image id not resident");
             return RCN_ERR_NOT_FOUND;
         }
-        slots[2 * p] = a->second.slot;
-        slots[2 * p + 1] = b->second.slot;
-        kq_max = std::max(kq_max, a->second.K);
-        kt_max = std::max(kt_max, b->second.K);
-        ktp_max = std::max(ktp_max, b->second.Kp);
-        rows += a->second.K;
-        pd += (int64_t)a->second.K * b->second.K;
+        slots[2 * p] = a->slot;
+        slots[2 * p + 1] = b->slot;
+        kq_max = std::max(kq_max, a->K);
+        kt_max = std::max(kt_max, b->K);
+        ktp_max = std::max(ktp_max, b->Kp);
+        rows += a->K;
+        pd += (int64_t)a->K * b->K;
     }
     if (out_stride < kq_max) {
         ctx->set_error("rcn_match_grid: out_stride smaller than a query image's K");
@@ -1381,7 +1399,7 @@ int rcn_int_match_grid(rcn_ctx *ctx, const int32_t *pairs_host, int32_t n_pairs,
             std::vector<std::pair<int64_t, int>> order((size_t)n_groups);
             for (int g = 0; g < n_groups; ++g) {
                 int64_t wgt = 0;
-                for (int r = 0; r < groups[g].y; ++r) wgt += ctx->images.find(pairs_host[2 * (groups[g].x + r) + 1])->second.K;
+                for (int r = 0; r < groups[g].y; ++r) wgt += lookup(pairs_host[2 * (groups[g].x + r) + 1])->K;
                 order[g] = std::make_pair(-wgt, g);
             }
             std::stable_sort(order.begin(), order.end());
@@ -1448,7 +1466,7 @@ int rcn_int_match_grid(rcn_ctx *ctx, const int32_t *pairs_host, int32_t n_pairs,
             RCN_HIP(hipStreamWaitEvent(sb, ctx->ba_ev[1 + (c & 3)], 0));
         }
         int64_t rows_c = 0;
-        for (int p = p0; p < p1; ++p) rows_c += ctx->images.find(pairs_host[2 * p])->second.K;
+        for (int p = p0; p < p1; ++p) rows_c += lookup(pairs_host[2 * p])->K;
         ra.pair_base = p0;
         ra.fb_list = ctx->fb_list.as<unsigned long long>() + row_prefix; ra.fb_count = ccnt + 2 * c;
         ra.sv_list = ctx->sv_list.as<unsigned long long>() + row_prefix; ra.sv_count = ccnt + 2 * c + 1;
