@@ -9,4 +9,5 @@ ctx = _lib.Context(0)
 sc = synth_ba.make_scene(nc, npts, seed=2024)
 for i in range(reps):
     P, I, X, s = ba.solve_scene(ctx, sc)
-    print("run %d: %d iterations %.4f s (%.2f it/s) rms %.6f -> %.6f n=%d" % (i, s["iterations"], s["solve_seconds"], s["iterations"] / s["solve_seconds"], s["initial_rms_px"], s["final_rms_px"], s["reduced_dim"]))
+    print("run %d: %d iterations %.4f s (%.2f it/s) rms %.6f -> %.6f n=%d" % (i, s["iterations"], s["solve_seconds"], s["iterations"] / s["solve_seconds"], s["initial_rms_px"], s["final_rms_px"], s["reduced_dim"]),
+          "| per iteration: schur %.3f chol %.3f tri %.3f ms" % tuple(1e3 * s[k] / max(1, s["iterations"]) for k in ("schur_seconds", "cholesky_seconds", "trisolve_seconds")))
