@@ -458,6 +458,40 @@ def main():
                                 "value_tables_left_in_hbm": float(n2 * (n2 - 1) // 2) * K2 * K2 * 20 / dt2b,
                                 "rows_reranked": int(st2["rows_reranked"]), "rows_exact_fallback": int(st2["rows_exact_fallback"]), "rows_total": int(st2["rows_total"])}
                 del loc2_dev
+                # the reference's ACTIVE descriptor is SIFT (128-d, FeatureDetector.cpp:9-10): K1 at D = 128 on a cfg2-sized grid
+                # of SIFT-like rows (its README's 76 s matching stage is 100 images)
+                n3, K3 = 100, 1500
+                pool3 = synth.world_pool("sift", 4 * K3, seed=1234)
+                loc3 = np.stack([synth.image_descriptors("sift", i, K3, pool3, seed=1234) for i in range(n3)])
+                loc3_dev = torch.from_numpy(loc3).to(dev)
+                from reconstructor_amd.matcher import HipL2Matcher, all_pairs
+                m3 = HipL2Matcher(ctx=ctx)
+                m3.clear()
+                m3.upload_batch_device(0, n3, loc3_dev.data_ptr(), K3, 128)
+                pr3 = all_pairs(n3)
+                o3 = torch.empty((len(pr3), K3), dtype=torch.int32, device=dev)
+                c3 = torch.empty((len(pr3),), dtype=torch.int32, device=dev)
+                torch.cuda.synchronize(dev)
+                for _ in range(3):
+                    m3.match_grid_device(pr3, o3.data_ptr(), K3, c3.data_ptr())
+                ctx.check(ctx.lib.rcn_synchronize(ctx.h))
+                m3.stats(); m3.profile(True)
+                t3 = time.perf_counter()
+                for _ in range(20):
+                    m3.match_grid_device(pr3, o3.data_ptr(), K3, c3.data_ptr())
+                ctx.check(ctx.lib.rcn_synchronize(ctx.h))
+                dt3 = (time.perf_counter() - t3) / 20
+                st3 = m3.stats(); m3.profile(False)
+                cms3 = st3["coarse_ms"] / max(1, st3["profiled_calls"])
+                pd3 = float(st3["pair_distances"])
+                line["sift128"] = {"workload": "100 images x 1500 SIFT-like keypoints x 128-d, 4950 image pairs (tables left in HBM)",
+                                   "value": pd3 / dt3, "unit": "pair-distances/s", "ms_per_step": 1e3 * dt3, "matches_found": int(c3.sum().item()),
+                                   "roofline": {"bound": "mfma", "kernel": "k_coarse_top2<128>", "achieved": 2.0 * 128 * pd3 / (cms3 * 1e-3) / 1e12,
+                                                "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": 2.0 * 128 * pd3 / (cms3 * 1e-3) / 1e12 / MFMA_F16_PEAK_TFLOPS,
+                                                "launch_ms": cms3, "traffic": measured_traffic("k_coarse_top2<128>@100x1500")[0]}}
+                m3.clear()
+                del loc3_dev, o3, c3
+                shard.reserve(n_img, K, D)         # the clear above dropped the shard's images: nothing is matched through it again
             if not args.no_cpu_baseline:
                 images = [local[i] for i in range(min(local.shape[0], 64))]
                 line["cpu_baseline"] = cpu_baseline(images, host_threads())
