@@ -86,3 +86,55 @@ def test_plugin_calls_from_four_threads(gpu_ctx):
         assert np.array_equal(res[k][0], exp) and (res[k][0] >= 0).sum() == cnt
         m0, c0, _ = orc_fmat.filter_pair(two[k][0], two[k][1])
         assert np.array_equal(res[k][1], m0) and res[k][2] == c0
+
+
+def test_shard_and_list_errors(gpu_ctx):
+    """Misuse of the sharded-grid / host-list / session entry points returns a status, never a crash."""
+    import torch
+    from reconstructor_amd import ba, pairgrid
+    lib = gpu_ctx.lib
+    sh = pairgrid.Shard(gpu_ctx, 0, 1, pairgrid.unique_id())
+    try:
+        with pytest.raises(_lib.RcnError) as e:                   # exchange before reserve
+            sh.exchange(None)
+        assert e.value.code == -1 and "reserve" in str(e.value)
+        with pytest.raises(_lib.RcnError):                        # match before exchange
+            sh.match(0.7)
+        gpu_ctx.check(lib.rcn_desc_clear(gpu_ctx.h))
+        sh.reserve(3, 64, 32)
+        with pytest.raises(_lib.RcnError) as e:                   # rows do not fit the slot
+            sh.put_image(0, np.zeros((65, 32), np.float32))
+        assert e.value.code == -1
+        with pytest.raises(_lib.RcnError):                        # not an image of the grid
+            sh.put_image(3, np.zeros((4, 32), np.float32))
+        with pytest.raises(_lib.RcnError):                        # a row count beyond the slot
+            sh.exchange(torch.zeros((3, 64, 32), device="cuda").data_ptr(), [64, 65, 1])
+        with pytest.raises(_lib.RcnError) as e:                   # lists without a match into the ctx's own tables
+            gpu_ctx.check(lib.rcn_shard_lists(sh.h, np.zeros(4, np.int64).ctypes.data, None, 0, C.byref(C.c_int64())))
+        assert e.value.code == -1
+        assert lib.rcn_shard_reserve(sh.h, 0, 64, 32, None) == -1 and lib.rcn_shard_reserve(sh.h, 3, 0, 32, None) == -1
+        assert lib.rcn_shard_create(gpu_ctx.h, 1, 1, (C.c_uint8 * 128)(), C.byref(C.c_void_p())) == -1     # rank >= world
+    finally:
+        sh.close()
+    total = C.c_int64()
+    assert lib.rcn_match_compact_begin(gpu_ctx.h, None, 8, None, 3, np.zeros(4, np.int64).ctypes.data, None, 0, C.byref(total)) == -1
+    assert lib.rcn_match_compact_begin(gpu_ctx.h, None, 8, None, 0, np.zeros(1, np.int64).ctypes.data, None, 0, C.byref(total)) == 0 and total.value == 0
+    assert lib.rcn_match_compact_wait(gpu_ctx.h) == 0
+    ses = ba.BaSession(gpu_ctx)
+    try:
+        with pytest.raises(_lib.RcnError) as e:                   # nothing to solve
+            ses.solve()
+        assert e.value.code == -1 and "camera" in str(e.value)
+        ses.add_camera(np.zeros(6), np.ones(6))
+        with pytest.raises(_lib.RcnError):                        # landmark index out of range
+            ses.add_observations([0], [0], [[1, 2]])
+        ses.add_points(np.zeros((2, 3)))
+        with pytest.raises(_lib.RcnError):                        # camera index out of range
+            ses.add_observations([0], [1], [[1, 2]])
+        with pytest.raises(_lib.RcnError) as e:                   # no sweep yet
+            ses.remove_outliers()
+        assert "sweep" in str(e.value)
+        assert ses.counts() == (1, 2, 0)
+    finally:
+        ses.close()
+    assert lib.rcn_desc_sample_device(gpu_ctx.h, None, 1, 1, 1, 4, 4, None, 5, 300, None) == -1            # D > 256
