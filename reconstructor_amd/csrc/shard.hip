@@ -38,6 +38,7 @@ struct rcn_shard {
     int32_t n_images = 0, per = 0, K = 0, D = 0;
     int slab = -1;
     bool own_table = false;            // the last rcn_shard_match wrote into the ctx's own tables
+    bool f32_queued = false;           // ev_f32 has been recorded: a later writer of the landing buffer waits for it
     std::vector<int32_t> pairs;        // this rank's share of the canonical grid
     int64_t bytes_f16 = 0, bytes_f32 = 0;   // payload sizes of the last exchange (whole gather, all ranks)
 };
@@ -234,6 +235,8 @@ int rcn_shard_put_image(rcn_shard *sh, int32_t img_id, const float *desc_host, i
     }
     RCN_HIP(hipSetDevice(ctx->device));
     float *slot = sh->landing.as<float>() + ((size_t)sh->rank * sh->per + (img_id - lo)) * sh->K * sh->D;
+    // the fp32 all-gather of the previous exchange (side stream) still reads this rank's block
+    if (sh->f32_queued) RCN_HIP(hipStreamWaitEvent(ctx->stream, sh->ev_f32, 0));
     if (K_img > 0)
         RCN_HIP(hipMemcpyAsync(slot, desc_host, (size_t)K_img * sh->D * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
     if (K_img < sh->K)
@@ -261,6 +264,9 @@ int rcn_shard_exchange(rcn_shard *sh, const float *local_desc_dev, const int32_t
             if (local_K[i] < 0 || local_K[i] > K) { ctx->set_error("rcn_shard_exchange: a row count exceeds the reserved slot"); return RCN_ERR_ARG; }
             sh->local_K[i] = local_K[i];
         }
+    // the fp32 all-gather of the previous exchange (side stream) reads `mine` and fills the rest of the landing
+    // buffer: nothing of this exchange may overtake it (a no-op when a grid call with exact stages ran in between)
+    if (sh->f32_queued) RCN_HIP(hipStreamWaitEvent(st, sh->ev_f32, 0));
     if (local_desc_dev && local_desc_dev != mine && cnt > 0)
         RCN_HIP(hipMemcpyAsync(mine, local_desc_dev, (size_t)cnt * K * D * sizeof(float), hipMemcpyDeviceToDevice, st));
     // rows in use per slot: every rank's block of counts, all-gathered (always: whether the images are
@@ -313,6 +319,7 @@ int rcn_shard_exchange(rcn_shard *sh, const float *local_desc_dev, const int32_t
     RCN_NCCL(ncclAllGather(mine, landing, blk32, ncclChar, sh->comm32, sh->side));
     RCN_HIP(hipEventRecord(sh->ev_f32, sh->side));
     ctx->f32_ready = sh->ev_f32;
+    sh->f32_queued = true;
     sh->bytes_f16 = (int64_t)world * (blk16 + blkhn + blkn2);
     sh->bytes_f32 = (int64_t)world * blk32;
     return RCN_OK;

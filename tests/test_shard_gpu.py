@@ -82,6 +82,29 @@ def test_every_exchange_sees_fresh_data(shard):
         assert np.array_equal(o.cpu().numpy(), exp) and np.array_equal(c.cpu().numpy(), ec)
 
 
+def test_exchange_twice_without_a_grid_call(shard):
+    """Two exchanges in a row (the second with other rows), then one grid call: the fp32 gather of the first, still on
+    the side stream, must not be overtaken by the second exchange's copy into the landing buffer."""
+    import torch
+    from reconstructor_amd.matcher import all_pairs
+    n, K, D = 6, 2048, 256
+    a = synth.descriptor_set("superpoint", n, K, n_world=4096, seed=7)
+    b = synth.descriptor_set("superpoint", n, K, n_world=4096, seed=8)
+    da, db = (torch.from_numpy(np.stack(x)).cuda() for x in (a, b))
+    P = n * (n - 1) // 2
+    out = torch.empty((P, K), dtype=torch.int32, device="cuda")
+    cnt = torch.empty((P,), dtype=torch.int32, device="cuda")
+    shard.ctx.check(shard.ctx.lib.rcn_desc_clear(shard.ctx.h))
+    shard.reserve(n, K, D)
+    torch.cuda.synchronize()
+    shard.exchange(da.data_ptr())
+    shard.exchange(db.data_ptr())
+    shard.match(0.7, out.data_ptr(), K, cnt.data_ptr())
+    shard.ctx.check(shard.ctx.lib.rcn_synchronize(shard.ctx.h))
+    exp, ec = orc.match_grid(b, all_pairs(n), threads=8)
+    assert np.array_equal(out.cpu().numpy(), exp) and np.array_equal(cnt.cpu().numpy(), ec)
+
+
 def test_compact_to_host_lists(shard):
     """rcn_match_compact_*: per pair the (query, train) lists in ascending query order, offsets from the counts."""
     import torch
