@@ -33,9 +33,13 @@
  *   - Plus = add on the tangent coordinates, then clamp to the box (ParameterBlock::Plus);
  *     a bounds-constrained problem starts from the projection of x onto the box (IterationZero)
  *   - bounds present => projected Armijo line search along the step before evaluation
- *     (TrustRegionMinimizer::DoLineSearch).  DEVIATION: Ceres interpolates with a cubic through
- *     values and gradients; here a backtrack uses the quadratic through f(0), f'(0), f(a).
- *     summary.line_search_backtracks counts how often that code ran (0 on every committed case).
+ *     (TrustRegionMinimizer::DoLineSearch -> ArmijoLineSearch::DoSearch, line_search.cc, with Solver::Options'
+ *     defaults: sufficient decrease 1e-4, contraction limits [1e-3, 0.6] x step, at most 20 iterations, minimum step
+ *     1e-9 / |delta|_inf, CUBIC interpolation).  A backtrack minimises, on the contraction interval, the polynomial
+ *     through value AND directional derivative of f at 0, at the current trial and (from the second backtrack on)
+ *     at the previous one -- a cubic, then a quintic (polynomial.cc: FindInterpolatingPolynomial by a full-pivot
+ *     LU, MinimizePolynomial over the interval's midpoint, its ends and the REAL PARTS of all roots of the
+ *     derivative).  A failed search leaves the full step.  summary.line_search_backtracks counts the backtracks.
  *   - parameter tolerance, function tolerance (both before the accept test), rho =
  *     cost_change / model_cost_change, accept if rho > 1e-3:
  *     radius /= max(1/3, 1-(2 rho-1)^3), decrease factor reset to 2; reject: radius /= factor,
@@ -285,6 +289,185 @@ static int inv3_spd(const double *V, double *Vi)
 }
 
 /* ---------------------------------------------------------------------------------------- */
+
+/* ---- Ceres' line-search polynomials (internal/ceres/polynomial.cc), restated ----------------------- */
+typedef struct { double x, v, g; int v_ok, g_ok; } LsSample;
+
+static double ls_poly_eval(const double *p, int deg, double x)
+{
+    double v = 0.0;
+    for (int i = 0; i <= deg; ++i) v = v * x + p[i];
+    return v;
+}
+
+/* FindInterpolatingPolynomial: one equation per valid value / gradient, solved by Gaussian elimination with
+ * full pivoting (Eigen FullPivLU with threshold 0: a zero pivot leaves the remaining unknowns at zero).
+ * Coefficients highest power first; returns the degree. */
+static int ls_fit(const LsSample *s, int ns, double *coef)
+{
+    int nc = 0;
+    for (int i = 0; i < ns; ++i) nc += (s[i].v_ok != 0) + (s[i].g_ok != 0);
+    const int deg = nc - 1;
+    double A[6][6], b[6], y[6];
+    int perm[6], row = 0;
+    for (int i = 0; i < ns; ++i) {
+        if (s[i].v_ok) {
+            for (int j = 0; j <= deg; ++j) A[row][j] = pow(s[i].x, deg - j);
+            b[row++] = s[i].v;
+        }
+        if (s[i].g_ok) {
+            for (int j = 0; j < deg; ++j) A[row][j] = (deg - j) * pow(s[i].x, deg - j - 1);
+            A[row][deg] = 0.0;
+            b[row++] = s[i].g;
+        }
+    }
+    for (int j = 0; j < nc; ++j) perm[j] = j;
+    int rank = 0;
+    for (int k = 0; k < nc; ++k) {
+        int pi = k, pj = k;
+        double best = 0.0;
+        for (int i = k; i < nc; ++i)
+            for (int j = k; j < nc; ++j)
+                if (fabs(A[i][j]) > best) { best = fabs(A[i][j]); pi = i; pj = j; }
+        if (best == 0.0) break;
+        for (int j = 0; j < nc; ++j) { double t = A[k][j]; A[k][j] = A[pi][j]; A[pi][j] = t; }
+        { double t = b[k]; b[k] = b[pi]; b[pi] = t; }
+        for (int i = 0; i < nc; ++i) { double t = A[i][k]; A[i][k] = A[i][pj]; A[i][pj] = t; }
+        { int t = perm[k]; perm[k] = perm[pj]; perm[pj] = t; }
+        for (int i = k + 1; i < nc; ++i) {
+            const double f = A[i][k] / A[k][k];
+            for (int j = k; j < nc; ++j) A[i][j] -= f * A[k][j];
+            b[i] -= f * b[k];
+        }
+        rank = k + 1;
+    }
+    for (int k = nc - 1; k >= 0; --k) {
+        if (k >= rank) { y[k] = 0.0; continue; }
+        double t = b[k];
+        for (int j = k + 1; j < rank; ++j) t -= A[k][j] * y[j];
+        y[k] = t / A[k][k];
+    }
+    for (int k = 0; k < nc; ++k) coef[perm[k]] = y[k];
+    return deg;
+}
+
+/* FindPolynomialRoots, real parts only (what MinimizePolynomial asks for): leading zeros dropped, closed forms
+ * for degree 1 and 2 (the quadratic as polynomial.cc's FindQuadraticPolynomialRoots), simultaneous
+ * (Durand-Kerner) iteration on the monic polynomial where Ceres takes the eigenvalues of the companion matrix.
+ * Returns the number of roots. */
+static int ls_root_real_parts(const double *p, int deg, double *re)
+{
+    while (deg > 0 && p[0] == 0.0) { ++p; --deg; }
+    if (deg == 0) return 0;
+    if (deg == 1) { re[0] = -p[1] / p[0]; return 1; }
+    if (deg == 2) {
+        const double a = p[0], b = p[1], c = p[2], D = b * b - 4.0 * a * c, sD = sqrt(fabs(D));
+        if (D >= 0.0) {
+            if (b >= 0.0) { re[0] = (-b - sD) / (2.0 * a); re[1] = (2.0 * c) / (-b - sD); }
+            else { re[0] = (2.0 * c) / (-b + sD); re[1] = (-b + sD) / (2.0 * a); }
+        } else re[0] = re[1] = -b / (2.0 * a);
+        return 2;
+    }
+    double m[8], zr[8], zi[8], bound = 0.0;
+    for (int i = 0; i <= deg; ++i) m[i] = p[i] / p[0];
+    for (int i = 1; i <= deg; ++i) if (fabs(m[i]) > bound) bound = fabs(m[i]);
+    bound += 1.0;                                  /* Cauchy: every root lies within */
+    {
+        double cr = 1.0, ci = 0.0;                  /* powers of 0.4 + 0.9 i, scaled to half the bound */
+        for (int k = 0; k < deg; ++k) {
+            zr[k] = 0.5 * bound * cr; zi[k] = 0.5 * bound * ci;
+            const double nr = cr * 0.4 - ci * 0.9, ni = cr * 0.9 + ci * 0.4;
+            cr = nr; ci = ni;
+        }
+    }
+    for (int it = 0; it < 2000; ++it) {
+        double moved = 0.0, size = 0.0;
+        for (int k = 0; k < deg; ++k) {
+            double pr = 1.0, pim = 0.0;             /* monic p(z_k) by Horner */
+            for (int i = 1; i <= deg; ++i) {
+                const double tr = pr * zr[k] - pim * zi[k] + m[i], ti = pr * zi[k] + pim * zr[k];
+                pr = tr; pim = ti;
+            }
+            double qr = 1.0, qi = 0.0;              /* prod_{j != k} (z_k - z_j) */
+            for (int j = 0; j < deg; ++j) {
+                if (j == k) continue;
+                const double dr = zr[k] - zr[j], di = zi[k] - zi[j];
+                const double tr = qr * dr - qi * di, ti = qr * di + qi * dr;
+                qr = tr; qi = ti;
+            }
+            const double den = qr * qr + qi * qi;
+            if (den == 0.0) continue;
+            const double sr = (pr * qr + pim * qi) / den, si = (pim * qr - pr * qi) / den;
+            zr[k] -= sr; zi[k] -= si;
+            moved = fmax(moved, fmax(fabs(sr), fabs(si)));
+            size = fmax(size, fmax(fabs(zr[k]), fabs(zi[k])));
+        }
+        if (moved <= 1e-16 * fmax(size, 1e-300)) break;
+    }
+    for (int k = 0; k < deg; ++k) re[k] = zr[k];
+    return deg;
+}
+
+/* MinimizePolynomial over [lo, hi]: the midpoint, the two ends, then every root of the derivative inside */
+static double ls_minimize(const double *p, int deg, double lo, double hi)
+{
+    double best_x = 0.5 * (lo + hi), best = ls_poly_eval(p, deg, best_x);
+    const double vlo = ls_poly_eval(p, deg, lo), vhi = ls_poly_eval(p, deg, hi);
+    if (vlo < best) { best = vlo; best_x = lo; }
+    if (vhi < best) { best = vhi; best_x = hi; }
+    if (deg < 2) return best_x;
+    double dp[8], re[8];
+    for (int i = 0; i < deg; ++i) dp[i] = (deg - i) * p[i];
+    const int nr = ls_root_real_parts(dp, deg - 1, re);
+    for (int i = 0; i < nr; ++i) {
+        if (re[i] < lo || re[i] > hi) continue;
+        const double v = ls_poly_eval(p, deg, re[i]);
+        if (v < best) { best = v; best_x = re[i]; }
+    }
+    return best_x;
+}
+
+/* LineSearch::InterpolatingPolynomialMinimizingStepSize, CUBIC: samples are the start point (value and
+ * gradient), the current trial and, once there is one, the previous trial */
+static double ls_next_step(const LsSample *start, const LsSample *prev, const LsSample *cur, double lo, double hi)
+{
+    if (!cur->v_ok) return fmin(fmax(cur->x * 0.5, lo), hi);
+    LsSample s[3];
+    int ns = 0;
+    s[ns++] = *start;
+    s[ns++] = *cur;
+    if (prev->v_ok) s[ns++] = *prev;
+    double coef[6];
+    const int deg = ls_fit(s, ns, coef);
+    return ls_minimize(coef, deg, lo, hi);
+}
+
+/* test hook: the next Armijo step from up to three samples (x, value, gradient, value_ok, gradient_ok) */
+double orc_ls_next_step(const double *start, const double *prev, const double *cur, double lo, double hi)
+{
+    LsSample a = {start[0], start[1], start[2], start[3] != 0.0, start[4] != 0.0};
+    LsSample b = {prev[0], prev[1], prev[2], prev[3] != 0.0, prev[4] != 0.0};
+    LsSample c = {cur[0], cur[1], cur[2], cur[3] != 0.0, cur[4] != 0.0};
+    return ls_next_step(&a, &b, &c, lo, hi);
+}
+
+/* sum_o r_o' (Jc_o dc + Jp_o dp): the gradient J'r of the tangent space, against a direction */
+static double dir_derivative(const Prob *P, const double *r, const double *Jc, const double *Jp, const double *dc, const double *dp)
+{
+    double acc = 0.0;
+#pragma omp parallel for reduction(+ : acc) schedule(static)
+    for (int o = 0; o < P->no; ++o) {
+        const int c = P->ocam[o], j = P->opt[o];
+        for (int i = 0; i < 2; ++i) {
+            double m = 0.0;
+            for (int k = 0; k < P->cam_dim[c]; ++k) m += Jc[20 * (size_t)o + 10 * i + k] * dc[P->cam_off[c] + k];
+            for (int k = 0; k < 3; ++k) m += Jp[6 * (size_t)o + 3 * i + k] * dp[3 * j + k];
+            acc += r[2 * o + i] * m;
+        }
+    }
+    return acc;
+}
+
 int orc_ba_solve(int n_cams, int n_points, int n_obs, double *poses, double *intr, double *pts,
                  const double *obs_uv, const int32_t *obs_cam, const int32_t *obs_pt,
                  const rcn_ba_options *opt, rcn_ba_summary *sum, int threads)
@@ -346,6 +529,7 @@ int orc_ba_solve(int n_cams, int n_points, int n_obs, double *poses, double *int
     double *poses2 = (double *)malloc(sizeof(double) * 6 * n_cams), *intr2 = (double *)malloc(sizeof(double) * 6 * n_cams);
     double *pts2 = (double *)malloc(sizeof(double) * NP3);
     double *ugc = (double *)malloc(sizeof(double) * NN), *ugp = (double *)malloc(sizeof(double) * NP3); /* unscaled gradient */
+    double *r2 = NULL, *Jc2 = NULL, *Jp2 = NULL; /* residuals / Jacobians at a line-search trial (allocated on first use) */
 
     const double t_start = now_s();
     /* TrustRegionMinimizer::IterationZero: a bounds-constrained problem starts from the
@@ -547,25 +731,44 @@ int orc_ba_solve(int n_cams, int n_points, int n_obs, double *poses, double *int
         for (int i = 0; i < 3 * n_points; ++i) dlp[i] = stp[i] * sp[i];
 
         double cand_cost;
-        if (P.mode == 1) { /* bounds present: projected Armijo search along delta from step 1 */
-            double g0 = 0.0;
-            for (int i = 0; i < n; ++i) g0 += ugc[i] * dlc[i];
-            for (int i = 0; i < 3 * n_points; ++i) g0 += ugp[i] * dlp[i];
+        if (P.mode == 1) { /* bounds present: ArmijoLineSearch::DoSearch along delta, first trial the full step */
+            double g0 = 0.0, dmax = 0.0;
+            for (int i = 0; i < n; ++i) { g0 += ugc[i] * dlc[i]; dmax = fmax(dmax, fabs(dlc[i])); }
+            for (int i = 0; i < 3 * n_points; ++i) { g0 += ugp[i] * dlp[i]; dmax = fmax(dmax, fabs(dlp[i])); }
+            const LsSample start = {0.0, cost, g0, 1, 1};
+            LsSample prev = {0.0, 0.0, 0.0, 0, 0}, cur;
             double a = 1.0;
-            for (int ls = 0;; ++ls) {
+            int found = 0;
+            for (int it = 0;;) {
+                /* LineSearchFunction::Evaluate: value and directional derivative at Plus(x, a delta) */
                 for (int i = 0; i < n; ++i) stc[i] = a * dlc[i];
                 for (int i = 0; i < 3 * n_points; ++i) stp[i] = a * dlp[i];
                 sum->bound_projections += plus(&P, poses, intr, pts, stc, stp, poses2, intr2, pts2);
-                cand_cost = evaluate(&P, poses2, intr2, pts2, NULL, NULL, NULL);
-                if (isfinite(cand_cost) && cand_cost <= cost + 1e-4 * a * g0) break;
-                if (ls >= 20) { a = 1.0; break; }
-                double an = -g0 * a * a / (2.0 * (cand_cost - cost - g0 * a)); /* quadratic fit */
-                if (!isfinite(an)) an = 0.5 * a;
-                an = fmin(fmax(an, 1e-3 * a), 0.6 * a);
+                cur.x = a; cur.g = 0.0; cur.g_ok = 0;
+                if (it == 0) { /* the first trial passes almost always: no gradient until a backtrack needs one */
+                    cur.v = evaluate(&P, poses2, intr2, pts2, NULL, NULL, NULL);
+                    cur.v_ok = isfinite(cur.v);
+                    if (cur.v_ok && cur.v <= cost + 1e-4 * g0 * cur.x) { found = 1; break; }
+                }
+                if (!r2) {
+                    r2 = (double *)malloc(sizeof(double) * 2 * NO); Jc2 = (double *)malloc(sizeof(double) * 20 * NO);
+                    Jp2 = (double *)malloc(sizeof(double) * 6 * NO);
+                }
+                cur.v = evaluate(&P, poses2, intr2, pts2, r2, Jc2, Jp2);
+                cur.v_ok = isfinite(cur.v);
+                if (cur.v_ok) {
+                    cur.g = dir_derivative(&P, r2, Jc2, Jp2, dlc, dlp);
+                    cur.g_ok = isfinite(cur.g);
+                }
+                if (cur.v_ok && cur.v <= cost + 1e-4 * g0 * cur.x) { found = 1; break; }
+                if (++it >= 20) break;
+                const double an = ls_next_step(&start, &prev, &cur, 1e-3 * cur.x, 0.6 * cur.x);
+                if (an * dmax < 1e-9) break;
+                prev = cur;
                 a = an;
                 sum->line_search_backtracks++;
             }
-            if (a != 1.0) {
+            if (found && a != 1.0) {
                 for (int i = 0; i < n; ++i) dlc[i] *= a;
                 for (int i = 0; i < 3 * n_points; ++i) dlp[i] *= a;
             }
@@ -632,7 +835,7 @@ int orc_ba_solve(int n_cams, int n_points, int n_obs, double *poses, double *int
 
     free(r); free(Jc); free(Jp); free(W); free(Y); free(Vinv); free(gp); free(sc); free(sp);
     free(dgc); free(dgp); free(gc); free(S); free(yc); free(stc); free(stp); free(dlc); free(dlp);
-    free(poses2); free(intr2); free(pts2); free(ugc); free(ugp);
+    free(poses2); free(intr2); free(pts2); free(ugc); free(ugp); free(r2); free(Jc2); free(Jp2);
     free(P.pt_off); free(P.cam_off); free(P.cam_dim); free(P.cols); free(P.cam_obs_off); free(P.cam_obs);
     return RCN_OK;
 }

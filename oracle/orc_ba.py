@@ -17,6 +17,8 @@ def register(L):
                                C.POINTER(BaOptions), C.POINTER(BaSummary), C.c_int]
     L.orc_ba_default_options.restype = None
     L.orc_ba_default_options.argtypes = [C.c_int, C.POINTER(BaOptions)]
+    L.orc_ls_next_step.restype = C.c_double
+    L.orc_ls_next_step.argtypes = [_f64p, _f64p, _f64p, C.c_double, C.c_double]
 
 
 def _lib():
@@ -31,6 +33,12 @@ def residual_jacobian(pose, intr, X, uv, jac=True):
                                     np.ascontiguousarray(X, np.float64), np.ascontiguousarray(uv, np.float64),
                                     res, J.ctypes.data if jac else None)
     return res, J
+
+
+def ls_next_step(start, prev, cur, lo, hi):
+    """The line search's next trial step from samples (x, value, gradient, value_ok, gradient_ok)."""
+    a, b, c = (np.ascontiguousarray(v, np.float64) for v in (start, prev, cur))
+    return float(_lib().orc_ls_next_step(a, b, c, float(lo), float(hi)))
 
 
 def default_options(n_cams):

@@ -20,6 +20,7 @@
 // The LM control flow on the host follows Ceres' TrustRegionMinimizer / LevenbergMarquardt
 // strategy step by step (same order of tests as the CPU restatement used for parity).
 #include "rcn_internal.h"
+#include "ba_linesearch.h"
 
 #include <cfloat>
 #include <chrono>
@@ -110,6 +111,41 @@ __device__ __forceinline__ double block_sum(double v, double *sh)
     return s;  // valid on thread 0
 }
 
+// residual of one observation and (JAC) its 2 x 15 Jacobian over [pose 6 | intrinsics 6 | point 3]
+template <bool JAC>
+__device__ __forceinline__ void obs_residual(const double *ps, const double *in, const double *X, const double *uv,
+                                             double &r0, double &r1, double (*J)[15])
+{
+    double p[3], R[9], dpdw[9];
+    rotate(ps, X, p, R, dpdw, JAC);
+    p[0] += ps[3]; p[1] += ps[4]; p[2] += ps[5];
+    const double iz = 1.0 / p[2];
+    const double x = p[0] * iz, y = p[1] * iz;
+    const double rr = x * x + y * y;
+    const double dist = in[4] * rr + in[5] * rr * rr;
+    const double xd = x + dist, yd = y + dist;
+    r0 = in[0] * xd + in[2] - uv[0];
+    r1 = in[1] * yd + in[3] - uv[1];
+    if (JAC) {
+        const double g = in[4] + 2.0 * in[5] * rr;
+        const double a00 = 1.0 + 2.0 * g * x, a01 = 2.0 * g * y, a10 = 2.0 * g * x, a11 = 1.0 + 2.0 * g * y;
+        const double b02 = -x * iz, b12 = -y * iz;
+        double q[6];
+        q[0] = in[0] * (a00 * iz); q[1] = in[0] * (a01 * iz); q[2] = in[0] * (a00 * b02 + a01 * b12);
+        q[3] = in[1] * (a10 * iz); q[4] = in[1] * (a11 * iz); q[5] = in[1] * (a10 * b02 + a11 * b12);
+        for (int i = 0; i < 2; ++i) {
+            const double *qi = q + 3 * i;
+            for (int k = 0; k < 3; ++k) {
+                J[i][k] = qi[0] * dpdw[k] + qi[1] * dpdw[3 + k] + qi[2] * dpdw[6 + k];
+                J[i][3 + k] = qi[k];
+                J[i][12 + k] = qi[0] * R[k] + qi[1] * R[3 + k] + qi[2] * R[6 + k];
+            }
+        }
+        J[0][6] = xd; J[0][7] = 0; J[0][8] = 1; J[0][9] = 0; J[0][10] = in[0] * rr; J[0][11] = in[0] * rr * rr;
+        J[1][6] = 0; J[1][7] = yd; J[1][8] = 0; J[1][9] = 1; J[1][10] = in[1] * rr; J[1][11] = in[1] * rr * rr;
+    }
+}
+
 // K4: residual and tangent Jacobian per observation; per-block partial of sum r^2.
 template <bool JAC>
 __global__ __launch_bounds__(256) void k_ba_eval(BaDev d, const double *poses, const double *intr,
@@ -123,35 +159,11 @@ __global__ __launch_bounds__(256) void k_ba_eval(BaDev d, const double *poses, c
         double ps[6], in[6], X[3];
         for (int i = 0; i < 6; ++i) { ps[i] = poses[6 * c + i]; in[i] = intr[6 * c + i]; }
         for (int i = 0; i < 3; ++i) X[i] = pts[3 * j + i];
-        double p[3], R[9], dpdw[9];
-        rotate(ps, X, p, R, dpdw, JAC);
-        p[0] += ps[3]; p[1] += ps[4]; p[2] += ps[5];
-        const double iz = 1.0 / p[2];
-        const double x = p[0] * iz, y = p[1] * iz;
-        const double rr = x * x + y * y;
-        const double dist = in[4] * rr + in[5] * rr * rr;
-        const double xd = x + dist, yd = y + dist;
-        const double r0 = in[0] * xd + in[2] - d.uv[2 * o], r1 = in[1] * yd + in[3] - d.uv[2 * o + 1];
+        double r0, r1, J[2][15];
+        obs_residual<JAC>(ps, in, X, d.uv + 2 * (size_t)o, r0, r1, J);
         c2 = r0 * r0 + r1 * r1;
         if (JAC) {
             d.r[2 * o] = r0; d.r[2 * o + 1] = r1;
-            const double g = in[4] + 2.0 * in[5] * rr;
-            const double a00 = 1.0 + 2.0 * g * x, a01 = 2.0 * g * y, a10 = 2.0 * g * x, a11 = 1.0 + 2.0 * g * y;
-            const double b02 = -x * iz, b12 = -y * iz;
-            double q[6];
-            q[0] = in[0] * (a00 * iz); q[1] = in[0] * (a01 * iz); q[2] = in[0] * (a00 * b02 + a01 * b12);
-            q[3] = in[1] * (a10 * iz); q[4] = in[1] * (a11 * iz); q[5] = in[1] * (a10 * b02 + a11 * b12);
-            double J[2][15];
-            for (int i = 0; i < 2; ++i) {
-                const double *qi = q + 3 * i;
-                for (int k = 0; k < 3; ++k) {
-                    J[i][k] = qi[0] * dpdw[k] + qi[1] * dpdw[3 + k] + qi[2] * dpdw[6 + k];
-                    J[i][3 + k] = qi[k];
-                    J[i][12 + k] = qi[0] * R[k] + qi[1] * R[3 + k] + qi[2] * R[6 + k];
-                }
-            }
-            J[0][6] = xd; J[0][7] = 0; J[0][8] = 1; J[0][9] = 0; J[0][10] = in[0] * rr; J[0][11] = in[0] * rr * rr;
-            J[1][6] = 0; J[1][7] = yd; J[1][8] = 0; J[1][9] = 1; J[1][10] = in[1] * rr; J[1][11] = in[1] * rr * rr;
             const int dc = d.cam_dim[c];
             for (int i = 0; i < 2; ++i) {
                 for (int k = 0; k < 10; ++k) d.Jc[20 * (size_t)o + 10 * i + k] = k < dc ? J[i][d.cols[10 * c + k]] : 0.0;
@@ -161,6 +173,53 @@ __global__ __launch_bounds__(256) void k_ba_eval(BaDev d, const double *poses, c
     }
     const double s = block_sum(c2, sh);
     if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+
+// Line search (bounds present): directional derivative of the cost at a trial point along the step held in
+// d.dlc / d.dlp,  sum_o r_o' (Jc_o dlc + Jp_o dlp)  -- the tangent-space gradient J'r against the direction
+// (LineSearchFunction::Evaluate); nothing is stored, the Jacobian of an observation lives in registers.
+__global__ __launch_bounds__(256) void k_ba_dirgrad(BaDev d, const double *poses, const double *intr,
+                                                     const double *pts, double *partial)
+{
+    __shared__ double sh[4];
+    const int o = blockIdx.x * blockDim.x + threadIdx.x;
+    double acc = 0.0;
+    if (o < d.no) {
+        const int c = d.ocam[o], j = d.opt[o];
+        double ps[6], in[6], X[3];
+        for (int i = 0; i < 6; ++i) { ps[i] = poses[6 * c + i]; in[i] = intr[6 * c + i]; }
+        for (int i = 0; i < 3; ++i) X[i] = pts[3 * j + i];
+        double r[2], J[2][15];
+        obs_residual<true>(ps, in, X, d.uv + 2 * (size_t)o, r[0], r[1], J);
+        const int dc = d.cam_dim[c], off = d.cam_off[c];
+        for (int i = 0; i < 2; ++i) {
+            double m = 0.0;
+            for (int k = 0; k < 10; ++k) if (k < dc) m += J[i][d.cols[10 * c + k]] * d.dlc[off + k];
+            for (int k = 0; k < 3; ++k) m += J[i][12 + k] * d.dlp[3 * (size_t)j + k];
+            acc += r[i] * m;
+        }
+    }
+    const double s = block_sum(acc, sh);
+    if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+
+// max |v| over two arrays (the line search's |direction|_inf); *out zeroed by the caller.  Non-negative doubles
+// order like their bit patterns: one integer atomicMax per workgroup, order-independent.
+__global__ __launch_bounds__(256) void k_ba_absmax(const double *a, size_t na, const double *b, size_t nb, double *out)
+{
+    __shared__ double sh[4];
+    double m = 0.0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < na + nb; i += (size_t)gridDim.x * 256) {
+        const double v = fabs(i < na ? a[i] : b[i - na]);
+        if (v > m || v != v) m = v;
+    }
+    for (int o = 32; o; o >>= 1) { const double v = __shfl_down(m, o); if (v > m || v != v) m = v; }
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 1; i < 4; ++i) if (sh[i] > m || sh[i] != sh[i]) m = sh[i];
+        atomicMax(reinterpret_cast<unsigned long long *>(out), (unsigned long long)__double_as_longlong(m));
+    }
 }
 
 // out[slot] = scale * sum(partial[0..n)) in a fixed order (deterministic)
@@ -1736,32 +1795,52 @@ int rcn_int_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_option
         }
         invalid_run = 0;
         double cand_cost = hs[1], dn2 = hs[3], xn2 = hs[4];
-        if (opt->intrinsics_mode == 1) {   // projected Armijo search along delta (bounds present)
+        if (opt->intrinsics_mode == 1) {
+            // bounds present: ArmijoLineSearch::DoSearch along delta, first trial the full step (already evaluated).
+            // A trial that fails the sufficient-decrease test also gets its directional derivative
+            // (k_ba_dirgrad against d.dlc / d.dlp = a * delta, hence the division by a).
             const double g0 = hs[8];
-            double a = 1.0;
+            rcn_ls::Sample start, prev, cur;
+            start.x = 0.0; start.v = cost; start.g = g0; start.v_ok = start.g_ok = true;
+            double a = 1.0, dmax = -1.0;
             int bt = 0;
-            for (int ls = 0;; ++ls) {
-                if (std::isfinite(cand_cost) && cand_cost <= cost + 1e-4 * a * g0) break;
-                if (ls >= 20) { a = 1.0; break; }
-                double an = -g0 * a * a / (2.0 * (cand_cost - cost - g0 * a));
-                if (!std::isfinite(an)) an = 0.5 * a;
-                an = std::min(std::max(an, 1e-3 * a), 0.6 * a);
+            bool found = false;
+            auto trial = [&](double alpha) -> hipError_t {   // candidate, its cost and the step norms at alpha
+                k_ba_plus<<<pbk, 256, 0, st>>>(d, alpha, d.partial, pbk);
+                for (int q = 0; q < 2; ++q) k_finish_sum<<<1, 256, 0, st>>>(d.partial + (size_t)q * pbk, pbk, d.scal + 3 + q, 1.0);
+                hipError_t e = eval(false, d.poses2, d.intr2, d.pts2, 1);
+                if (e != hipSuccess) return e;
+                e = read_scal(5);
+                cand_cost = hs[1]; dn2 = hs[3]; xn2 = hs[4];
+                return e;
+            };
+            for (int it = 0;;) {
+                cur = rcn_ls::Sample();
+                cur.x = a; cur.v = cand_cost; cur.v_ok = std::isfinite(cand_cost);
+                if (cur.v_ok && cur.v <= cost + 1e-4 * g0 * a) { found = true; break; }
+                if (cur.v_ok) {
+                    if (no > 0) k_ba_dirgrad<<<eb, 256, 0, st>>>(d, d.poses2, d.intr2, d.pts2, d.partial);
+                    k_finish_sum<<<1, 256, 0, st>>>(d.partial, no > 0 ? eb : 0, d.scal + 10, 1.0);
+                }
+                if (dmax < 0.0) {                    // |delta|_inf, once per search (the first trial is a = 1)
+                    RCN_HIP(hipMemsetAsync(d.scal + 11, 0, sizeof(double), st));
+                    k_ba_absmax<<<std::max(1, std::min(1024, (std::max(n, 3 * np) + 255) / 256)), 256, 0, st>>>(
+                        d.dlc, (size_t)n, d.dlp, 3 * (size_t)np, d.scal + 11);
+                }
+                RCN_HIP(hipGetLastError());
+                RCN_HIP(read_scal(12));
+                if (cur.v_ok) { cur.g = hs[10] / a; cur.g_ok = std::isfinite(cur.g); }
+                if (dmax < 0.0) dmax = hs[11] / a;
+                if (++it >= 20) break;
+                const double an = rcn_ls::next_step(start, prev, cur, 1e-3 * a, 0.6 * a);
+                if (an * dmax < 1e-9) break;
+                prev = cur;
                 a = an;
                 sum->line_search_backtracks++;
                 ++bt;
-                k_ba_plus<<<pbk, 256, 0, st>>>(d, a, d.partial, pbk);
-                for (int q = 0; q < 2; ++q) k_finish_sum<<<1, 256, 0, st>>>(d.partial + (size_t)q * pbk, pbk, d.scal + 3 + q, 1.0);
-                RCN_HIP(eval(false, d.poses2, d.intr2, d.pts2, 1));
-                RCN_HIP(read_scal(5));
-                cand_cost = hs[1]; dn2 = hs[3]; xn2 = hs[4];
+                RCN_HIP(trial(a));
             }
-            if (a == 1.0 && bt) {   // search gave up: restore the full step
-                k_ba_plus<<<pbk, 256, 0, st>>>(d, 1.0, d.partial, pbk);
-                for (int q = 0; q < 2; ++q) k_finish_sum<<<1, 256, 0, st>>>(d.partial + (size_t)q * pbk, pbk, d.scal + 3 + q, 1.0);
-                RCN_HIP(eval(false, d.poses2, d.intr2, d.pts2, 1));
-                RCN_HIP(read_scal(5));
-                cand_cost = hs[1]; dn2 = hs[3]; xn2 = hs[4];
-            }
+            if (!found && bt) RCN_HIP(trial(1.0));   // the search gave up: the full step stands
         }
         if (!std::isfinite(cand_cost)) cand_cost = DBL_MAX;
         if (std::sqrt(dn2) <= opt->parameter_tolerance * (std::sqrt(xn2) + opt->parameter_tolerance)) {

@@ -92,6 +92,26 @@ def test_bounds_active_matches_oracle(gpu_ctx):
     assert abs(s1["final_rms_px"] - s0["final_rms_px"]) <= 1e-5
 
 
+@pytest.mark.parametrize("seed,backtracks", [(1, 8), (7, 11), (10, 10)])
+def test_bounds_line_search_follows_the_oracle(gpu_ctx, seed, backtracks):
+    """Far-off starts with >= 10 cameras (focal lengths bounded, BundleAdjuster.cpp:117-121): the full LM step
+    fails the sufficient-decrease test several times and the projected Armijo search backtracks through the
+    cubic / quintic interpolants -- same trial steps, same accepted points as the CPU oracle."""
+    from reconstructor_amd import ba
+    sc = synth_ba.make_scene(12, 200, obs_per_point=6, seed=seed, perturb=(0.4, 2.0, 1.5))
+    P0, I0, X0, s0 = orc_ba.solve(sc, threads=4)
+    P1, I1, X1, s1 = ba.solve_scene(gpu_ctx, sc)
+    print(seed, "oracle", s0["iterations"], s0["line_search_backtracks"], s0["final_rms_px"],
+          "gpu", s1["iterations"], s1["line_search_backtracks"], s1["final_rms_px"])
+    assert s0["line_search_backtracks"] == backtracks          # the case does what it is here for
+    assert s1["line_search_backtracks"] == s0["line_search_backtracks"]
+    assert s1["iterations"] == s0["iterations"] and s1["termination"] == s0["termination"]
+    n = min(len(s0["cost_trace"]), len(s1["cost_trace"]))
+    assert np.allclose(s1["cost_trace"][:n], s0["cost_trace"][:n], rtol=1e-6)
+    assert abs(s1["final_rms_px"] - s0["final_rms_px"]) <= RMS_TOL_PX
+    assert np.allclose(P1, P0, atol=1e-5) and np.allclose(X1, X0, atol=1e-4)
+
+
 def test_cfg5_properties(gpu_ctx):
     """BASELINE cfg 5 (1000 cams / 100k points / 1M observations): too big for the CPU oracle
     inside the suite, so size-independent properties: monotone cost trace, gauge untouched,

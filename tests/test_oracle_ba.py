@@ -88,3 +88,58 @@ def test_parameter_tolerance_ignores_blocks_outside_the_reduced_program():
     assert s0["termination"] == 3 == s1["termination"]                       # RCN_BA_CONVERGENCE_PARAMETER
     assert s0["iterations"] == s1["iterations"] and s0["iterations"] >= 3
     assert np.allclose(s0["cost_trace"], s1["cost_trace"], rtol=1e-6)
+
+
+def _next_step_numpy(start, prev, cur, lo, hi):
+    """InterpolatingPolynomialMinimizingStepSize written with numpy's own solver and root finder."""
+    if not cur[3]:
+        return min(max(cur[0] * 0.5, lo), hi)
+    S = [start, cur] + ([prev] if prev[3] else [])
+    deg = sum(int(s[3]) + int(s[4]) for s in S) - 1
+    A, b = [], []
+    for s in S:
+        if s[3]:
+            A.append([s[0] ** (deg - j) for j in range(deg + 1)]); b.append(s[1])
+        if s[4]:
+            A.append([(deg - j) * s[0] ** (deg - j - 1) if j < deg else 0.0 for j in range(deg + 1)]); b.append(s[2])
+    c = np.linalg.solve(np.array(A), np.array(b))
+    best_x = (lo + hi) / 2
+    best = np.polyval(c, best_x)
+    for x in (lo, hi):
+        if np.polyval(c, x) < best:
+            best, best_x = np.polyval(c, x), x
+    for r in np.roots(np.polyder(c)):
+        if lo <= r.real <= hi and np.polyval(c, r.real) < best:
+            best, best_x = np.polyval(c, r.real), r.real
+    return best_x
+
+
+def test_line_search_polynomials_against_numpy():
+    """Cubic (two samples) and quintic (three samples) interpolants, samples without a valid gradient, and the
+    no-valid-value bisection: the oracle's elimination / root iteration against numpy's LAPACK paths."""
+    rng = np.random.default_rng(0)
+    for _ in range(1500):
+        f0, g0 = rng.uniform(1, 100), -rng.uniform(0.1, 50)
+        x1 = rng.uniform(0.05, 1.0)
+        cur = [x1, f0 + rng.uniform(-0.5, 5) * abs(g0) * x1, rng.normal() * 30, 1, rng.random() > 0.1]
+        prev = [0, 0, 0, 0, 0]
+        if rng.random() < 0.5:
+            x2 = x1 / rng.uniform(0.2, 0.9)
+            prev = [x2, f0 + rng.uniform(0, 9) * abs(g0) * x2, rng.normal() * 30, 1, rng.random() > 0.1]
+        lo, hi = 1e-3 * x1, 0.6 * x1
+        got = orc_ba.ls_next_step([0, f0, g0, 1, 1], prev, cur, lo, hi)
+        exp = _next_step_numpy([0, f0, g0, 1, 1], prev, cur, lo, hi)
+        assert lo <= got <= hi and abs(got - exp) <= 1e-9 * exp
+    assert orc_ba.ls_next_step([0, 5, -1, 1, 1], [0, 0, 0, 0, 0], [0.8, np.inf, 0, 0, 0], 8e-4, 0.48) == 0.4
+
+
+def test_bounds_line_search_backtracks_and_still_descends():
+    """Far-off starts with bounded focal lengths: the Armijo search runs (8 / 11 / 10 backtracks), every accepted
+    step lowers the cost and the solves end at the noise floor."""
+    for seed, backtracks in ((1, 8), (7, 11), (10, 10)):
+        sc = synth_ba.make_scene(12, 200, obs_per_point=6, seed=seed, perturb=(0.4, 2.0, 1.5))
+        P, I, X, s = orc_ba.solve(sc, threads=4)
+        assert s["line_search_backtracks"] == backtracks and s["termination"] == 1
+        tr = np.array(s["cost_trace"][: s["iterations"] + 1])
+        assert (np.diff(tr) <= 0).all() and s["final_rms_px"] < 0.7
+        assert (I[:, :2] <= 1000.0).all()
