@@ -254,8 +254,8 @@ typedef struct {
     int32_t unsuccessful_steps;
     int32_t invalid_steps;
     int32_t termination;        /* RCN_BA_* */
-    int32_t line_search_backtracks;
-    int32_t bound_projections;
+    int32_t line_search_backtracks; /* backtracks of the projected Armijo search (bounds present: >= 10 cameras) */
+    int32_t bound_projections;  /* focal lengths clamped to their upper bound by a Plus */
     int32_t reduced_dim;        /* rows of the reduced camera system */
     int32_t pair_lists_reused;  /* 1: the Schur build's observation-pair lists were still valid (rcn_ba_session_solve on an unchanged graph) */
     int32_t reserved;
