@@ -1333,7 +1333,11 @@ int rcn_int_match_grid(rcn_ctx *ctx, const int32_t *pairs_host, int32_t n_pairs,
     const int kq_stride = tiles * RCN_QT;
     int idx_bits = 1;
     while ((1 << idx_bits) < ktp_max) ++idx_bits;
-    const bool mfma = ctx->DP != 0 && idx_bits <= 13 && !ctx->force_exact && kq_max > 0 && kt_max >= 2;
+    // The packed candidate keeps the train row in its low idx_bits and the accumulator's leading 32 - idx_bits bits
+    // above them: up to 16 index bits (65536 rows per image) leave sign + exponent + 7 mantissa bits, and the
+    // certificates price that quantum (k_filter: upper bounds are truncated value + one quantum), so a coarser
+    // value only sends more rows to the exact re-rank -- it never changes a result.
+    const bool mfma = ctx->DP != 0 && idx_bits <= 16 && !ctx->force_exact && kq_max > 0 && kt_max >= 2;
     const uint32_t idx_mask = (1u << idx_bits) - 1u;
     const int owner_stride = std::max(1, kt_max);
 

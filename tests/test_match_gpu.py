@@ -194,9 +194,9 @@ def test_power_of_two_scale_invariance(matcher, kind):
         assert np.array_equal(matcher.match_pair(ims[0] * f, ims[1] * f), base), k
 
 
-def test_more_than_8192_train_rows_takes_the_generic_path(matcher):
-    """K2 > 8192: the row index no longer fits the 13 packed bits of the coarse pass and the owner table
-    of the uniqueness step no longer fits LDS -- exact kernel + global owner table, same answers."""
+def test_more_than_8192_train_rows_stay_on_the_mfma_path(matcher):
+    """K2 > 8192: the row index takes 14..16 of the candidate's 32 bits (a coarser value: more rows re-ranked, same
+    answers) and the owner table of the uniqueness step no longer fits LDS (global owner table)."""
     rng = np.random.default_rng(17)
     t = rng.standard_normal((9000, 32)).astype(np.float32)
     q = np.concatenate([t[rng.choice(9000, 200, replace=False)] + 0.05 * rng.standard_normal((200, 32)).astype(np.float32),
@@ -210,12 +210,40 @@ def test_more_than_8192_train_rows_takes_the_generic_path(matcher):
     out, counts = matcher.match_grid(np.array([[0, 1], [1, 0]], np.int32), 9000)
     exp2, c2 = orc.match_grid([q, t], np.array([[0, 1], [1, 0]]), threads=4)
     assert np.array_equal(out, exp2) and np.array_equal(counts, c2)
+    assert matcher.stats()["used_mfma_path"] == 1
+    matcher.clear()
+
+
+@pytest.mark.parametrize("kind,K", [("sift", 12000), ("superpoint", 20000)])
+def test_large_images_match_the_oracle(matcher, kind, K):
+    """Well past 8192 keypoints per image (a full-resolution SIFT run; the reference resizes to 512 px and never gets
+    there): 14 / 15 index bits, most rows still certified by the coarse pass alone."""
+    ims = synth.descriptor_set(kind, 2, K, n_world=2 * K, seed=29)
+    matcher.clear()
+    matcher.upload(0, ims[0]); matcher.upload(1, ims[1])
+    out, counts = matcher.match_grid(np.array([[0, 1], [1, 0]], np.int32), K)
+    st = matcher.stats()
+    exp, c = orc.match_grid(ims, np.array([[0, 1], [1, 0]]), threads=8)
+    assert np.array_equal(out, exp) and np.array_equal(counts, c) and c.min() > K // 20
+    assert st["used_mfma_path"] == 1 and st["rows_exact_fallback"] < 0.2 * st["rows_total"], st
+    matcher.clear()
+
+
+def test_more_than_65536_rows_take_the_generic_path(matcher):
+    """Beyond 16 index bits the exact kernel answers alone."""
+    rng = np.random.default_rng(5)
+    t = rng.standard_normal((66000, 8)).astype(np.float32)
+    q = np.concatenate([t[rng.choice(66000, 40, replace=False)] + 0.01 * rng.standard_normal((40, 8)).astype(np.float32),
+                        rng.standard_normal((24, 8)).astype(np.float32)])
+    got = matcher.match_pair(q, t)
+    exp, cnt = orc.match_pair(q, t)
+    assert np.array_equal(got, exp) and cnt >= 30
     assert matcher.stats()["used_mfma_path"] == 0
     matcher.clear()
 
 
-def test_exactly_8192_rows_still_on_the_mfma_path(matcher):
-    """K = 8192 is the largest image the packed 13-bit row index supports."""
+def test_exactly_8192_rows_on_the_mfma_path(matcher):
+    """K = 8192: the largest image with a 13-bit row index and an LDS owner table."""
     ims = synth.descriptor_set("orb", 2, 8192, n_world=20000, seed=23)
     exp, cnt = orc.match_pair(ims[0], ims[1])
     assert np.array_equal(matcher.match_pair(ims[0], ims[1]), exp) and cnt > 500
