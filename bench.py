@@ -336,6 +336,51 @@ def run_grid(torch, dist, dev, shard, n_img, K, local_dev, steps, warmup, world,
     return dt, st, n_matches, list_bytes, shard.info()
 
 
+def host_boundary_leg(torch, dev, shard, images, steps=5):
+    """The same step entered through the HOST side of the boundary: every image handed over as host rows
+    (rcn_shard_put_image: one H2D copy per image, pageable memory as a detector's std::vector would be, then
+    pinned), exchange, match, lists back in host memory.  The PCIe-inclusive rate; never `value`."""
+    import ctypes as C
+    ctx = shard.ctx
+    n, K = images.shape[0], images.shape[1]
+    P = n * (n - 1) // 2
+    out = {}
+    pin = C.c_void_p()
+    ctx.check(ctx.lib.rcn_host_alloc(C.byref(pin), images.nbytes))
+    pinned = np.ctypeslib.as_array((C.c_float * images.size).from_address(pin.value)).reshape(images.shape)
+    pinned[...] = images
+    try:
+        for name, src in (("pageable", images), ("pinned", pinned)):
+            shard.reserve(n, K, D)
+            lists = None
+            def step():
+                nonlocal lists
+                for i in range(n):
+                    shard.put_image(i, src[i])
+                shard.exchange(None)
+                shard.match(0.7)                      # tables owned by the ctx
+                off = np.zeros(P + 1, np.int64)
+                if lists is None:
+                    ctx.check(ctx.lib.rcn_synchronize(ctx.h))
+                    lists = (np.zeros((8 << 20, 2), np.int32), off)      # room for 8 Mi matches (cfg2 finds 2.5 M)
+                tot = C.c_int64(0)
+                ctx.check(ctx.lib.rcn_shard_lists(shard.h, lists[1].ctypes.data, lists[0].ctypes.data, lists[0].shape[0], C.byref(tot)))
+                return tot.value
+            step()
+            ctx.check(ctx.lib.rcn_synchronize(ctx.h))
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                m = step()
+            ctx.check(ctx.lib.rcn_synchronize(ctx.h))
+            dt = (time.perf_counter() - t0) / steps
+            out[name] = {"ms_per_step": 1e3 * dt, "value": float(P) * K * K / dt, "unit": "pair-distances/s", "matches_found": int(m)}
+    finally:
+        ctx.lib.rcn_host_free(pin)
+    out["note"] = ("host rows in (%.0f MB per step over PCIe, one synchronous copy per image), host lists out; "
+                   "the resident-input step is `value` / `cfg2.value`" % (images.nbytes / 1e6))
+    return out
+
+
 def grid_line(K, n_img, n_pairs_total, dt, steps, st, world, my_pairs):
     """value / roofline of one measured grid (pair-distances of the whole job per second; K1 against the f16 MFMA peak)."""
     pd_job = float(n_pairs_total) * K * K
@@ -457,6 +502,7 @@ def main():
                                 "host_list_bytes_per_step": lb2, "roofline": roof2,
                                 "value_tables_left_in_hbm": float(n2 * (n2 - 1) // 2) * K2 * K2 * 20 / dt2b,
                                 "rows_reranked": int(st2["rows_reranked"]), "rows_exact_fallback": int(st2["rows_exact_fallback"]), "rows_total": int(st2["rows_total"])}
+                line["cfg2"]["host_boundary"] = host_boundary_leg(torch, dev, shard, loc2)
                 del loc2_dev
                 # the reference's ACTIVE descriptor is SIFT (128-d, FeatureDetector.cpp:9-10): K1 at D = 128 on a cfg2-sized grid
                 # of SIFT-like rows (its README's 76 s matching stage is 100 images)

@@ -71,6 +71,8 @@ int rcn_create(int device_id, rcn_ctx **out)
     // The shipping library reads no environment variable.
     const char *w4 = std::getenv("RCN_COARSE_W4");
     ctx->coarse_w4 = w4 && w4[0] == '1';
+    const char *s16 = std::getenv("RCN_COARSE_S16");
+    ctx->coarse_shape = s16 ? (s16[0] == '1' ? 1 : 0) : -1;
     const char *fe = std::getenv("RCN_FORCE_EXACT");
     ctx->force_exact = fe && fe[0] == '1';
     const char *nio = getenv("RCN_MATCH_NO_ORDER");

@@ -22,6 +22,7 @@
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 #define RCN_QT 512          // query rows per workgroup (8 waves x 64)
@@ -204,10 +205,19 @@ struct CoarseArgs {
 //   s_barrier per tile behind a counted s_waitcnt vmcnt (never 0 in steady state).
 // ABL (ablation bits, diagnostics only -- results are wrong unless ABL == 0):
 //   1 skip the top-2 epilogue, 8 stage only the first tiles.
-template <int DP, int ABL>
+// SH: MFMA shape.  0: v_mfma_f32_32x32x16_f16 (two 32-column blocks per wave, 16 accumulators per lane and tile);
+//   1: v_mfma_f32_16x16x32_f16 -- the same 64 query columns per wave as four 16-column blocks, a 32-row train block as
+//   two 16-row halves, 4 accumulators per lane and tile; same operand bytes per MAC from LDS, same registers, same
+//   VALU per element, twice the MFMA instructions at half the passes.  The chip holds a different clock on the two
+//   shapes under load (MI355X_MICROARCH.md, DVFS give-back item 7), which is why both exist.
+template <int DP, int ABL, int SH = 0>
 __global__ __launch_bounds__(512, 2) void k_coarse_top2(CoarseArgs a)
 {
     constexpr int KS = DP / 16;
+    constexpr int NCB = SH ? 4 : 2;                 // column (query) blocks per wave
+    constexpr int CW = SH ? 16 : 32;                // their width
+    constexpr int NKS = SH ? DP / 32 : DP / 16;     // k-steps per tile row block
+    constexpr int CPK = SH ? 4 : 2;                 // 16-byte chunks of a row one k-step consumes
     constexpr int ROWB = DP * 2;
     constexpr int TILEB = RCN_BT * ROWB;
     constexpr int GLSZ = DP == 32 ? 4 : 16;          // bytes per lane per LDS-DMA instruction
@@ -227,19 +237,20 @@ __global__ __launch_bounds__(512, 2) void k_coarse_top2(CoarseArgs a)
     const ImgDev qi = a.imgs[a.pairs[2 * p0]];
     if (qt * RCN_QT >= qi.K) return;
 
-    const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int r = SH ? (lane & 15) : (lane & 31), h = SH ? (lane >> 4) : (lane >> 5);   // row / column in the block, k group
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
 
     // query fragments, negated, resident for the whole item
-    half8 bq[2][KS];
+    half8 bq[NCB][NKS];
 #pragma unroll
-    for (int cb = 0; cb < 2; ++cb) {
-        const int qrow = qt * RCN_QT + w * 64 + cb * 32 + r;  // < Kp (Kp is a multiple of 512)
+    for (int cb = 0; cb < NCB; ++cb) {
+        const int qrow = qt * RCN_QT + w * 64 + cb * CW + r;  // < Kp (Kp is a multiple of 512)
         const char *base = reinterpret_cast<const char *>(qi.f16) + (size_t)qrow * ROWB;
         const int sw = swz<DP>(qrow);
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            uint4 v = *reinterpret_cast<const uint4 *>(base + (((ks * 2 + h) ^ sw) << 4));
+        for (int ks = 0; ks < NKS; ++ks) {
+            uint4 v = *reinterpret_cast<const uint4 *>(base + (((ks * CPK + h) ^ sw) << 4));
             v.x ^= 0x80008000u; v.y ^= 0x80008000u; v.z ^= 0x80008000u; v.w ^= 0x80008000u;
             bq[cb][ks] = __builtin_bit_cast(half8, v);
         }
@@ -314,8 +325,9 @@ __global__ __launch_bounds__(512, 2) void k_coarse_top2(CoarseArgs a)
 #pragma unroll
     for (int i = 0; i < RCN_PD; ++i) stage_next();
 
-    unsigned m1[2], m2[2];
-    f32x16 pX0, pX1, pY0, pY1;
+    unsigned m1[NCB], m2[NCB];
+    f32x16 pX0, pX1, pY0, pY1;          // SH 0: current / previous row block, two column blocks
+    f32x4 qX[2][4], qY[2][4];           // SH 1: [16-row half][column block]
     auto top2 = [&](int cb, unsigned u) {
         // med3(m1,m2,u) spelled so that isel forms v_med3_u32 (scheduler sees a plain VALU op)
         const unsigned lo = min(m1[cb], m2[cb]), hi = max(m1[cb], m2[cb]);
@@ -334,6 +346,7 @@ __global__ __launch_bounds__(512, 2) void k_coarse_top2(CoarseArgs a)
     // cur <- hn + A.B for row block (tile, rb); prev (row block before it) is folded into top-2
     auto step = [&](f32x16 &c0, f32x16 &c1, const f32x16 &p0v, const f32x16 &p1v, unsigned tile,
                     unsigned hnl, int rb, unsigned prev_rowbase) {
+        if constexpr (SH == 0) {
         const int lrow = rb * 32 + r;
         const unsigned arow = tile + lrow * ROWB;
         const int sw = swz<DP>(lrow);
@@ -375,6 +388,53 @@ __global__ __launch_bounds__(512, 2) void k_coarse_top2(CoarseArgs a)
             kstep(ks, f0, f1);
             kstep(ks + 1, f1, f0);
         }
+        }
+    };
+    // SH 1.  cur <- hn + A.B for row block (tile, rb) as 2 halves x 4 column blocks of 16x16x32 MFMAs; the 32 values a
+    // lane holds of the row block before it are folded into the top-2 between them.  Element (half s, block cb, reg)
+    // is train row 16 s + 4 h + reg of the block: 16 s + reg goes into the packed index here, 4 h at the very end.
+    auto step16 = [&](f32x4 (&c)[2][4], const f32x4 (&pv)[2][4], unsigned tile, unsigned hnl, int rb, unsigned prev_rowbase) {
+        if constexpr (SH == 1) {
+            const int lrow = rb * 32 + r;                    // + 16 for the second half: same swizzle (period <= 16 rows)
+            const unsigned arow0 = tile + lrow * ROWB, arow1 = arow0 + 16 * ROWB;
+            const int sw = swz<DP>(lrow);
+            u32x4 hA, hB, f0a, f0b, f1a, f1b;
+            hA = lds_read(hnl + (rb * 32 + 0 + 4 * h) * 4);
+            hB = lds_read(hnl + (rb * 32 + 16 + 4 * h) * 4);
+            f0a = lds_read(arow0 + ((h ^ sw) << 4));
+            f0b = lds_read(arow1 + ((h ^ sw) << 4));
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(hA), "+v"(hB), "+v"(f0a), "+v"(f0b));
+            f32x4 hn[2];
+            hn[0] = __builtin_bit_cast(f32x4, hA);
+            hn[1] = __builtin_bit_cast(f32x4, hB);
+            constexpr int EPK = 32 / NKS;                    // previous-block elements folded per k-step
+            auto kstep = [&](int ks, u32x4 &ca_, u32x4 &cb_, u32x4 &na_, u32x4 &nb_) {
+                // naming the last accumulator ties the wait BEHIND the previous k-step's MFMAs
+                if (ks > 0) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ca_), "+v"(cb_), "+v"(c[1][3]));
+                if (ks + 1 < NKS) {
+                    na_ = lds_read(arow0 + ((((ks + 1) * 4 + h) ^ sw) << 4));
+                    nb_ = lds_read(arow1 + ((((ks + 1) * 4 + h) ^ sw) << 4));
+                }
+                const half8 av[2] = {__builtin_bit_cast(half8, ca_), __builtin_bit_cast(half8, cb_)};
+#pragma unroll
+                for (int m = 0; m < 8; ++m) {
+                    const int sh = m >> 2, cb = m & 3;
+                    c[sh][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av[sh], bq[cb][ks], ks == 0 ? hn[sh] : c[sh][cb], 0, 0, 0);
+                    if (!(ABL & 1)) {
+#pragma unroll
+                        for (int e = ks * EPK + m * EPK / 8; e < ks * EPK + (m + 1) * EPK / 8; ++e) {
+                            const int es = e >> 4, ecb = (e >> 2) & 3, er = e & 3;
+                            top2(ecb, (__float_as_uint(pv[es][ecb][er]) & hmask) | (prev_rowbase + 16 * es + er));
+                        }
+                    }
+                }
+            };
+#pragma unroll
+            for (int ks = 0; ks < NKS; ks += 2) {
+                kstep(ks, f0a, f0b, f1a, f1b);
+                if (ks + 1 < NKS) kstep(ks + 1, f1a, f1b, f0a, f0b);
+            }
+        }
     };
     const unsigned smem_base = (unsigned)(size_t)(const __attribute__((address_space(3))) char *)smem;
 
@@ -382,9 +442,15 @@ __global__ __launch_bounds__(512, 2) void k_coarse_top2(CoarseArgs a)
     for (int rr = 0; rr < R; ++rr) {
         const int nT = tiles_of(rr);
         if (nT == 0) continue;
-        m1[0] = m1[1] = m2[0] = m2[1] = 0xFFFFFFFFu;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) { pY0[i] = 3.0e38f; pY1[i] = 3.0e38f; }
+        for (int cb = 0; cb < NCB; ++cb) m1[cb] = m2[cb] = 0xFFFFFFFFu;
+        if constexpr (SH == 0) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { pY0[i] = 3.0e38f; pY1[i] = 3.0e38f; }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 32; ++i) qY[i >> 4][(i >> 2) & 3][i & 3] = 3.0e38f;
+        }
         for (int t = 0; t < nT; ++t, ++done) {
             stage_next();
             const int ahead = staged - done - 1;   // tiles issued after the one about to be read
@@ -395,30 +461,68 @@ __global__ __launch_bounds__(512, 2) void k_coarse_top2(CoarseArgs a)
             const unsigned tile = smem_base + (done % RCN_NBUF) * BUFB;
             const unsigned hnl = tile + TILEB + w * 256;
             const unsigned base = (unsigned)(t * RCN_BT);
-            step(pX0, pX1, pY0, pY1, tile, hnl, 0, base - 32u);   // epilogue of (t-1, rb 1)
-            step(pY0, pY1, pX0, pX1, tile, hnl, 1, base);         // epilogue of (t, rb 0)
-        }
-        if (ABL & 1) asm volatile("" ::"v"(pY0), "v"(pY1), "v"(pX0), "v"(pX1));
-        {   // drain: epilogue of the pair's last row block
-            const unsigned rowbase = (unsigned)((nT - 1) * RCN_BT + 32);
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                const unsigned idx = rowbase + (reg & 3) + 8 * (reg >> 2);
-                top2(0, (__float_as_uint(pY0[reg]) & hmask) | idx);
-                top2(1, (__float_as_uint(pY1[reg]) & hmask) | idx);
+            if constexpr (SH == 0) {
+                step(pX0, pX1, pY0, pY1, tile, hnl, 0, base - 32u);   // epilogue of (t-1, rb 1)
+                step(pY0, pY1, pX0, pX1, tile, hnl, 1, base);         // epilogue of (t, rb 0)
+            } else {
+                step16(qX, qY, tile, hnl, 0, base - 32u);
+                step16(qY, qX, tile, hnl, 1, base);
             }
         }
-        // lane l and l^32 hold the same query, disjoint train rows: merge, then lanes 0..31 store
+        if (ABL & 1) {
+            if constexpr (SH == 0) asm volatile("" ::"v"(pY0), "v"(pY1), "v"(pX0), "v"(pX1));
+            else {
 #pragma unroll
-        for (int cb = 0; cb < 2; ++cb) {
-            unsigned a1 = m1[cb] | (unsigned)(4 * h), a2 = m2[cb] | (unsigned)(4 * h);
-            if (m1[cb] == 0xFFFFFFFFu) a1 = 0xFFFFFFFFu;
-            if (m2[cb] == 0xFFFFFFFFu) a2 = 0xFFFFFFFFu;
-            unsigned b1 = __shfl_xor(a1, 32), b2 = __shfl_xor(a2, 32);
-            unsigned r1 = min(a1, b1);
-            unsigned r2 = min(max(a1, b1), min(a2, b2));
-            const int qrow = qt * RCN_QT + w * 64 + cb * 32 + r;
-            if (h == 0 && qrow < qi.K) a.cand[(size_t)(p0 + rr) * a.kq_stride + qrow] = make_uint2(r1, r2);
+                for (int i = 0; i < 8; ++i) asm volatile("" ::"v"(qY[i >> 2][i & 3]), "v"(qX[i >> 2][i & 3]));
+            }
+        }
+        {   // drain: epilogue of the pair's last row block
+            const unsigned rowbase = (unsigned)((nT - 1) * RCN_BT + 32);
+            if constexpr (SH == 0) {
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const unsigned idx = rowbase + (reg & 3) + 8 * (reg >> 2);
+                    top2(0, (__float_as_uint(pY0[reg]) & hmask) | idx);
+                    top2(1, (__float_as_uint(pY1[reg]) & hmask) | idx);
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 32; ++e) {
+                    const int es = e >> 4, ecb = (e >> 2) & 3, er = e & 3;
+                    top2(ecb, (__float_as_uint(qY[es][ecb][er]) & hmask) | (rowbase + 16 * es + er));
+                }
+            }
+        }
+        if constexpr (SH == 0) {
+            // lane l and l^32 hold the same query, disjoint train rows: merge, then lanes 0..31 store
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) {
+                unsigned a1 = m1[cb] | (unsigned)(4 * h), a2 = m2[cb] | (unsigned)(4 * h);
+                if (m1[cb] == 0xFFFFFFFFu) a1 = 0xFFFFFFFFu;
+                if (m2[cb] == 0xFFFFFFFFu) a2 = 0xFFFFFFFFu;
+                unsigned b1 = __shfl_xor(a1, 32), b2 = __shfl_xor(a2, 32);
+                unsigned r1 = min(a1, b1);
+                unsigned r2 = min(max(a1, b1), min(a2, b2));
+                const int qrow = qt * RCN_QT + w * 64 + cb * 32 + r;
+                if (h == 0 && qrow < qi.K) a.cand[(size_t)(p0 + rr) * a.kq_stride + qrow] = make_uint2(r1, r2);
+            }
+        } else {
+            // lanes l, l^16, l^32, l^48 hold the same query, disjoint train rows (4 h + reg of every 16): two merges
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) {
+                unsigned a1 = m1[cb] | (unsigned)(4 * h), a2 = m2[cb] | (unsigned)(4 * h);
+                if (m1[cb] == 0xFFFFFFFFu) a1 = 0xFFFFFFFFu;
+                if (m2[cb] == 0xFFFFFFFFu) a2 = 0xFFFFFFFFu;
+#pragma unroll
+                for (int o = 16; o <= 32; o <<= 1) {
+                    const unsigned b1 = __shfl_xor(a1, o), b2 = __shfl_xor(a2, o);
+                    const unsigned r1 = min(a1, b1);
+                    a2 = min(max(a1, b1), min(a2, b2));
+                    a1 = r1;
+                }
+                const int qrow = qt * RCN_QT + w * 64 + cb * 16 + r;
+                if (h == 0 && qrow < qi.K) a.cand[(size_t)(p0 + rr) * a.kq_stride + qrow] = make_uint2(a1, a2);
+            }
         }
     }
 }
@@ -1251,13 +1355,13 @@ template <int DP> static hipError_t launch_coarse_w4(rcn_ctx *ctx, const CoarseA
     return hipGetLastError();
 }
 
-template <int DP, int ABL = 0> static hipError_t launch_coarse(rcn_ctx *ctx, const CoarseArgs &ca, int blocks)
+template <int DP, int ABL = 0, int SH = 0> static hipError_t launch_coarse(rcn_ctx *ctx, const CoarseArgs &ca, int blocks)
 {
     const size_t lds = (size_t)RCN_NBUF * (RCN_BT * DP * 2 + 8 * 256) + RCN_TBL_BYTES;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_coarse_top2<DP, ABL>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_coarse_top2<DP, ABL, SH>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    k_coarse_top2<DP, ABL><<<blocks, 512, lds, ctx->stream>>>(ca);
+    k_coarse_top2<DP, ABL, SH><<<blocks, 512, lds, ctx->stream>>>(ca);
     return hipGetLastError();
 }
 
@@ -1445,22 +1549,36 @@ int rcn_int_match_grid(rcn_ctx *ctx, const int32_t *pairs_host, int32_t n_pairs,
                 case 128: e = launch_coarse_w4<128>(ctx, ca, blocks); break;
                 default: e = launch_coarse_w4<256>(ctx, ca, blocks); break;
                 }
-            } else
-            switch (ctx->DP) {
-            case 32: e = launch_coarse<32>(ctx, ca, blocks); break;
-            case 64: e = launch_coarse<64>(ctx, ca, blocks); break;
-            case 128: e = launch_coarse<128>(ctx, ca, blocks); break;
-            default:
+            } else {
+                // MFMA shape: v_mfma_f32_16x16x32_f16 at D = 256 (+4 % by wall, A/B on one box: the chip holds a higher
+                // clock on it under this kernel's load), v_mfma_f32_32x32x16_f16 below (D = 128: -2.5 % on the other
+                // shape -- half the MFMA work per tile makes that kernel issue-bound, and 16x16x32 issues twice as many)
+                const int shape = ctx->coarse_shape >= 0 ? ctx->coarse_shape : (ctx->DP == 256 ? 1 : 0);
+                if (shape == 1) {
+                    switch (ctx->DP) {
+                    case 32: e = launch_coarse<32, 0, 1>(ctx, ca, blocks); break;
+                    case 64: e = launch_coarse<64, 0, 1>(ctx, ca, blocks); break;
+                    case 128: e = launch_coarse<128, 0, 1>(ctx, ca, blocks); break;
+                    default:
 #ifdef RCN_DIAG
-                switch (ctx->ablate) {   // RCN_COARSE_ABL: timing experiments only (diagnostic build)
-                case 1: e = launch_coarse<256, 1>(ctx, ca, blocks); break;
-                case 9: e = launch_coarse<256, 9>(ctx, ca, blocks); break;
-                default: e = launch_coarse<256>(ctx, ca, blocks); break;
-                }
+                        switch (ctx->ablate) {   // RCN_COARSE_ABL: timing experiments only (diagnostic build)
+                        case 1: e = launch_coarse<256, 1, 1>(ctx, ca, blocks); break;
+                        case 9: e = launch_coarse<256, 9, 1>(ctx, ca, blocks); break;
+                        default: e = launch_coarse<256, 0, 1>(ctx, ca, blocks); break;
+                        }
 #else
-                e = launch_coarse<256>(ctx, ca, blocks);
+                        e = launch_coarse<256, 0, 1>(ctx, ca, blocks);
 #endif
-                break;
+                        break;
+                    }
+                } else {
+                    switch (ctx->DP) {
+                    case 32: e = launch_coarse<32>(ctx, ca, blocks); break;
+                    case 64: e = launch_coarse<64>(ctx, ca, blocks); break;
+                    case 128: e = launch_coarse<128>(ctx, ca, blocks); break;
+                    default: e = launch_coarse<256>(ctx, ca, blocks); break;
+                    }
+                }
             }
             RCN_HIP(e);
         }

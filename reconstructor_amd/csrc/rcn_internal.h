@@ -114,6 +114,7 @@ struct rcn_ctx {
     // library they are compile-time constants and the alternative code is dead.
 #ifdef RCN_DIAG
     bool coarse_w4 = false;    // RCN_COARSE_W4=1: the one-wave-per-SIMD form of K1 (k_coarse_w4, coarse_w4.h) instead of k_coarse_top2
+    int coarse_shape = -1;     // RCN_COARSE_S16=0/1: force k_coarse_top2's MFMA shape (0: 32x32x16, 1: 16x16x32) at every D; -1: the shipping choice
     int ablate = 0;            // RCN_COARSE_ABL
     int chunks = 1;            // RCN_MATCH_CHUNKS: >1 overlaps re-rank(c) with coarse(c+1) on two streams
     bool force_exact = false;  // RCN_FORCE_EXACT=1: skip the MFMA coarse pass
@@ -122,6 +123,7 @@ struct rcn_ctx {
     bool ba_trsv_fwd = false;  // RCN_BA_TRSV_FWD=1: separate forward substitution instead of the rhs row inside the factorisation
 #else
     static constexpr bool coarse_w4 = false;
+    static constexpr int coarse_shape = -1;
     static constexpr int ablate = 0, chunks = 1;
     static constexpr bool force_exact = false, no_item_order = false, ba_atomics = false, ba_trsv_fwd = false;
 #endif

@@ -19,8 +19,11 @@ from reconstructor_amd import _lib, synth
 from reconstructor_amd.matcher import HipL2Matcher, all_pairs
 assert b"DIAGNOSTIC" in _lib.load().rcn_version()
 m = HipL2Matcher(device=0)
-for kind, n, K in (("superpoint", 10, 2048), ("sift", 8, [1500, 700, 2048, 64, 513, 1, 900, 1300]), ("superpoint", 5, 300)):
-    ims = synth.descriptor_set(kind, n, K, n_world=4096, seed=11)
+for kind, n, K in (("superpoint", 10, 2048), ("sift", 8, [1500, 700, 2048, 64, 513, 1, 900, 1300]), ("superpoint", 5, 300),
+                   ("orb", 6, 900), ("sift64", 6, 700)):
+    ims = synth.descriptor_set("sift" if kind == "sift64" else kind, n, K, n_world=4096, seed=11)
+    if kind == "sift64":                      # a 64-d descriptor (DP = 64 instantiation): the first half of the SIFT rows
+        ims = [np.ascontiguousarray(im[:, :64]) for im in ims]
     pairs = all_pairs(n)
     exp, ec = orc.match_grid(ims, pairs, threads=8)
     m.clear()
@@ -35,9 +38,12 @@ print("OK")
 
 
 @pytest.mark.gpu
-def test_w4_form_equals_the_oracle_on_every_launch():
+@pytest.mark.parametrize("switch,value", [("RCN_COARSE_W4", "1"), ("RCN_COARSE_S16", "0"), ("RCN_COARSE_S16", "1")])
+def test_other_forms_of_k1_equal_the_oracle_on_every_launch(switch, value):
+    """RCN_COARSE_W4: k_coarse_w4; RCN_COARSE_S16 = 0 / 1: k_coarse_top2 forced onto v_mfma_f32_32x32x16_f16 /
+    v_mfma_f32_16x16x32_f16 at every D (the shipping library picks per D)."""
     diag = os.path.join(ROOT, "tools", "librcn_diag.so")
     assert os.path.exists(diag), "run __graft_entry__.build() first"
-    r = subprocess.run([sys.executable, "-c", SCRIPT % ROOT], env=dict(os.environ, RCN_LIB=diag, RCN_COARSE_W4="1"),
+    r = subprocess.run([sys.executable, "-c", SCRIPT % ROOT], env=dict(os.environ, RCN_LIB=diag, **{switch: value}),
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr
