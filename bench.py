@@ -389,7 +389,7 @@ def grid_line(K, n_img, n_pairs_total, dt, steps, st, world, my_pairs):
     flops = 2.0 * D * float(st["pair_distances"])      # 2*D flop per pair-distance, this rank's launch
     achieved = flops / (coarse_ms * 1e-3) / 1e12 if coarse_ms > 0 else 0.0
     traffic, tnote = measured_traffic("k_coarse_top2<256>@%dx%d" % (n_img, K)) if world == 1 else (None, "PMC passes are single-GPU")
-    roof = {"bound": "mfma", "kernel": "k_coarse_top2<256>", "achieved": achieved, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
+    roof = {"bound": "mfma", "kernel": "k_coarse_top2<256, 0, 1> (v_mfma_f32_16x16x32_f16)", "achieved": achieved, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": achieved / MFMA_F16_PEAK_TFLOPS, "traffic": traffic,
             "traffic_note": "HBM bytes per launch from rocprofv3 --pmc passes on this exact source (profiles/r02_match_traffic.json); " + str(tnote),
             "algorithmic_hbm_bytes_per_launch": float(n_img) * K * D * 2 + 8.0 * float(st["rows_total"]),
@@ -532,7 +532,7 @@ def main():
                 pd3 = float(st3["pair_distances"])
                 line["sift128"] = {"workload": "100 images x 1500 SIFT-like keypoints x 128-d, 4950 image pairs (tables left in HBM)",
                                    "value": pd3 / dt3, "unit": "pair-distances/s", "ms_per_step": 1e3 * dt3, "matches_found": int(c3.sum().item()),
-                                   "roofline": {"bound": "mfma", "kernel": "k_coarse_top2<128>", "achieved": 2.0 * 128 * pd3 / (cms3 * 1e-3) / 1e12,
+                                   "roofline": {"bound": "mfma", "kernel": "k_coarse_top2<128, 0, 0> (v_mfma_f32_32x32x16_f16)", "achieved": 2.0 * 128 * pd3 / (cms3 * 1e-3) / 1e12,
                                                 "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": 2.0 * 128 * pd3 / (cms3 * 1e-3) / 1e12 / MFMA_F16_PEAK_TFLOPS,
                                                 "launch_ms": cms3, "traffic": measured_traffic("k_coarse_top2<128>@100x1500")[0]}}
                 m3.clear()
