@@ -36,6 +36,20 @@ template <class M> inline void rotationToAngleAxis(const M &T, double w[3])
     const double angle = 2.0 * std::atan2(n, q[0]);
     for (int i = 0; i < 3; ++i) w[i] = q[1 + i] / n * angle;
 }
+// BundleAdjuster.cpp:157-185: angle-axis + translation back into the 4x4 pose; the axis is divided by (angle + 1e-6),
+// i.e. it is not exactly unit length -- restated as the reference has it.
+template <class M> inline void angleAxisToPose(const double *w6, M &T)
+{
+    const double *w = w6;
+    const double angle = std::sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+    const double x = w[0] / (angle + 1e-6), y = w[1] / (angle + 1e-6), z = w[2] / (angle + 1e-6);
+    const double c = std::cos(angle), s = std::sin(angle), t = 1 - c;
+    T(0, 0) = t * x * x + c;     T(0, 1) = t * x * y - s * z; T(0, 2) = t * x * z + s * y;
+    T(1, 0) = t * x * y + s * z; T(1, 1) = t * y * y + c;     T(1, 2) = t * y * z - s * x;
+    T(2, 0) = t * x * z - s * y; T(2, 1) = t * y * z + s * x; T(2, 2) = t * z * z + c;
+    for (int i = 0; i < 3; ++i) { T(i, 3) = w6[3 + i]; T(3, i) = 0; }
+    T(3, 3) = 1;
+}
 }  // namespace detail
 
 class BundleAdjuster {
@@ -93,16 +107,8 @@ public:
         }
         for (int l = 0; l < nCams; ++l) {                                   // :157-185
             const int g = imgIdxOrder[l];
-            const double *w = &extr[6 * l];
-            const double angle = std::sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
-            const double x = w[0] / (angle + 1e-6), y = w[1] / (angle + 1e-6), z = w[2] / (angle + 1e-6);  // non-unit axis, as the reference
-            const double c = std::cos(angle), s = std::sin(angle), t = 1 - c;
             Pose4 T = imgIdx2camPose[g];
-            T(0, 0) = t * x * x + c;     T(0, 1) = t * x * y - s * z; T(0, 2) = t * x * z + s * y;
-            T(1, 0) = t * x * y + s * z; T(1, 1) = t * y * y + c;     T(1, 2) = t * y * z - s * x;
-            T(2, 0) = t * x * z - s * y; T(2, 1) = t * y * z + s * x; T(2, 2) = t * z * z + c;
-            for (int i = 0; i < 3; ++i) { T(i, 3) = extr[6 * l + 3 + i]; T(3, i) = 0; }
-            T(3, 3) = 1;
+            detail::angleAxisToPose(&extr[6 * l], T);
             imgIdx2camPose[g] = T;
             PinholeCamera &K = imgIdx2camIntrinsics[g];
             K.fX = intr[6 * l]; K.fY = intr[6 * l + 1]; K.cX = intr[6 * l + 2]; K.cY = intr[6 * l + 3];

@@ -84,3 +84,33 @@ def test_cpp_adapter_matches_oracle(tmp_path):
     kept = np.add.reduceat(keep.astype(np.int32), pt_off[:-1])
     # removeOutlierLandmarks resets landmarkId only for the observations still in an outlier's track
     assert left == inl.sum() and unassigned == kept[~inl].sum()
+
+
+def _write_ba_scene(f, sc, order):
+    nc, npts = sc["poses"].shape[0], sc["points"].shape[0]
+    f.write(struct.pack("ii", nc, npts)); f.write(np.array(order, np.int32).tobytes())
+    for l in range(nc):
+        T = np.eye(4); T[:3, :3] = synth_ba.rodrigues(sc["poses"][l, :3]); T[:3, 3] = sc["poses"][l, 3:]
+        f.write(T.astype(np.float64).tobytes())
+    f.write(sc["intrinsics"].astype(np.float64).tobytes())
+    for j in range(npts):
+        obs = np.nonzero(sc["obs_pt"] == j)[0]
+        f.write(sc["points"][j].astype(np.float64).tobytes()); f.write(struct.pack("i", len(obs)))
+        for o in obs:
+            f.write(struct.pack("iii", int(sc["obs_cam"][o]), int(sc["obs_uv"][o, 0]), int(sc["obs_uv"][o, 1])))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nc,npts", [(7, 150), (12, 300)])
+def test_cpp_session_adapter_equals_the_repacking_adapter(tmp_path, nc, npts):
+    """The reference's incremental loop through HipBundleSession.h (device-resident session, sends only what was added)
+    and through HipBundleAdjuster.h (whole problem every call) on equal containers: equal bit for bit after every view,
+    including across an erase that forces the session to rebuild.  12 views: the bounded-intrinsics branch (>= 10)."""
+    binary = os.path.join(ROOT, "tests", "cpp", "session_adapter_test")
+    assert os.path.exists(binary), "run __graft_entry__.build() first"
+    sc = synth_ba.make_scene(nc, npts, obs_per_point=4, seed=21)
+    inp = tmp_path / "scene.bin"
+    with open(inp, "wb") as f:
+        _write_ba_scene(f, sc, [3 * i + 1 for i in range(nc)])
+    r = subprocess.run([binary, str(inp)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "session_adapter_test ok" in r.stdout and "1 rebuild(s)" in r.stdout, r.stdout + r.stderr
