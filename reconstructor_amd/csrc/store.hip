@@ -212,7 +212,8 @@ int rcn_store_save(const char *path, const rcn_store_contents *c)
     const std::string tmp = std::string(path) + ".tmp";
     FILE *f = fopen(tmp.c_str(), "wb");
     if (!f) return RCN_ERR_IO;
-    Writer w{f};
+    Writer w;
+    w.f = f;
     StoreHeader h;
     memset(&h, 0, sizeof(h));
     memcpy(h.magic, "RCNSTORE", 8);
