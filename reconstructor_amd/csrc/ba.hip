@@ -1774,16 +1774,23 @@ int rcn_int_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_option
                 if (m <= 0) break;
                 k_gemm_q<0><<<32 * ((4 * m + 7) / 8), 256, 0, st>>>(d.S, d.L, npad, kb, m, d.Linv);
                 hipEvent_t evP = ctx->ba_ev[1 + (kb & 3)];
-                if (m > 1) RCN_HIP(hipEventRecord(evP, st));
+                // The bulk update of this step may start once the panel is there.  While the bulk kernel is the longer
+                // side of a step (large trailing matrix: ~0.06 us per tile pair against ~100 us of chain) its release is
+                // recorded right behind the panel, so that it follows its predecessor without a bubble; once the chain is
+                // the longer side, the record (6.6 us on the chain stream) moves behind the first trailing column: the bulk
+                // kernel starts ~16 us later and still finishes well before the next gate asks for it.
+                const bool bulk_bound = 0.0575 * (double)(m - 1) * (double)(m - 1) > 55.0;
+                if (m > 1 && bulk_bound) RCN_HIP(hipEventRecord(evP, st));
                 if (have_rest) k_ring_gate<<<1, 64, 0, st>>>(ring_done, kb, d.flag);      // rest(kb-1) touched column kb+1
                 have_rest = 0;
+                k_gemm_q<1><<<32 * ((4 * m + 7) / 8), 256, 0, st>>>(d.S, d.L, npad, kb, m, d.Linv);
                 if (m > 1) {
+                    if (!bulk_bound) RCN_HIP(hipEventRecord(evP, st));
                     RCN_HIP(hipStreamWaitEvent(sb, evP, 0));
                     k_gemm_nt_ring<0><<<gemm_nt_grid(m - 1), 256, GST * GSTAGE_BYTES, sb>>>(d.S, d.L, npad, kb, m - 1, NB / 8);
                     k_ring_signal<<<1, 1, 0, sb>>>(ring_done, kb + 1);
                     have_rest = 1;
                 }
-                k_gemm_q<1><<<32 * ((4 * m + 7) / 8), 256, 0, st>>>(d.S, d.L, npad, kb, m, d.Linv);
             }
             RCN_HIP(hipGetLastError());
         }
