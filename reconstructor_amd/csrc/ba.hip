@@ -811,14 +811,18 @@ __global__ void k_ring_signal(int *counter, int value)
     __hip_atomic_store(counter, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-__global__ __launch_bounds__(64) void k_ring_gate(const int *counter, int need, int *flag)
+__device__ __forceinline__ void ring_wait(const int *counter, int need, int *flag)    // one thread
 {
-    if (threadIdx.x != 0) return;
     const unsigned long long t0 = wall_clock64();                // 100 MHz, independent of the shader clock
     while (__hip_atomic_load(counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < need) {
         __builtin_amdgcn_s_sleep(8);
         if (wall_clock64() - t0 > 200000000ull) { *flag = 3; break; }
     }
+}
+
+__global__ __launch_bounds__(64) void k_ring_gate(const int *counter, int need, int *flag)
+{
+    if (threadIdx.x == 0) ring_wait(counter, need, flag);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -892,7 +896,11 @@ __device__ unsigned long long g_stamps[32];
 #else
 #define STAMP(i)
 #endif
-__global__ __launch_bounds__(256) void k_chol_diag(double *S, int ld, int kb, double *Linv, int *flag, int store_L)
+// ring_done / ring_need: in the chain-bound steps of the factorisation (the host decides) this kernel also does the gate's
+// job on its way out -- by then the bulk update the first trailing column of this step waits for has long finished, so
+// the check is free and the chain loses a 5-us kernel; ring_need < 0: nothing to wait for here.
+__global__ __launch_bounds__(256) void k_chol_diag(double *S, int ld, int kb, double *Linv, int *flag, int store_L,
+                                                    const int *ring_done, int ring_need)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     double *L = reinterpret_cast<double *>(smem_raw);  // [128][DL]
@@ -966,7 +974,10 @@ __global__ __launch_bounds__(256) void k_chol_diag(double *S, int ld, int kb, do
     __syncthreads();
     STAMP(1);
     for (int c0 = 0; c0 < NB; c0 += LB) {
-        if (misc[0] != 0.0) { if (t == 0) *flag = 1; return; }
+        if (misc[0] != 0.0) {
+            if (t == 0) { *flag = 1; if (ring_need >= 0) ring_wait(ring_done, ring_need, flag); }
+            return;
+        }
         const int r0 = c0 + LB;
         if (r0 >= NB) break;
         // 1b. rows below: X = A * D^-T as 16x16 MFMA tiles (one wave per tile), in place:
@@ -1141,6 +1152,7 @@ __global__ __launch_bounds__(256) void k_chol_diag(double *S, int ld, int kb, do
             if (c <= r) *reinterpret_cast<f64x2 *>(out + (size_t)r * NB + c) = (f64x2){at(r, c), at(r, c + 1)};
     }
     STAMP(17);
+    if (ring_need >= 0 && t == 0) ring_wait(ring_done, ring_need, flag);
 }
 
 // Dense blocked Cholesky, GEMM side.  S holds the reduced system and its trailing updates; the
@@ -1769,8 +1781,12 @@ int rcn_int_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_option
             // -- device-scope fences write the L2 back under the bulk kernel -- and a signal kernel costs what the record does.
             int *ring_done = d.flag + 2;
             for (int kb = 0; kb < nblk; ++kb) {
-                k_chol_diag<<<1, 256, NB * DL * 8, st>>>(d.S, npad, kb, d.Linv, d.flag, kb == nblk - 1);
                 const int m = nblk - kb - 1;
+                // chain-bound steps: the diagonal kernel itself waits (at its end) for the bulk update of step kb - 1
+                // (only where the bulk kernel is short against the diagonal kernel, ~30 us: a wait that actually has to wait would
+                // hold up the panel behind it -- measured: +1 % at 500 / 1000 cameras when every chain-bound step did this)
+                const bool gate_in_diag = have_rest && m > 0 && 0.0575 * (double)m * (double)m <= 30.0;
+                k_chol_diag<<<1, 256, NB * DL * 8, st>>>(d.S, npad, kb, d.Linv, d.flag, kb == nblk - 1, ring_done, gate_in_diag ? kb : -1);
                 if (m <= 0) break;
                 k_gemm_q<0><<<32 * ((4 * m + 7) / 8), 256, 0, st>>>(d.S, d.L, npad, kb, m, d.Linv);
                 hipEvent_t evP = ctx->ba_ev[1 + (kb & 3)];
@@ -1781,7 +1797,7 @@ int rcn_int_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_option
                 // kernel starts ~16 us later and still finishes well before the next gate asks for it.
                 const bool bulk_bound = 0.0575 * (double)(m - 1) * (double)(m - 1) > 55.0;
                 if (m > 1 && bulk_bound) RCN_HIP(hipEventRecord(evP, st));
-                if (have_rest) k_ring_gate<<<1, 64, 0, st>>>(ring_done, kb, d.flag);      // rest(kb-1) touched column kb+1
+                if (have_rest && !gate_in_diag) k_ring_gate<<<1, 64, 0, st>>>(ring_done, kb, d.flag);      // rest(kb-1) touched column kb+1
                 have_rest = 0;
                 k_gemm_q<1><<<32 * ((4 * m + 7) / 8), 256, 0, st>>>(d.S, d.L, npad, kb, m, d.Linv);
                 if (m > 1) {

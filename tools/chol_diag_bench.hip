@@ -22,7 +22,7 @@ int main()
     for (int rep = 0; rep < 3; ++rep) {
         (void)hipMemcpy(dA, A.data(), n * n * 8, hipMemcpyHostToDevice);
         (void)hipEventRecord(e0);
-        k_chol_diag<<<1, 256, NB * DL * 8>>>(dA, n, 0, dLinv, dflag, 1);
+        k_chol_diag<<<1, 256, NB * DL * 8>>>(dA, n, 0, dLinv, dflag, 1, nullptr, -1);
         (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
         float ms; (void)hipEventElapsedTime(&ms, e0, e1);
         unsigned long long st[32];
