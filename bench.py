@@ -493,12 +493,14 @@ def main():
                 pool2 = synth.world_pool("superpoint", 4 * K2, seed=1234)
                 loc2 = np.stack([synth.image_descriptors("superpoint", i, K2, pool2, seed=1234) for i in range(n2)])
                 loc2_dev = torch.from_numpy(loc2).to(dev)
-                dt2, st2, nm2, lb2, info2 = run_grid(torch, dist, dev, shard, n2, K2, loc2_dev, 20, 3, 1)
+                # three windows of 20 steps, the median one is reported (a window is 0.17 s: one clock transient moves it by 10 %)
+                runs2 = sorted((run_grid(torch, dist, dev, shard, n2, K2, loc2_dev, 20, 3, 1) for _ in range(3)), key=lambda r: r[0])
+                dt2, st2, nm2, lb2, info2 = runs2[1]
                 v2, ms2, roof2 = grid_line(K2, n2, n2 * (n2 - 1) // 2, dt2, 20, st2, 1, info2["n_pairs"])
                 # and with the tables left in HBM (round 1's definition of the step), for comparison
                 dt2b, st2b, _, _, _ = run_grid(torch, dist, dev, shard, n2, K2, loc2_dev, 20, 3, 1, materialise=False)
                 line["cfg2"] = {"workload": "cfg2: %d images x %d keypoints x %d-d, %d image pairs" % (n2, K2, D, n2 * (n2 - 1) // 2),
-                                "value": v2, "unit": "pair-distances/s", "steps": 20, "warmup": 3, "ms_per_step": ms2, "matches_found": nm2,
+                                "value": v2, "unit": "pair-distances/s", "steps": 20, "warmup": 3, "windows": "median of 3", "ms_per_step": ms2, "matches_found": nm2,
                                 "host_list_bytes_per_step": lb2, "roofline": roof2,
                                 "value_tables_left_in_hbm": float(n2 * (n2 - 1) // 2) * K2 * K2 * 20 / dt2b,
                                 "rows_reranked": int(st2["rows_reranked"]), "rows_exact_fallback": int(st2["rows_exact_fallback"]), "rows_total": int(st2["rows_total"])}
