@@ -17,6 +17,9 @@ the BA legs (cfg 4 / cfg 5; BA does not shard: "replicas only") and the two wide
 
   python bench.py [--gpus N] [--steps K] [--warmup W]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+`python bench.py --gpus N` with N > 1 and no launcher around it starts the N ranks itself (a child
+`python -m torch.distributed.run`, before this process has touched the GPU); fewer than N visible devices is an
+error (exit 2) -- it never falls back to a smaller world.
 
 Control plane (rendezvous id, barriers, max-over-ranks time): torch.distributed / gloo.  Data plane:
 RCCL called directly from librcn.so.  Prints ONE JSON line on rank 0.
@@ -319,6 +322,7 @@ def run_grid(torch, dist, dev, shard, n_img, K, local_dev, steps, warmup, world,
     m = HipL2Matcher(ctx=ctx)
     m.stats()                 # clears counters
     m.profile(True)
+    shard.profile(True)       # HIP events around exchange / fp32 gather / match, on the streams they run on
     fence()
     t0 = time.perf_counter()
     for _ in range(steps):
@@ -329,6 +333,8 @@ def run_grid(torch, dist, dev, shard, n_img, K, local_dev, steps, warmup, world,
     dt = time.perf_counter() - t0
     st = m.stats()
     m.profile(False)
+    st["shard_times"] = shard.times()
+    shard.profile(False)
     n_matches = int(counts[:P].sum().item()) if P else 0
     list_bytes = 8 * (lists.total.value if lists is not None else 0)
     if lists is not None:
@@ -398,6 +404,26 @@ def grid_line(K, n_img, n_pairs_total, dt, steps, st, world, my_pairs):
     return pd_job * steps / dt, dt / steps * 1e3, roof
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` (N > 1) outside a launcher: run the N ranks as a child torch.distributed.run and
+    exit with its code.  Nothing here initialises the GPU (device_count() does not), so starting children is safe."""
+    import socket
+    import subprocess
+    import torch
+    have = torch.cuda.device_count()
+    if have < args.gpus:
+        sys.stderr.write("bench.py: --gpus %d asked for, %d device(s) visible: refusing to run a smaller world\n" % (args.gpus, have))
+        raise SystemExit(2)
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -410,6 +436,10 @@ def main():
     ap.add_argument("--no-ba", action="store_true", help="skip the BA / epipolar / sweep legs")
     ap.add_argument("--no-cfg2", action="store_true", help="skip the configs[1] sub-measurement of the N = 1 line")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)          # does not return
 
     import torch
     import torch.distributed as dist
@@ -417,8 +447,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit("--gpus must equal WORLD_SIZE")
+    if world != args.gpus:
+        sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE is %d: the line would not describe the run\n" % (args.gpus, world))
+        raise SystemExit(2)
+    if torch.cuda.device_count() <= local_rank:
+        sys.stderr.write("bench.py: rank %d has no device %d (%d visible)\n" % (rank, local_rank, torch.cuda.device_count()))
+        raise SystemExit(2)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -456,10 +490,13 @@ def main():
 
     dt, st, n_matches, list_bytes, info = run_grid(torch, dist, dev, shard, n_img, K, local_dev, args.steps, args.warmup, world)
 
+    tm = st["shard_times"]
+    phase = [tm["exchange_ms"] / max(1, tm["exchanges"]), tm["f32_gather_ms"] / max(1, tm["exchanges"]), tm["match_ms"] / max(1, tm["matches"])]
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64)
+        t = torch.tensor([dt] + phase, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        dt = float(t[0].item())
+        phase = [float(x) for x in t[1:].tolist()]
         tot = torch.tensor([float(n_matches), float(list_bytes), float(st["rows_reranked"]), float(st["rows_exact_fallback"]), float(st["rows_total"])], dtype=torch.float64)
         dist.all_reduce(tot)
         n_matches, list_bytes = int(tot[0].item()), int(tot[1].item())
@@ -485,6 +522,11 @@ def main():
                        "exchange_bytes_f16_payload": int(info["exchange_bytes_f16"]), "exchange_bytes_f32_side_stream": int(info["exchange_bytes_f32"]),
                        "rows_reranked": rows[0], "rows_exact_fallback": rows[1], "rows_total": rows[2]},
             "roofline": roof,
+            # the collective side of the step, per step, max over ranks (HIP events inside librcn.so): `ranks` is
+            # ncclCommCount of the communicator the gathers ran on; the fp32 gather runs on a side stream BESIDE the
+            # coarse kernel (it is inside match_ms, not added to it)
+            "rccl": {"ranks": int(info["comm_ranks"]), "exchange_ms": phase[0], "f32_gather_ms_side_stream": phase[1], "match_ms": phase[2],
+                     "host_syncs_per_exchange": 1},
         }
         if world == 1:
             if not args.no_cfg2 and args.workload != "cfg2":

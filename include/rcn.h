@@ -75,6 +75,10 @@ int rcn_desc_upload_batch_device(rcn_ctx *ctx, int32_t first_img_id, int32_t n_i
  * own [C][Hc][Wc] output is (Hc*Wc, Wc, 1), a channel-last copy is (1, Wc*C, C).  Asynchronous on the ctx stream. */
 int rcn_desc_sample_device(rcn_ctx *ctx, const float *desc_map_dev, int64_t stride_c, int64_t stride_y, int64_t stride_x,
                            int32_t Hc, int32_t Wc, const int32_t *kp_xy_dev, int32_t K, int32_t D, float *out_rows_dev);
+/* A keypoint outside [0, 8*Wc) x [0, 8*Hc) reads nothing (the reference's tensor indexing throws there): its row is
+ * written as zeros and counted.  rcn_desc_sample_errors waits for the ctx stream and returns RCN_ERR_ARG (count in
+ * *n_out_of_range, may be NULL) when any keypoint of the calls since the last read was outside; the count is cleared. */
+int rcn_desc_sample_errors(rcn_ctx *ctx, int32_t *n_out_of_range);
 int rcn_desc_clear(rcn_ctx *ctx);
 int rcn_desc_count(const rcn_ctx *ctx);
 
@@ -193,8 +197,30 @@ typedef struct {
     int64_t n_pairs;              /* this rank's share */
     int64_t exchange_bytes_f16;   /* whole all-gather (all ranks' blocks): fp16 rows + half-norms + norms */
     int64_t exchange_bytes_f32;   /* whole all-gather of the fp32 rows (side stream) */
+    int32_t comm_ranks;           /* ncclCommCount of the communicator the collectives run on */
+    int32_t reserved;
 } rcn_shard_stats;
 int rcn_shard_info(const rcn_shard *sh, rcn_shard_stats *out);
+
+/* Failure handling.  rcn_shard_exchange is the only collective after rcn_shard_create, and it opens with a status vote:
+ * an all-gather of one word per rank next to the row counts, in front of its single host synchronisation.  A failure
+ * that only THIS rank saw -- rcn_shard_reserve could not allocate, rcn_shard_put_image was refused, or the host driver
+ * reports one of its own through rcn_shard_fail -- is remembered in the shard; the rank must still call
+ * rcn_shard_exchange, which then returns an error on EVERY rank (the failing rank its own code, the others RCN_ERR_COMM
+ * naming it) before any further collective is entered, so no peer is left waiting.  rcn_shard_match refuses to run until
+ * an exchange has gone through again. */
+int rcn_shard_fail(rcn_shard *sh, int32_t code /* negative RCN_ERR_* */);
+
+/* Phase times of the sharded step, HIP events on the streams the work runs on: enable, run steps (at most 64 are
+ * kept), read the sums (waits for the shard's streams; clears them). */
+typedef struct {
+    int32_t exchanges, matches;   /* calls summed below */
+    double  exchange_ms;          /* rcn_shard_exchange on the ctx stream: vote + counts, statistics, all-reduce, fp16 conversion, fp16 all-gather */
+    double  f32_gather_ms;        /* all-gather of the fp32 rows on the side stream (beside the coarse kernel) */
+    double  match_ms;             /* rcn_shard_match: this rank's share of the grid */
+} rcn_shard_times;
+int rcn_shard_profile(rcn_shard *sh, int enable);
+int rcn_shard_profile_read(rcn_shard *sh, rcn_shard_times *out);
 
 /* ---- bundle adjustment -----------------------------------------------------------------
  * Flat form of what BundleAdjuster::adjust packs (BundleAdjuster.cpp:17-97):
@@ -380,6 +406,18 @@ int rcn_coords_clear(rcn_ctx *ctx);
  * small host-to-device copy. */
 int rcn_match_table_filter_device(rcn_ctx *ctx, const int32_t *pairs_host, int32_t n_pairs, int32_t *table_dev,
                                   int64_t stride, int32_t *counts_dev, int32_t *out_status_dev);
+
+/* The body of the pair loop (:232-275) for a list of pairs over resident images, results on the HOST: match, then --
+ * filter != 0 -- the filter above on the table where it lies in HBM, then the dense table (as rcn_match_grid), the
+ * counts and (status_host, may be NULL) the filter's verdict per pair (rcn_fmat_filter's out_count; -2 everywhere when
+ * filter == 0).  HipPairGridDriver.h uses it for the pairs the loop matches a second time the other way round. */
+int rcn_match_grid_filtered(rcn_ctx *ctx, const int32_t *pairs_host, int32_t n_pairs, float ratio, int32_t filter,
+                            int32_t *out_host, int64_t out_stride, int32_t *counts_host, int32_t *status_host);
+/* The same filter on the tables the last rcn_shard_match(sh, ratio, NULL, 0, NULL) left in the shard's ctx, in place,
+ * before rcn_shard_lists.  The coordinates of EVERY image of the grid must have been uploaded to this rank's ctx
+ * (rcn_coords_upload: 8 bytes per keypoint, handed round by the host like the image list itself).
+ * status_host (may be NULL): verdict per pair of this rank, rcn_shard_pairs order. */
+int rcn_shard_filter(rcn_shard *sh, int32_t *status_host);
 
 /* ---- store: features + matches on disk -------------------------------------------------------
  * The cache of features / matches the reference lists as a TODO (README.md:39): one versioned binary

@@ -15,8 +15,7 @@ SO = os.path.join(HERE, "librcn.so")
 SO_DIAG = os.path.join(ROOT, "tools", "librcn_diag.so")
 SOURCES = ["ctx.hip", "match.hip", "ba.hip", "ba_session.hip", "validity.hip", "fmat.hip", "shard.hip", "store.hip", "desc.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
-         "-munsafe-fp-atomics"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 LIBS = ["-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib"]
 
 

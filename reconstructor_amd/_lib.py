@@ -17,7 +17,7 @@ ERRORS = {-1: "RCN_ERR_ARG", -2: "RCN_ERR_HIP", -3: "RCN_ERR_NO_DEVICE",
 # every symbol include/rcn.h declares (tests check the library exports exactly these)
 SYMBOLS = [
     "rcn_create", "rcn_destroy", "rcn_last_error", "rcn_version", "rcn_set_stream",
-    "rcn_synchronize", "rcn_desc_upload", "rcn_desc_upload_device", "rcn_desc_upload_batch_device", "rcn_desc_sample_device", "rcn_desc_clear",
+    "rcn_synchronize", "rcn_desc_upload", "rcn_desc_upload_device", "rcn_desc_upload_batch_device", "rcn_desc_sample_device", "rcn_desc_sample_errors", "rcn_desc_clear",
     "rcn_desc_count", "rcn_match_pair", "rcn_match_grid", "rcn_match_grid_device",
     "rcn_match_last_stats", "rcn_match_profile", "rcn_ba_default_options", "rcn_ba_solve",
     "rcn_landmark_validity", "rcn_landmark_validity_device",
@@ -27,6 +27,7 @@ SYMBOLS = [
     "rcn_shard_owned_images", "rcn_shard_pair_count", "rcn_shard_pairs", "rcn_shard_unique_id",
     "rcn_shard_create", "rcn_shard_destroy", "rcn_shard_ctx", "rcn_shard_reserve", "rcn_shard_put_image", "rcn_shard_exchange",
     "rcn_shard_match", "rcn_shard_lists", "rcn_shard_info", "rcn_device_count",
+    "rcn_shard_fail", "rcn_shard_profile", "rcn_shard_profile_read", "rcn_shard_filter", "rcn_match_grid_filtered",
     "rcn_ba_session_create", "rcn_ba_session_destroy", "rcn_ba_session_add_camera", "rcn_ba_session_cameras",
     "rcn_ba_session_add_points", "rcn_ba_session_add_observations", "rcn_ba_session_counts", "rcn_ba_session_graph",
     "rcn_ba_session_solve", "rcn_ba_session_read_points", "rcn_ba_session_points_device", "rcn_ba_session_validity",
@@ -51,7 +52,13 @@ class MatchStats(C.Structure):
 
 class ShardStats(C.Structure):
     _fields_ = [("rank", C.c_int32), ("world", C.c_int32), ("n_images", C.c_int32), ("images_per_rank", C.c_int32),
-                ("n_pairs", C.c_int64), ("exchange_bytes_f16", C.c_int64), ("exchange_bytes_f32", C.c_int64)]
+                ("n_pairs", C.c_int64), ("exchange_bytes_f16", C.c_int64), ("exchange_bytes_f32", C.c_int64),
+                ("comm_ranks", C.c_int32), ("reserved", C.c_int32)]
+
+
+class ShardTimes(C.Structure):
+    _fields_ = [("exchanges", C.c_int32), ("matches", C.c_int32), ("exchange_ms", C.c_double),
+                ("f32_gather_ms", C.c_double), ("match_ms", C.c_double)]
 
 
 class StoreContents(C.Structure):
@@ -140,6 +147,8 @@ def load():
     L.rcn_desc_upload_batch_device.argtypes = [vp, i32, i32, vp, i32, i32]
     L.rcn_desc_sample_device.restype = C.c_int
     L.rcn_desc_sample_device.argtypes = [vp, vp, i64, i64, i64, i32, i32, vp, i32, i32, vp]
+    L.rcn_desc_sample_errors.restype = C.c_int
+    L.rcn_desc_sample_errors.argtypes = [vp, C.POINTER(i32)]
     L.rcn_desc_clear.restype = C.c_int
     L.rcn_desc_clear.argtypes = [vp]
     L.rcn_desc_count.restype = C.c_int
@@ -208,6 +217,16 @@ def load():
     L.rcn_shard_match.argtypes = [vp, f32, vp, i64, vp]
     L.rcn_shard_info.restype = C.c_int
     L.rcn_shard_info.argtypes = [vp, C.POINTER(ShardStats)]
+    L.rcn_shard_filter.restype = C.c_int
+    L.rcn_shard_filter.argtypes = [vp, vp]
+    L.rcn_match_grid_filtered.restype = C.c_int
+    L.rcn_match_grid_filtered.argtypes = [vp, vp, i32, f32, i32, vp, i64, vp, vp]
+    L.rcn_shard_fail.restype = C.c_int
+    L.rcn_shard_fail.argtypes = [vp, i32]
+    L.rcn_shard_profile.restype = C.c_int
+    L.rcn_shard_profile.argtypes = [vp, C.c_int]
+    L.rcn_shard_profile_read.restype = C.c_int
+    L.rcn_shard_profile_read.argtypes = [vp, C.POINTER(ShardTimes)]
     L.rcn_ba_session_create.restype = C.c_int
     L.rcn_ba_session_create.argtypes = [vp, C.POINTER(vp)]
     L.rcn_ba_session_destroy.restype = None

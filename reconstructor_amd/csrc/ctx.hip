@@ -98,7 +98,7 @@ void rcn_destroy(rcn_ctx *ctx)
     (void)hipStreamSynchronize(ctx->stream);
     rcn_match_release(ctx);
     DevBuf *bufs[] = {&ctx->img_table, &ctx->pairs_dev, &ctx->groups_dev, &ctx->cand, &ctx->owner,
-                      &ctx->fb_list, &ctx->sv_list, &ctx->counters, &ctx->out_tmp, &ctx->cnt_tmp};
+                      &ctx->fb_list, &ctx->sv_list, &ctx->counters, &ctx->out_tmp, &ctx->cnt_tmp, &ctx->scale_dev, &ctx->desc_bad};
     for (DevBuf *b : bufs) b->release();
     for (DevBuf &b : ctx->ba_ws) b.release();
     ctx->lm_ws.release();

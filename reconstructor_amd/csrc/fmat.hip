@@ -763,12 +763,19 @@ extern "C" int rcn_match_table_filter_device(rcn_ctx *ctx, const int32_t *pairs_
                                              int64_t stride, int32_t *counts_dev, int32_t *out_status_dev)
 {
     if (!ctx) return RCN_ERR_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    return rcn_int_table_filter(ctx, pairs_host, n_pairs, table_dev, stride, counts_dev, out_status_dev);
+}
+
+// the same with ctx->mu held by the caller (shard.hip, rcn_match_grid_filtered)
+int rcn_int_table_filter(rcn_ctx *ctx, const int32_t *pairs_host, int32_t n_pairs, int32_t *table_dev,
+                         int64_t stride, int32_t *counts_dev, int32_t *out_status_dev)
+{
     if (n_pairs < 0 || (n_pairs > 0 && (!pairs_host || !table_dev || !counts_dev)) || stride < 0) {
         ctx->set_error("rcn_match_table_filter_device: bad argument");
         return RCN_ERR_ARG;
     }
     if (n_pairs == 0) return RCN_OK;
-    std::lock_guard<std::mutex> lk(ctx->mu);
     RCN_HIP(hipSetDevice(ctx->device));
     std::vector<PairXY> &px = ctx->fm_pairs_host;          // kept in the ctx: uploaded asynchronously
     px.resize((size_t)n_pairs);

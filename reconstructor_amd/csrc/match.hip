@@ -113,10 +113,12 @@ __global__ __launch_bounds__(256) void k_rowstats(const float *__restrict__ x, i
 // fp32 rows -> scaled fp16 rows (chunk-swizzled) + biased half-norms.
 template <int DP>
 __global__ void k_prepare(const float *__restrict__ x, const double *__restrict__ nrm2, int K,
-                          int Kp, int D, float scale, double half_s2, double bias,
+                          int Kp, int D, const ScaleDev *__restrict__ sc,
                           _Float16 *__restrict__ f16, float *__restrict__ hn)
 {
     constexpr int CPR = DP / 8;
+    const float scale = sc->sf;
+    const double half_s2 = sc->hs2, bias = sc->bias;
     int gid = blockIdx.x * blockDim.x + threadIdx.x;
     int row = gid / CPR, c = gid % CPR;
     if (row >= Kp) return;
@@ -141,12 +143,14 @@ __global__ void k_prepare(const float *__restrict__ x, const double *__restrict_
 // Same for a batch of n equally shaped images ([n][K][D] fp32 -> [n][Kp][DP] fp16).
 template <int DP>
 __global__ void k_prepare_batch(const float *__restrict__ x, const double *__restrict__ nrm2,
-                                int n, int Kslot, int Kp, int D, float scale, double half_s2,
-                                double bias, _Float16 *__restrict__ f16, float *__restrict__ hn,
+                                int n, int Kslot, int Kp, int D, const ScaleDev *__restrict__ sc,
+                                _Float16 *__restrict__ f16, float *__restrict__ hn,
                                 const int32_t *__restrict__ Ks)
 {
     // every image owns a slot of Kslot fp32 rows; Ks (may be NULL = Kslot everywhere) holds the rows in use
     constexpr int CPR = DP / 8;
+    const float scale = sc->sf;
+    const double half_s2 = sc->hs2, bias = sc->bias;
     const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const long grow = gid / CPR;
     const int c = (int)(gid % CPR);
@@ -170,6 +174,42 @@ __global__ void k_prepare_batch(const float *__restrict__ x, const double *__res
     }
     *reinterpret_cast<half8 *>(f16 + (size_t)grow * DP + ((c ^ swz<DP>(row)) * 8)) = v;
     if (c == 0) hn[grow] = row < K ? (float)(half_s2 * nrm2[(size_t)img * Kslot + row] + bias) : RCN_PAD_HN;
+}
+
+// The global scale from the row statistics (counters[0]: max |x| as fp32 bits, counters[2..3]: max |x|^2 as fp64
+// bits), on the device: the arithmetic of rcn_int_prepare_all's host path, operation for operation (frexp / ldexp /
+// ceil are exact; sqrt is correctly rounded on both sides), so that every GPU of a sharded grid -- and a one-GPU run
+// through the host path -- arrives at the same constants.
+__host__ __device__ inline void fix_scale(float maxabs, double maxn2, int DPa, ScaleDev *o)
+{
+    if (!(maxabs > 0.f && maxabs <= 3.4028234e38f)) maxabs = 1.f;          // zero, NaN, infinity
+    if (!(maxn2 > 0.0 && maxn2 <= 1.7976931348623157e308)) maxn2 = 1.0;
+    // s = 2^e with s*maxabs in (2^13, 2^14]  (fp16 max is 65504; the query side is negated only)
+    int ex;
+    (void)frexp((double)maxabs, &ex);  // maxabs = m * 2^ex, m in [0.5,1)
+    const double s = ldexp(1.0, 14 - ex);
+    // the norm bound is rounded UP to a 1/16-octave grid so that it (and BIAS) stays put while
+    // images of similar norm come and go: then only new images need converting
+    int en;
+    const double mn = frexp(maxn2 * (1.0 + 1e-12), &en);            // in [0.5, 1)
+    const double maxn2q = ldexp(ceil(mn * 32.0) / 32.0, en);
+    const double bias = 0.5625 * s * s * maxn2q + 1.0;  // accumulator >= s^2 Nmax^2/16 > 0 for every (q,t)
+    const double n_max = sqrt(maxn2q), u = ldexp(1.0, -11);
+    o->s = s; o->s2 = s * s; o->hs2 = 0.5 * s * s; o->bias = bias;
+    o->c_in = (2 * u + u * u) * s * s;
+    o->c_sub = ldexp(1.0, -14) * sqrt((double)DPa) * s;
+    o->c_acc = (DPa + 8) * ldexp(1.0, -23);
+    o->n_max = n_max;
+    o->hn_max = 0.5 * s * s * n_max * n_max + bias;
+    o->rel_slack = 1e-9;
+    o->sf = (float)s; o->pad = 0.f;
+}
+__global__ void k_fix_scale(const unsigned *__restrict__ counters, int DPa, ScaleDev *__restrict__ out)
+{
+    if (threadIdx.x || blockIdx.x) return;
+    const float maxabs = __uint_as_float(counters[0]);
+    const double maxn2 = __longlong_as_double(*reinterpret_cast<const long long *>(counters + 2));
+    fix_scale(maxabs, maxn2, DPa, out);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -575,15 +615,7 @@ struct RerankArgs {
     int32_t n_pairs, kq_stride, D, qblocks, pair_base;
     uint32_t idx_mask;
     float ratio;
-    // error model of the coarse pass, in accumulator units unless stated
-    double s2;          // s^2
-    double bias;        // BIAS
-    double c_in;        // (2u+u^2) s^2            x |q| Nmax
-    double c_sub;       // 2^-14 sqrt(DP) s        x (|q| + Nmax)
-    double c_acc;       // (DP+8) 2^-23
-    double hn_max;      // s^2 Nmax^2 / 2 + BIAS
-    double n_max;       // Nmax
-    double rel_slack;   // relative slack for the fp64 evaluation of the bound itself
+    const ScaleDev *sc;  // error model of the coarse pass, in HBM: see rcn_internal.h
     int32_t all_to_fallback;
 };
 
@@ -603,7 +635,7 @@ __device__ __forceinline__ int certify(double ea, int ia, double eb, double lbnc
 }
 
 // coarse-error bound for one query, accumulator units
-__device__ __forceinline__ double coarse_eps(const RerankArgs &a, double nq2)
+__device__ __forceinline__ double coarse_eps(const ScaleDev &a, double nq2)
 {
     const double nq = sqrt(nq2) * (1.0 + 1e-12);
     const double mag = a.s2 * nq * a.n_max;
@@ -611,7 +643,7 @@ __device__ __forceinline__ double coarse_eps(const RerankArgs &a, double nq2)
            6.0e-8 * a.hn_max;
 }
 // accumulator value -> squared distance (both real-valued), minus/plus the evaluation slack
-__device__ __forceinline__ double acc_to_d2(const RerankArgs &a, double nq2, double acc)
+__device__ __forceinline__ double acc_to_d2(const ScaleDev &a, double nq2, double acc)
 {
     return nq2 + (2.0 / a.s2) * (acc - a.bias);
 }
@@ -640,6 +672,7 @@ __global__ __launch_bounds__(RCN_FB) void k_filter(RerankArgs a)
     __shared__ unsigned wbase[2][RCN_FB / 64];
     const int pl = blockIdx.x / a.qblocks, pair = a.pair_base + pl;
     const int q = (blockIdx.x - pl * a.qblocks) * blockDim.x + threadIdx.x;
+    const ScaleDev S = *a.sc;
     const ImgDev qi = a.imgs[a.pairs[2 * pair]];
     const ImgDev ti = a.imgs[a.pairs[2 * pair + 1]];
     bool surv = false, fb = false;
@@ -651,13 +684,13 @@ __global__ __launch_bounds__(RCN_FB) void k_filter(RerankArgs a)
             else {
                 const uint2 c = a.cand[(size_t)pair * a.kq_stride + q];
                 const double nq2 = qi.nrm2[q];
-                const double eps = coarse_eps(a, nq2);
-                const double slack = a.rel_slack * (nq2 + a.n_max * a.n_max);
+                const double eps = coarse_eps(S, nq2);
+                const double slack = S.rel_slack * (nq2 + S.n_max * S.n_max);
                 // every row has acc >= trunc(best); both candidates have acc < trunc(second)+quantum
                 const double lo = (double)__uint_as_float(c.x & ~a.idx_mask);
                 const double hi = (double)__uint_as_float((c.y & ~a.idx_mask) + a.idx_mask + 1u);
-                double lb0 = acc_to_d2(a, nq2, lo - eps) - slack;
-                const double ub1 = acc_to_d2(a, nq2, hi + eps) + slack;
+                double lb0 = acc_to_d2(S, nq2, lo - eps) - slack;
+                const double ub1 = acc_to_d2(S, nq2, hi + eps) + slack;
                 if (lb0 < 0.0) lb0 = 0.0;
                 surv = ratio_pass(lb0, ub1, a.ratio);
                 // certified PASS from the coarse values alone: the best candidate's exact
@@ -668,8 +701,8 @@ __global__ __launch_bounds__(RCN_FB) void k_filter(RerankArgs a)
                 if (surv && ti.K > 2) {
                     const double hi0 = (double)__uint_as_float((c.x & ~a.idx_mask) + a.idx_mask + 1u);
                     const double lo1 = (double)__uint_as_float(c.y & ~a.idx_mask);
-                    const double ub0 = acc_to_d2(a, nq2, hi0 + eps) + slack;
-                    double lbnc = acc_to_d2(a, nq2, lo1 - eps) - slack;
+                    const double ub0 = acc_to_d2(S, nq2, hi0 + eps) + slack;
+                    double lbnc = acc_to_d2(S, nq2, lo1 - eps) - slack;
                     if (lbnc < 0.0) lbnc = 0.0;
                     if (ub0 >= 0.0 && ub0 < lbnc && ratio_pass(ub0, lbnc, a.ratio)) {
                         *o = (int32_t)(c.x & a.idx_mask);
@@ -715,6 +748,7 @@ __global__ __launch_bounds__(64) void k_rerank_lds(RerankArgs a)
     const unsigned n = *a.sv_count;
     const int D = a.D;
     const int nchunk = (D + 31) / 32;
+    const ScaleDev S = *a.sc;
     for (unsigned g = blockIdx.x; g * 64u < n; g += gridDim.x) {
         const unsigned sidx = g * 64u + lane;
         const bool live = sidx < n;
@@ -759,7 +793,7 @@ __global__ __launch_bounds__(64) void k_rerank_lds(RerankArgs a)
             if (ti.K > 2) {
                 const double nq2 = qi.nrm2[q];
                 const double lbacc = (double)__uint_as_float(c.y & ~a.idx_mask);
-                double lbnc = acc_to_d2(a, nq2, lbacc - coarse_eps(a, nq2)) - a.rel_slack * (nq2 + a.n_max * a.n_max);
+                double lbnc = acc_to_d2(S, nq2, lbacc - coarse_eps(S, nq2)) - S.rel_slack * (nq2 + S.n_max * S.n_max);
                 if (lbnc < 0.0) lbnc = 0.0;
                 ok = acc < lbnc && ratio_pass(acc, lbnc, a.ratio);
             }
@@ -774,6 +808,7 @@ __global__ __launch_bounds__(64) void k_rerank_lds(RerankArgs a)
 __global__ void k_rerank_generic(RerankArgs a)
 {
     const unsigned n = *a.sv_count;
+    const ScaleDev S = *a.sc;
     for (unsigned s = blockIdx.x * blockDim.x + threadIdx.x; s < n; s += gridDim.x * blockDim.x) {
         const unsigned long long e = a.sv_list[s];
         const int pair = (int)(e >> 32), q = (int)(e & 0xFFFFFFFFu);
@@ -789,7 +824,7 @@ __global__ void k_rerank_generic(RerankArgs a)
         if (ti.K > 2) {
             const double nq2 = qi.nrm2[q];
             const double lbacc = (double)__uint_as_float(c.y & ~a.idx_mask);
-            lbnc = acc_to_d2(a, nq2, lbacc - coarse_eps(a, nq2)) - a.rel_slack * (nq2 + a.n_max * a.n_max);
+            lbnc = acc_to_d2(S, nq2, lbacc - coarse_eps(S, nq2)) - S.rel_slack * (nq2 + S.n_max * S.n_max);
         }
         int res = certify(ea, ia, eb, lbnc, a.ratio);
         if (res == -2) {
@@ -1062,6 +1097,7 @@ int rcn_match_release(rcn_ctx *ctx)
     ctx->images.clear();
     for (Slab &sl : ctx->slabs) free_slab(sl);
     ctx->slabs.clear();
+    ctx->table_host.clear();
     ctx->prepared = false;
     ctx->D = ctx->DP = 0;
     return RCN_OK;
@@ -1257,52 +1293,73 @@ static int upload_batch(rcn_ctx *ctx, int32_t first_id, int32_t n, const float *
     return rcn_int_slab_rowstats(ctx, si, 0, n);
 }
 
-template <int DP> static void launch_prepare_batch(rcn_ctx *ctx, const Slab &sl, float s, double hs2, double bias)
+template <int DP> static void launch_prepare_batch(rcn_ctx *ctx, const Slab &sl)
 {
     // only the slots this ctx converts itself (all of them unless the slab is an all-gather landing buffer)
     if (sl.conv_n <= 0) return;
     const long nthr = (long)sl.conv_n * sl.Kp * (DP / 8);
     const size_t f = sl.conv_first;
     k_prepare_batch<DP><<<(unsigned)((nthr + 255) / 256), 256, 0, ctx->stream>>>(
-        sl.f32 + f * sl.K * sl.D, sl.nrm2 + f * sl.K, sl.conv_n, sl.K, sl.Kp, sl.D, s, hs2, bias,
+        sl.f32 + f * sl.K * sl.D, sl.nrm2 + f * sl.K, sl.conv_n, sl.K, sl.Kp, sl.D, ctx->scale_dev.as<ScaleDev>(),
         sl.f16 + f * sl.Kp * DP, sl.hn + f * sl.Kp, sl.Ks_dev ? sl.Ks_dev + f : nullptr);
 }
 
-template <int DP> static void launch_prepare(rcn_ctx *ctx, const ImgHost &im, float s, double hs2, double bias)
+template <int DP> static void launch_prepare(rcn_ctx *ctx, const ImgHost &im)
 {
     const int n = im.Kp * (DP / 8);
-    k_prepare<DP><<<(n + 255) / 256, 256, 0, ctx->stream>>>(im.f32, im.nrm2, im.K, im.Kp, ctx->D, s,
-                                                            hs2, bias, im.f16, im.hn);
+    k_prepare<DP><<<(n + 255) / 256, 256, 0, ctx->stream>>>(im.f32, im.nrm2, im.K, im.Kp, ctx->D, ctx->scale_dev.as<ScaleDev>(),
+                                                            im.f16, im.hn);
+}
+
+// Host copies of the scale constants after a device-side fix (k_fix_scale): one small read behind the stream.
+int rcn_int_resolve_scale(rcn_ctx *ctx)
+{
+    if (!ctx->scale_on_device) return RCN_OK;
+    RCN_HIP(hipMemcpyAsync(&ctx->scale_host, ctx->scale_dev.p, sizeof(ScaleDev), hipMemcpyDeviceToHost, ctx->stream));
+    RCN_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->scale = ctx->scale_host.s;
+    ctx->bias = ctx->scale_host.bias;
+    ctx->max_norm = ctx->scale_host.n_max;
+    ctx->scale_on_device = false;
+    return RCN_OK;
 }
 
 // Fix the global scale / bias, (re)build every image's fp16 copy and the device image table.
+// Two ways to the scale.  Host (default): read the row statistics, compare with the scale in force, convert only what
+// is new or what a moved scale invalidates -- two host synchronisations.  Device (ctx->want_dev_scale, the sharded
+// exchange): k_fix_scale computes the same constants in HBM behind the all-reduce of the statistics and every dirty
+// image is converted with them; the host reads nothing and does not wait (it may only do so when every resident image
+// is dirty, i.e. about to be converted anyway -- always the case for a landing buffer).
 int rcn_int_prepare_all(rcn_ctx *ctx)
 {
     if (ctx->prepared) return RCN_OK;
-    unsigned hc[4] = {0, 0, 0, 0};
-    RCN_HIP(hipMemcpyAsync(hc, ctx->counters.p, 16, hipMemcpyDeviceToHost, ctx->stream));
-    RCN_HIP(hipStreamSynchronize(ctx->stream));
-    float maxabs;
-    double maxn2;
-    memcpy(&maxabs, &hc[0], 4);
-    memcpy(&maxn2, &hc[2], 8);
-    if (!(maxabs > 0.f) || !std::isfinite(maxabs)) maxabs = 1.f;
-    if (!(maxn2 > 0.0) || !std::isfinite(maxn2)) maxn2 = 1.0;
-    // s = 2^e with s*maxabs in (2^13, 2^14]  (fp16 max is 65504; the query side is negated only)
-    int ex;
-    (void)std::frexp((double)maxabs, &ex);  // maxabs = m * 2^ex, m in [0.5,1)
-    const double s = std::ldexp(1.0, 14 - ex);
-    // the norm bound is rounded UP to a 1/16-octave grid so that it (and BIAS) stays put while
-    // images of similar norm come and go: then only new images need converting
-    int en;
-    const double mn = std::frexp(maxn2 * (1.0 + 1e-12), &en);            // in [0.5, 1)
-    const double maxn2q = std::ldexp(std::ceil(mn * 32.0) / 32.0, en);
-    const double bias = 0.5625 * s * s * maxn2q + 1.0;  // accumulator >= s^2 Nmax^2/16 > 0 for every (q,t)
-    const bool moved = s != ctx->scale || bias != ctx->bias;
-    ctx->scale = s;
-    ctx->max_norm = std::sqrt(maxn2q);
-    ctx->bias = bias;
-    const double hs2 = 0.5 * s * s;
+    RCN_HIP(ctx->scale_dev.reserve(sizeof(ScaleDev)));
+    const int DPa = ctx->DP ? ctx->DP : 32;
+    bool on_device = ctx->want_dev_scale;
+    if (on_device)
+        for (const auto &kv : ctx->images) on_device = on_device && kv.second.dirty;
+    bool moved = false;
+    if (on_device) {
+        k_fix_scale<<<1, 64, 0, ctx->stream>>>(ctx->counters.as<unsigned>(), DPa, ctx->scale_dev.as<ScaleDev>());
+        RCN_HIP(hipGetLastError());
+        ctx->scale_on_device = true;
+    } else {
+        { int rcs = rcn_int_resolve_scale(ctx); if (rcs) return rcs; }
+        unsigned hc[4] = {0, 0, 0, 0};
+        RCN_HIP(hipMemcpyAsync(hc, ctx->counters.p, 16, hipMemcpyDeviceToHost, ctx->stream));
+        RCN_HIP(hipStreamSynchronize(ctx->stream));
+        float maxabs;
+        double maxn2;
+        memcpy(&maxabs, &hc[0], 4);
+        memcpy(&maxn2, &hc[2], 8);
+        fix_scale(maxabs, maxn2, DPa, &ctx->scale_host);
+        const double s = ctx->scale_host.s, bias = ctx->scale_host.bias;
+        moved = s != ctx->scale || bias != ctx->bias;
+        ctx->scale = s;
+        ctx->max_norm = ctx->scale_host.n_max;
+        ctx->bias = bias;
+        RCN_HIP(hipMemcpyAsync(ctx->scale_dev.p, &ctx->scale_host, sizeof(ScaleDev), hipMemcpyHostToDevice, ctx->stream));
+    }
 
     std::vector<ImgDev> table;
     table.reserve(ctx->images.size());
@@ -1315,10 +1372,10 @@ int rcn_int_prepare_all(rcn_ctx *ctx)
         if (need && im.slab >= 0) slab_dirty[im.slab] = 1;
         if (ctx->DP && im.slab < 0 && need) {
             switch (ctx->DP) {
-            case 32: launch_prepare<32>(ctx, im, (float)s, hs2, ctx->bias); break;
-            case 64: launch_prepare<64>(ctx, im, (float)s, hs2, ctx->bias); break;
-            case 128: launch_prepare<128>(ctx, im, (float)s, hs2, ctx->bias); break;
-            default: launch_prepare<256>(ctx, im, (float)s, hs2, ctx->bias); break;
+            case 32: launch_prepare<32>(ctx, im); break;
+            case 64: launch_prepare<64>(ctx, im); break;
+            case 128: launch_prepare<128>(ctx, im); break;
+            default: launch_prepare<256>(ctx, im); break;
             }
             RCN_HIP(hipGetLastError());
         }
@@ -1330,18 +1387,25 @@ int rcn_int_prepare_all(rcn_ctx *ctx)
             const Slab &sl = ctx->slabs[si];
             if (!sl.live || !slab_dirty[si]) continue;
             switch (ctx->DP) {
-            case 32: launch_prepare_batch<32>(ctx, sl, (float)s, hs2, ctx->bias); break;
-            case 64: launch_prepare_batch<64>(ctx, sl, (float)s, hs2, ctx->bias); break;
-            case 128: launch_prepare_batch<128>(ctx, sl, (float)s, hs2, ctx->bias); break;
-            default: launch_prepare_batch<256>(ctx, sl, (float)s, hs2, ctx->bias); break;
+            case 32: launch_prepare_batch<32>(ctx, sl); break;
+            case 64: launch_prepare_batch<64>(ctx, sl); break;
+            case 128: launch_prepare_batch<128>(ctx, sl); break;
+            default: launch_prepare_batch<256>(ctx, sl); break;
             }
             RCN_HIP(hipGetLastError());
         }
-    RCN_HIP(ctx->img_table.reserve(std::max<size_t>(1, table.size()) * sizeof(ImgDev)));
-    if (!table.empty())
-        RCN_HIP(hipMemcpyAsync(ctx->img_table.p, table.data(), table.size() * sizeof(ImgDev),
-                               hipMemcpyHostToDevice, ctx->stream));
-    RCN_HIP(hipStreamSynchronize(ctx->stream));
+    // the image table: uploaded only when it differs from what the device already holds (a per-step exchange into the
+    // same landing buffer leaves it unchanged); the staging vector lives in the ctx, so nothing waits for the copy
+    const bool same = table.size() == ctx->table_host.size() && ctx->img_table.p &&
+                      (table.empty() || memcmp(table.data(), ctx->table_host.data(), table.size() * sizeof(ImgDev)) == 0);
+    if (!same) {
+        RCN_HIP(hipStreamSynchronize(ctx->stream));       // a previous upload may still read the staging vector
+        ctx->table_host.swap(table);
+        RCN_HIP(ctx->img_table.reserve(std::max<size_t>(1, ctx->table_host.size()) * sizeof(ImgDev)));
+        if (!ctx->table_host.empty())
+            RCN_HIP(hipMemcpyAsync(ctx->img_table.p, ctx->table_host.data(), ctx->table_host.size() * sizeof(ImgDev),
+                                   hipMemcpyHostToDevice, ctx->stream));
+    }
     ctx->prepared = true;
     return RCN_OK;
 }
@@ -1469,15 +1533,7 @@ int rcn_int_match_grid(rcn_ctx *ctx, const int32_t *pairs_host, int32_t n_pairs,
     ra.out = out_dev; ra.out_stride = out_stride;
     ra.n_pairs = n_pairs; ra.kq_stride = kq_stride; ra.D = ctx->D; ra.idx_mask = idx_mask;
     ra.ratio = ratio;
-    const double s = ctx->scale, u = std::ldexp(1.0, -11);
-    const int DPa = ctx->DP ? ctx->DP : 32;
-    ra.s2 = s * s; ra.bias = ctx->bias;
-    ra.c_in = (2 * u + u * u) * s * s;
-    ra.c_sub = std::ldexp(1.0, -14) * std::sqrt((double)DPa) * s;
-    ra.c_acc = (DPa + 8) * std::ldexp(1.0, -23);
-    ra.n_max = ctx->max_norm;
-    ra.hn_max = 0.5 * s * s * ctx->max_norm * ctx->max_norm + ctx->bias;
-    ra.rel_slack = 1e-9;
+    ra.sc = ctx->scale_dev.as<ScaleDev>();
     ra.all_to_fallback = mfma ? 0 : 1;
 
     // groups: runs of consecutive pairs that share the query image, cut at RCN_GROUP
@@ -1637,11 +1693,7 @@ int rcn_int_match_grid(rcn_ctx *ctx, const int32_t *pairs_host, int32_t n_pairs,
     ctx->last_stats.pair_distances = pd;
     ctx->last_stats.used_mfma_path = mfma ? 1 : 0;
     ctx->last_stats.rows_exact_fallback = -1;
-    {
-        const double nq = ctx->max_norm;
-        const double eps = ra.c_in * nq * nq + ra.c_sub * 2 * nq + ra.c_acc * (ra.hn_max + ra.s2 * nq * nq) + 6.0e-8 * ra.hn_max;
-        ctx->last_stats.err_bound_d2 = 2.0 * eps / ra.s2;
-    }
+    ctx->last_stats.err_bound_d2 = -1.0;      // from the scale constants, lazily (rcn_match_last_stats)
     return RCN_OK;
 }
 
@@ -1725,6 +1777,37 @@ int rcn_match_grid(rcn_ctx *ctx, const int32_t *pairs_host, int32_t n_pairs, flo
     return RCN_OK;
 }
 
+// Lines :232-275 of the pair loop for a list of pairs: match, then (filter != 0) the epipolar filter on the table
+// where it lies in HBM, then the dense table, the counts and the filter's verdict per pair back to the host.
+int rcn_match_grid_filtered(rcn_ctx *ctx, const int32_t *pairs_host, int32_t n_pairs, float ratio, int32_t filter,
+                            int32_t *out_host, int64_t out_stride, int32_t *counts_host, int32_t *status_host)
+{
+    if (!ctx) return RCN_ERR_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    if (n_pairs < 0 || (n_pairs > 0 && (!pairs_host || !out_host || !counts_host)) || out_stride < 1) {
+        ctx->set_error("rcn_match_grid_filtered: bad argument");
+        return RCN_ERR_ARG;
+    }
+    if (n_pairs == 0) return RCN_OK;
+    RCN_HIP(hipSetDevice(ctx->device));
+    RCN_HIP(ctx->out_tmp.reserve((size_t)n_pairs * out_stride * sizeof(int32_t)));
+    RCN_HIP(ctx->cnt_tmp.reserve(2 * (size_t)n_pairs * sizeof(int32_t)));       // counts, then the verdicts
+    int32_t *tab = ctx->out_tmp.as<int32_t>(), *cnt = ctx->cnt_tmp.as<int32_t>(), *ver = cnt + n_pairs;
+    int rc = rcn_int_match_grid(ctx, pairs_host, n_pairs, ratio, tab, out_stride, cnt);
+    if (rc) return rc;
+    if (filter) {
+        rc = rcn_int_table_filter(ctx, pairs_host, n_pairs, tab, out_stride, cnt, ver);
+        if (rc) return rc;
+    }
+    RCN_HIP(hipMemcpyAsync(out_host, tab, (size_t)n_pairs * out_stride * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    RCN_HIP(hipMemcpyAsync(counts_host, cnt, (size_t)n_pairs * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    if (status_host && filter) RCN_HIP(hipMemcpyAsync(status_host, ver, (size_t)n_pairs * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    RCN_HIP(hipStreamSynchronize(ctx->stream));
+    if (status_host && !filter)
+        for (int p = 0; p < n_pairs; ++p) status_host[p] = -2;        // "not filtered"
+    return RCN_OK;
+}
+
 int rcn_match_pair(rcn_ctx *ctx, const float *q_host, int32_t K1, const float *t_host, int32_t K2,
                    int32_t D, float ratio, int32_t *out_train_for_query, int32_t *out_count)
 {
@@ -1778,6 +1861,16 @@ int rcn_match_last_stats(const rcn_ctx *cctx, rcn_match_stats *out)
         ctx->last_stats.rows_reranked = 0;
         for (int c = 0; c < RCN_CHUNKS; ++c) { ctx->last_stats.rows_exact_fallback += n[2 * c]; ctx->last_stats.rows_reranked += n[2 * c + 1]; }
     }
+    if (ctx->last_stats.err_bound_d2 < 0.0 && ctx->scale_dev.p) {
+        { int rcs = rcn_int_resolve_scale(ctx); if (rcs) return rcs; }
+        ScaleDev m;
+        fix_scale(1.f, 1.0, ctx->DP ? ctx->DP : 32, &m);                 // c_acc only depends on DP
+        const double s2 = ctx->scale * ctx->scale, nq = ctx->max_norm, u = std::ldexp(1.0, -11);
+        const double hn_max = 0.5 * s2 * nq * nq + ctx->bias;
+        const double eps = (2 * u + u * u) * s2 * nq * nq + std::ldexp(1.0, -14) * std::sqrt((double)(ctx->DP ? ctx->DP : 32)) * ctx->scale * 2 * nq +
+                           m.c_acc * (hn_max + s2 * nq * nq) + 6.0e-8 * hn_max;
+        ctx->last_stats.err_bound_d2 = 2.0 * eps / s2;
+    }
     if (ctx->ev_n > 0 && ctx->ev_made) {
         RCN_HIP(hipStreamSynchronize(ctx->stream));
         const int n = ctx->ev_n < 64 ? ctx->ev_n : 64;
@@ -1806,6 +1899,7 @@ int rcn_diag_coarse_table(rcn_ctx *ctx, uint32_t *cand_host, int64_t capacity_wo
     if (!ctx || !model) return RCN_ERR_ARG;
     std::lock_guard<std::mutex> lk(ctx->mu);
     const int64_t words = 2 * (int64_t)ctx->last_n_pairs * ctx->last_kq_stride;
+    { int rcs = rcn_int_resolve_scale(ctx); if (rcs) return rcs; }
     model[0] = ctx->scale; model[1] = ctx->bias; model[2] = ctx->max_norm; model[3] = (double)ctx->last_idx_mask;
     model[4] = (double)ctx->last_kq_stride; model[5] = (double)ctx->DP;
     model[6] = 0.5 * ctx->scale * ctx->scale * ctx->max_norm * ctx->max_norm + ctx->bias; model[7] = (double)ctx->last_n_pairs;

@@ -72,6 +72,24 @@ struct Slab {
     bool live = false;
 };
 
+// The global fp16 scale and what follows from it, kept in HBM: fixed either by the host
+// (rcn_int_prepare_all, after reading the row statistics) or by k_fix_scale on the device (the sharded exchange,
+// which must not wait for the host between its collectives).  Every kernel that needs a constant reads it here.
+struct ScaleDev {
+    double s;           // power of two
+    double s2;          // s^2
+    double hs2;         // s^2 / 2
+    double bias;        // BIAS, accumulator units
+    double c_in;        // (2u+u^2) s^2            x |q| Nmax
+    double c_sub;       // 2^-14 sqrt(DP) s        x (|q| + Nmax)
+    double c_acc;       // (DP+8) 2^-23
+    double hn_max;      // s^2 Nmax^2 / 2 + BIAS
+    double n_max;       // Nmax
+    double rel_slack;   // relative slack for the fp64 evaluation of the bound itself
+    float  sf;          // (float)s
+    float  pad;
+};
+
 // fused table filter (fmat.hip): per-pair keypoint coordinate lists
 struct PairXY { const int32_t *q, *t; int32_t Kq, pad; };
 
@@ -94,6 +112,12 @@ struct rcn_ctx {
     double scale = 0.0;      // s, power of two (0 = nothing prepared yet)
     double bias = 0.0;       // BIAS in accumulator units
     double max_norm = 0.0;   // max |x| over resident rows
+    DevBuf scale_dev;        // one ScaleDev: what the kernels read
+    DevBuf desc_bad;         // desc.hip: keypoints outside their descriptor map since the last rcn_desc_sample_errors
+    ScaleDev scale_host;     // staging of the host-fixed scale (uploaded asynchronously)
+    bool scale_on_device = false;   // the last scale was fixed by k_fix_scale: scale / bias / max_norm above are stale until resolved
+    bool want_dev_scale = false;    // shard.hip: fix the next scale on the device (no host read of the statistics)
+    std::vector<ImgDev> table_host; // image table as last uploaded (unchanged tables are not uploaded again)
     DevBuf img_table, pairs_dev, groups_dev, cand, owner, fb_list, sv_list, counters, out_tmp, cnt_tmp;
     hipEvent_t f32_ready = nullptr;   // shard.hip: set while an all-gather of fp32 rows may be in flight on a side stream
     // host materialisation (store.hip): offsets, two alternating staging buffers, copy stream
@@ -153,11 +177,19 @@ struct BaResident {
 };
 int rcn_int_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_options *opt, rcn_ba_summary *sum, const BaResident *res);
 int rcn_match_release(rcn_ctx *ctx);
+// store.hip: rcn_match_compact_begin / _wait with ctx->mu already held
+int rcn_int_compact_begin(rcn_ctx *ctx, const int32_t *table_dev, int64_t stride, const int32_t *counts_dev,
+                          int32_t n_pairs, int64_t *offsets_host, int32_t *qt_host, int64_t capacity, int64_t *total_out);
+int rcn_int_compact_wait(rcn_ctx *ctx);
+// fmat.hip: rcn_match_table_filter_device with ctx->mu already held
+int rcn_int_table_filter(rcn_ctx *ctx, const int32_t *pairs_host, int32_t n_pairs, int32_t *table_dev,
+                         int64_t stride, int32_t *counts_dev, int32_t *out_status_dev);
 // match.hip internals shared with shard.hip (all expect ctx->mu held)
 int rcn_int_slab_attach(rcn_ctx *ctx, int32_t first_id, int32_t n_images, int32_t n_slots, const float *src,
                         int32_t K, int32_t D, int32_t conv_first, int32_t conv_n, int *slab_out,
                         const int32_t *Ks_host, const int32_t *Ks_dev);
 int rcn_int_slab_rowstats(rcn_ctx *ctx, int slab, int32_t first, int32_t n);
 int rcn_int_prepare_all(rcn_ctx *ctx);
+int rcn_int_resolve_scale(rcn_ctx *ctx);     // host copies of scale / bias / max_norm are current afterwards (may synchronise)
 int rcn_int_match_grid(rcn_ctx *ctx, const int32_t *pairs_host, int32_t n_pairs, float ratio,
                        int32_t *out_dev, int64_t out_stride, int32_t *counts_dev);

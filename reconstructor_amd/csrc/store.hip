@@ -58,7 +58,10 @@ __global__ __launch_bounds__(256) void k_cmp_fill(const int32_t *__restrict__ ta
         __syncthreads();
         int base = pos;
         for (int i = 0; i < w; ++i) base += wsum[i];
-        if (tr >= 0) dst[base + (int)__popcll(m & ((1ull << lane) - 1ull))] = make_int2((int)q, tr);
+        // never past the pair's range: a table whose non-negative entries outnumber counts[pair] (not yet through the
+        // uniqueness pass, stale counts) loses its surplus instead of overwriting the next pair's list
+        const int at = base + (int)__popcll(m & ((1ull << lane) - 1ull));
+        if (tr >= 0 && at < total) dst[at] = make_int2((int)q, tr);
         pos += wsum[0] + wsum[1] + wsum[2] + wsum[3];
         __syncthreads();
     }
@@ -86,6 +89,22 @@ int rcn_match_compact_begin(rcn_ctx *ctx, const int32_t *table_dev, int64_t stri
 {
     if (!ctx) return RCN_ERR_ARG;
     std::lock_guard<std::mutex> lk(ctx->mu);
+    return rcn_int_compact_begin(ctx, table_dev, stride, counts_dev, n_pairs, offsets_host, qt_host, capacity, total_out);
+}
+
+int rcn_match_compact_wait(rcn_ctx *ctx)
+{
+    if (!ctx) return RCN_ERR_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    return rcn_int_compact_wait(ctx);
+}
+
+}  // extern "C"
+
+// the two above with ctx->mu held by the caller (rcn_shard_lists keeps it across table lookup, compaction and wait)
+int rcn_int_compact_begin(rcn_ctx *ctx, const int32_t *table_dev, int64_t stride, const int32_t *counts_dev,
+                          int32_t n_pairs, int64_t *offsets_host, int32_t *qt_host, int64_t capacity, int64_t *total_out)
+{
     if (n_pairs < 0 || stride < 0 || capacity < 0 || !offsets_host || !total_out ||
         (n_pairs > 0 && (!table_dev || !counts_dev)) || (capacity > 0 && !qt_host)) {
         ctx->set_error("rcn_match_compact_begin: bad argument");
@@ -134,13 +153,13 @@ int rcn_match_compact_begin(rcn_ctx *ctx, const int32_t *table_dev, int64_t stri
     return RCN_OK;
 }
 
-int rcn_match_compact_wait(rcn_ctx *ctx)
+int rcn_int_compact_wait(rcn_ctx *ctx)
 {
-    if (!ctx) return RCN_ERR_ARG;
-    std::lock_guard<std::mutex> lk(ctx->mu);
     if (ctx->cmp_last >= 0 && ctx->cmp_busy[ctx->cmp_last]) RCN_HIP(hipEventSynchronize(ctx->cmp_ev[ctx->cmp_last]));
     return RCN_OK;
 }
+
+extern "C" {
 
 // ---- store file --------------------------------------------------------------------------------
 // layout (little endian, version 1):
@@ -274,15 +293,17 @@ int rcn_store_open(const char *path, rcn_store **out)
             int32_t rec[2];
             if (end - p < 8) { ok = false; break; }
             memcpy(rec, p, 8); p += 8;
-            const size_t db = sizeof(float) * (size_t)std::max(rec[1], 0) * s->h.D, cb = s->h.has_coords ? 8 * (size_t)std::max(rec[1], 0) : 0;
-            if (rec[1] < 0 || (size_t)(end - p) < db + cb) { ok = false; break; }
+            // sizes from two int32 header fields: checked by division, so a crafted K x D cannot wrap to a small byte count
+            const size_t left = (size_t)(end - p), K = (size_t)std::max(rec[1], 0), rowb = sizeof(float) * (size_t)s->h.D + (s->h.has_coords ? 8 : 0);
+            if (rec[1] < 0 || (rowb > 0 && K > left / rowb)) { ok = false; break; }
+            const size_t db = sizeof(float) * K * s->h.D, cb = s->h.has_coords ? 8 * K : 0;
             s->ids.push_back(rec[0]); s->Ks.push_back(rec[1]);
             s->desc.push_back(reinterpret_cast<const float *>(p)); p += db;
             s->coords.push_back(s->h.has_coords ? reinterpret_cast<const int32_t *>(p) : nullptr); p += cb;
         }
         if (ok && s->h.n_pairs > 0) {
             const size_t pb = 8 * (size_t)s->h.n_pairs, ob = 8 * ((size_t)s->h.n_pairs + 1), qb = 8 * (size_t)s->h.total_matches;
-            if ((size_t)(end - p) != pb + ob + qb) ok = false;
+            if ((uint64_t)s->h.total_matches > (uint64_t)(end - p) / 8 || (size_t)(end - p) != pb + ob + qb) ok = false;
             else {
                 s->pairs = reinterpret_cast<const int32_t *>(p); p += pb;
                 // the offsets may sit at an address that is only 4-byte aligned: keep an aligned copy
@@ -291,6 +312,7 @@ int rcn_store_open(const char *path, rcn_store **out)
                 s->offsets = oc;
                 s->qt = reinterpret_cast<const int32_t *>(p);
                 ok = oc[0] == 0 && oc[s->h.n_pairs] == s->h.total_matches;
+                for (int pi = 0; ok && pi < s->h.n_pairs; ++pi) ok = oc[pi + 1] >= oc[pi];     // as rcn_store_save demands: consumers slice qt by these
             }
         } else if (ok && p != end) ok = false;
     }

@@ -13,7 +13,11 @@
 //            what the loop stores when it meets (j,i) after (i,j) (:219-227).  A pair whose forward
 //            matching stored NOTHING has no entry to invert: the loop then matches (j,i) in its own right
 //            (query = j), and so does this driver, in a second pass over those pairs.
-// The geometric filter (:237-269) is not applied here; HipGeometricFilter.h / rcn_match_table_filter_device do that.
+//   filter   matchFeatures(features, featureMatches, true) also runs the geometric filter of :237-269 on every pair
+//            with at least 7 matches (rcn_shard_filter: the match table never leaves HBM); the recommended binding
+//            for the whole loop.
+// Failure: a rank whose local step fails still enters rcn_shard_exchange, whose status vote ends the collective
+// phase on every rank together (include/rcn.h, rcn_shard_fail); the driver then throws -- it cannot hang.
 #pragma once
 #include <atomic>
 #include <stdexcept>
@@ -63,19 +67,25 @@ public:
     int world() const { return world_; }
     rcn_ctx *context(int rank = 0) { return ctx_[rank]; }
 
-    // features[imgId] for imgId = 0 .. n-1 (SequentialReconstructor.h:205); fills featureMatches (:226)
-    void matchFeatures(std::unordered_map<int, std::vector<FeaturePtr<>>> &features, FeatureMatches &featureMatches)
+    // features[imgId] for imgId = 0 .. n-1 (SequentialReconstructor.h:205); fills featureMatches (:226).
+    // filter = the argument of SequentialReconstructor::matchFeatures(bool filter): pairs with at least 7 matches keep
+    // only the inliers of the fundamental-matrix search (:237-269, rcn_shard_filter on the table in HBM); a pair for
+    // which no model is found stores nothing and is therefore matched again the other way round, like a pair without
+    // matches.
+    void matchFeatures(std::unordered_map<int, std::vector<FeaturePtr<>>> &features, FeatureMatches &featureMatches, bool filter = false)
     {
         const int n = (int)features.size();
         if (n < 2) return;
+        // everything that can be checked without a GPU is checked before a thread is started: no rank may walk away
+        // from a collective because of something every rank could have known
         int Kmax = 0, D = 0;
         for (int i = 0; i < n; ++i) {
             auto it = features.find(i);
             if (it == features.end()) throw std::runtime_error("HipPairGridDriver: image ids must be 0 .. n-1");
             Kmax = std::max(Kmax, (int)it->second.size());
-            if (!it->second.empty()) {
-                const int d = (int)it->second[0]->featDesc.desc.size();
-                if (D && d != D) throw std::runtime_error("descriptor lengths differ");
+            for (const auto &f : it->second) {
+                const int d = (int)f->featDesc.desc.size();
+                if (D && d != D) throw std::runtime_error("HipPairGridDriver: descriptor lengths differ");
                 D = d;
             }
         }
@@ -90,24 +100,40 @@ public:
             RankOut &o = out[r];
             rcn_shard *sh = shard_[r];
             auto fail = [&](const char *what) { o.err = std::string(what) + ": " + rcn_last_error(ctx_[r]); };
-            // NB every rank walks the same sequence of collectives even after a local failure would be
-            // unrecoverable anyway: errors are reported after the join
-            if (rcn_shard_reserve(sh, n, Kmax, D, nullptr) != RCN_OK) { fail("rcn_shard_reserve"); return; }
+            // Local phase.  A failure here is this rank's alone: it is recorded (the library remembers its own, the
+            // driver reports the rest through rcn_shard_fail) and the rank STILL enters rcn_shard_exchange, whose
+            // status vote makes every rank leave the collective phase together with an error.
+            bool local_ok = rcn_shard_reserve(sh, n, Kmax, D, nullptr) == RCN_OK;
+            if (!local_ok) fail("rcn_shard_reserve");
             int32_t lo = 0, cnt = 0;
             rcn_shard_owned_images(n, world_, r, &lo, &cnt);
             std::vector<float> dense;
-            for (int img = lo; img < lo + cnt; ++img) {
+            for (int img = lo; local_ok && img < lo + cnt; ++img) {
                 const auto &f = features[img];
                 dense.resize(f.size() * (size_t)D);
                 for (size_t k = 0; k < f.size(); ++k) {
                     const std::vector<float> &d = f[k]->featDesc.desc;
-                    if ((int)d.size() != D) { o.err = "descriptor lengths differ"; return; }
                     std::copy(d.begin(), d.end(), dense.begin() + k * D);
                 }
-                if (rcn_shard_put_image(sh, img, dense.data(), (int32_t)f.size()) != RCN_OK) { fail("rcn_shard_put_image"); return; }
+                if (rcn_shard_put_image(sh, img, dense.data(), (int32_t)f.size()) != RCN_OK) { fail("rcn_shard_put_image"); local_ok = false; }
             }
-            if (rcn_shard_exchange(sh, nullptr, nullptr) != RCN_OK) { fail("rcn_shard_exchange"); return; }
+            if (local_ok && filter) {
+                // integer pixel coordinates of every image of the grid (featuresToCvPoints, utils.cpp:165-177): 8 bytes
+                // per keypoint, to every rank -- a pair's train image may be anybody's
+                std::vector<int32_t> xy;
+                for (int img = 0; local_ok && img < n; ++img) {
+                    const auto &f = features[img];
+                    xy.resize(2 * f.size() + 2);
+                    for (size_t k = 0; k < f.size(); ++k) { xy[2 * k] = f[k]->featCoord.x; xy[2 * k + 1] = f[k]->featCoord.y; }
+                    if (rcn_coords_upload(ctx_[r], img, xy.data(), (int32_t)f.size()) != RCN_OK) { fail("rcn_coords_upload"); local_ok = false; }
+                }
+            }
+            if (!local_ok) rcn_shard_fail(sh, RCN_ERR_ARG);
+            // Collective phase: the one call every rank makes whatever happened above.
+            if (rcn_shard_exchange(sh, nullptr, nullptr) != RCN_OK) { if (o.err.empty()) fail("rcn_shard_exchange"); return; }
+            // From here on nothing is collective: a failing rank simply reports after the join.
             if (rcn_shard_match(sh, ratioThresh, nullptr, 0, nullptr) != RCN_OK) { fail("rcn_shard_match"); return; }
+            if (filter && rcn_shard_filter(sh, nullptr) != RCN_OK) { fail("rcn_shard_filter"); return; }
             const int64_t P = rcn_shard_pair_count(n, world_, r);
             o.pairs.resize(2 * (size_t)P);
             rcn_shard_pairs(n, world_, r, o.pairs.data());
@@ -124,7 +150,10 @@ public:
             if (R > 0) {
                 o.rev_out.assign((size_t)R * Kmax, -1);
                 o.rev_cnt.assign(R, 0);
-                if (rcn_match_grid(ctx_[r], o.rev_pairs.data(), R, ratioThresh, o.rev_out.data(), Kmax, o.rev_cnt.data()) != RCN_OK) { fail("rcn_match_grid"); return; }
+                if (rcn_match_grid_filtered(ctx_[r], o.rev_pairs.data(), R, ratioThresh, filter ? 1 : 0, o.rev_out.data(), Kmax, o.rev_cnt.data(), nullptr) != RCN_OK) {
+                    fail("rcn_match_grid_filtered");
+                    return;
+                }
             }
         });
         for (const auto &o : out)
@@ -151,6 +180,9 @@ public:
             }
         }
     }
+
+    // Test hook: the next matchFeatures reports a failure of its own on this rank in front of the exchange.
+    void injectLocalFailure(int rank) { if (rank >= 0 && rank < world_) rcn_shard_fail(shard_[rank], RCN_ERR_ARG); }
 
 private:
     template <class F> void run(F &&body)

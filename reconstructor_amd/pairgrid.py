@@ -103,6 +103,19 @@ class Shard:
         self.ctx.check(self.ctx.lib.rcn_shard_info(self.h, C.byref(s)))
         return {k: getattr(s, k) for k, _ in s._fields_}
 
+    def fail(self, code=-1):
+        """Report a failure of this rank's own host-side step: the next exchange() then fails on every rank together."""
+        self.ctx.check(self.ctx.lib.rcn_shard_fail(self.h, int(code)))
+
+    def profile(self, enable=True):
+        self.ctx.check(self.ctx.lib.rcn_shard_profile(self.h, 1 if enable else 0))
+
+    def times(self):
+        """Phase times (HIP events) summed since the last call: exchange / fp32 gather / match, in ms."""
+        t = _lib.ShardTimes()
+        self.ctx.check(self.ctx.lib.rcn_shard_profile_read(self.h, C.byref(t)))
+        return {k: getattr(t, k) for k, _ in t._fields_}
+
     def close(self):
         if getattr(self, "h", None):
             self.ctx.lib.rcn_shard_destroy(self.h)

@@ -28,7 +28,7 @@ def world_pool(kind, n_world, seed=1234):
     raise ValueError(kind)
 
 
-def image_descriptors(kind, img_id, K, pool, seed=1234, sigma=None):
+def image_descriptors(kind, img_id, K, pool, seed=1234, sigma=None, return_pick=False):
     """K descriptors of image `img_id`: K distinct pool rows + noise, in the kind's format."""
     r = _rng(seed, img_id)
     n_world = pool.shape[0]
@@ -41,10 +41,38 @@ def image_descriptors(kind, img_id, K, pool, seed=1234, sigma=None):
         s = 0.04 if sigma is None else sigma
         d += (s * r.standard_normal(d.shape, dtype=np.float32)).astype(np.float32)
         d /= np.linalg.norm(d, axis=1, keepdims=True).astype(np.float32)
-        return np.ascontiguousarray(d, np.float32)
-    s = 6.0 if sigma is None else sigma
-    d = np.rint(d + s * r.standard_normal(d.shape)).clip(0, 255)
-    return np.ascontiguousarray(d, np.float32)
+        d = np.ascontiguousarray(d, np.float32)
+    else:
+        s = 6.0 if sigma is None else sigma
+        d = np.ascontiguousarray(np.rint(d + s * r.standard_normal(d.shape)).clip(0, 255), np.float32)
+    return (d, pick) if return_pick else d
+
+
+def scene_set(kind, n_images, K, n_world=None, seed=1234, noise_px=0.5, outlier_frac=0.05):
+    """A descriptor set WITH geometry, the input of the whole pair loop (match + epipolar filter,
+    SequentialReconstructor.cpp:199-279): every world descriptor belongs to a 3-d point, image i is a pinhole view of
+    the scene (cameras on a ring looking at the origin, as synth_ba.make_scene) and a keypoint's integer pixel
+    coordinates (Feature<int>::featCoord) are the projection of its point plus noise, truncated; a share of keypoints
+    gets coordinates unrelated to its point (what the filter is there to reject).
+    Returns (descriptors, coords, picks): per image (K_i, D) fp32, (K_i, 2) int32, (K_i,) world-point ids."""
+    from . import synth_ba
+    ks = K if hasattr(K, "__len__") else [K] * n_images
+    if n_world is None:
+        n_world = 4 * max(ks)
+    pool = world_pool(kind, n_world, seed)
+    sc = synth_ba.make_scene(n_images, n_world, obs_per_point=2, seed=seed, width=1024, height=768)
+    ims, coords, picks = [], [], []
+    for i in range(n_images):
+        d, pick = image_descriptors(kind, i, ks[i], pool, seed, return_pick=True)
+        r = _rng(seed, 0x4000_0000 + i)
+        uv, _ = synth_ba.project(sc["poses_gt"][i][None, :], sc["intr_gt"][i][None, :], sc["points_gt"][pick])
+        uv = uv + noise_px * r.standard_normal(uv.shape)
+        bad = r.random(len(pick)) < outlier_frac
+        uv[bad] = np.c_[r.uniform(0, 1024, bad.sum()), r.uniform(0, 768, bad.sum())]
+        ims.append(d)
+        coords.append(np.ascontiguousarray(np.trunc(uv).astype(np.int32)))
+        picks.append(pick)
+    return ims, coords, picks
 
 
 def descriptor_set(kind, n_images, K, n_world=None, seed=1234, first_image=0, count=None):

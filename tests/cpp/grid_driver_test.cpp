@@ -1,8 +1,10 @@
 // grid_driver_test.cpp -- drives HipPairGridDriver the way SequentialReconstructor::matchFeatures is driven
-// (SequentialReconstructor.cpp:199-279, filter off): `features` in, `featureMatches` out, on every visible GPU
+// (SequentialReconstructor.cpp:199-279): `features` in, `featureMatches` out, on every visible GPU
 // (RCCL communicators even at world size 1).  Input written by tests/test_cpp_grid_driver.py:
-//   i32 n, i32 D, then per image: i32 K, K*D floats.      Output: i32 world, i32 n_entries, then per map entry
+//   i32 n, i32 D, then per image: i32 K, K*D floats, K*2 i32 pixel coordinates.
+// Output: i32 world, i32 n_entries, then per map entry
 //   (ascending (i, j)): i32 i, i32 j, i32 count, count x (i32 query, i32 train) in ascending query order.
+// argv: in out [devices (0 = all)] [filter 0/1] [rank whose local step is made to fail, -1 = none]
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
@@ -22,22 +24,34 @@ int main(int argc, char **argv)
     int32_t n, D;
     rd(f, &n, 4); rd(f, &D, 4);
     std::unordered_map<int, std::vector<FeaturePtr<>>> features;
-    std::vector<float> row(D);
     for (int i = 0; i < n; ++i) {
         int32_t K;
         rd(f, &K, 4);
         features[i] = {};
-        for (int k = 0; k < K; ++k) {
-            rd(f, row.data(), 4 * (size_t)D);
-            features[i].push_back(std::make_shared<Feature<>>(FeatCoord<>(k, k), FeatDesc(row.begin(), row.end())));
-        }
+        std::vector<float> rows((size_t)K * D);
+        std::vector<int32_t> xy(2 * (size_t)K);
+        rd(f, rows.data(), 4 * rows.size());
+        rd(f, xy.data(), 4 * xy.size());
+        for (int k = 0; k < K; ++k)
+            features[i].push_back(std::make_shared<Feature<>>(FeatCoord<>(xy[2 * k], xy[2 * k + 1]),
+                                                              FeatDesc(rows.begin() + (size_t)k * D, rows.begin() + (size_t)(k + 1) * D)));
     }
+    const bool filter = argc > 4 && atoi(argv[4]) != 0;
+    const int inject = argc > 5 ? atoi(argv[5]) : -1;
     FeatureMatches featureMatches;
     int world = 0;
     try {
         HipPairGridDriver driver(argc > 3 ? atoi(argv[3]) : 0);
         world = driver.world();
-        driver.matchFeatures(features, featureMatches);
+        if (inject >= 0) {
+            // fault injection: the rank reports a failure of its own; every entry point must come back with an error
+            // (the driver throws) instead of leaving the peers inside a collective -- and the driver must work again after
+            driver.injectLocalFailure(inject);
+            bool threw = false;
+            try { driver.matchFeatures(features, featureMatches, filter); } catch (const std::exception &e) { threw = true; fprintf(stderr, "injected: %s\n", e.what()); }
+            if (!threw || !featureMatches.empty()) { fprintf(stderr, "the injected failure went unnoticed\n"); return 3; }
+        }
+        driver.matchFeatures(features, featureMatches, filter);
     } catch (const std::exception &e) {
         fprintf(stderr, "%s\n", e.what());
         return 1;

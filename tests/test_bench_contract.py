@@ -65,3 +65,19 @@ def test_bench_source_emits_every_contract_key():
         assert re.search(r'"%s"\s*[:\]]' % k, src), k
     assert "--gpus" in src and "--steps" in src and "--warmup" in src
     assert "from oracle" in src          # only in the cpu_baseline legs
+
+
+def test_bench_refuses_a_world_it_cannot_build():
+    """`python bench.py --gpus N` starts the N ranks itself; with fewer than N devices visible (none, in the build
+    container) it exits non-zero with a message instead of running -- and reporting -- a smaller world."""
+    import subprocess
+    import sys
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 2 and "refusing" in r.stderr and r.stdout.strip() == ""
+    env["WORLD_SIZE"] = "2"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 2 and "WORLD_SIZE" in r.stderr
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert '"rccl"' in src and "torch.distributed.run" in src

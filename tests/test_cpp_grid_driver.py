@@ -8,7 +8,7 @@ import subprocess
 import numpy as np
 import pytest
 
-from oracle import orc
+from oracle import orc, orc_fmat
 from reconstructor_amd import synth
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -22,10 +22,11 @@ def test_driver_compiles_without_gpu():
     assert os.path.exists(BIN)
 
 
-def reference_loop(ims):
-    """SequentialReconstructor.cpp:202-279 in sequential order with the filter off: (i, j) is matched with
-    query = i unless the inverse pair already has an entry, in which case that entry is inverted; a pair that
-    stored nothing leaves no entry, so its inverse is matched in its own right."""
+def reference_loop(ims, coords=None):
+    """SequentialReconstructor.cpp:202-279 in sequential order: (i, j) is matched with query = i unless the inverse
+    pair already has an entry, in which case that entry is inverted; a pair that stored nothing leaves no entry, so its
+    inverse is matched in its own right.  coords given = matchFeatures(filter = true): a pair with at least 7 matches
+    keeps the inliers of the fundamental-matrix search only, and stores NOTHING when no model is found (:237-269)."""
     n = len(ims)
     fm = {}
     for i in range(n):
@@ -36,25 +37,26 @@ def reference_loop(ims):
                 fm[(i, j)] = {t: q for q, t in fm[(j, i)].items()}
                 continue
             out, cnt = orc.match_pair(ims[i], ims[j]) if len(ims[i]) and len(ims[j]) else (np.zeros(0, np.int32), 0)
-            if cnt:
-                fm[(i, j)] = {int(q): int(out[q]) for q in np.nonzero(out >= 0)[0]}
+            q = np.nonzero(out >= 0)[0]
+            if coords is not None and cnt >= 7:
+                mask, count, _ = orc_fmat.filter_grid(np.array([0, cnt], np.int32), coords[i][q], coords[j][out[q]])
+                if count[0] < 0:
+                    continue                               # inlierMatchIds.size() == 0 -> continue (:252-255)
+                q = q[mask]
+            if len(q):
+                fm[(i, j)] = {int(a): int(out[a]) for a in q}
     return fm
 
 
-@pytest.mark.gpu
-def test_cpp_grid_driver_equals_the_reference_loop(tmp_path):
-    assert os.path.exists(BIN), "run __graft_entry__.build() first"
-    # ragged K; image 3 shares no world point with the others' pool -> mostly empty pairs both ways; image 5 is empty
-    ims = synth.descriptor_set("sift", 7, [300, 420, 64, 200, 513, 0, 97], n_world=900, seed=13)
-    ims[3] = synth.descriptor_set("sift", 1, 200, n_world=400, seed=999)[0]
-    ims[6] = ims[0][7:8].copy()    # ONE keypoint: as a train image it yields nothing (K2 < 2), as a query it matches
+def _run_driver(tmp_path, ims, coords, D, *extra):
     inp, outp = tmp_path / "in.bin", tmp_path / "out.bin"
     with open(inp, "wb") as f:
-        f.write(struct.pack("ii", len(ims), 128))
-        for im in ims:
+        f.write(struct.pack("ii", len(ims), D))
+        for im, xy in zip(ims, coords):
             f.write(struct.pack("i", len(im)))
             f.write(np.ascontiguousarray(im, np.float32).tobytes())
-    r = subprocess.run([BIN, str(inp), str(outp)], capture_output=True, text=True, timeout=300)
+            f.write(np.ascontiguousarray(xy, np.int32).tobytes())
+    r = subprocess.run([BIN, str(inp), str(outp), *[str(e) for e in extra]], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     raw = np.frombuffer(open(outp, "rb").read(), np.int32)
     world, n_entries = raw[0], raw[1]
@@ -65,8 +67,49 @@ def test_cpp_grid_driver_equals_the_reference_loop(tmp_path):
         qt = raw[pos + 3:pos + 3 + 2 * c].reshape(-1, 2)
         got[(int(i), int(j))] = {int(q): int(t) for q, t in qt}
         pos += 3 + 2 * c
+    return got, r
+
+
+@pytest.mark.gpu
+def test_cpp_grid_driver_equals_the_reference_loop(tmp_path):
+    assert os.path.exists(BIN), "run __graft_entry__.build() first"
+    # ragged K; image 3 shares no world point with the others' pool -> mostly empty pairs both ways; image 5 is empty
+    ims = synth.descriptor_set("sift", 7, [300, 420, 64, 200, 513, 0, 97], n_world=900, seed=13)
+    ims[3] = synth.descriptor_set("sift", 1, 200, n_world=400, seed=999)[0]
+    ims[6] = ims[0][7:8].copy()    # ONE keypoint: as a train image it yields nothing (K2 < 2), as a query it matches
+    coords = [np.zeros((len(im), 2), np.int32) for im in ims]
+    got, _ = _run_driver(tmp_path, ims, coords, 128)
     exp = reference_loop(ims)
     assert set(got) == set(exp)
     assert all(got[k] == exp[k] for k in exp)
     # the second pass really ran: some pair has an entry one way only
     assert (6, 0) in exp and (0, 6) not in exp
+
+
+@pytest.mark.gpu
+def test_cpp_grid_driver_whole_pair_loop_with_the_filter(tmp_path):
+    """matchFeatures(filter = true) from C++ -- match, epipolar filter on the table in HBM, lists, second pass --
+    against a sequential restatement of SequentialReconstructor.cpp:199-279 over the two CPU oracles, bit-equal."""
+    assert os.path.exists(BIN), "run __graft_entry__.build() first"
+    ims, coords, _ = synth.scene_set("sift", 7, [300, 320, 280, 310, 18, 300, 0], n_world=900, seed=5)
+    coords[5][:] = 91          # every sample of a pair with image 5 is degenerate: no model -> nothing stored -> reverse pass
+    got, _ = _run_driver(tmp_path, ims, coords, 128, 0, 1)
+    exp = reference_loop(ims, coords)
+    plain = reference_loop(ims)
+    assert set(got) == set(exp)
+    assert all(got[k] == exp[k] for k in exp)
+    assert sum(len(v) for v in exp.values()) < sum(len(v) for v in plain.values())       # the filter removed something
+    assert any(k not in exp for k in plain)                                              # and dropped whole pairs (no model)
+    assert any(0 < len(v) < 7 for v in exp.values())                                     # pairs below 7 matches pass unfiltered
+
+
+@pytest.mark.gpu
+def test_cpp_grid_driver_local_failure_fails_everywhere_and_recovers(tmp_path):
+    """Fault injection at world size 1 (the only size a one-GPU box has): a rank that reports a local failure still
+    enters the exchange, whose status vote fails the call; the driver throws instead of hanging and works afterwards."""
+    ims = synth.descriptor_set("sift", 4, [120, 90, 100, 64], n_world=300, seed=3)
+    coords = [np.zeros((len(im), 2), np.int32) for im in ims]
+    got, r = _run_driver(tmp_path, ims, coords, 128, 0, 0, 0)
+    assert "injected:" in r.stderr and "rcn_shard_exchange" in r.stderr
+    exp = reference_loop(ims)
+    assert got == exp

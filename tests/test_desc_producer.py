@@ -89,3 +89,31 @@ def test_detector_writes_straight_into_the_landing_buffer(gpu_ctx):
         assert np.array_equal(out.cpu().numpy(), exp) and np.array_equal(cnt.cpu().numpy(), ec) and ec.sum() > 0
     finally:
         sh.close()
+
+
+@pytest.mark.gpu
+def test_keypoints_outside_the_map_read_nothing_and_are_reported(gpu_ctx):
+    """The reference indexes the descriptor tensor with keypoint / 8 (FeatureSuperPoint.cpp:191-195), which throws outside
+    the map; here such a keypoint reads nothing, its row is zeros, and rcn_desc_sample_errors reports it."""
+    import ctypes as C
+    import torch
+    m, kp = _map_and_keypoints(3, K=64)
+    Cn, Hc, Wc = m.shape
+    kp = kp.copy()
+    kp[5] = (8 * Wc, 3)            # one cell right of the map
+    kp[9] = (4, 8 * Hc + 7)        # below it
+    kp[11] = (-1, 2)               # negative
+    dm, dk = torch.from_numpy(m).cuda(), torch.from_numpy(kp).cuda()
+    out = torch.full((len(kp), 256), 7.0, dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    n_bad = C.c_int32(-1)
+    assert gpu_ctx.lib.rcn_desc_sample_errors(gpu_ctx.h, C.byref(n_bad)) == 0 and n_bad.value == 0
+    gpu_ctx.check(gpu_ctx.lib.rcn_desc_sample_device(gpu_ctx.h, dm.data_ptr(), Hc * Wc, Wc, 1, Hc, Wc, dk.data_ptr(), len(kp), 256, out.data_ptr()))
+    assert gpu_ctx.lib.rcn_desc_sample_errors(gpu_ctx.h, C.byref(n_bad)) == -1 and n_bad.value == 3
+    assert b"outside the descriptor map" in gpu_ctx.lib.rcn_last_error(gpu_ctx.h)
+    got = out.cpu().numpy()
+    ok = np.ones(len(kp), bool)
+    ok[[5, 9, 11]] = False
+    assert (got[~ok] == 0).all()
+    assert got[ok].tobytes() == orc.desc_sample(m, kp[ok]).tobytes()
+    assert gpu_ctx.lib.rcn_desc_sample_errors(gpu_ctx.h, C.byref(n_bad)) == 0 and n_bad.value == 0      # read clears

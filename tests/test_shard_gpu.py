@@ -176,3 +176,75 @@ def test_ragged_images_through_the_slots(shard):
     for p in range(P):
         q = np.nonzero(exp[p] >= 0)[0]
         assert np.array_equal(qt[offs[p]:offs[p + 1], 0], q) and np.array_equal(qt[offs[p]:offs[p + 1], 1], exp[p][q])
+
+
+def test_local_failure_is_voted_and_every_entry_point_fails(shard):
+    """Fault injection at world size 1 (every rank runs this code at N > 1): a failure only this rank saw -- a refused
+    put_image, or one the host driver reports through rcn_shard_fail -- is remembered, travels in the status vote at
+    the head of the next exchange, and that exchange fails BEFORE the statistics / payload collectives (where a peer
+    would otherwise wait for ever); match and lists refuse to run on the abandoned exchange; the next exchange is clean."""
+    import torch
+    from reconstructor_amd import _lib
+    from reconstructor_amd.matcher import all_pairs
+    ims = synth.descriptor_set("sift", 4, 200, n_world=500, seed=77)
+    exp, ec = orc.match_grid(ims, all_pairs(4), threads=4)
+    out, cnt = _run(shard, ims, False)
+    assert np.array_equal(out.cpu().numpy(), exp)
+    dev = torch.from_numpy(np.ascontiguousarray(np.stack(ims))).cuda()
+    torch.cuda.synchronize()
+    shard.reserve(4, 200, 128)
+    with pytest.raises(_lib.RcnError) as e:
+        shard.put_image(0, np.zeros((201, 128), np.float32))              # does not fit the slot: local failure
+    assert e.value.code == -1
+    with pytest.raises(_lib.RcnError) as e:
+        shard.exchange(dev.data_ptr())                                    # valid arguments, but the vote carries the failure
+    assert e.value.code == -1 and "put_image" in str(e.value)
+    with pytest.raises(_lib.RcnError) as e:
+        shard.match(0.7)
+    assert "no successful rcn_shard_exchange" in str(e.value)
+    with pytest.raises(_lib.RcnError):
+        shard.lists()
+    out, cnt = _run(shard, ims, False)                                     # the vote cleared the status
+    assert np.array_equal(out.cpu().numpy(), exp) and np.array_equal(cnt.cpu().numpy(), ec)
+    shard.fail(-2)                                                         # a failure of the host driver's own
+    with pytest.raises(_lib.RcnError) as e:
+        shard.exchange(dev.data_ptr())
+    assert e.value.code == -2
+    with pytest.raises(_lib.RcnError):
+        shard.match(0.7)
+    out, cnt = _run(shard, ims, True)
+    assert np.array_equal(out.cpu().numpy(), exp) and np.array_equal(cnt.cpu().numpy(), ec)
+
+
+def test_phase_times_and_communicator_size(shard):
+    ims = synth.descriptor_set("superpoint", 5, 256, n_world=600, seed=8)
+    shard.profile(True)
+    for _ in range(3):
+        _run(shard, ims, False)
+    t = shard.times()
+    assert t["exchanges"] == 3 and t["matches"] == 3
+    assert t["exchange_ms"] > 0 and t["match_ms"] > 0 and t["f32_gather_ms"] >= 0
+    assert shard.times()["exchanges"] == 0                                 # read clears
+    shard.profile(False)
+    assert shard.info()["comm_ranks"] == 1
+
+
+def test_device_side_scale_equals_the_host_side_scale(shard, gpu_ctx):
+    """The exchange fixes the fp16 scale on the device (k_fix_scale behind the all-reduce, no host read); the plain
+    upload path fixes it on the host.  Same constants: the packed candidate tables of the coarse pass -- which depend on
+    scale and bias bit for bit -- lead to the same rows taking the same route, and the results are equal."""
+    from reconstructor_amd.matcher import HipL2Matcher, all_pairs
+    ims = synth.descriptor_set("sift", 5, 300, n_world=700, seed=21)
+    ims[2] = ims[2] * np.float32(64.0)                                     # a scale that is not the default one
+    out, cnt = _run(shard, ims, False)
+    st_dev = HipL2Matcher(ctx=gpu_ctx).stats()
+    m = HipL2Matcher(ctx=gpu_ctx)
+    m.clear()
+    for i, im in enumerate(ims):
+        m.upload(i, im)
+    tab, c2 = m.match_grid(all_pairs(5), 300)
+    st_host = m.stats()
+    m.clear()
+    assert np.array_equal(out.cpu().numpy(), tab) and np.array_equal(cnt.cpu().numpy(), c2)
+    for k in ("rows_reranked", "rows_exact_fallback", "err_bound_d2", "rows_total"):
+        assert st_dev[k] == st_host[k], k
