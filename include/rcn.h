@@ -290,6 +290,9 @@ typedef struct {
     double  cholesky_seconds;   /* dense factorisation of the reduced system */
     double  trisolve_seconds;   /* triangular solves + back-substitution + model/candidate evaluation */
     double  cost_trace[160];    /* cost after each iteration, [0] = initial */
+    double  jacobian_seconds;   /* HIP-event time of the residual + Jacobian kernel (k_ba_eval<true>: 224 B written per observation), summed */
+    int32_t jacobian_evals;     /* launches summed into jacobian_seconds */
+    int32_t reserved2;
 } rcn_ba_summary;
 
 int rcn_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *problem, const rcn_ba_options *options,

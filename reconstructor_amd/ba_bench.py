@@ -4,6 +4,7 @@ shard -- "replicas only").  cfg 4: 200 cams / 20k pts / 200k obs; cfg 5: 1000 ca
 from . import ba, synth_ba
 
 FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X FP64 matrix, vendor figure quoted in SURVEY.md section 8
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 
 
 def run_config(ctx, n_cams, n_points, seed=2024, repeats=2):
@@ -16,7 +17,17 @@ def run_config(ctx, n_cams, n_points, seed=2024, repeats=2):
     n = best["reduced_dim"]
     npad = (n + 127) // 128 * 128
     chol_flop = npad ** 3 / 3.0
+    no = sc["obs_cam"].shape[0]
+    # No * (30 + 2 + 2) * 8 B per pass over the observations -- 2 x 15 Jacobian entries, the residual and
+    # the two indices per observation; the kernel timed is the one that produces them (k_ba_eval<true>, HIP events inside
+    # the solve).  It actually writes 224 B (the 2 x 13 TANGENT columns + residual) and reads 40 B per observation.
+    jac_s = best["jacobian_seconds"] / max(1, best["jacobian_evals"])
+    alg = no * (30 + 2 + 2) * 8.0
     return sc, {
+        "stream_roofline": {"bound": "hbm", "kernel": "k_ba_eval<true> (residual + Jacobian rows, one pass over the observations)",
+                            "achieved": alg / max(jac_s, 1e-12) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": alg / max(jac_s, 1e-12) / 1e9 / HBM_PEAK_GBS, "launch_us": 1e6 * jac_s, "launches": best["jacobian_evals"],
+                            "algorithmic_bytes_per_launch": alg, "bytes_moved_per_launch": no * (224.0 + 40.0), "traffic": None},
         "workload": "%d cams / %d points / %d observations" % (n_cams, n_points, sc["obs_cam"].shape[0]),
         "lm_iterations": best["iterations"], "solve_seconds": best["solve_seconds"],
         "lm_iterations_per_s": best["iterations"] / best["solve_seconds"],

@@ -31,20 +31,32 @@
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 typedef double f64x2 __attribute__((ext_vector_type(2)));
 
+// Observation rows.  Everything the solver keeps per observation -- 2x10 tangent camera Jacobian, 2x3 point Jacobian,
+// residual -- is ONE 224-byte row, so that the per-camera gathers (k_ba_cam_raw) fetch whole rows, while the kernels
+// that stream over all observations (k_ba_eval<true> writes the rows, k_ba_model reads them) move a wave's 64 rows as
+// one contiguous 14-KiB block with 16-byte accesses and transpose through LDS: a lane-per-observation access to the
+// rows themselves puts 64 lanes on 64 different lines per instruction (measured at 0.7 TB/s in round 2).
+#define JROW 28          // doubles per row: [0..19] Jc (2 x 10), [20..25] Jp (2 x 3), [26..27] r
+#define JCH (JROW / 2)   // 16-byte chunks per row
+#define JLD 30           // LDS row stride in doubles: 240 B keeps rows 16-B aligned and ds_*_b128 by row conflict-free
+#define WROW 30          // doubles per row of a W / Y plane
+#define WCH (WROW / 2)
+
 struct BaDev {
-    int nc, np, no, n, npad, mode, use_wy;   // use_wy: the per-observation W/Y table is current (MFMA Schur path)
+    int nc, np, no, n, npad, mode, use_wy;   // use_wy: unused (the per-observation W / Y table is always built)
     double ub;
     double *poses, *intr, *pts;        // current point
     double *poses2, *intr2, *pts2;     // candidate
     const double *uv;
     const int *ocam, *opt, *pt_off, *cam_obs_off, *cam_obs, *cam_off, *cam_dim, *cols;
-    double *r, *Jc, *Jp;               // per observation: residual 2, camera Jacobian 2x10, point 2x3
+    double *J;                         // per observation ONE row of JROW doubles: camera Jacobian 2x10 | point Jacobian 2x3 | residual 2
     double *Uraw, *gcraw, *Vraw, *gpraw; // unscaled J'J / J'r blocks
     double *sc, *sp, *dgc, *dgp;       // Jacobi scale, clamped diag(Js'Js)
     double *Vinv, *gps, *rhs, *S, *L, *Linv, *yc, *stc, *stp, *dlc, *dlp;   // S: reduced system, L: its sub-diagonal Cholesky tiles
     double *partial, *scal;            // reduction scratch, scalars
     double *csplit;                    // [n_cams][split][256] partial per-camera sums when a camera is split over workgroups
-    double *WY;                        // per observation [2][3][10]: scaled W_o = Jc'Jp and Y_o = W_o Vinv, camera index fastest
+    double *WY;                        // two planes of [n_obs][3][10], camera index fastest: scaled W_o = Jc'Jp at WY, Y_o = W_o Vinv at WY + 30 n_obs
+    double *tobs;                      // per observation W_o' y_c (3): the back-substitution's per-observation term
     int *flag;
 };
 
@@ -146,13 +158,45 @@ __device__ __forceinline__ void obs_residual(const double *ps, const double *in,
     }
 }
 
-// K4: residual and tangent Jacobian per observation; per-block partial of sum r^2.
+// A wave's rows [row0, row0 + nrows) of a dense [rows][CH * 2] double array <-> its LDS block (row stride JLD), moved
+// as 16-byte chunks in memory order: each instruction touches 1 KiB of consecutive addresses.
+template <int CH>
+__device__ __forceinline__ void rows_to_lds(const double *__restrict__ src, size_t row0, int nrows, double *__restrict__ lds, int lane)
+{
+    const f64x2 *g = reinterpret_cast<const f64x2 *>(src + row0 * (2 * CH));
+    f64x2 v[CH];
+#pragma unroll
+    for (int it = 0; it < CH; ++it) {
+        const int c = it * 64 + lane;
+        v[it] = c < nrows * CH ? g[c] : (f64x2){0.0, 0.0};
+    }
+#pragma unroll
+    for (int it = 0; it < CH; ++it) {
+        const int c = it * 64 + lane, row = c / CH, part = c - row * CH;
+        if (c < nrows * CH) *reinterpret_cast<f64x2 *>(lds + row * JLD + 2 * part) = v[it];
+    }
+}
+template <int CH>
+__device__ __forceinline__ void lds_to_rows(double *__restrict__ dst, size_t row0, int nrows, const double *__restrict__ lds, int lane)
+{
+    f64x2 *g = reinterpret_cast<f64x2 *>(dst + row0 * (2 * CH));
+#pragma unroll
+    for (int it = 0; it < CH; ++it) {
+        const int c = it * 64 + lane, row = c / CH, part = c - row * CH;
+        if (c < nrows * CH) g[c] = *reinterpret_cast<const f64x2 *>(lds + row * JLD + 2 * part);
+    }
+}
+
+// K4: residual and tangent Jacobian per observation; per-block partial of sum r^2.  JAC: every lane builds its row in
+// LDS, the wave stores its 64 rows as one contiguous block (HBM-bound: 224 B written per observation).
 template <bool JAC>
 __global__ __launch_bounds__(256) void k_ba_eval(BaDev d, const double *poses, const double *intr,
                                                   const double *pts, double *partial)
 {
     __shared__ double sh[4];
+    __shared__ __attribute__((aligned(16))) double stage[JAC ? 4 * 64 * JLD : 2];
     const int o = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     double c2 = 0.0;
     if (o < d.no) {
         const int c = d.ocam[o], j = d.opt[o];
@@ -163,13 +207,26 @@ __global__ __launch_bounds__(256) void k_ba_eval(BaDev d, const double *poses, c
         obs_residual<JAC>(ps, in, X, d.uv + 2 * (size_t)o, r0, r1, J);
         c2 = r0 * r0 + r1 * r1;
         if (JAC) {
-            d.r[2 * o] = r0; d.r[2 * o + 1] = r1;
             const int dc = d.cam_dim[c];
+            double row[JROW];
+#pragma unroll
             for (int i = 0; i < 2; ++i) {
-                for (int k = 0; k < 10; ++k) d.Jc[20 * (size_t)o + 10 * i + k] = k < dc ? J[i][d.cols[10 * c + k]] : 0.0;
-                for (int k = 0; k < 3; ++k) d.Jp[6 * (size_t)o + 3 * i + k] = J[i][12 + k];
+#pragma unroll
+                for (int k = 0; k < 10; ++k) row[10 * i + k] = k < dc ? J[i][d.cols[10 * c + k]] : 0.0;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) row[20 + 3 * i + k] = J[i][12 + k];
             }
+            row[26] = r0; row[27] = r1;
+            f64x2 *my = reinterpret_cast<f64x2 *>(stage + (w * 64 + lane) * JLD);
+#pragma unroll
+            for (int k = 0; k < JCH; ++k) my[k] = (f64x2){row[2 * k], row[2 * k + 1]};
         }
+    }
+    if (JAC) {
+        __syncthreads();
+        const size_t row0 = (size_t)blockIdx.x * blockDim.x + 64 * w;
+        const int nrows = (int)min((long long)64, (long long)d.no - (long long)row0);
+        if (nrows > 0) lds_to_rows<JCH>(d.J, row0, nrows, stage + w * 64 * JLD, lane);
     }
     const double s = block_sum(c2, sh);
     if (threadIdx.x == 0) partial[blockIdx.x] = s;
@@ -240,8 +297,8 @@ __global__ void k_ba_point_raw(BaDev d)
     double V[9] = {0}, g[3] = {0};
     for (int o = d.pt_off[j]; o < d.pt_off[j + 1]; ++o)
         for (int i = 0; i < 2; ++i) {
-            const double *q = d.Jp + 6 * (size_t)o + 3 * i;
-            const double ri = d.r[2 * o + i];
+            const double *q = d.J + JROW * (size_t)o + 20 + 3 * i;       // Jp and r: 64 contiguous bytes of the row
+            const double ri = d.J[JROW * (size_t)o + 26 + i];
             for (int a = 0; a < 3; ++a) {
                 g[a] += q[a] * ri;
                 for (int b = 0; b < 3; ++b) V[3 * a + b] += q[a] * q[b];
@@ -259,7 +316,7 @@ __global__ void k_ba_point_raw(BaDev d)
 #define CR_GROUPS 8
 __global__ __launch_bounds__(128 * CR_GROUPS) void k_ba_cam_raw(BaDev d, int split)
 {
-    __shared__ double sh[CR_GROUPS][32 * 22];
+    __shared__ __attribute__((aligned(16))) double sh[CR_GROUPS][32 * 22];
     __shared__ double part[CR_GROUPS][110];
     const int c = blockIdx.x / split, sidx = blockIdx.x - c * split, g = threadIdx.x >> 7, t = threadIdx.x & 127;
     // thread t < 110 of a group owns one entry: 0..99 of U (a = t/10, b = t%10), 100..109 of g
@@ -269,21 +326,23 @@ __global__ __launch_bounds__(128 * CR_GROUPS) void k_ba_cam_raw(BaDev d, int spl
         const int base = base0 + 32 * g;
         // stage 32 observations' (Jc 20 + r 2) rows in LDS
         __syncthreads();
-        {   // 704 elements over 128 threads: six per thread, the index loads and then the value loads issued together
-            int oo[6];
+        {   // 32 observations x (Jc 10 chunks + r 1 chunk) of 16 bytes over 128 threads: three per thread, the index
+            // loads and then the row loads issued together
+            int oo[3], prt[3];
 #pragma unroll
-            for (int q = 0; q < 6; ++q) {
-                const int i = t + 128 * q, e = base + i / 22;
-                oo[q] = (i < 32 * 22 && e < e1) ? d.cam_obs[e] : -1;
+            for (int q = 0; q < 3; ++q) {
+                const int i = t + 128 * q, e = base + i / 11;
+                prt[q] = i % 11;
+                oo[q] = (i < 32 * 11 && e < e1) ? d.cam_obs[e] : -1;
             }
-            double vv[6];
+            f64x2 vv[3];
 #pragma unroll
-            for (int q = 0; q < 6; ++q) {
-                const int k = (t + 128 * q) % 22;
-                vv[q] = oo[q] < 0 ? 0.0 : (k < 20 ? d.Jc[20 * (size_t)oo[q] + k] : d.r[2 * (size_t)oo[q] + (k - 20)]);
-            }
+            for (int q = 0; q < 3; ++q)
+                vv[q] = oo[q] < 0 ? (f64x2){0.0, 0.0}
+                                  : *reinterpret_cast<const f64x2 *>(d.J + JROW * (size_t)oo[q] + (prt[q] < 10 ? 2 * prt[q] : 26));
 #pragma unroll
-            for (int q = 0; q < 6; ++q) if (t + 128 * q < 32 * 22) sh[g][t + 128 * q] = vv[q];
+            for (int q = 0; q < 3; ++q)
+                if (t + 128 * q < 32 * 11) *reinterpret_cast<f64x2 *>(&sh[g][((t + 128 * q) / 11) * 22 + 2 * prt[q]]) = vv[q];
         }
         __syncthreads();
         if (t < 110) {
@@ -367,7 +426,7 @@ __global__ void k_ba_point_solve(BaDev d, double inv_radius)
 // scaled W_o = (Jc' Jp) (10 x 3) of one observation
 __device__ __forceinline__ void load_W(const BaDev &d, int o, int c, int j, double *W)
 {
-    const double *jc = d.Jc + 20 * (size_t)o, *jp = d.Jp + 6 * (size_t)o;
+    const double *jc = d.J + JROW * (size_t)o, *jp = jc + 20;
     const int off = d.cam_off[c], dc = d.cam_dim[c];
     for (int a = 0; a < 10; ++a) {
         const double sa = a < dc ? d.sc[off + a] : 0.0;
@@ -394,8 +453,8 @@ __global__ __launch_bounds__(256) void k_ba_schur(BaDev d, double *Sb)
         const int dc = d.cam_dim[c], dc2 = d.cam_dim[c2];
         if (dc == 0 || dc2 == 0) continue;
         const int off = d.cam_off[c], off2 = d.cam_off[c2];
-        const double *jc = d.Jc + 20 * (size_t)o, *jp = d.Jp + 6 * (size_t)o;
-        const double *jc2 = d.Jc + 20 * (size_t)o2, *jp2 = d.Jp + 6 * (size_t)o2;
+        const double *jc = d.J + JROW * (size_t)o, *jp = jc + 20;
+        const double *jc2 = d.J + JROW * (size_t)o2, *jp2 = jc2 + 20;
         double *blk = Sb + ((size_t)c * d.nc + c2) * 100;
 #pragma unroll
         for (int rep = 0; rep < 2; ++rep) {
@@ -562,14 +621,14 @@ __global__ __launch_bounds__(256) void k_ba_wy(BaDev d)
     const int c = d.ocam[o], j = d.opt[o];
     double w[3] = {0.0, 0.0, 0.0}, y[3] = {0.0, 0.0, 0.0};
     if (a < d.cam_dim[c]) {
-        const double *jc = d.Jc + 20 * (size_t)o, *jp = d.Jp + 6 * (size_t)o, *Vi = d.Vinv + 9 * (size_t)j;
+        const double *jc = d.J + JROW * (size_t)o, *jp = jc + 20, *Vi = d.Vinv + 9 * (size_t)j;
         const double sa = d.sc[d.cam_off[c] + a];
         const double ja0 = jc[a] * sa, ja1 = jc[10 + a] * sa;
         for (int m = 0; m < 3; ++m) w[m] = (ja0 * jp[m] + ja1 * jp[3 + m]) * d.sp[3 * (size_t)j + m];
         for (int m = 0; m < 3; ++m) y[m] = w[0] * Vi[m] + w[1] * Vi[3 + m] + w[2] * Vi[6 + m];
     }
-    double *out = d.WY + 60 * (size_t)o;
-    for (int m = 0; m < 3; ++m) { out[10 * m + a] = w[m]; out[30 + 10 * m + a] = y[m]; }
+    double *outw = d.WY + WROW * (size_t)o, *outy = outw + WROW * (size_t)d.no;
+    for (int m = 0; m < 3; ++m) { outw[10 * m + a] = w[m]; outy[10 * m + a] = y[m]; }
 }
 
 // acc -= [Y of the listed first observations] [W of the listed second observations]^T for `cnt`
@@ -579,7 +638,7 @@ __global__ __launch_bounds__(256) void k_ba_wy(BaDev d)
 // SMB: MFMA steps (of 4 k) per trip of the gather loop -- 4 for the short lists of the one-wave kernel,
 // 12 (16 pairs' worth of gathers in flight) where a wave walks hundreds of pairs
 template <bool RHS, int SMB>
-__device__ __forceinline__ f64x4 schur_mfma_chunk(const double *__restrict__ WY, unsigned long long pr, int cnt, int lane, f64x4 acc,
+__device__ __forceinline__ f64x4 schur_mfma_chunk(const double *__restrict__ Wt, const double *__restrict__ Yt, unsigned long long pr, int cnt, int lane, f64x4 acc,
                                                   const int *__restrict__ opt = nullptr, const double *__restrict__ gps = nullptr)
 {
     const int i = lane & 15, kk = lane >> 4, K = 3 * cnt;
@@ -591,8 +650,8 @@ __device__ __forceinline__ f64x4 schur_mfma_chunk(const double *__restrict__ WY,
             const unsigned long long e = __shfl(pr, p & 63);
             a[u] = 0.0; b[u] = 0.0;
             if (k < K && i < 10) {
-                a[u] = WY[60 * (size_t)(e >> 32) + 30 + 10 * m + i];
-                b[u] = WY[60 * (size_t)(e & 0xFFFFFFFFu) + 10 * m + i];
+                a[u] = Yt[WROW * (size_t)(e >> 32) + 10 * m + i];
+                b[u] = Wt[WROW * (size_t)(e & 0xFFFFFFFFu) + 10 * m + i];
             }
             if (RHS && k < K && i == 10) b[u] = gps[3 * (size_t)opt[(unsigned)(e & 0xFFFFFFFFu)] + m];
         }
@@ -621,7 +680,7 @@ __global__ __launch_bounds__(256) void k_ba_schur_mfma(BaDev d, const int *off, 
     for (int base = e0; base < e1; base += 64) {
         const int cnt = min(64, e1 - base);
         const unsigned long long pr = lane < cnt ? list[base + lane] : 0ull;
-        acc = schur_mfma_chunk<false, 4>(d.WY, pr, cnt, lane, acc);
+        acc = schur_mfma_chunk<false, 4>(d.WY, d.WY + WROW * (size_t)d.no, pr, cnt, lane, acc);
     }
     // C/D layout: column = lane & 15, row = (lane >> 4) + 4 * reg
     const int col = lane & 15, r0 = lane >> 4;
@@ -649,7 +708,7 @@ __global__ __launch_bounds__(512) void k_ba_schur_mfma_wg(BaDev d, const int *of
     for (int base = e0 + 64 * w; base < e1; base += 64 * 8) {
         const int cnt = min(64, e1 - base);
         const unsigned long long pr = lane < cnt ? list[base + lane] : 0ull;
-        acc = schur_mfma_chunk<false, 12>(d.WY, pr, cnt, lane, acc);
+        acc = schur_mfma_chunk<false, 12>(d.WY, d.WY + WROW * (size_t)d.no, pr, cnt, lane, acc);
     }
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) part[w][((lane >> 4) + 4 * reg) * 16 + (lane & 15)] = acc[reg];
@@ -695,12 +754,12 @@ __global__ __launch_bounds__(1024) void k_ba_schur_diag_mfma(BaDev d, const int 
         const int cnt = min(64, (o1 - base + W - 1) / W);
         unsigned long long pr = 0ull;
         if (lane < cnt) { const unsigned o = (unsigned)d.cam_obs[base + W * lane]; pr = ((unsigned long long)o << 32) | o; }
-        acc = schur_mfma_chunk<true, SMB>(d.WY, pr, cnt, lane, acc, d.opt, d.gps);
+        acc = schur_mfma_chunk<true, SMB>(d.WY, d.WY + WROW * (size_t)d.no, pr, cnt, lane, acc, d.opt, d.gps);
     }
     for (int base = off[key] + ww; base < off[key + 1]; base += W * 64) {   // the same camera seen twice by one landmark
         const int cnt = min(64, (off[key + 1] - base + W - 1) / W);
         const unsigned long long pr = lane < cnt ? list[base + W * lane] : 0ull;
-        acc = schur_mfma_chunk<false, SMB>(d.WY, pr, cnt, lane, acc);
+        acc = schur_mfma_chunk<false, SMB>(d.WY, d.WY + WROW * (size_t)d.no, pr, cnt, lane, acc);
     }
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) part[w][((lane >> 4) + 4 * reg) * 16 + (lane & 15)] = acc[reg];
@@ -1353,7 +1412,32 @@ __global__ __launch_bounds__(128) void k_trsv_bwd(const double *S /* = L: sub-di
 }
 
 // ---------------------------------------------------------------------------------------
-// K8: point back-substitution, scaled step = -y
+// K8: point back-substitution, scaled step = -y.  Two passes: per observation  t_o = W_o' y_c  out of the W plane (a
+// wave's 64 rows of 240 B staged through LDS as one contiguous block), then per point  -Vinv (g_p - sum_o t_o)  over the
+// point's observations in order.
+__global__ __launch_bounds__(256) void k_ba_backsub_obs(BaDev d)
+{
+    __shared__ __attribute__((aligned(16))) double stage[4 * 64 * JLD];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const size_t row0 = (size_t)blockIdx.x * blockDim.x + 64 * w;
+    const int nrows = (int)min((long long)64, (long long)d.no - (long long)row0);
+    double *mine = stage + w * 64 * JLD;
+    if (nrows > 0) rows_to_lds<WCH>(d.WY, row0, nrows, mine, lane);
+    __syncthreads();
+    if (lane >= nrows) return;
+    const size_t o = row0 + lane;
+    const int c = d.ocam[o], dc = d.cam_dim[c];
+    const double *y = d.yc + d.cam_off[c];
+    const f64x2 *Wr = reinterpret_cast<const f64x2 *>(mine + lane * JLD);
+    double W[WROW];
+#pragma unroll
+    for (int k = 0; k < WCH; ++k) { const f64x2 v = Wr[k]; W[2 * k] = v[0]; W[2 * k + 1] = v[1]; }
+    double t0 = 0.0, t1 = 0.0, t2 = 0.0;
+#pragma unroll
+    for (int a = 0; a < 10; ++a)
+        if (a < dc) { const double ya = y[a]; t0 += W[a] * ya; t1 += W[10 + a] * ya; t2 += W[20 + a] * ya; }
+    d.tobs[3 * o] = t0; d.tobs[3 * o + 1] = t1; d.tobs[3 * o + 2] = t2;
+}
 __global__ void k_ba_backsub(BaDev d)
 {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1361,34 +1445,44 @@ __global__ void k_ba_backsub(BaDev d)
     if (j >= d.np) return;
     double tt[3] = {d.gps[3 * (size_t)j], d.gps[3 * (size_t)j + 1], d.gps[3 * (size_t)j + 2]};
     for (int o = d.pt_off[j]; o < d.pt_off[j + 1]; ++o) {
-        const int c = d.ocam[o], dc = d.cam_dim[c];
-        const double *y = d.yc + d.cam_off[c];
-        if (d.use_wy) {   // tabulated W_o, [m][a]
-            const double *W = d.WY + 60 * (size_t)o;
-            for (int a = 0; a < dc; ++a) { tt[0] -= W[a] * y[a]; tt[1] -= W[10 + a] * y[a]; tt[2] -= W[20 + a] * y[a]; }
-        } else {
-            double W[30];
-            load_W(d, o, c, j, W);
-            for (int a = 0; a < dc; ++a) { tt[0] -= W[3 * a] * y[a]; tt[1] -= W[3 * a + 1] * y[a]; tt[2] -= W[3 * a + 2] * y[a]; }
-        }
+        tt[0] -= d.tobs[3 * (size_t)o]; tt[1] -= d.tobs[3 * (size_t)o + 1]; tt[2] -= d.tobs[3 * (size_t)o + 2];
     }
     const double *Vi = d.Vinv + 9 * (size_t)j;
     for (int a = 0; a < 3; ++a) d.stp[3 * (size_t)j + a] = -(Vi[3 * a] * tt[0] + Vi[3 * a + 1] * tt[1] + Vi[3 * a + 2] * tt[2]);
 }
 
-// model: sum_o m (r + m/2), m = Js step  (partial per block)
+// model: sum_o m (r + m/2), m = Js step  (partial per block); observation rows staged through LDS like k_ba_eval writes them
 __global__ __launch_bounds__(256) void k_ba_model(BaDev d, double *partial)
 {
     __shared__ double sh[4];
-    const int o = blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ __attribute__((aligned(16))) double stage[4 * 64 * JLD];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const size_t row0 = (size_t)blockIdx.x * blockDim.x + 64 * w;
+    const int nrows = (int)min((long long)64, (long long)d.no - (long long)row0);
+    double *mine = stage + w * 64 * JLD;
+    if (nrows > 0) rows_to_lds<JCH>(d.J, row0, nrows, mine, lane);
+    __syncthreads();
     double acc = 0.0;
-    if (o < d.no) {
+    if (lane < nrows) {
+        const size_t o = row0 + lane;
         const int c = d.ocam[o], j = d.opt[o], off = d.cam_off[c], dc = d.cam_dim[c];
+        const f64x2 *Jr = reinterpret_cast<const f64x2 *>(mine + lane * JLD);
+        double row[JROW];
+#pragma unroll
+        for (int k = 0; k < JCH; ++k) { const f64x2 v = Jr[k]; row[2 * k] = v[0]; row[2 * k + 1] = v[1]; }
+        double sc[10], sp[3];
+#pragma unroll
+        for (int k = 0; k < 10; ++k) sc[k] = k < dc ? d.sc[off + k] * d.stc[off + k] : 0.0;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) sp[k] = d.sp[3 * (size_t)j + k] * d.stp[3 * (size_t)j + k];
+#pragma unroll
         for (int i = 0; i < 2; ++i) {
             double m = 0.0;
-            for (int k = 0; k < dc; ++k) m += d.Jc[20 * (size_t)o + 10 * i + k] * d.sc[off + k] * d.stc[off + k];
-            for (int k = 0; k < 3; ++k) m += d.Jp[6 * (size_t)o + 3 * i + k] * d.sp[3 * (size_t)j + k] * d.stp[3 * (size_t)j + k];
-            acc += m * (d.r[2 * o + i] + 0.5 * m);
+#pragma unroll
+            for (int k = 0; k < 10; ++k) if (k < dc) m += row[10 * i + k] * sc[k];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) m += row[20 + 3 * i + k] * sp[k];
+            acc += m * (row[26 + i] + 0.5 * m);
         }
     }
     const double s = block_sum(acc, sh);
@@ -1606,7 +1700,7 @@ int rcn_int_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_option
     int *p_ocam = ints, *p_opt = p_ocam + no, *p_camobs = p_opt + no, *p_ptoff = p_camobs + no,
         *p_camobsoff = p_ptoff + np + 1, *p_camoff = p_camobsoff + nc + 1, *p_camdim = p_camoff + nc + 1,
         *p_cols = p_camdim + nc, *p_flag = p_cols + 10 * (size_t)nc;
-    d.r = ws.get<double>(2 * (size_t)no); d.Jc = ws.get<double>(20 * (size_t)no); d.Jp = ws.get<double>(6 * (size_t)no);
+    d.J = ws.get<double>(JROW * (size_t)no + 2); d.tobs = ws.get<double>(3 * (size_t)no);
     d.Uraw = ws.get<double>(100 * (size_t)nc); d.gcraw = ws.get<double>(10 * (size_t)nc);
     d.Vraw = ws.get<double>(9 * (size_t)np); d.gpraw = ws.get<double>(3 * (size_t)np);
     const size_t nvec = (size_t)npad + 3 * (size_t)np + 16;
@@ -1621,14 +1715,14 @@ int rcn_int_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_option
     double *Sb = ws.get<double>(100 * (size_t)nc * nc);
     // gather lists of the Schur build (RCN_BA_SCHUR_ATOMICS=1 falls back to the atomic form)
     const bool gather = !ctx->ba_atomics;
-    d.use_wy = gather ? 1 : 0;
+    d.use_wy = 1;
     size_t npairs_lower = 0;
     for (int j = 0; j < np; ++j) { const size_t k = pt_off[j + 1] - pt_off[j]; npairs_lower += k * k; }   // upper bound
     const int nkeys = nc * nc;
     int *pk = ws.get<int>(gather ? 3 * (size_t)nkeys + 4 + (nkeys + 1023) / 1024 : 4);
     int *pk_cnt = pk, *pk_off = pk + nkeys + 1, *pk_fill = pk + 2 * nkeys + 2, *pk_sums = pk + 3 * (size_t)nkeys + 4;
     unsigned long long *pk_list = ws.get<unsigned long long>(gather ? std::max<size_t>(npairs_lower, 1) : 1);
-    d.WY = ws.get<double>(gather ? 60 * (size_t)std::max(no, 1) : 1);
+    d.WY = ws.get<double>(2 * WROW * (size_t)std::max(no, 1));        // W and Y planes: the Schur gathers and the back-substitution read them
     // few cameras: split every camera over several workgroups so that the per-camera kernels fill the chip
     const int csplit = nc >= 128 ? 1 : std::max(1, std::min(16, 512 / std::max(nc, 1)));
     d.csplit = ws.get<double>((size_t)std::max(nc, 1) * csplit * 256);
@@ -1694,11 +1788,22 @@ int rcn_int_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_option
         if (e != hipSuccess) return e;
         return hipStreamSynchronize(st);
     };
-    // cost at (poses,intr,pts) -> scal[slot]; JAC also refreshes r, Jc, Jp and the raw blocks
+    // cost at (poses,intr,pts) -> scal[slot]; JAC also refreshes the observation rows and the raw blocks
+    bool jac_pending = false;
     auto eval = [&](bool jac, const double *ps, const double *in, const double *x, int slot) -> hipError_t {
         if (no > 0) {
-            if (jac) k_ba_eval<true><<<eb, 256, 0, st>>>(d, ps, in, x, d.partial);
-            else k_ba_eval<false><<<eb, 256, 0, st>>>(d, ps, in, x, d.partial);
+            if (jac) {
+                // the streaming kernel of the solve, timed on its own (summary.jacobian_seconds): 224 B written per observation
+                if (jac_pending) {       // the previous pair of events has long completed (a read of the scalars came after it)
+                    float ms = 0.f;
+                    if (hipEventElapsedTime(&ms, ctx->ba_tev[4], ctx->ba_tev[5]) == hipSuccess) { sum->jacobian_seconds += 1e-3 * ms; sum->jacobian_evals++; }
+                    else (void)hipGetLastError();
+                }
+                (void)hipEventRecord(ctx->ba_tev[4], st);
+                k_ba_eval<true><<<eb, 256, 0, st>>>(d, ps, in, x, d.partial);
+                (void)hipEventRecord(ctx->ba_tev[5], st);
+                jac_pending = true;
+            } else k_ba_eval<false><<<eb, 256, 0, st>>>(d, ps, in, x, d.partial);
         }
         k_finish_sum<<<1, 256, 0, st>>>(d.partial, no > 0 ? eb : 0, d.scal + slot, 0.5);
         if (jac) {
@@ -1747,8 +1852,8 @@ int rcn_int_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_option
         if (npad > n) RCN_HIP(hipMemsetAsync(d.S + (size_t)n * npad, 0, sizeof(double) * (size_t)(npad - n) * npad, st));
         RCN_HIP(hipMemsetAsync(d.rhs, 0, sizeof(double) * npad, st));
         if (np > 0) k_ba_point_solve<<<(np + 127) / 128, 128, 0, st>>>(d, ir);
+        if (no > 0) k_ba_wy<<<(unsigned)((10 * (size_t)no + 255) / 256), 256, 0, st>>>(d);
         if (gather) {
-            if (no > 0) k_ba_wy<<<(unsigned)((10 * (size_t)no + 255) / 256), 256, 0, st>>>(d);
             if (nc > 1) {
                 const int nlow = nc * (nc - 1) / 2;
                 if (npairs_lower / (size_t)nlow > 128) k_ba_schur_mfma_wg<<<nlow, 512, 0, st>>>(d, pk_off, pk_list);   // long lists: a workgroup per block
@@ -1816,6 +1921,7 @@ int rcn_int_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_option
         for (int kb = nblk - 1; kb >= 0; --kb) k_trsv_bwd<<<kb + 1, 128, 0, st>>>(d.L, npad, kb, d.Linv, d.yc, d.rhs);
         RCN_HIP(hipGetLastError());
         RCN_HIP(hipMemcpyAsync(d.yc, d.rhs, sizeof(double) * npad, hipMemcpyDeviceToDevice, st));
+        if (no > 0) k_ba_backsub_obs<<<eb, 256, 0, st>>>(d);
         k_ba_backsub<<<std::max((std::max(n, np) + 127) / 128, 1), 128, 0, st>>>(d);
         if (no > 0) k_ba_model<<<eb, 256, 0, st>>>(d, d.partial);
         k_finish_sum<<<1, 256, 0, st>>>(d.partial, no > 0 ? eb : 0, d.scal + 2, -1.0);
@@ -1927,6 +2033,11 @@ int rcn_int_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_option
     }
     RCN_HIP(hipStreamSynchronize(st));
     sum->solve_seconds = now_s() - t_start;
+    if (jac_pending) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, ctx->ba_tev[4], ctx->ba_tev[5]) == hipSuccess) { sum->jacobian_seconds += 1e-3 * ms; sum->jacobian_evals++; }
+        else (void)hipGetLastError();
+    }
     sum->iterations = iter;
     sum->termination = termination;
     sum->final_cost = cost;

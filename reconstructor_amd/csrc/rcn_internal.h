@@ -162,7 +162,7 @@ struct rcn_ctx {
     uint64_t ba_pair_token = 0;         // whose pair lists the Schur-build workspace holds (0 = nobody's)
     hipStream_t aux_stream = nullptr;   // lookahead stream of the Cholesky
     hipEvent_t ba_ev[9];
-    hipEvent_t ba_tev[4];            // phase timing of rcn_ba_solve
+    hipEvent_t ba_tev[6];            // phase timing of rcn_ba_solve ([4], [5]: around k_ba_eval<true>)
     bool ba_ev_made = false;
 
     void set_error(const std::string &s) { err = s; }

@@ -91,13 +91,17 @@ def test_cpp_grid_driver_whole_pair_loop_with_the_filter(tmp_path):
     """matchFeatures(filter = true) from C++ -- match, epipolar filter on the table in HBM, lists, second pass --
     against a sequential restatement of SequentialReconstructor.cpp:199-279 over the two CPU oracles, bit-equal."""
     assert os.path.exists(BIN), "run __graft_entry__.build() first"
-    ims, coords, _ = synth.scene_set("sift", 7, [300, 320, 280, 310, 18, 300, 0], n_world=900, seed=5)
+    # image 4 is small enough for every pair with it to stay below 7 matches (unfiltered); no pair has 8..13 matches,
+    # where the LMedS branch picks among exact fits by rounding noise and only the shape of the answer is comparable
+    # between two implementations (DESIGN.md section 10)
+    ims, coords, _ = synth.scene_set("sift", 7, [300, 320, 280, 310, 12, 300, 0], n_world=900, seed=5)
     coords[5][:] = 91          # every sample of a pair with image 5 is degenerate: no model -> nothing stored -> reverse pass
     got, _ = _run_driver(tmp_path, ims, coords, 128, 0, 1)
     exp = reference_loop(ims, coords)
     plain = reference_loop(ims)
+    assert not any(8 <= len(v) <= 13 for v in plain.values())
     assert set(got) == set(exp)
-    assert all(got[k] == exp[k] for k in exp)
+    assert [k for k in exp if got[k] != exp[k]] == []
     assert sum(len(v) for v in exp.values()) < sum(len(v) for v in plain.values())       # the filter removed something
     assert any(k not in exp for k in plain)                                              # and dropped whole pairs (no model)
     assert any(0 < len(v) < 7 for v in exp.values())                                     # pairs below 7 matches pass unfiltered
