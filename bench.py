@@ -282,7 +282,39 @@ class PinnedLists:
             self.ctx.lib.rcn_host_free(p)
 
 
-def run_grid(torch, dist, dev, shard, n_img, K, local_dev, steps, warmup, world, materialise=True):
+def parity_cfg2(out, counts):
+    """Every pair of the cfg2 table against the CPU oracle's: row hash + count per pair, tests/golden/match_cfg2_full.npz."""
+    from reconstructor_amd import tablehash
+    path = os.path.join(ROOT, "tests", "golden", "match_cfg2_full.npz")
+    if not os.path.exists(path):
+        return {"equal_to_cpu": None, "note": "fixture missing"}
+    g = np.load(path)
+    P, K = len(g["pairs"]), int(g["K"])
+    h, c = tablehash.row_hashes(out[:P].cpu().numpy(), K)
+    return {"equal_to_cpu": bool(np.array_equal(h, g["hashes"]) and np.array_equal(c, g["counts"]) and np.array_equal(counts[:P].cpu().numpy(), g["counts"])),
+            "pairs_compared": int(P), "matches_found_cpu": int(g["matches_found"]),
+            "source": "tests/golden/match_cfg2_full.npz (oracle/match_oracle.c over all 4950 pairs: 64-bit row hash + count per pair)"}
+
+
+def parity_cfg3(world, rank):
+    """The sampled pairs of cfg3 this rank computed (pair number p -> rank p % world) against the CPU oracle: 512 pairs by
+    row hash + count, 64 from every residue of the pair number modulo 8 (tests/golden/match_cfg3_sample512.npz)."""
+    def check(out, counts):
+        import torch
+        from reconstructor_amd import tablehash
+        path = os.path.join(ROOT, "tests", "golden", "match_cfg3_sample512.npz")
+        if not os.path.exists(path):
+            return {"equal_to_cpu": None, "note": "fixture missing"}
+        g = np.load(path)
+        mine = np.nonzero(g["pair_numbers"] % world == rank)[0]
+        rows = torch.from_numpy(g["pair_numbers"][mine] // world).to(out.device)          # row of pair p in this rank's table
+        h, c = tablehash.row_hashes(out[rows].cpu().numpy(), int(g["K"]))
+        ok = bool(np.array_equal(h, g["hashes"][mine]) and np.array_equal(c, g["counts"][mine]) and np.array_equal(counts[rows].cpu().numpy(), g["counts"][mine]))
+        return {"equal_to_cpu": ok, "pairs_compared": int(len(mine))}
+    return check
+
+
+def run_grid(torch, dist, dev, shard, n_img, K, local_dev, steps, warmup, world, materialise=True, check=None):
     """warmup + `steps` timed steps of exchange -> match -> materialise through the sharded-grid ABI.
     Returns (seconds of the timed region on this rank, stats of the timed steps, matches found, lists bytes)."""
     ctx = shard.ctx
@@ -339,6 +371,7 @@ def run_grid(torch, dist, dev, shard, n_img, K, local_dev, steps, warmup, world,
     list_bytes = 8 * (lists.total.value if lists is not None else 0)
     if lists is not None:
         lists.close()
+    st["parity"] = check(out, counts) if check is not None else None      # outside the timed region: the table is still in HBM
     return dt, st, n_matches, list_bytes, shard.info()
 
 
@@ -488,7 +521,10 @@ def main():
     local_dev = torch.from_numpy(local).to(dev) if hi > lo else torch.zeros((1, K, D), dtype=torch.float32, device=dev)
     n_pairs_total = n_img * (n_img - 1) // 2
 
-    dt, st, n_matches, list_bytes, info = run_grid(torch, dist, dev, shard, n_img, K, local_dev, args.steps, args.warmup, world)
+    is_cfg = (n_img, K) == WORKLOADS[args.workload]
+    main_check = parity_cfg3(world, rank) if (is_cfg and args.workload == "cfg3") else (parity_cfg2 if (is_cfg and args.workload == "cfg2" and world == 1) else None)
+    dt, st, n_matches, list_bytes, info = run_grid(torch, dist, dev, shard, n_img, K, local_dev, args.steps, args.warmup, world, check=main_check)
+    par = st.get("parity") or {"equal_to_cpu": None, "pairs_compared": 0}
 
     tm = st["shard_times"]
     phase = [tm["exchange_ms"] / max(1, tm["exchanges"]), tm["f32_gather_ms"] / max(1, tm["exchanges"]), tm["match_ms"] / max(1, tm["matches"])]
@@ -497,10 +533,13 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t[0].item())
         phase = [float(x) for x in t[1:].tolist()]
-        tot = torch.tensor([float(n_matches), float(list_bytes), float(st["rows_reranked"]), float(st["rows_exact_fallback"]), float(st["rows_total"])], dtype=torch.float64)
+        tot = torch.tensor([float(n_matches), float(list_bytes), float(st["rows_reranked"]), float(st["rows_exact_fallback"]), float(st["rows_total"]),
+                            float(par["pairs_compared"]), 0.0 if par["equal_to_cpu"] in (True, None) else 1.0], dtype=torch.float64)
         dist.all_reduce(tot)
         n_matches, list_bytes = int(tot[0].item()), int(tot[1].item())
-        rows = [int(x) for x in tot[2:].tolist()]
+        rows = [int(x) for x in tot[2:5].tolist()]
+        if par["equal_to_cpu"] is not None:
+            par = {"equal_to_cpu": tot[6].item() == 0.0, "pairs_compared": int(tot[5].item())}
     else:
         rows = [int(st["rows_reranked"]), int(st["rows_exact_fallback"]), int(st["rows_total"])]
 
@@ -520,7 +559,10 @@ def main():
                        "pairs_per_rank": int(info["n_pairs"]), "pair_matches_per_s": n_pairs_total * args.steps / dt,
                        "matches_found": n_matches, "host_list_bytes_per_step": list_bytes,
                        "exchange_bytes_f16_payload": int(info["exchange_bytes_f16"]), "exchange_bytes_f32_side_stream": int(info["exchange_bytes_f32"]),
-                       "rows_reranked": rows[0], "rows_exact_fallback": rows[1], "rows_total": rows[2]},
+                       "rows_reranked": rows[0], "rows_exact_fallback": rows[1], "rows_total": rows[2],
+                       # the table of the LAST timed step against the CPU oracle (outside the timed region): cfg3 = 512 sampled
+                       # pairs by row hash + count, 64 per residue of the pair number mod 8, over all ranks; cfg2 = all 4950 pairs
+                       "equal_to_cpu": par["equal_to_cpu"], "pairs_compared_with_cpu": par["pairs_compared"]},
             "roofline": roof,
             # the collective side of the step, per step, max over ranks (HIP events inside librcn.so): `ranks` is
             # ncclCommCount of the communicator the gathers ran on; the fp32 gather runs on a side stream BESIDE the
@@ -536,13 +578,14 @@ def main():
                 loc2 = np.stack([synth.image_descriptors("superpoint", i, K2, pool2, seed=1234) for i in range(n2)])
                 loc2_dev = torch.from_numpy(loc2).to(dev)
                 # three windows of 20 steps, the median one is reported (a window is 0.17 s: one clock transient moves it by 10 %)
-                runs2 = sorted((run_grid(torch, dist, dev, shard, n2, K2, loc2_dev, 20, 3, 1) for _ in range(3)), key=lambda r: r[0])
+                runs2 = sorted((run_grid(torch, dist, dev, shard, n2, K2, loc2_dev, 20, 3, 1, check=parity_cfg2) for _ in range(3)), key=lambda r: r[0])
                 dt2, st2, nm2, lb2, info2 = runs2[1]
                 v2, ms2, roof2 = grid_line(K2, n2, n2 * (n2 - 1) // 2, dt2, 20, st2, 1, info2["n_pairs"])
                 # and with the tables left in HBM (round 1's definition of the step), for comparison
                 dt2b, st2b, _, _, _ = run_grid(torch, dist, dev, shard, n2, K2, loc2_dev, 20, 3, 1, materialise=False)
                 line["cfg2"] = {"workload": "cfg2: %d images x %d keypoints x %d-d, %d image pairs" % (n2, K2, D, n2 * (n2 - 1) // 2),
                                 "value": v2, "unit": "pair-distances/s", "steps": 20, "warmup": 3, "windows": "median of 3", "ms_per_step": ms2, "matches_found": nm2,
+                                "equal_to_cpu": st2["parity"]["equal_to_cpu"], "parity": st2["parity"],
                                 "host_list_bytes_per_step": lb2, "roofline": roof2,
                                 "value_tables_left_in_hbm": float(n2 * (n2 - 1) // 2) * K2 * K2 * 20 / dt2b,
                                 "rows_reranked": int(st2["rows_reranked"]), "rows_exact_fallback": int(st2["rows_exact_fallback"]), "rows_total": int(st2["rows_total"])}

@@ -57,6 +57,7 @@ struct BaDev {
     double *csplit;                    // [n_cams][split][256] partial per-camera sums when a camera is split over workgroups
     double *WY;                        // two planes of [n_obs][3][10], camera index fastest: scaled W_o = Jc'Jp at WY, Y_o = W_o Vinv at WY + 30 n_obs
     double *tobs;                      // per observation W_o' y_c (3): the back-substitution's per-observation term
+    double *crot;                      // per camera CROT doubles: the camera part of the rotation and its derivative (k_ba_cam_rot)
     int *flag;
 };
 
@@ -110,6 +111,85 @@ __device__ __forceinline__ void rotate(const double *w, const double *X, double 
     }
 }
 
+// The part of rotate() that depends on the camera alone -- R(w), Jr(w), cos, sin, the axis: trigonometry, a square root
+// and divisions -- tabulated once per camera and evaluation (k_ba_cam_rot), so that the per-observation kernel is left
+// with products: CROT doubles per camera, [0..8] R, [9..17] Jr, [18] cos, [19] sin, [20..22] axis, [23] 1 = small angle
+// (first-order branch of ceres::AngleAxisRotatePoint), [24..26] w.
+#define CROT 28
+__global__ void k_ba_cam_rot(const double *__restrict__ poses, int nc, double *__restrict__ tab)
+{
+    const int cidx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (cidx >= nc) return;
+    const double *w = poses + 6 * (size_t)cidx;
+    double *o = tab + CROT * (size_t)cidx;
+    const double th2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
+    double R[9], Jr[9], c = 1.0, s = 0.0, n[3] = {0.0, 0.0, 0.0};
+    const bool big = th2 > DBL_EPSILON;
+    if (big) {
+        const double th = sqrt(th2);
+        c = cos(th); s = sin(th);
+        n[0] = w[0] / th; n[1] = w[1] / th; n[2] = w[2] / th;
+        const double hs = sin(0.5 * th), omc = 2.0 * hs * hs;
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) R[3 * i + j] = omc * n[i] * n[j] + (i == j ? c : 0.0);
+        R[1] -= s * n[2]; R[2] += s * n[1];
+        R[3] += s * n[2]; R[5] -= s * n[0];
+        R[6] -= s * n[1]; R[7] += s * n[0];
+        double a, b;
+        if (th < 1e-2) {
+            a = 0.5 - th2 / 24.0 + th2 * th2 / 720.0;
+            b = 1.0 / 6.0 - th2 / 120.0 + th2 * th2 / 5040.0;
+        } else {
+            a = omc / th2;
+            b = (th - s) / (th2 * th);
+        }
+        const double K[9] = {0, -w[2], w[1], w[2], 0, -w[0], -w[1], w[0], 0};
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j)
+                Jr[3 * i + j] = -a * K[3 * i + j] + b * (K[3 * i] * K[j] + K[3 * i + 1] * K[3 + j] + K[3 * i + 2] * K[6 + j]) + (i == j ? 1.0 : 0.0);
+    } else {
+        R[0] = 1; R[1] = -w[2]; R[2] = w[1]; R[3] = w[2]; R[4] = 1; R[5] = -w[0]; R[6] = -w[1]; R[7] = w[0]; R[8] = 1;
+        for (int i = 0; i < 9; ++i) Jr[i] = (i % 4 == 0) ? 1.0 : 0.0;
+    }
+    for (int i = 0; i < 9; ++i) { o[i] = R[i]; o[9 + i] = Jr[i]; }
+    o[18] = c; o[19] = s; o[20] = n[0]; o[21] = n[1]; o[22] = n[2]; o[23] = big ? 0.0 : 1.0;
+    o[24] = w[0]; o[25] = w[1]; o[26] = w[2]; o[27] = 0.0;
+}
+
+// rotate() with the camera part read from the table: the same expressions in the same order
+__device__ __forceinline__ void rotate_tab(const double *__restrict__ cr, const double *X, double *p, double *R, double *dpdw)
+{
+#pragma unroll
+    for (int i = 0; i < 9; ++i) R[i] = cr[i];
+    if (cr[23] == 0.0) {
+        const double c = cr[18], s = cr[19];
+        const double n[3] = {cr[20], cr[21], cr[22]};
+        const double cx[3] = {n[1] * X[2] - n[2] * X[1], n[2] * X[0] - n[0] * X[2], n[0] * X[1] - n[1] * X[0]};
+        const double tmp = (n[0] * X[0] + n[1] * X[1] + n[2] * X[2]) * (1.0 - c);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) p[i] = X[i] * c + cx[i] * s + n[i] * tmp;
+        const double Xx[9] = {0, -X[2], X[1], X[2], 0, -X[0], -X[1], X[0], 0};
+        double M[9];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+                M[3 * i + j] = -(R[3 * i] * Xx[j] + R[3 * i + 1] * Xx[3 + j] + R[3 * i + 2] * Xx[6 + j]);
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+                dpdw[3 * i + j] = M[3 * i] * cr[9 + j] + M[3 * i + 1] * cr[12 + j] + M[3 * i + 2] * cr[15 + j];
+    } else {
+        const double w[3] = {cr[24], cr[25], cr[26]};
+        p[0] = X[0] + w[1] * X[2] - w[2] * X[1];
+        p[1] = X[1] + w[2] * X[0] - w[0] * X[2];
+        p[2] = X[2] + w[0] * X[1] - w[1] * X[0];
+        dpdw[0] = 0; dpdw[1] = X[2]; dpdw[2] = -X[1]; dpdw[3] = -X[2]; dpdw[4] = 0; dpdw[5] = X[0];
+        dpdw[6] = X[1]; dpdw[7] = -X[0]; dpdw[8] = 0;
+    }
+}
+
 __device__ __forceinline__ double block_sum(double v, double *sh)
 {
     const int t = threadIdx.x;
@@ -126,10 +206,11 @@ __device__ __forceinline__ double block_sum(double v, double *sh)
 // residual of one observation and (JAC) its 2 x 15 Jacobian over [pose 6 | intrinsics 6 | point 3]
 template <bool JAC>
 __device__ __forceinline__ void obs_residual(const double *ps, const double *in, const double *X, const double *uv,
-                                             double &r0, double &r1, double (*J)[15])
+                                             double &r0, double &r1, double (*J)[15], const double *crot = nullptr)
 {
     double p[3], R[9], dpdw[9];
-    rotate(ps, X, p, R, dpdw, JAC);
+    if (JAC && crot) rotate_tab(crot, X, p, R, dpdw);
+    else rotate(ps, X, p, R, dpdw, JAC);
     p[0] += ps[3]; p[1] += ps[4]; p[2] += ps[5];
     const double iz = 1.0 / p[2];
     const double x = p[0] * iz, y = p[1] * iz;
@@ -190,11 +271,12 @@ __device__ __forceinline__ void lds_to_rows(double *__restrict__ dst, size_t row
 // K4: residual and tangent Jacobian per observation; per-block partial of sum r^2.  JAC: every lane builds its row in
 // LDS, the wave stores its 64 rows as one contiguous block (HBM-bound: 224 B written per observation).
 template <bool JAC>
-__global__ __launch_bounds__(256) void k_ba_eval(BaDev d, const double *poses, const double *intr,
-                                                  const double *pts, double *partial)
+__global__ __launch_bounds__(JAC ? 128 : 256) void k_ba_eval(BaDev d, const double *poses, const double *intr,
+                                                              const double *pts, double *partial)
 {
+    constexpr int NW = JAC ? 2 : 4;          // JAC: 30 KB of LDS per workgroup, five workgroups per CU
     __shared__ double sh[4];
-    __shared__ __attribute__((aligned(16))) double stage[JAC ? 4 * 64 * JLD : 2];
+    __shared__ __attribute__((aligned(16))) double stage[JAC ? NW * 64 * JLD : 2];
     const int o = blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     double c2 = 0.0;
@@ -204,15 +286,24 @@ __global__ __launch_bounds__(256) void k_ba_eval(BaDev d, const double *poses, c
         for (int i = 0; i < 6; ++i) { ps[i] = poses[6 * c + i]; in[i] = intr[6 * c + i]; }
         for (int i = 0; i < 3; ++i) X[i] = pts[3 * j + i];
         double r0, r1, J[2][15];
-        obs_residual<JAC>(ps, in, X, d.uv + 2 * (size_t)o, r0, r1, J);
+        obs_residual<JAC>(ps, in, X, d.uv + 2 * (size_t)o, r0, r1, J, JAC ? d.crot + CROT * (size_t)c : nullptr);
         c2 = r0 * r0 + r1 * r1;
         if (JAC) {
-            const int dc = d.cam_dim[c];
+            // tangent columns of this camera, WITHOUT indexing J by a run-time column (that would put J in scratch
+            // memory): the host lays them out as the first `npose` pose columns (0, 3 or 6: camera 0 / camera 1 / the
+            // others, BundleAdjuster.cpp:100-105) followed, in intrinsics mode 1, by fx fy k1 k2 = columns 6 7 10 11
+            const int dc = d.cam_dim[c], nin = d.mode == 1 ? 4 : 0, npose = dc - nin;
             double row[JROW];
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
+                const double I4[4] = {nin ? J[i][6] : 0.0, nin ? J[i][7] : 0.0, nin ? J[i][10] : 0.0, nin ? J[i][11] : 0.0};
 #pragma unroll
-                for (int k = 0; k < 10; ++k) row[10 * i + k] = k < dc ? J[i][d.cols[10 * c + k]] : 0.0;
+                for (int k = 0; k < 10; ++k) {
+                    const double a6 = k < 6 ? J[i][k] : I4[k - 6 < 4 ? k - 6 : 3];                    // npose == 6
+                    const double a3 = k < 3 ? J[i][k] : (k - 3 < 4 ? I4[k - 3 < 4 ? k - 3 : 3] : 0.0);   // npose == 3
+                    const double a0 = k < 4 ? I4[k < 4 ? k : 3] : 0.0;                                  // npose == 0
+                    row[10 * i + k] = k < dc ? (npose == 6 ? a6 : npose == 3 ? a3 : a0) : 0.0;
+                }
 #pragma unroll
                 for (int k = 0; k < 3; ++k) row[20 + 3 * i + k] = J[i][12 + k];
             }
@@ -1415,9 +1506,9 @@ __global__ __launch_bounds__(128) void k_trsv_bwd(const double *S /* = L: sub-di
 // K8: point back-substitution, scaled step = -y.  Two passes: per observation  t_o = W_o' y_c  out of the W plane (a
 // wave's 64 rows of 240 B staged through LDS as one contiguous block), then per point  -Vinv (g_p - sum_o t_o)  over the
 // point's observations in order.
-__global__ __launch_bounds__(256) void k_ba_backsub_obs(BaDev d)
+__global__ __launch_bounds__(128) void k_ba_backsub_obs(BaDev d)
 {
-    __shared__ __attribute__((aligned(16))) double stage[4 * 64 * JLD];
+    __shared__ __attribute__((aligned(16))) double stage[2 * 64 * JLD];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const size_t row0 = (size_t)blockIdx.x * blockDim.x + 64 * w;
     const int nrows = (int)min((long long)64, (long long)d.no - (long long)row0);
@@ -1452,10 +1543,10 @@ __global__ void k_ba_backsub(BaDev d)
 }
 
 // model: sum_o m (r + m/2), m = Js step  (partial per block); observation rows staged through LDS like k_ba_eval writes them
-__global__ __launch_bounds__(256) void k_ba_model(BaDev d, double *partial)
+__global__ __launch_bounds__(128) void k_ba_model(BaDev d, double *partial)
 {
     __shared__ double sh[4];
-    __shared__ __attribute__((aligned(16))) double stage[4 * 64 * JLD];
+    __shared__ __attribute__((aligned(16))) double stage[2 * 64 * JLD];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const size_t row0 = (size_t)blockIdx.x * blockDim.x + 64 * w;
     const int nrows = (int)min((long long)64, (long long)d.no - (long long)row0);
@@ -1701,6 +1792,7 @@ int rcn_int_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_option
         *p_camobsoff = p_ptoff + np + 1, *p_camoff = p_camobsoff + nc + 1, *p_camdim = p_camoff + nc + 1,
         *p_cols = p_camdim + nc, *p_flag = p_cols + 10 * (size_t)nc;
     d.J = ws.get<double>(JROW * (size_t)no + 2); d.tobs = ws.get<double>(3 * (size_t)no);
+    d.crot = ws.get<double>(CROT * (size_t)nc);
     d.Uraw = ws.get<double>(100 * (size_t)nc); d.gcraw = ws.get<double>(10 * (size_t)nc);
     d.Vraw = ws.get<double>(9 * (size_t)np); d.gpraw = ws.get<double>(3 * (size_t)np);
     const size_t nvec = (size_t)npad + 3 * (size_t)np + 16;
@@ -1726,8 +1818,8 @@ int rcn_int_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_option
     // few cameras: split every camera over several workgroups so that the per-camera kernels fill the chip
     const int csplit = nc >= 128 ? 1 : std::max(1, std::min(16, 512 / std::max(nc, 1)));
     d.csplit = ws.get<double>((size_t)std::max(nc, 1) * csplit * 256);
-    const int eb = (no + 255) / 256, pbk = (std::max(nc, np) + 255) / 256;
-    d.partial = ws.get<double>(4 * (size_t)std::max(std::max(eb, pbk), 1) + 16);
+    const int eb = (no + 255) / 256, ebj = (no + 127) / 128, pbk = (std::max(nc, np) + 255) / 256;
+    d.partial = ws.get<double>(4 * (size_t)std::max(std::max(ebj, pbk), 1) + 16);
     d.scal = ws.get<double>(32);
     if (ws.err != hipSuccess) { ctx->set_error(std::string("rcn_ba_solve: workspace: ") + hipGetErrorString(ws.err)); return RCN_ERR_HIP; }
     d.uv = uv; d.ocam = p_ocam; d.opt = p_opt; d.cam_obs = p_camobs; d.pt_off = p_ptoff; d.cam_obs_off = p_camobsoff;
@@ -1799,13 +1891,14 @@ int rcn_int_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_option
                     if (hipEventElapsedTime(&ms, ctx->ba_tev[4], ctx->ba_tev[5]) == hipSuccess) { sum->jacobian_seconds += 1e-3 * ms; sum->jacobian_evals++; }
                     else (void)hipGetLastError();
                 }
+                k_ba_cam_rot<<<(nc + 127) / 128, 128, 0, st>>>(ps, nc, d.crot);
                 (void)hipEventRecord(ctx->ba_tev[4], st);
-                k_ba_eval<true><<<eb, 256, 0, st>>>(d, ps, in, x, d.partial);
+                k_ba_eval<true><<<ebj, 128, 0, st>>>(d, ps, in, x, d.partial);
                 (void)hipEventRecord(ctx->ba_tev[5], st);
                 jac_pending = true;
             } else k_ba_eval<false><<<eb, 256, 0, st>>>(d, ps, in, x, d.partial);
         }
-        k_finish_sum<<<1, 256, 0, st>>>(d.partial, no > 0 ? eb : 0, d.scal + slot, 0.5);
+        k_finish_sum<<<1, 256, 0, st>>>(d.partial, no > 0 ? (jac ? ebj : eb) : 0, d.scal + slot, 0.5);
         if (jac) {
             if (np > 0) k_ba_point_raw<<<(np + 127) / 128, 128, 0, st>>>(d);
             k_ba_cam_raw<<<nc * csplit, 128 * CR_GROUPS, 0, st>>>(d, csplit);
@@ -1921,10 +2014,10 @@ int rcn_int_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_option
         for (int kb = nblk - 1; kb >= 0; --kb) k_trsv_bwd<<<kb + 1, 128, 0, st>>>(d.L, npad, kb, d.Linv, d.yc, d.rhs);
         RCN_HIP(hipGetLastError());
         RCN_HIP(hipMemcpyAsync(d.yc, d.rhs, sizeof(double) * npad, hipMemcpyDeviceToDevice, st));
-        if (no > 0) k_ba_backsub_obs<<<eb, 256, 0, st>>>(d);
+        if (no > 0) k_ba_backsub_obs<<<ebj, 128, 0, st>>>(d);
         k_ba_backsub<<<std::max((std::max(n, np) + 127) / 128, 1), 128, 0, st>>>(d);
-        if (no > 0) k_ba_model<<<eb, 256, 0, st>>>(d, d.partial);
-        k_finish_sum<<<1, 256, 0, st>>>(d.partial, no > 0 ? eb : 0, d.scal + 2, -1.0);
+        if (no > 0) k_ba_model<<<ebj, 128, 0, st>>>(d, d.partial);
+        k_finish_sum<<<1, 256, 0, st>>>(d.partial, no > 0 ? ebj : 0, d.scal + 2, -1.0);
         // candidate at alpha = 1 (+ norms, gradient.delta, finite check) and its cost
         k_ba_plus<<<pbk, 256, 0, st>>>(d, 1.0, d.partial, pbk);
         for (int q = 0; q < 4; ++q) k_finish_sum<<<1, 256, 0, st>>>(d.partial + (size_t)q * pbk, pbk, d.scal + 3 + q, 1.0);

@@ -321,6 +321,7 @@ int rcn_shard_exchange(rcn_shard *sh, const float *local_desc_dev, const int32_t
     float *mine = landing ? landing + (size_t)sh->rank * per * K * D : nullptr;
     hipStream_t st = ctx->stream;
     sh->exchanged = false;
+    sh->own_table = false;            // whatever the ctx's own tables hold belongs to the previous exchange
     const int pslot = sh->prof_x % 64;
     const bool prof = sh->profile && sh->prof_made;
     if (prof) RCN_HIP(hipEventRecord(sh->pev[pslot][0], st));

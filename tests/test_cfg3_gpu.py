@@ -1,6 +1,7 @@
 """GPU suite: BASELINE.json configs[2] in full -- 1000 images x 4096 keypoints x 256-d, all 499 500 image pairs on
 one GPU through the sharded-grid path (world size 1: the code every rank runs) -- checked against oracle outputs
-for 64 sampled pairs (tests/golden/match_cfg3_sample.npz, written by tests/golden/make_cfg3_golden.py) and
+for 64 sampled pairs outright (tests/golden/match_cfg3_sample.npz), for 512 more by row hash and count, 64 from every
+residue of the pair number modulo 8 (match_cfg3_sample512.npz; both written by tests/golden/make_cfg3_golden.py), and
 through properties of the whole 8 GB match table."""
 import os
 
@@ -11,6 +12,7 @@ from reconstructor_amd import synth
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "match_cfg3_sample.npz")
+GOLD512 = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "match_cfg3_sample512.npz")
 
 
 def test_cfg3_full_grid(gpu_ctx):
@@ -42,6 +44,14 @@ def test_cfg3_full_grid(gpu_ctx):
             qt = g["qt"][lo:hi].astype(np.int32)
             assert int(cnt[p].item()) == int(c) == len(q), (i, j)
             assert np.array_equal(q, qt[:, 0]) and np.array_equal(row[q], qt[:, 1]), (i, j)
+        # ---- 512 more pairs, 64 from every rank's share of an 8-GPU deal (pair number mod 8), by row hash + count
+        from reconstructor_amd import tablehash
+        g5 = np.load(GOLD512)
+        assert all(np.bincount(g5["pair_numbers"] % 8, minlength=8) == 64)
+        rows = out[torch.from_numpy(g5["pair_numbers"]).cuda()].cpu().numpy()
+        h, c = tablehash.row_hashes(rows, K)
+        assert np.array_equal(c, g5["counts"]) and np.array_equal(cnt[torch.from_numpy(g5["pair_numbers"]).cuda()].cpu().numpy(), g5["counts"])
+        assert np.array_equal(h, g5["hashes"]), g5["pairs"][h != g5["hashes"]][:8]
         # ---- the whole table: counts, index range, no train row claimed twice within a pair
         total = 0
         for a in range(0, P, 16384):

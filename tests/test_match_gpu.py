@@ -265,3 +265,28 @@ def test_null_pair_list_is_the_canonical_grid(matcher):
     with pytest.raises(Exception):
         matcher.ctx.check(matcher.ctx.lib.rcn_match_grid(matcher.ctx.h, None, 7, 0.7, out.ctypes.data, 130, counts.ctypes.data))
     matcher.clear()
+
+
+def test_cfg2_full_grid_equals_the_oracle(matcher):
+    """BASELINE.json configs[1] in full: all 4950 pairs of 100 x 2048 x 256, every pair's row hash and match count
+    against the CPU oracle's (tests/golden/match_cfg2_full.npz, written by tests/golden/make_cfg2_golden.py)."""
+    import torch
+    from reconstructor_amd import tablehash
+    g = np.load(os.path.join(G, "match_cfg2_full.npz"))
+    n, K, seed = int(g["n_images"]), int(g["K"]), int(g["seed"])
+    pool = synth.world_pool("superpoint", 4 * K, seed=seed)
+    block = torch.from_numpy(np.stack([synth.image_descriptors("superpoint", i, K, pool, seed=seed) for i in range(n)])).cuda()
+    P = len(g["pairs"])
+    out = torch.empty((P, K), dtype=torch.int32, device="cuda")
+    cnt = torch.empty((P,), dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    matcher.clear()
+    matcher.upload_batch_device(0, n, block.data_ptr(), K, 256)
+    matcher.match_grid_device(g["pairs"], out.data_ptr(), K, cnt.data_ptr())
+    matcher.ctx.check(matcher.ctx.lib.rcn_synchronize(matcher.ctx.h))
+    h, c = tablehash.row_hashes(out.cpu().numpy(), K)
+    assert np.array_equal(c, g["counts"]) and np.array_equal(cnt.cpu().numpy(), g["counts"])
+    bad = np.nonzero(h != g["hashes"])[0]
+    assert len(bad) == 0, ("pairs whose table differs from the oracle's", g["pairs"][bad][:8])
+    assert int(c.sum()) == int(g["matches_found"])
+    matcher.clear()
