@@ -91,7 +91,7 @@ class Shard:
         offs = np.zeros(P + 1, np.int64)
         total = C.c_int64(0)
         rc = self.ctx.lib.rcn_shard_lists(self.h, offs.ctypes.data, None, 0, C.byref(total))
-        if rc not in (0, -1):
+        if rc != 0 and not (rc == -1 and total.value > 0):      # -1 with a total: the sizing call's "capacity too small"
             self.ctx.check(rc)
         qt = np.zeros((max(1, total.value), 2), np.int32)
         if total.value:
