@@ -961,18 +961,41 @@ __global__ void k_ring_signal(int *counter, int value)
     __hip_atomic_store(counter, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-__device__ __forceinline__ void ring_wait(const int *counter, int need, int *flag)    // one thread
+// one thread: relaxed poll (an sc1 load) with a 2-second limit (100 MHz wall clock, independent of the shader clock)
+__device__ __forceinline__ void ring_wait(const int *counter, int need, int *flag)
 {
-    const unsigned long long t0 = wall_clock64();                // 100 MHz, independent of the shader clock
-    while (__hip_atomic_load(counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < need) {
+    const unsigned long long t0 = wall_clock64();
+    while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
         __builtin_amdgcn_s_sleep(8);
         if (wall_clock64() - t0 > 200000000ull) { *flag = 3; break; }
     }
 }
 
-__global__ __launch_bounds__(64) void k_ring_gate(const int *counter, int need, int *flag)
+// Cross-stream hand-offs of the factorisation: every stream owns counters that say how far it has come, and a kernel
+// that needs another stream's result waits for the counter itself.
+//   publish  a kernel's first thread stores the counter of the work that PRECEDES it on its stream: stream order has
+//            completed that work and the kernel boundary has released its writes, so the store needs no fence and costs
+//            the publishing stream nothing (a trailing signal kernel would cost ~5 us of the chain per step);
+//   wait     thread 0 of every workgroup polls (relaxed), then ONE agent-scope acquire, then the workgroup barrier:
+//            the consumer recipe of MI355X_MICROARCH.md (inter-workgroup visibility), after which plain loads are safe.
+struct Gate { const int *c0; int n0; const int *c1; int n1; int *pub; int pubval; int *flag; };
+__device__ __forceinline__ void gate_enter(const Gate &g)
 {
-    if (threadIdx.x == 0) ring_wait(counter, need, flag);
+    if (threadIdx.x == 0) {
+        if (g.pub && blockIdx.x == 0) __hip_atomic_store(g.pub, g.pubval, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (g.c0) ring_wait(g.c0, g.n0, g.flag);
+        if (g.c1) ring_wait(g.c1, g.n1, g.flag);
+        if (g.c0 || g.c1) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+    }
+    if (g.c0 || g.c1) __syncthreads();
+}
+
+__global__ __launch_bounds__(64) void k_ring_gate(Gate g)
+{
+    gate_enter(g);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1049,9 +1072,12 @@ __device__ unsigned long long g_stamps[32];
 // ring_done / ring_need: in the chain-bound steps of the factorisation (the host decides) this kernel also does the gate's
 // job on its way out -- by then the bulk update the first trailing column of this step waits for has long finished, so
 // the check is free and the chain loses a 5-us kernel; ring_need < 0: nothing to wait for here.
-__global__ __launch_bounds__(256) void k_chol_diag(double *S, int ld, int kb, double *Linv, int *flag, int store_L,
-                                                    const int *ring_done, int ring_need)
+#define CDW 4          // waves of the diagonal kernel: wave 0 owns the leaves, the others the matrix work between them.  Four, one
+                       // per SIMD: the unrolled leaf code wants ~340 registers (eight waves at 256 spill 400 bytes per lane), and
+                       // the doubling steps below deal their tiles to exactly four waves
+__global__ __launch_bounds__(64 * CDW) void k_chol_diag(double *S, int ld, int kb, double *Linv, int *flag, int store_L, Gate g)
 {
+    gate_enter(g);
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     double *L = reinterpret_cast<double *>(smem_raw);  // [128][DL]
     __shared__ double rd[NB + 2 + 64];                  // reciprocals of L's diagonal; [NB] = breakdown flag; [NB+2..] pivot column line
@@ -1060,9 +1086,21 @@ __global__ __launch_bounds__(256) void k_chol_diag(double *S, int ld, int kb, do
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     double *A = S + ((size_t)kb * NB) * ld + (size_t)kb * NB;
     if (t == 0) misc[0] = 0.0;
-    for (int i = t; i < NB * NB; i += 256) {
-        const int r = i / NB, c = i % NB;
-        L[r * DL + c] = c <= r ? A[(size_t)r * ld + c] : 0.0;
+    {   // the block, 128 KB, as 16-byte loads ALL in flight before the first is used (round 2 loaded element by element
+        // with 256 threads: ~25 us of this kernel's 83 were this loop)
+        constexpr int PER = NB * (NB / 2) / (64 * CDW);      // 16-byte chunks per thread
+        f64x2 v[PER];
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+            const int i = t + 64 * CDW * q, r = i / (NB / 2), c2 = i % (NB / 2);
+            v[q] = *reinterpret_cast<const f64x2 *>(A + (size_t)r * ld + 2 * c2);
+        }
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+            const int i = t + 64 * CDW * q, r = i / (NB / 2), c = 2 * (i % (NB / 2));
+            L[r * DL + c] = c <= r ? v[q][0] : 0.0;
+            L[r * DL + c + 1] = c + 1 <= r ? v[q][1] : 0.0;
+        }
     }
     __syncthreads();
     STAMP(0);
@@ -1125,7 +1163,7 @@ __global__ __launch_bounds__(256) void k_chol_diag(double *S, int ld, int kb, do
     STAMP(1);
     for (int c0 = 0; c0 < NB; c0 += LB) {
         if (misc[0] != 0.0) {
-            if (t == 0) { *flag = 1; if (ring_need >= 0) ring_wait(ring_done, ring_need, flag); }
+            if (t == 0) *flag = 1;
             return;
         }
         const int r0 = c0 + LB;
@@ -1134,7 +1172,7 @@ __global__ __launch_bounds__(256) void k_chol_diag(double *S, int ld, int kb, do
         //     X[r][c] = sum_{k<=c} A[r][k] * Dinv[c][k]
         {
             const int leaf = c0 / LB, ntile = (NB - r0) / 16;
-            for (int tile = w; tile < ntile; tile += 4) {
+            for (int tile = w; tile < ntile; tile += CDW) {
                 double *At = L + (r0 + 16 * tile) * DL + c0;
                 f64x4 acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
@@ -1156,7 +1194,7 @@ __global__ __launch_bounds__(256) void k_chol_diag(double *S, int ld, int kb, do
         //     1..3 update the rest of the square, so the serial leaf work hides behind the MFMA work.
         {
             const int nt = (NB - r0) / 16, ntile = nt * (nt + 1) / 2;
-            for (int tile = w == 0 ? 0 : w; tile < ntile; tile += (w == 0 ? ntile : 3)) {
+            for (int tile = w == 0 ? 0 : w; tile < ntile; tile += (w == 0 ? ntile : CDW - 1)) {
                 int tr = (int)((sqrtf(8.f * tile + 1.f) - 1.f) * 0.5f);
                 while ((tr + 1) * (tr + 2) / 2 <= tile) ++tr;
                 while (tr * (tr + 1) / 2 > tile) --tr;
@@ -1183,7 +1221,7 @@ __global__ __launch_bounds__(256) void k_chol_diag(double *S, int ld, int kb, do
     // The factor of the diagonal tile itself is read by nobody (panels and triangular solves use its
     // inverse) except for the right-hand-side row inside the LAST tile (k_ba_y_from_row): stored on request.
     if (store_L)
-        for (int i = t; i < NB * NB; i += 256) {
+        for (int i = t; i < NB * NB; i += 64 * CDW) {
             const int r = i / NB, c = i % NB;
             if (c <= r) A[(size_t)r * ld + c] = L[r * DL + c];
         }
@@ -1193,7 +1231,7 @@ __global__ __launch_bounds__(256) void k_chol_diag(double *S, int ld, int kb, do
     STAMP(15);
     // 2b. the 32x32 leaf inverses from the 16x16 ones: in every 32-block the off-diagonal 16x16
     //     block becomes  -Dinv_hi * (L_hi,lo * Dinv_lo)  in place (one wave per 32-block).
-    {
+    if (w < 4) {
         const int i = 2 * w + 1, j = 2 * w;
         double *Bt = L + (LB * i) * DL + LB * j;
         f64x4 acc = {0.0, 0.0, 0.0, 0.0};
@@ -1291,18 +1329,17 @@ __global__ __launch_bounds__(256) void k_chol_diag(double *S, int ld, int kb, do
     STAMP(16);
     double *out = Linv + (size_t)kb * NB * NB;
     // (the strict upper triangle of every Linv tile is zeroed once per solve and never written, except
-    // for the zero beside an odd diagonal entry.)  A thread moves two neighbouring columns of four rows apart.
+    // for the zero beside an odd diagonal entry.)  A thread moves two neighbouring columns of CDW rows apart.
     {
         const int c = 2 * (t & 63);
         auto at = [&](int r, int cc) -> double {
             return cc > r ? 0.0 : (r / LB == cc / LB) ? dinv_at(L, rd, r / LB, r % LB, cc % LB) : L[r * DL + cc];   // all off-diagonal entries are in place
         };
 #pragma unroll 8
-        for (int r = t >> 6; r < NB; r += 4)
+        for (int r = t >> 6; r < NB; r += CDW)
             if (c <= r) *reinterpret_cast<f64x2 *>(out + (size_t)r * NB + c) = (f64x2){at(r, c), at(r, c + 1)};
     }
     STAMP(17);
-    if (ring_need >= 0 && t == 0) ring_wait(ring_done, ring_need, flag);
 }
 
 // Dense blocked Cholesky, GEMM side.  S holds the reduced system and its trailing updates; the
@@ -1320,15 +1357,17 @@ __global__ __launch_bounds__(256) void k_chol_diag(double *S, int ld, int kb, do
 // (blockIdx & 7), i.e. run on the same XCD and share the strip in its L2.
 // k_gemm_nt_ring (the rest of the trailing update, S[i,j] -= L[i,kb] L[j,kb]^T for kb+1 < j <= i)
 // runs beside them on a second stream (lookahead) and is built for throughput.
+// first / m: the tiles kb + 1 + first .. kb + 1 + first + m - 1 of the tile column (the critical tile is first = 0, m = 1)
 template <int MODE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(96)))
-void k_gemm_q(double *S, double *L, int ld, int kb, int m, const double *Linv)
+void k_gemm_q(double *S, double *L, int ld, int kb, int first, int m, const double *Linv, Gate g)
 {
+    gate_enter(g);
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     const int strip = 8 * (slot >> 2) + xcd, qj = slot & 3;      // strip: 32 rows of the tile column, qj: 32 output columns
     if (strip >= 4 * m) return;
     const int tj = MODE == 0 ? kb : kb + 1;
-    const size_t row0 = (size_t)(kb + 1) * NB + 32 * (size_t)strip;
+    const size_t row0 = (size_t)(kb + 1 + first) * NB + 32 * (size_t)strip;
     const double *A = (MODE == 0 ? S : L) + row0 * ld + (size_t)kb * NB;
     const double *B = MODE == 0 ? Linv + (size_t)kb * NB * NB + (size_t)(32 * qj) * NB
                                 : L + ((size_t)tj * NB + 32 * qj) * ld + (size_t)kb * NB;
@@ -1457,6 +1496,154 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt_ring(double *S, const double
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg)
                 if (!(DBG & 2) || acc[i][j][reg] == 1.2345e300) C[(size_t)(wr + 16 * i + fk + 4 * reg) * ld + wc + 16 * j + fr] = acc[i][j][reg];
+}
+
+// Bulk trailing update, second form (round 3).  Same tile, ring and operand layout as k_gemm_nt_ring; what changes is
+// where a wave waits.  Measured on the ring form (tools/gemm_nt_bench, tools/mfma_f64_peak): the bare
+// v_mfma_f64_16x16x4_f64 loop sustains 77 TFLOP/s on this chip (64 cycles per MFMA at ~2.36 GHz: f64 is not
+// clock-limited), the ring form's loop alone 58 (operands + barrier exposed once per 8-k stage) and a K = 128 pass 37:
+// a third of a pass is the C tile -- 128 KB read into the accumulators BEFORE the first MFMA, 128 KB stored after the last.
+//   * operand fragments are double-buffered in registers: the ds_read_b128s of stage s+1 are issued in front of the 32
+//     MFMAs of stage s, so a wave never waits for LDS between two MFMA bursts (only for the stage barrier);
+//   * the accumulators start at zero and the C tile is folded in ON THE WAY: the wave's sixteen 16x16 tiles of C are
+//     requested two at a time at the even stages 0, 2, .. 14 and added to their accumulators one stage (~2500 cycles)
+//     later -- no load of C is waited for, and what is left at the end is the store.  C moves through buffer
+//     instructions (one descriptor in SGPRs, one per-lane offset, wave-uniform row / tile offsets as scalar offsets): with
+//     128 accumulator and 64 operand registers per lane there is no room for per-tile 64-bit addresses.
+// NST = stages of 8 k per pass, a compile-time 16 or 32 (K = 128 or 256: one or two panels per pass): with the stage
+// index known at compile time every wait count below is a literal and the loop has no branch.
+// map: the launch's tiles, one word (row << 16 | column, relative to tile kb + 2; ~0 = none) per workgroup, dealt so that
+// the eight XCDs -- workgroup b runs on XCD b % 8 -- carry equal shares of whole supertiles (build_bulk_maps).
+template <int DBG, int NST>
+__global__ __launch_bounds__(256, 2) void k_gemm_nt_pipe(double *S, const double *L, int ld, int kb, const unsigned *__restrict__ map)
+{
+    static_assert(NST % 4 == 0 && NST >= 16, "C tiles are folded in during stages 0 .. 15");
+    extern __shared__ __attribute__((aligned(16))) char gsm[];
+    const unsigned e = map[blockIdx.x];
+    if (e == ~0u) return;
+    const int ti = kb + 2 + (int)(e >> 16), tj = kb + 2 + (int)(e & 0xffffu);
+    const double *A = L + ((size_t)ti * NB) * ld + (size_t)kb * NB;
+    const double *B = L + ((size_t)tj * NB) * ld + (size_t)kb * NB;
+    const int t = threadIdx.x, lane = t & 63;
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6);      // wave-uniform, and the compiler should know: everything derived
+                                                               // from it (ring slots, C descriptor, tile offsets) lives in SGPRs
+    const int wr = (w >> 1) * 64, wc = (w & 1) * 64;
+    const int fr = lane & 15, fk = lane >> 4;
+    // the wave's 64 x 64 part of the C tile through a buffer descriptor: per-lane byte offset of its corner element,
+    // everything else (tile row / column, register row) is wave-uniform and travels as the scalar offset
+    double *Cw = S + ((size_t)ti * NB + wr) * ld + (size_t)tj * NB + wc;
+    const __amdgpu_buffer_rsrc_t crs = __builtin_amdgcn_make_buffer_rsrc(Cw, 0, (int)(64 * (size_t)ld * 8), 0x00020000);
+    const int cvo = (int)(((size_t)fk * ld + fr) * 8);
+    const int ld8 = ld * 8;        // one row of the system in bytes (the C part of a wave spans 64 rows: far below 2^31)
+    f64x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f64x4){0.0, 0.0, 0.0, 0.0};
+    const double *srcA = A + (size_t)(32 * w + fr) * ld + 2 * fk;
+    const double *srcB = B + (size_t)(32 * w + fr) * ld + 2 * fk;
+    auto issue = [&](int s) {
+        char *buf = gsm + (s % GST) * GSTAGE_BYTES + 2048 * w;
+        const int k0 = 8 * s;
+        if (DBG & 4) return;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(srcA + (size_t)(16 * q) * ld + k0),
+                                             (__attribute__((address_space(3))) void *)(buf + 1024 * q), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(srcB + (size_t)(16 * q) * ld + k0),
+                                             (__attribute__((address_space(3))) void *)(buf + 8192 + 1024 * q), 16, 0, 0);
+        }
+    };
+    const unsigned base = (unsigned)(size_t)(const __attribute__((address_space(3))) char *)gsm;
+    const unsigned offA = base + (unsigned)((wr >> 4) * 1024 + fk * 256 + fr * 16);
+    const unsigned offB = base + (unsigned)(8192 + (wc >> 4) * 1024 + fk * 256 + fr * 16);
+    f64x2 ra[2][4], rb[2][4];
+    // wait until at most n of this wave's vector-memory operations (LDS-DMA pieces and C loads, in issue order) are pending
+    auto wait_vm = [&](int n) {
+        switch (n) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+        case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+        case 16: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+        case 20: asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
+        }
+    };
+    // "=&v": an LDS read writes its destination when the data returns -- it must not share a register with an address
+    auto read_stage = [&](int P, int s) {
+        const unsigned so = (unsigned)((s % GST) * GSTAGE_BYTES);
+        asm volatile("ds_read_b128 %0, %8\n\tds_read_b128 %1, %8 offset:1024\n\tds_read_b128 %2, %8 offset:2048\n\tds_read_b128 %3, %8 offset:3072\n\t"
+                     "ds_read_b128 %4, %9\n\tds_read_b128 %5, %9 offset:1024\n\tds_read_b128 %6, %9 offset:2048\n\tds_read_b128 %7, %9 offset:3072"
+                     : "=&v"(ra[P][0]), "=&v"(ra[P][1]), "=&v"(ra[P][2]), "=&v"(ra[P][3]), "=&v"(rb[P][0]), "=&v"(rb[P][1]), "=&v"(rb[P][2]), "=&v"(rb[P][3])
+                     : "v"(offA + so), "v"(offB + so) : "memory");
+    };
+    for (int s = 0; s < GST; ++s) issue(s);
+    wait_vm(12);
+    __builtin_amdgcn_s_barrier();
+    read_stage(0, 0);
+    // Stage s sits in register buffer s & 1.  Per stage: make stage s + 1 visible (its DMA pieces have landed for every
+    // wave) and refill the ring slot stage s has just left; even stage s < 16: request C tiles (i, j) = (s / 4, s % 4 and + 1);
+    // request the operands of stage s + 1; odd stage s < 16: fold the two tiles requested one stage ago in; the 32 MFMAs.
+    // Pending operations YOUNGER than the DMA of stage s + 1, which the barrier's wait allows for: the DMA of stages
+    // s + 2 and s + 3 (where they exist) and, at an odd stage, the 8 loads of C requested at the stage before.
+    typedef int v2i __attribute__((ext_vector_type(2)));
+    v2i craw[2][4];
+#pragma unroll
+    for (int s = 0; s < NST; ++s) {
+        const int P = s & 1;
+        const bool c_req = (s & 1) == 0 && s < 16, c_fold = (s & 1) == 1 && s < 16;
+        const int ci = (s >> 2) & 3, cj = s & 2;       // the pair of tiles of this stage (even) or of the one before (odd)
+        // my reads of stage s (requested one stage ago) have returned: the fragments are in their registers and the ring
+        // slot is free on my side.  The ONLY LDS wait of the step -- the reads of stage s + 1 requested below stay in flight
+        // behind this step's MFMAs (a wait in front of the MFMAs would wait for them too: the counter is in-order)
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ra[P][0]), "+v"(ra[P][1]), "+v"(ra[P][2]), "+v"(ra[P][3]), "+v"(rb[P][0]), "+v"(rb[P][1]), "+v"(rb[P][2]), "+v"(rb[P][3]) :: "memory");
+        if (s + 1 < NST) {
+            wait_vm(4 * ((s + 2 < NST) + (s + 3 < NST)) + (c_fold ? 8 : 0));
+            __builtin_amdgcn_s_barrier();
+            if (s + GST < NST) issue(s + GST);                      // into the slot of stage s
+        }
+        if (c_req && !(DBG & 1)) {
+            // inline asm: a load the compiler issues itself it also waits for itself, with vmcnt(0) -- the counter is in-order and
+            // it cannot tell the DMA pieces behind the load from the load -- which would drain the ring at every second stage
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg)
+                    asm volatile("buffer_load_dwordx2 %0, %1, %2, %3 offen" : "=&v"(craw[jj][reg]) : "v"(cvo + 128 * (cj + jj)), "s"(crs), "s"((16 * ci + 4 * reg) * ld8) : "memory");
+        }
+        if (s + 1 < NST) read_stage(1 - P, s + 1);
+        if (c_fold && !(DBG & 1)) {
+            wait_vm(4 * (s + GST < NST));                           // younger than the C loads: this stage's DMA
+            asm volatile("" : "+v"(craw[0][0]), "+v"(craw[0][1]), "+v"(craw[0][2]), "+v"(craw[0][3]), "+v"(craw[1][0]), "+v"(craw[1][1]), "+v"(craw[1][2]), "+v"(craw[1][3]));
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    union { v2i r; double d; } u;
+                    u.r = craw[jj][reg];
+                    acc[ci][cj + jj][reg] -= u.d;          // the accumulators hold A B' - C: the sign turns at the store
+                }
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(ra[P][i][h], rb[P][j][h], acc[i][j], 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg)
+                if (!(DBG & 2) || acc[i][j][reg] == 1.2345e300) {
+                    union { v2i r; double d; } u;
+                    u.d = -acc[i][j][reg];                  // C - A B'
+                    __builtin_amdgcn_raw_buffer_store_b64(u.r, crs, cvo + 128 * j, (16 * i + 4 * reg) * ld8, 0);
+                }
 }
 
 // forward substitution step kb: y_kb = Linv_kb b_kb ; b_i -= L[i,kb] y_kb for i > kb.
@@ -1674,6 +1861,52 @@ __global__ __launch_bounds__(256) void k_ba_gradmax(BaDev d, double *out)
 // =========================================================================================
 // host side
 // =========================================================================================
+// Tile maps of the bulk trailing update for a factorisation of nblk blocks: for every trailing size mt (tiles per side of
+// the lower triangle the update covers) the list of its mt (mt + 1) / 2 tiles in launch order.  Workgroups go round-robin
+// to the 8 XCDs (block b -> XCD b % 8, observed, speed only), and a supertile's workgroups should share an XCD -- its
+// panel tiles then stay in that XCD's L2 -- so WHOLE supertiles (4 x 4 tiles, 2 x 2 below 24) are dealt to the XCDs,
+// heaviest first to the least loaded (round 2 dealt 8 x 8 supertiles in index order: the busiest XCD carried 1.3x the
+// mean at mt = 45 and 2.4x at mt = 20).  Entry b of a map = tile of workgroup b (row << 16 | col), ~0 = none.
+static int build_bulk_maps(rcn_ctx *ctx, int nblk)
+{
+    if (ctx->bulk_map_nblk == nblk && ctx->bulk_map.p) return RCN_OK;
+    std::vector<unsigned> all;
+    ctx->bulk_map_off.assign((size_t)std::max(nblk, 1), 0);
+    ctx->bulk_map_grid.assign((size_t)std::max(nblk, 1), 0);
+    for (int mt = 1; mt <= nblk - 2; ++mt) {
+        const int SS = mt >= 24 ? 4 : 2, R = (mt + SS - 1) / SS;
+        std::vector<std::vector<unsigned>> st;
+        for (int sr = 0; sr < R; ++sr)
+            for (int sc = 0; sc <= sr; ++sc) {
+                std::vector<unsigned> tl;
+                for (int r = sr * SS; r < std::min(mt, sr * SS + SS); ++r)
+                    for (int c = sc * SS; c < sc * SS + SS; ++c)
+                        if (c <= r) tl.push_back(((unsigned)r << 16) | (unsigned)c);
+                if (!tl.empty()) st.push_back(std::move(tl));
+            }
+        std::stable_sort(st.begin(), st.end(), [](const std::vector<unsigned> &a, const std::vector<unsigned> &b) { return a.size() > b.size(); });
+        std::vector<unsigned> per[8];
+        for (auto &tl : st) {
+            int x = 0;
+            for (int i = 1; i < 8; ++i)
+                if (per[i].size() < per[x].size()) x = i;
+            per[x].insert(per[x].end(), tl.begin(), tl.end());
+        }
+        size_t slots = 0;
+        for (auto &v : per) slots = std::max(slots, v.size());
+        ctx->bulk_map_off[mt] = (int)all.size();
+        ctx->bulk_map_grid[mt] = (int)(8 * slots);
+        for (size_t sl = 0; sl < slots; ++sl)
+            for (int x = 0; x < 8; ++x) all.push_back(sl < per[x].size() ? per[x][sl] : ~0u);
+    }
+    if (all.empty()) all.push_back(~0u);
+    RCN_HIP(hipStreamSynchronize(ctx->stream));          // nobody may still read the old maps
+    RCN_HIP(ctx->bulk_map.reserve(all.size() * sizeof(unsigned)));
+    RCN_HIP(hipMemcpy(ctx->bulk_map.p, all.data(), all.size() * sizeof(unsigned), hipMemcpyHostToDevice));
+    ctx->bulk_map_nblk = nblk;
+    return RCN_OK;
+}
+
 namespace {
 
 struct Ws {   // growable device workspace out of ctx->ba_ws
@@ -1854,7 +2087,8 @@ int rcn_int_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_option
     RCN_HIP(hipMemsetAsync(d.S, 0, sizeof(double) * (size_t)npad * npad, st));   // upper part / padding never rewritten
     RCN_HIP(hipMemsetAsync(d.Linv, 0, sizeof(double) * (size_t)nblk * NB * NB, st));   // upper triangles of the tile inverses stay zero
     RCN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_chol_diag), hipFuncAttributeMaxDynamicSharedMemorySize, NB * DL * 8));
-    RCN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_nt_ring<0>), hipFuncAttributeMaxDynamicSharedMemorySize, GST * GSTAGE_BYTES));
+    RCN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_nt_pipe<0, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, GST * GSTAGE_BYTES));
+    { int rcm = build_bulk_maps(ctx, nblk); if (rcm) return rcm; }
     RCN_HIP(hipStreamSynchronize(st));   // host vectors go out of use; timing starts with inputs resident
     const double t_start = now_s();        // the pair lists of the Schur build are part of the solve (only the pack is not)
     const bool pairs_cached = res && res->pair_token != 0 && ctx->ba_pair_token == res->pair_token;
@@ -1940,7 +2174,7 @@ int rcn_int_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_option
         }
         const double ir = 1.0 / radius;
         RCN_HIP(hipEventRecord(ctx->ba_tev[0], st));
-        RCN_HIP(hipMemsetAsync(d.flag, 0, 4 * sizeof(int), st));      // [0] breakdown / gate flag, [2] bulk-stream step counter
+        RCN_HIP(hipMemsetAsync(d.flag, 0, 8 * sizeof(int), st));      // [0] breakdown / gate flag, [2..6] progress counters of the factorisation's streams
         if (!gather) RCN_HIP(hipMemsetAsync(Sb, 0, sizeof(double) * 100 * (size_t)nc * nc, st));
         if (npad > n) RCN_HIP(hipMemsetAsync(d.S + (size_t)n * npad, 0, sizeof(double) * (size_t)(npad - n) * npad, st));
         RCN_HIP(hipMemsetAsync(d.rhs, 0, sizeof(double) * npad, st));
@@ -1965,49 +2199,74 @@ int rcn_int_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_option
         if (rhs_row) k_ba_S_rhs_row<<<(n + 1 + 255) / 256, 256, 0, st>>>(d);
         RCN_HIP(hipGetLastError());
         RCN_HIP(hipEventRecord(ctx->ba_tev[1], st));
-        // dense Cholesky, right-looking, 128-wide panels, lookahead 1: the serial chain
-        // [first trailing tile column -> diagonal block -> panel] of step kb+1 runs on `st`
-        // while the rest of step kb's trailing update runs on the auxiliary stream
-        {
-            hipStream_t sb = ctx->aux_stream;
-            RCN_HIP(hipEventRecord(ctx->ba_ev[0], st));
-            RCN_HIP(hipStreamWaitEvent(sb, ctx->ba_ev[0], 0));      // aux starts behind everything queued so far
-            int have_rest = 0;
-            // bulk -> chain hand-off: a counter in device memory behind a one-wave gate kernel instead of an event wait
-            // (d.flag[2]: trailing updates complete).  The chain -> bulk hand-off stays an event: the chain's side of it is
-            // one record; a completion count inside the panel kernel (release fence per workgroup) was measured far slower
-            // -- device-scope fences write the L2 back under the bulk kernel -- and a signal kernel costs what the record does.
-            int *ring_done = d.flag + 2;
+        // Dense Cholesky, right-looking, 128-wide panels, on three streams with critical-tile-first ordering.  Step k:
+        //   D(k)  diagonal block (k, k) -> its factor's inverse                                   k_chol_diag      chain A
+        //   T(k)  the critical tile: L(k+1, k) = S(k+1, k) Linv_k', then S(k+1, k+1) -= L(k+1, k) L(k+1, k)'
+        //         -- all D(k+1) needs of panel k                                                 k_gemm_q<0/1>    chain A
+        //   P(k)  the rest of the panel, rows >= k + 2                                           k_gemm_q<0>      panels B
+        //   C(k)  the rest of the first trailing column, S(i, k+1) -= L(i, k) L(k+1, k)'         k_gemm_q<1>      panels B
+        //   B(k)  the bulk update of columns >= k + 2                                            k_gemm_nt_ring   bulk C
+        // The serial chain is D(k) T(k) D(k+1) T(k+1) ...: two small launches between two diagonal blocks where round 2 had the
+        // whole panel, a gate and the whole first column (131 us per step, of which 83 the diagonal block).  Cross-stream
+        // dependencies travel through five device counters (Gate, above):
+        //   T(k)  waits for C(k-1) [S(k+1, k) complete] and B(k-1) [tile (k+1, k+1) updated by every earlier panel]
+        //   P(k)  waits for D(k) and B(k-2);   C(k) for T(k) and B(k-1);   B(k) for P(k)
+        // and every counter is published by the FIRST thread of the kernel that follows the work on its own stream.
+        // A wait that times out (2 s: a runtime that does not let the three streams progress side by side) raises flag 3;
+        // the factorisation is then repeated on one stream in plain order, and every later one runs that way (ctx->chol_safe).
+        auto factorise = [&](bool safe) -> hipError_t {
+            hipStream_t sA = st, sB = safe ? st : ctx->panel_stream, sC = safe ? st : ctx->aux_stream;
+            int *cD = d.flag + 2, *cT = d.flag + 3, *cP = d.flag + 4, *cC = d.flag + 5, *cB = d.flag + 6;
+            const Gate none = {nullptr, 0, nullptr, 0, nullptr, 0, d.flag};
+            auto gate = [&](const int *c0, int n0, const int *c1, int n1, int *pub, int pubval) {
+                Gate g = {safe ? nullptr : c0, n0, safe ? nullptr : c1, n1, safe ? nullptr : pub, pubval, d.flag};
+                return g;
+            };
+            if (!safe) {
+                hipError_t e = hipEventRecord(ctx->ba_ev[0], sA);
+                if (e == hipSuccess) e = hipStreamWaitEvent(sB, ctx->ba_ev[0], 0);     // B and C start behind everything queued so far
+                if (e == hipSuccess) e = hipStreamWaitEvent(sC, ctx->ba_ev[0], 0);
+                if (e != hipSuccess) return e;
+            }
             for (int kb = 0; kb < nblk; ++kb) {
-                const int m = nblk - kb - 1;
-                // chain-bound steps: the diagonal kernel itself waits (at its end) for the bulk update of step kb - 1
-                // (only where the bulk kernel is short against the diagonal kernel, ~30 us: a wait that actually has to wait would
-                // hold up the panel behind it -- measured: +1 % at 500 / 1000 cameras when every chain-bound step did this)
-                const bool gate_in_diag = have_rest && m > 0 && 0.0575 * (double)m * (double)m <= 30.0;
-                k_chol_diag<<<1, 256, NB * DL * 8, st>>>(d.S, npad, kb, d.Linv, d.flag, kb == nblk - 1, ring_done, gate_in_diag ? kb : -1);
+                const int m = nblk - kb - 1;          // tiles below the diagonal block
+                // D(kb): publishes "T(kb-1) done"
+                k_chol_diag<<<1, 64 * CDW, NB * DL * 8, sA>>>(d.S, npad, kb, d.Linv, d.flag, kb == nblk - 1, gate(nullptr, 0, nullptr, 0, cT, kb));
                 if (m <= 0) break;
-                k_gemm_q<0><<<32 * ((4 * m + 7) / 8), 256, 0, st>>>(d.S, d.L, npad, kb, m, d.Linv);
-                hipEvent_t evP = ctx->ba_ev[1 + (kb & 3)];
-                // The bulk update of this step may start once the panel is there.  While the bulk kernel is the longer
-                // side of a step (large trailing matrix: ~0.06 us per tile pair against ~100 us of chain) its release is
-                // recorded right behind the panel, so that it follows its predecessor without a bubble; once the chain is
-                // the longer side, the record (6.6 us on the chain stream) moves behind the first trailing column: the bulk
-                // kernel starts ~16 us later and still finishes well before the next gate asks for it.
-                const bool bulk_bound = 0.0575 * (double)(m - 1) * (double)(m - 1) > 55.0;
-                if (m > 1 && bulk_bound) RCN_HIP(hipEventRecord(evP, st));
-                if (have_rest && !gate_in_diag) k_ring_gate<<<1, 64, 0, st>>>(ring_done, kb, d.flag);      // rest(kb-1) touched column kb+1
-                have_rest = 0;
-                k_gemm_q<1><<<32 * ((4 * m + 7) / 8), 256, 0, st>>>(d.S, d.L, npad, kb, m, d.Linv);
+                const int gq1 = 32;                   // grid of k_gemm_q for one tile: strips 0..3 on 4 of the 8 XCD slots
+                // T(kb), first half: publishes "D(kb) done"; waits for C(kb-1) and B(kb-1)
+                k_gemm_q<0><<<gq1, 256, 0, sA>>>(d.S, d.L, npad, kb, 0, 1, d.Linv, gate(cC, kb, cB, kb, cD, kb + 1));
+                k_gemm_q<1><<<gq1, 256, 0, sA>>>(d.S, d.L, npad, kb, 0, 1, d.Linv, none);
+                // On B and C the waits are ONE-WAVE gate kernels in front of the work, never inside it: a grid of a thousand
+                // workgroups that spins while it holds its CU slots could keep the very kernel it waits for from becoming resident.
                 if (m > 1) {
-                    if (!bulk_bound) RCN_HIP(hipEventRecord(evP, st));
-                    RCN_HIP(hipStreamWaitEvent(sb, evP, 0));
-                    k_gemm_nt_ring<0><<<gemm_nt_grid(m - 1), 256, GST * GSTAGE_BYTES, sb>>>(d.S, d.L, npad, kb, m - 1, NB / 8);
-                    k_ring_signal<<<1, 1, 0, sb>>>(ring_done, kb + 1);
-                    have_rest = 1;
+                    const int gq = 32 * ((4 * (m - 1) + 7) / 8);
+                    // P(kb): its gate publishes "C(kb-1) done" and waits for D(kb) and B(kb-2)
+                    if (!safe) k_ring_gate<<<1, 64, 0, sB>>>(gate(cD, kb + 1, cB, kb - 1, cC, kb));
+                    k_gemm_q<0><<<gq, 256, 0, sB>>>(d.S, d.L, npad, kb, 1, m - 1, d.Linv, none);
+                    // C(kb): its gate publishes "P(kb) done" and waits for T(kb) and B(kb-1)
+                    if (!safe) k_ring_gate<<<1, 64, 0, sB>>>(gate(cT, kb + 1, cB, kb, cP, kb + 1));
+                    k_gemm_q<1><<<gq, 256, 0, sB>>>(d.S, d.L, npad, kb, 1, m - 1, d.Linv, none);
+                    // B(kb): its gate publishes "B(kb-1) done" and waits for P(kb)
+                    if (!safe) k_ring_gate<<<1, 64, 0, sC>>>(gate(cP, kb + 1, nullptr, 0, cB, kb));
+                    k_gemm_nt_pipe<0, 16><<<ctx->bulk_map_grid[m - 1], 256, GST * GSTAGE_BYTES, sC>>>(d.S, d.L, npad, kb, ctx->bulk_map.as<unsigned>() + ctx->bulk_map_off[m - 1]);
+                } else if (!safe) {
+                    // one tile left below the diagonal block: no panel rest and no bulk update, but T(kb) still waits to hear
+                    // that C(kb-1) and B(kb-1) are done
+                    k_ring_gate<<<1, 64, 0, sB>>>(gate(nullptr, 0, nullptr, 0, cC, kb));
+                    k_ring_gate<<<1, 64, 0, sC>>>(gate(nullptr, 0, nullptr, 0, cB, kb));
                 }
             }
-            RCN_HIP(hipGetLastError());
-        }
+            hipError_t e = hipGetLastError();
+            if (e != hipSuccess || safe) return e;
+            // the chain continues (triangular solves) behind the last kernels of the other two streams
+            e = hipEventRecord(ctx->ba_ev[1], sB);
+            if (e == hipSuccess) e = hipStreamWaitEvent(sA, ctx->ba_ev[1], 0);
+            if (e == hipSuccess) e = hipEventRecord(ctx->ba_ev[2], sC);
+            if (e == hipSuccess) e = hipStreamWaitEvent(sA, ctx->ba_ev[2], 0);
+            return e;
+        };
+        RCN_HIP(factorise(ctx->chol_safe));
         RCN_HIP(hipEventRecord(ctx->ba_tev[2], st));
         if (rhs_row) k_ba_y_from_row<<<(npad + 255) / 256, 256, 0, st>>>(d);
         else for (int kb = 0; kb < nblk; ++kb) k_trsv_fwd<<<nblk - kb, 128, 0, st>>>(d.L, npad, kb, d.Linv, d.rhs, d.yc);
@@ -2034,6 +2293,14 @@ int rcn_int_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_option
             RCN_HIP(hipEventElapsedTime(&ms, ctx->ba_tev[0], ctx->ba_tev[1])); sum->schur_seconds += 1e-3 * ms;
             RCN_HIP(hipEventElapsedTime(&ms, ctx->ba_tev[1], ctx->ba_tev[2])); sum->cholesky_seconds += 1e-3 * ms;
             RCN_HIP(hipEventElapsedTime(&ms, ctx->ba_tev[2], ctx->ba_tev[3])); sum->trisolve_seconds += 1e-3 * ms;
+        }
+        if (hflag == 3 && !ctx->chol_safe) {
+            // a cross-stream wait of the factorisation gave up: this runtime does not run the three streams side by side.
+            // Not a numerical failure: switch to the one-stream schedule for good and redo this iteration's linear solve.
+            ctx->chol_safe = true;
+            --iter;
+            reuse_diag = true;       // the LM diagonal of this iteration is already in place
+            continue;
         }
         reuse_diag = true;
         const double model_change = hs[2];

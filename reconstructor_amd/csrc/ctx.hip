@@ -56,6 +56,14 @@ int rcn_create(int device_id, rcn_ctx **out)
             (void)hipGetLastError();
             ctx->aux_stream = nullptr;
         }
+        if (hipExtStreamCreateWithCUMask(&ctx->panel_stream, (uint32_t)mask.size(), mask.data()) != hipSuccess) {
+            (void)hipGetLastError();
+            ctx->panel_stream = nullptr;
+        }
+    }
+    if (!ctx->panel_stream && hipStreamCreateWithFlags(&ctx->panel_stream, hipStreamNonBlocking) != hipSuccess) {
+        delete ctx;
+        return RCN_ERR_HIP;
     }
     if (!ctx->aux_stream && hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking) != hipSuccess) {
         delete ctx;
@@ -83,6 +91,8 @@ int rcn_create(int device_id, rcn_ctx **out)
     ctx->ba_atomics = bat && bat[0] == '1';
     const char *btf = getenv("RCN_BA_TRSV_FWD");
     ctx->ba_trsv_fwd = btf && btf[0] == '1';
+    const char *cs = std::getenv("RCN_CHOL_SAFE");
+    ctx->chol_safe = cs && cs[0] == '1';
     const char *ch = std::getenv("RCN_MATCH_CHUNKS");
     ctx->chunks = ch ? std::atoi(ch) : 1;
 #endif
@@ -98,7 +108,7 @@ void rcn_destroy(rcn_ctx *ctx)
     (void)hipStreamSynchronize(ctx->stream);
     rcn_match_release(ctx);
     DevBuf *bufs[] = {&ctx->img_table, &ctx->pairs_dev, &ctx->groups_dev, &ctx->cand, &ctx->owner,
-                      &ctx->fb_list, &ctx->sv_list, &ctx->counters, &ctx->out_tmp, &ctx->cnt_tmp, &ctx->scale_dev, &ctx->desc_bad};
+                      &ctx->fb_list, &ctx->sv_list, &ctx->counters, &ctx->out_tmp, &ctx->cnt_tmp, &ctx->scale_dev, &ctx->desc_bad, &ctx->bulk_map};
     for (DevBuf *b : bufs) b->release();
     for (DevBuf &b : ctx->ba_ws) b.release();
     ctx->lm_ws.release();
@@ -119,6 +129,7 @@ void rcn_destroy(rcn_ctx *ctx)
     }
     ctx->cmp_off.release(); ctx->cmp_qt[0].release(); ctx->cmp_qt[1].release();
     if (ctx->aux_stream) (void)hipStreamDestroy(ctx->aux_stream);
+    if (ctx->panel_stream) (void)hipStreamDestroy(ctx->panel_stream);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }

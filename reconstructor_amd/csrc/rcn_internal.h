@@ -160,7 +160,13 @@ struct rcn_ctx {
     DevBuf fm_csr, fm_pairs;   // fused table filter: CSR of the matched points, per-pair coordinate pointers
     std::map<int32_t, std::pair<DevBuf, int32_t>> coords;   // image id -> (K x 2 int32 pixel coordinates in HBM, K)
     uint64_t ba_pair_token = 0;         // whose pair lists the Schur-build workspace holds (0 = nobody's)
-    hipStream_t aux_stream = nullptr;   // lookahead stream of the Cholesky
+    hipStream_t aux_stream = nullptr;   // lookahead stream of the Cholesky: bulk trailing updates (CU mask leaves one CU per XCD to the diagonal kernel)
+    hipStream_t panel_stream = nullptr; // second chain stream of the Cholesky: panels and first trailing columns behind the critical tile (same CU mask)
+    // tile maps of the bulk trailing update (ba.hip, build_bulk_maps): one per trailing size, balanced over the XCDs
+    DevBuf bulk_map;
+    std::vector<int> bulk_map_off, bulk_map_grid;
+    int bulk_map_nblk = 0;
+    bool chol_safe = false;             // a device-counter hand-off timed out once: factorise on one stream, in plain order, from then on
     hipEvent_t ba_ev[9];
     hipEvent_t ba_tev[6];            // phase timing of rcn_ba_solve ([4], [5]: around k_ba_eval<true>)
     bool ba_ev_made = false;

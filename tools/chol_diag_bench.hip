@@ -19,10 +19,10 @@ int main()
     (void)hipMemset(dflag, 0, 4); (void)hipMemset(dLinv, 0, n * n * 8);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_chol_diag), hipFuncAttributeMaxDynamicSharedMemorySize, NB * DL * 8);
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-    for (int rep = 0; rep < 3; ++rep) {
+    for (int rep = 0; rep < 4; ++rep) {      // rep 0 also stores L (checked below); the others time the kernel as the chain runs it
         (void)hipMemcpy(dA, A.data(), n * n * 8, hipMemcpyHostToDevice);
         (void)hipEventRecord(e0);
-        k_chol_diag<<<1, 256, NB * DL * 8>>>(dA, n, 0, dLinv, dflag, 1, nullptr, -1);
+        k_chol_diag<<<1, 64 * CDW, NB * DL * 8>>>(dA, n, 0, dLinv, dflag, rep == 0, Gate{nullptr, 0, nullptr, 0, nullptr, 0, dflag});
         (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
         float ms; (void)hipEventElapsedTime(&ms, e0, e1);
         unsigned long long st[32];
@@ -31,7 +31,9 @@ int main()
         printf("factor(all leaves+trsm+trail)=%llu | store=", st[13] - st[0]);
         printf("%llu leafinv=%llu blockinv=%llu out=%llu\n", st[14] - st[13], st[15] - st[14], st[16] - st[15], st[17] - st[16]);
     }
-    // check: L L^T == A and Linv L == I
+    // check: L L^T == A and Linv L == I (one more run that stores L)
+    (void)hipMemcpy(dA, A.data(), n * n * 8, hipMemcpyHostToDevice);
+    k_chol_diag<<<1, 64 * CDW, NB * DL * 8>>>(dA, n, 0, dLinv, dflag, 1, Gate{nullptr, 0, nullptr, 0, nullptr, 0, dflag});
     std::vector<double> L(n * n), Li(n * n);
     (void)hipMemcpy(L.data(), dA, n * n * 8, hipMemcpyDeviceToHost); (void)hipMemcpy(Li.data(), dLinv, n * n * 8, hipMemcpyDeviceToHost);
     double e1m = 0, e2m = 0;

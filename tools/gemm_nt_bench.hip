@@ -29,6 +29,55 @@ int main()
         }
         printf("rep %d: ring %.1f us (%.1f TF)   %s\n", rep, ms1 * 1e3, flop / ms1 * 1e-9, hipGetErrorString(hipGetLastError()));
     }
+    // the pipelined form (k_gemm_nt_pipe) over the balanced tile map of this trailing size
+    {
+        rcn_ctx *bc = new rcn_ctx();
+        if (build_bulk_maps(bc, nblk) != RCN_OK) { printf("map build failed\n"); return 1; }
+        const unsigned *map = bc->bulk_map.as<unsigned>() + bc->bulk_map_off[mt];
+        const int pgrid = bc->bulk_map_grid[mt];
+        printf("  map: %d workgroups for %d tiles (the busiest XCD carries %d)\n", pgrid, mt * (mt + 1) / 2, pgrid / 8);
+#define PSET(D, N) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_nt_pipe<D, N>), hipFuncAttributeMaxDynamicSharedMemorySize, GST * GSTAGE_BYTES)
+        PSET(0, 16); PSET(4, 16); PSET(7, 16); PSET(0, 32); PSET(4, 32); PSET(7, 32);
+#define PRUN(D, N, what)                                                                                                   \
+        for (int rep = 0; rep < 2; ++rep) {                                                                                \
+            float m;                                                                                                       \
+            (void)hipEventRecord(e0);                                                                                      \
+            k_gemm_nt_pipe<D, N><<<pgrid, 256, GST * GSTAGE_BYTES>>>(S0, L, npad, 0, map);                        \
+            (void)hipEventRecord(e1); (void)hipEventSynchronize(e1); (void)hipEventElapsedTime(&m, e0, e1);                 \
+            if (rep) printf("  pipe K = %4d %s: %.1f us (%.1f TF)   %s\n", 8 * N, what, m * 1e3, flop * (N / 16.0) / m * 1e-9, hipGetErrorString(hipGetLastError())); \
+        }
+        PRUN(0, 16, "full") PRUN(4, 16, "no operand DMA") PRUN(7, 16, "loop only")
+        PRUN(0, 32, "full") PRUN(4, 32, "no operand DMA") PRUN(7, 32, "loop only")
+        // correctness of the pipelined form on one tile, against a non-zero C, for both pass lengths
+        for (int two = 0; two < 2; ++two) {
+            std::vector<double> c0((size_t)128 * npad);
+            for (size_t i = 0; i < c0.size(); ++i) c0[i] = (double)((i * 2654435761u) % 1000) * 1e-3;
+            (void)hipMemset(S1, 0, N * 8);
+            (void)hipMemcpy(S1 + (size_t)5 * 128 * npad, c0.data(), c0.size() * 8, hipMemcpyHostToDevice);
+            if (two) k_gemm_nt_pipe<0, 32><<<pgrid, 256, GST * GSTAGE_BYTES>>>(S1, L, npad, 0, map);
+            else k_gemm_nt_pipe<0, 16><<<pgrid, 256, GST * GSTAGE_BYTES>>>(S1, L, npad, 0, map);
+            std::vector<double> c2((size_t)128 * npad);
+            (void)hipMemcpy(c2.data(), S1 + (size_t)5 * 128 * npad, c2.size() * 8, hipMemcpyDeviceToHost);
+            double md2 = 0;
+            for (int i = 0; i < 128; ++i)
+                for (int j = 0; j < 128; ++j) {
+                    double sref = c0[(size_t)i * npad + 3 * 128 + j];
+                    for (int k = 0; k < (two ? 256 : 128); ++k) sref -= h[((size_t)5 * 128 + i) * npad + k] * h[((size_t)3 * 128 + j) * npad + k];
+                    md2 = fmax(md2, fabs(sref - c2[(size_t)i * npad + 3 * 128 + j]));
+                }
+            printf("max |pipe(K = %d) - host| on tile (5,3) = %.3e\n", two ? 256 : 128, md2);
+        }
+    }
+    // the loop on its own: K = 8 nst per pass for longer and longer passes (per-tile prologue / epilogue amortised)
+    for (int nst : {16, 32, 64, 128})
+        for (int v = 0; v < 2; ++v) {
+            float m;
+            (void)hipEventRecord(e0);
+            if (v == 0) k_gemm_nt_ring<0><<<gemm_nt_grid(mt), 256, GST * GSTAGE_BYTES>>>(S0, L, npad, 0, mt, nst);
+            else k_gemm_nt_ring<7><<<gemm_nt_grid(mt), 256, GST * GSTAGE_BYTES>>>(S0, L, npad, 0, mt, nst);
+            (void)hipEventRecord(e1); (void)hipEventSynchronize(e1); (void)hipEventElapsedTime(&m, e0, e1);
+            printf("  K = %4d variant %d: %.1f us (%.1f TF)\n", 8 * nst, v ? 7 : 0, m * 1e3, flop * (nst / 16.0) / m * 1e-9);
+        }
     // check one tile (ti = 5, tj = 3) against the host: S1 = 0 - A B^T
     (void)hipMemset(S1, 0, N * 8);
     k_gemm_nt_ring<0><<<gemm_nt_grid(mt), 256, GST * GSTAGE_BYTES>>>(S1, L, npad, 0, mt, 16);
