@@ -249,6 +249,159 @@ def sweep_leg(ctx, with_cpu):
     return out
 
 
+def cfg1_leg(ctx, with_cpu):
+    """BASELINE.json configs[0], the regime the reference actually runs in (README.md:50-53, SequentialReconstructor.cpp:978-1103):
+    25 images x ~1500 keypoints through the whole pair loop -- match, epipolar filter, host lists -- for SIFT-like 128-d and
+    ORB-as-float 32-d descriptors, then the incremental loop's 23 global bundle adjustments (3 -> 25 cameras) through the
+    device-resident session with the validity sweeps around every solve.  The Fountain JPEGs cannot be turned into
+    descriptors here (no OpenCV): a synthetic scene of the same shape stands in.  GPU beside the CPU oracle at the
+    reference's own 4 threads (MAX_NUM_THREADS, options.num_threads), same box, same inputs, results compared."""
+    import ctypes as C
+    import torch
+    from reconstructor_amd import ba, fmat, synth, synth_ba
+    from reconstructor_amd.matcher import HipL2Matcher, all_pairs
+    out = {"workload": "25 images x 1400..1592 keypoints (synthetic scene; the Fountain set needs OpenCV), 300 image pairs; then 23 global BAs, 3 -> 25 cameras"}
+    n = 25
+    ks = [1400 + 8 * ((7 * i) % 25) for i in range(n)]
+    pairs = all_pairs(n)
+    P, stride = len(pairs), max(ks)
+    m = HipL2Matcher(ctx=ctx)
+    sync = lambda: ctx.check(ctx.lib.rcn_synchronize(ctx.h))
+    for kind, D in (("sift", 128), ("orb", 32)):
+        ims, coords, _ = synth.scene_set(kind, n, ks, n_world=5000, seed=19)
+        m.clear()
+        t0 = time.perf_counter()
+        for i in range(n):
+            m.upload(i, ims[i])
+            m.upload_coords(i, coords[i])
+        sync()
+        t_up = time.perf_counter() - t0
+        tab = torch.empty((P, stride), dtype=torch.int32, device="cuda")
+        cnt = torch.empty((P,), dtype=torch.int32, device="cuda")
+        ver = torch.empty((P,), dtype=torch.int32, device="cuda")
+        offs = np.zeros(P + 1, np.int64)
+        qt = np.zeros((P * stride, 2), np.int32)
+        total = C.c_int64(0)
+        torch.cuda.synchronize()
+
+        def loop(split):
+            ts = [time.perf_counter()]
+            m.match_grid_device(pairs, tab.data_ptr(), stride, cnt.data_ptr())
+            if split:
+                sync(); ts.append(time.perf_counter())
+            m.filter_table_device(pairs, tab.data_ptr(), stride, cnt.data_ptr(), ver.data_ptr())
+            if split:
+                sync(); ts.append(time.perf_counter())
+            ctx.check(ctx.lib.rcn_match_compact_begin(ctx.h, C.c_void_p(tab.data_ptr()), stride, C.c_void_p(cnt.data_ptr()), P, offs.ctypes.data,
+                                                      qt.ctypes.data, len(qt), C.byref(total)))
+            ctx.check(ctx.lib.rcn_match_compact_wait(ctx.h))
+            ts.append(time.perf_counter())
+            return ts
+        loop(False)                                   # warm (workspaces)
+        ts = loop(True)
+        t_all = min((lambda r: r[-1] - r[0])(loop(False)) for _ in range(3))
+        g = {"upload_seconds": t_up, "match_seconds": ts[1] - ts[0], "filter_seconds": ts[2] - ts[1], "lists_seconds": ts[3] - ts[2],
+             "gpu_seconds": t_all, "matches_kept": int(total.value), "pairs_per_s": P / t_all,
+             "note": "gpu_seconds = match + filter + host lists back to back (no synchronisation in between); the three stage times are one run with a synchronisation after each"}
+        if with_cpu:
+            from oracle import orc, orc_fmat
+            orc.match_grid(ims[:2], np.array([[0, 1]], np.int32), threads=4)
+            t0 = time.perf_counter()
+            tab0, cnt0 = orc.match_grid(ims, pairs, threads=4)
+            t1 = time.perf_counter()
+            off, a, b = fmat.matches_to_csr(coords, pairs, tab0)
+            t2 = time.perf_counter()
+            mask, c0, _ = orc_fmat.filter_grid(off, a, b, threads=4)
+            t3 = time.perf_counter()
+            want = tab0.copy()
+            for p, (i, j) in enumerate(pairs):
+                q = np.flatnonzero(tab0[p, :ks[i]] >= 0)
+                if len(q) >= 7:
+                    want[p, q[~mask[off[p]:off[p + 1]]]] = -1
+            got = tab.cpu().numpy()
+            g.update({"cpu_seconds": (t1 - t0) + (t3 - t2), "cpu_match_seconds": t1 - t0, "cpu_filter_seconds": t3 - t2, "cpu_threads": 4,
+                      "equal_to_cpu": bool(np.array_equal(got, want) and np.array_equal(ver.cpu().numpy(), c0) and int((want >= 0).sum()) == int(total.value))})
+        out["pair_loop_%s%d" % (kind, D)] = g
+        del tab, cnt, ver
+    m.clear()
+
+    # ---- the incremental loop: a global BA after every registered view, sweeps around it (SequentialReconstructor.cpp:1040-1094)
+    sc = synth_ba.make_scene(25, 1500, obs_per_point=6, seed=31)
+    xy_all = sc["obs_uv"].astype(np.int32)
+    ses = ba.BaSession(ctx)
+    gpu_s, cpu_s, gpu_sweep_s, cpu_sweep_s, steps, equal = 0.0, 0.0, 0.0, 0.0, [], True
+    try:
+        sid, live = {}, np.zeros(len(sc["points"]), bool)
+        for ncam in range(1, n + 1):
+            ses.add_camera(sc["poses"][ncam - 1], sc["intrinsics"][ncam - 1])
+            keep = sc["obs_cam"] < ncam
+            live_now = np.bincount(sc["obs_pt"][keep], minlength=len(sc["points"])) >= 2
+            new_pts = np.flatnonzero(live_now & ~live)
+            o_new = np.flatnonzero((sc["obs_cam"] == ncam - 1) & live[sc["obs_pt"]])
+            ses.add_observations([sid[j] for j in sc["obs_pt"][o_new]], sc["obs_cam"][o_new], xy_all[o_new])
+            if len(new_pts):
+                first = ses.add_points(sc["points"][new_pts])
+                for k, j in enumerate(new_pts):
+                    sid[j] = first + k
+                o_tr = np.flatnonzero(np.isin(sc["obs_pt"], new_pts) & (sc["obs_cam"] < ncam))
+                ses.add_observations([sid[j] for j in sc["obs_pt"][o_tr]], sc["obs_cam"][o_tr], xy_all[o_tr])
+            live = live_now
+            if ncam < 3:
+                continue
+            poses, intr = ses.cameras()
+            flat = None
+            if with_cpu:
+                pt, cam, xy = ses.graph()
+                X = ses.points()
+                flat = {"poses": poses, "intrinsics": intr, "points": X, "obs_uv": xy.astype(np.float64), "obs_cam": cam, "obs_pt": pt}
+            p34 = synth_ba.poses_to_34(poses)
+            t0 = time.perf_counter()
+            inl_a, er_a = ses.validity(p34, 4.0, 1.0)
+            t1 = time.perf_counter()
+            sg = ses.solve()
+            t2 = time.perf_counter()
+            p34b = synth_ba.poses_to_34(ses.cameras()[0])
+            t3 = time.perf_counter()
+            inl_b, er_b = ses.validity(p34b, 4.0, 1.0)
+            _, removed = ses.remove_outliers()
+            t4 = time.perf_counter()
+            gpu_s += sg["solve_seconds"]
+            gpu_sweep_s += (t1 - t0) + (t4 - t3)
+            rec = {"cameras": ncam, "iterations": sg["iterations"], "rms_px": sg["final_rms_px"], "gpu_solve_ms": 1e3 * sg["solve_seconds"], "gpu_call_ms": 1e3 * (t2 - t1)}
+            if er_a or er_b or removed:
+                rec["sweeps_changed_the_graph"] = [int(er_a), int(er_b), int(removed)]
+            if with_cpu:
+                from oracle import orc_ba, orc_validity
+                pt_off = np.concatenate([[0], np.cumsum(np.bincount(flat["obs_pt"], minlength=len(flat["points"])))]).astype(np.int32)
+                t0 = time.perf_counter()
+                i0, k0 = orc_validity.landmark_validity(p34, intr, flat["points"], pt_off, flat["obs_cam"], flat["obs_uv"].astype(np.int32))
+                t1 = time.perf_counter()
+                P0, I0, X0, s0 = orc_ba.solve(flat, threads=4)
+                t2 = time.perf_counter()
+                orc_validity.landmark_validity(synth_ba.poses_to_34(P0), I0, X0, pt_off, flat["obs_cam"], flat["obs_uv"].astype(np.int32))
+                t3 = time.perf_counter()
+                cpu_s += s0["solve_seconds"]
+                cpu_sweep_s += (t1 - t0) + (t3 - t2)
+                ok = (s0["iterations"] == sg["iterations"] and abs(s0["final_rms_px"] - sg["final_rms_px"]) <= 1e-5 and
+                      np.array_equal(i0, inl_a) and int((~k0).sum()) == er_a and er_a == 0 and er_b == 0 and removed == 0)
+                rec.update({"cpu_solve_ms": 1e3 * s0["solve_seconds"], "equal_to_cpu": bool(ok)})
+                equal = equal and ok
+            steps.append(rec)
+    finally:
+        ses.close()
+    inc = {"solves": len(steps), "gpu_seconds": gpu_s + gpu_sweep_s, "gpu_solve_seconds": gpu_s, "gpu_sweep_seconds": gpu_sweep_s,
+           "lm_iterations": int(sum(r["iterations"] for r in steps)), "per_view": steps}
+    if with_cpu:
+        inc.update({"cpu_seconds": cpu_s + cpu_sweep_s, "cpu_solve_seconds": cpu_s, "cpu_sweep_seconds": cpu_sweep_s, "cpu_threads": 4, "equal_to_cpu": bool(equal)})
+    out["incremental_ba"] = inc
+    out["gpu_seconds"] = out["pair_loop_sift128"]["gpu_seconds"] + inc["gpu_seconds"]
+    if with_cpu:
+        out["cpu_seconds"] = out["pair_loop_sift128"]["cpu_seconds"] + inc["cpu_seconds"]
+        out["equal_to_cpu"] = bool(out["pair_loop_sift128"]["equal_to_cpu"] and out["pair_loop_orb32"]["equal_to_cpu"] and inc["equal_to_cpu"])
+        out["note"] = "gpu_seconds / cpu_seconds: the SIFT-shaped pair loop + the 23 solves with their sweeps (the ORB-shaped pair loop is listed beside it)"
+    return out
+
+
 class PinnedLists:
     """Pinned host buffers (rcn_host_alloc) for the materialised match lists; two alternate so that the host
     could still read step k's lists while step k+1's copy is in flight."""
@@ -636,6 +789,7 @@ def main():
                 line["ba"] = ba_leg(ctx, not args.no_cpu_baseline)
                 line["ba_lm_iterations_per_s"] = line["ba"]["cfg5"]["lm_iterations_per_s"]   # 1k cams / 100k pts / 1M obs
                 line["epipolar_filter"] = fmat_leg(ctx, not args.no_cpu_baseline)
+                line["cfg1"] = cfg1_leg(ctx, not args.no_cpu_baseline)
         print(json.dumps(line), flush=True)
     if shard is not None:
         shard.close()

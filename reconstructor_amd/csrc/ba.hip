@@ -1077,6 +1077,7 @@ __device__ unsigned long long g_stamps[32];
                        // the doubling steps below deal their tiles to exactly four waves
 __global__ __launch_bounds__(64 * CDW) void k_chol_diag(double *S, int ld, int kb, double *Linv, int *flag, int store_L, Gate g)
 {
+    __builtin_amdgcn_s_setprio(3);
     gate_enter(g);
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     double *L = reinterpret_cast<double *>(smem_raw);  // [128][DL]
@@ -1362,6 +1363,7 @@ template <int MODE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(96)))
 void k_gemm_q(double *S, double *L, int ld, int kb, int first, int m, const double *Linv, Gate g)
 {
+    __builtin_amdgcn_s_setprio(3);      // these waves share SIMDs with the bulk update's: their few MFMAs and loads go first
     gate_enter(g);
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     const int strip = 8 * (slot >> 2) + xcd, qj = slot & 3;      // strip: 32 rows of the tile column, qj: 32 output columns
@@ -1669,24 +1671,31 @@ __global__ __launch_bounds__(128) void k_trsv_fwd(const double *S /* = L: sub-di
 }
 
 // backward substitution step kb (descending): x_kb = Linv_kb^T y_kb ; y_j -= L[kb,j]^T x_kb for j < kb
-__global__ __launch_bounds__(128) void k_trsv_bwd(const double *S /* = L: sub-diagonal tiles */, int ld, int kb, const double *Linv, double *y, double *x)
+// 512 threads per workgroup: four groups of 128 split the 128 rows of each dot product (the 79 launches of a cfg-5
+// solve are a serial chain: 12.5 us each with one thread per column walking all 128 rows, ~1 ms per LM iteration)
+__global__ __launch_bounds__(512) void k_trsv_bwd(const double *S /* = L: sub-diagonal tiles */, int ld, int kb, const double *Linv, double *y, double *x)
 {
-    __shared__ double xk[NB], yk[NB];
-    const int t = threadIdx.x, j = blockIdx.x;  // j = 0..kb ; j == kb writes x
-    yk[t] = y[(size_t)kb * NB + t];
+    __shared__ double xk[NB], yk[NB], part[4][NB];
+    const int t = threadIdx.x & 127, g = threadIdx.x >> 7, j = blockIdx.x;  // j = 0..kb ; j == kb writes x
+    if (g == 0) yk[t] = y[(size_t)kb * NB + t];
     __syncthreads();
     const double *Lk = Linv + (size_t)kb * NB * NB;
     double s = 0.0;
-#pragma unroll 16
-    for (int m = 0; m < NB; ++m) s += Lk[(size_t)m * NB + t] * yk[m];   // zeros above the diagonal
-    xk[t] = s;
+#pragma unroll 8
+    for (int m = 32 * g; m < 32 * g + 32; ++m) s += Lk[(size_t)m * NB + t] * yk[m];   // zeros above the diagonal
+    part[g][t] = s;
     __syncthreads();
-    if (j == kb) { x[(size_t)kb * NB + t] = s; return; }
+    if (g == 0) xk[t] = (part[0][t] + part[1][t]) + (part[2][t] + part[3][t]);
+    __syncthreads();
+    if (j == kb) { if (g == 0) x[(size_t)kb * NB + t] = xk[t]; return; }
     const double *blk = S + ((size_t)kb * NB) * ld + (size_t)j * NB;  // L[kb, j] tile, rows m, col t
     double u = 0.0;
-#pragma unroll 16
-    for (int m = 0; m < NB; ++m) u += blk[(size_t)m * ld + t] * xk[m];
-    y[(size_t)j * NB + t] -= u;
+#pragma unroll 8
+    for (int m = 32 * g; m < 32 * g + 32; ++m) u += blk[(size_t)m * ld + t] * xk[m];
+    __syncthreads();
+    part[g][t] = u;
+    __syncthreads();
+    if (g == 0) y[(size_t)j * NB + t] -= (part[0][t] + part[1][t]) + (part[2][t] + part[3][t]);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -2270,7 +2279,7 @@ int rcn_int_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_option
         RCN_HIP(hipEventRecord(ctx->ba_tev[2], st));
         if (rhs_row) k_ba_y_from_row<<<(npad + 255) / 256, 256, 0, st>>>(d);
         else for (int kb = 0; kb < nblk; ++kb) k_trsv_fwd<<<nblk - kb, 128, 0, st>>>(d.L, npad, kb, d.Linv, d.rhs, d.yc);
-        for (int kb = nblk - 1; kb >= 0; --kb) k_trsv_bwd<<<kb + 1, 128, 0, st>>>(d.L, npad, kb, d.Linv, d.yc, d.rhs);
+        for (int kb = nblk - 1; kb >= 0; --kb) k_trsv_bwd<<<kb + 1, 512, 0, st>>>(d.L, npad, kb, d.Linv, d.yc, d.rhs);
         RCN_HIP(hipGetLastError());
         RCN_HIP(hipMemcpyAsync(d.yc, d.rhs, sizeof(double) * npad, hipMemcpyDeviceToDevice, st));
         if (no > 0) k_ba_backsub_obs<<<ebj, 128, 0, st>>>(d);

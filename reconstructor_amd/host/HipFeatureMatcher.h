@@ -5,8 +5,19 @@
 // one enum value + one `case` in SequentialReconstructor's constructor switch
 // (SequentialReconstructor.cpp:31-41) -- see INTEGRATION.md.
 // Re-entrant: the reference shares one matcher between 4 OpenMP threads
-// (SequentialReconstructor.cpp:202,232); the ctx serialises calls internally.
+// (SequentialReconstructor.cpp:202,232); the plugin serialises its callers.
+//
+// Per-image device cache.  The reference's loop hands the SAME images to the plugin again and again --
+// `auto features1 = features[imgId1]` copies the vector of shared pointers for every pair
+// (SequentialReconstructor.cpp:213-214), so image i crosses this boundary N - 1 times -- and FlannMatcher
+// re-packs both images on every call (featDescToCV, FeatureMatcher.cpp:11-25).  Here an image is recognised by
+// the Feature objects its shared pointers name (first, last, count, descriptor length, plus a signature of three
+// descriptor rows against in-place edits), packed and uploaded ONCE, and kept resident in the ctx (fp32 rows,
+// fp16 copy, norms) under an id of the plugin's own range; a pair call then is one rcn_match_grid over two
+// resident ids.  Least recently used images are replaced beyond `capacity` images.  Descriptors are written once
+// by the detector and never edited afterwards in the reference; a caller that does edit them calls invalidate().
 #pragma once
+#include <mutex>
 #include <stdexcept>
 #include <string>
 
@@ -61,22 +72,110 @@ public:
                        const std::pair<int, int> /*imgShape1*/, const std::pair<int, int> /*imgShape2*/) override
     {
         if (features1.empty() || features2.empty()) return;   // the reference asserts here (:39)
+        std::lock_guard<std::mutex> lk(mu_);                  // the cache and the pair of ids it hands out belong to one caller at a time
+        const int32_t pr[2] = {resident(features1), resident(features2)};
+        std::vector<int32_t> out(features1.size(), -1);
+        int32_t count = 0;
+        int rc = pr[0] == pr[1] ? RCN_ERR_ARG : rcn_match_grid(ctx_, pr, 1, ratioThresh, out.data(), (int64_t)features1.size(), &count);
+        if (pr[0] == pr[1]) {
+            // an image against itself (the loop never asks for it): not a grid pair of two residents -- the uncached call
+            int D1 = 0, D2 = 0;
+            const std::vector<float> q = featDescToDense(features1, D1), t = featDescToDense(features2, D2);
+            rc = rcn_match_pair(ctx_, q.data(), (int32_t)features1.size(), t.data(), (int32_t)features2.size(), D1, ratioThresh, out.data(), &count);
+        }
+        if (rc != RCN_OK) throw std::runtime_error(std::string("HipL2Matcher::matchFeatures: ") + rcn_last_error(ctx_));
+        for (size_t i = 0; i < out.size(); ++i)
+            if (out[i] >= 0) matches[(int)i] = out[i];
+    }
+    // The same call without the cache -- pack both images, upload both, match, on every call (what round 2 shipped; kept
+    // for the latency comparison of tests/cpp/plugin_loop_test.cpp and for callers whose descriptors change between calls)
+    void matchFeaturesUncached(const std::vector<FeaturePtr<>> &features1, const std::vector<FeaturePtr<>> &features2, std::map<int, int> &matches)
+    {
+        if (features1.empty() || features2.empty()) return;
         int D1 = 0, D2 = 0;
         const std::vector<float> q = featDescToDense(features1, D1), t = featDescToDense(features2, D2);
         if (D1 != D2) throw std::runtime_error("descriptor lengths differ");
         std::vector<int32_t> out(features1.size(), -1);
         int32_t count = 0;
-        const int rc = rcn_match_pair(ctx_, q.data(), (int32_t)features1.size(), t.data(), (int32_t)features2.size(),
-                                      D1, ratioThresh, out.data(), &count);
+        std::lock_guard<std::mutex> lk(mu_);
+        if (!cache_.empty()) { rcn_desc_clear(ctx_); cache_.clear(); }        // rcn_match_pair needs the ctx's D to itself
+        const int rc = rcn_match_pair(ctx_, q.data(), (int32_t)features1.size(), t.data(), (int32_t)features2.size(), D1, ratioThresh, out.data(), &count);
         if (rc != RCN_OK) throw std::runtime_error(std::string("rcn_match_pair: ") + rcn_last_error(ctx_));
         for (size_t i = 0; i < out.size(); ++i)
             if (out[i] >= 0) matches[(int)i] = out[i];
     }
+    // forget every cached image (descriptors were edited in place, or the ctx's descriptors were cleared behind the plugin's back)
+    void invalidate()
+    {
+        std::lock_guard<std::mutex> lk(mu_);
+        cache_.clear();
+    }
+    void setCapacity(size_t images) { std::lock_guard<std::mutex> lk(mu_); capacity_ = images < 2 ? 2 : images; }
+    size_t uploads() const { return uploads_; }               // images packed + uploaded so far (a 25-image loop: 25, not 600)
     rcn_ctx *context() { return ctx_; }
 
 private:
+    struct Entry {
+        const void *first, *last;
+        size_t K;
+        int D;
+        uint64_t sig;
+        int32_t id;
+        uint64_t stamp;
+    };
+    static uint64_t signature(const std::vector<FeaturePtr<>> &f)
+    {
+        uint64_t h = 1469598103934665603ull;
+        const size_t rows[3] = {0, f.size() / 2, f.size() - 1};
+        for (size_t r : rows) {
+            const std::vector<float> &d = f[r]->featDesc.desc;
+            const unsigned char *b = reinterpret_cast<const unsigned char *>(d.data());
+            for (size_t i = 0; i < d.size() * sizeof(float); ++i) { h ^= b[i]; h *= 1099511628211ull; }
+        }
+        return h;
+    }
+    // id under which the image is resident in the ctx, uploading it first when it is not (mu_ held)
+    int32_t resident(const std::vector<FeaturePtr<>> &f)
+    {
+        const int D = (int)f[0]->featDesc.desc.size();
+        const uint64_t sig = signature(f);
+        if (!cache_.empty() && cache_[0].D != D) {            // another descriptor kind: the ctx holds one D at a time
+            if (rcn_desc_clear(ctx_) != RCN_OK) throw std::runtime_error(std::string("rcn_desc_clear: ") + rcn_last_error(ctx_));
+            cache_.clear();
+        }
+        for (Entry &e : cache_)
+            if (e.first == f.front().get() && e.last == f.back().get() && e.K == f.size() && e.D == D && e.sig == sig) {
+                e.stamp = ++clock_;
+                return e.id;
+            }
+        Entry e{f.front().get(), f.back().get(), f.size(), D, sig, 0, ++clock_};
+        if (cache_.size() < capacity_) {
+            e.id = kIdBase + (int32_t)cache_.size();
+            cache_.push_back(e);
+        } else {
+            size_t lru = 0;
+            for (size_t i = 1; i < cache_.size(); ++i)
+                if (cache_[i].stamp < cache_[lru].stamp) lru = i;
+            e.id = cache_[lru].id;                            // re-uploading an id replaces the image it named
+            cache_[lru] = e;
+        }
+        int Dd = 0;
+        const std::vector<float> dense = featDescToDense(f, Dd);
+        if (rcn_desc_upload(ctx_, e.id, dense.data(), (int32_t)f.size(), D) != RCN_OK) {
+            for (size_t i = 0; i < cache_.size(); ++i)
+                if (cache_[i].id == e.id) { cache_.erase(cache_.begin() + i); break; }
+            throw std::runtime_error(std::string("rcn_desc_upload: ") + rcn_last_error(ctx_));
+        }
+        ++uploads_;
+        return e.id;
+    }
+    static constexpr int32_t kIdBase = 0x40000000;     // the plugin's own id range inside a shared ctx
     rcn_ctx *ctx_ = nullptr;
     bool owned_ = true;
+    std::mutex mu_;
+    std::vector<Entry> cache_;
+    size_t capacity_ = 64, uploads_ = 0;
+    uint64_t clock_ = 0;
     const float ratioThresh = 0.7;   // FeatureMatcher.h:45
 };
 

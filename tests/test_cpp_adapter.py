@@ -114,3 +114,46 @@ def test_cpp_session_adapter_equals_the_repacking_adapter(tmp_path, nc, npts):
         _write_ba_scene(f, sc, [3 * i + 1 for i in range(nc)])
     r = subprocess.run([binary, str(inp)], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "session_adapter_test ok" in r.stdout and "1 rebuild(s)" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+def test_plugin_loop_uploads_each_image_once(tmp_path):
+    """The reference's own loop through the unmodified plugin call (SequentialReconstructor.cpp:202-232: by-value copies of
+    the feature vectors, 4 host threads): every ordered pair equal to the oracle, every image packed and uploaded once
+    (the per-image device cache of HipL2Matcher), and the call at least 5x faster than re-uploading both images each time."""
+    from reconstructor_amd import synth
+    import __graft_entry__ as g
+    g.build_cpp_tests()
+    exe = os.path.join(ROOT, "tests", "cpp", "plugin_loop_test")
+    n = 25
+    ks = [1400 + 8 * ((7 * i) % 25) for i in range(n)]
+    ks[7] = 0                                                    # an image without keypoints: the loop skips its pairs
+    ims = synth.descriptor_set("sift", n, ks, n_world=5000, seed=19)
+    inp, outp = tmp_path / "loop_in.bin", tmp_path / "loop_out.bin"
+    with open(inp, "wb") as f:
+        f.write(struct.pack("ii", n, 128))
+        for im in ims:
+            f.write(struct.pack("i", len(im)))
+            f.write(np.ascontiguousarray(im, np.float32).tobytes())
+    r = subprocess.run([exe, str(inp), str(outp)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    raw = open(outp, "rb").read()
+    npairs = struct.unpack_from("i", raw, 0)[0]
+    assert npairs == 24 * 23
+    pos, got = 4, {}
+    for _ in range(npairs):
+        i, j, c = struct.unpack_from("iii", raw, pos)
+        pos += 12
+        qt = np.frombuffer(raw, np.int32, 2 * c, pos).reshape(-1, 2)
+        pos += 8 * c
+        got[(i, j)] = {int(q): int(t) for q, t in qt}
+    ms_cached, ms_uncached = struct.unpack_from("dd", raw, pos)
+    uploads = struct.unpack_from("q", raw, pos + 16)[0]
+    assert uploads == 24                                         # once per non-empty image, not once per call
+    pairs = np.array(sorted(got), np.int32)
+    exp, _ = orc.match_grid(ims, pairs, threads=0)
+    for p, (i, j) in enumerate(pairs):
+        q = np.nonzero(exp[p, :ks[i]] >= 0)[0]
+        assert got[(int(i), int(j))] == {int(a): int(exp[p, a]) for a in q}, (i, j)
+    print(r.stdout.strip())
+    assert ms_uncached >= 5.0 * ms_cached, (ms_cached, ms_uncached)
