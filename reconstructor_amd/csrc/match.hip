@@ -31,7 +31,7 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #define RCN_NBUF 4          // LDS ring depth (train tiles)
 #define RCN_PD 2            // prefetch distance, tiles
 #define RCN_CHUNKS 4        // pair-list chunks: coarse(c+1) overlaps re-rank(c)
-#define RCN_BT 64           // train rows per LDS tile
+#define RCN_BT 64           // train rows per LDS tile (k_coarse_w4; k_coarse_top2: coarse_bt)
 #define RCN_PAD_HN 1.0e30f  // half-norm of padded train rows: never a candidate
 
 // ---------------------------------------------------------------------------------------
@@ -220,6 +220,9 @@ __device__ __forceinline__ unsigned umed3(unsigned a, unsigned b, unsigned c)
     return r;
 }
 
+// train rows per LDS tile of k_coarse_top2
+__host__ __device__ constexpr int coarse_bt(int DP) { return DP == 256 ? 64 : 128; }
+
 struct CoarseArgs {
     const ImgDev *imgs;
     const int32_t *pairs;   // n_pairs x (query slot, train slot)
@@ -259,12 +262,17 @@ __global__ __launch_bounds__(512, 2) void k_coarse_top2(CoarseArgs a)
     constexpr int NKS = SH ? DP / 32 : DP / 16;     // k-steps per tile row block
     constexpr int CPK = SH ? 4 : 2;                 // 16-byte chunks of a row one k-step consumes
     constexpr int ROWB = DP * 2;
-    constexpr int TILEB = RCN_BT * ROWB;
+    // train rows per LDS tile = per stage barrier: 64 at D = 256, 128 below -- the same 32 KB of operands and the same 64 MFMA
+    // per wave between two barriers at D = 128 as at D = 256 (with 64-row tiles the D = 128 kernel met a barrier and a DMA wait
+    // every 32 MFMAs: round 2 measured 45.8 % there against 56 % at D = 256 with the same VALU work per element)
+    constexpr int BT = coarse_bt(DP);
+    constexpr int TILEB = BT * ROWB;
     constexpr int GLSZ = DP == 32 ? 4 : 16;          // bytes per lane per LDS-DMA instruction
     constexpr int PIECE = 64 * GLSZ;
     constexpr int NINST = TILEB / 8 / PIECE;         // tile pieces per wave
-    constexpr int NG = NINST + 1;                    // + the half-norm piece
-    constexpr int BUFB = TILEB + 8 * 256;
+    constexpr int HNP = BT / 64;                     // half-norm pieces (64 rows each) per wave
+    constexpr int NG = NINST + HNP;
+    constexpr int BUFB = TILEB + 8 * BT * 4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int b = blockIdx.x;
@@ -309,7 +317,7 @@ __global__ __launch_bounds__(512, 2) void k_coarse_top2(CoarseArgs a)
         TrainRec rec;
         rec.f16 = reinterpret_cast<const char *>(ti.f16);
         rec.hn = ti.hn;
-        rec.nT = ti.K >= 2 ? (ti.K + RCN_BT - 1) / RCN_BT : 0;
+        rec.nT = ti.K >= 2 ? (ti.K + BT - 1) / BT : 0;
         rec.pad = 0;
         tbl[tid] = rec;
     }
@@ -354,9 +362,11 @@ __global__ __launch_bounds__(512, 2) void k_coarse_top2(CoarseArgs a)
                         (const __attribute__((address_space(1))) void *)src,
                         (__attribute__((address_space(3))) void *)(bbase + off), 16, 0, 0);
             }
-            __builtin_amdgcn_global_load_lds(
-                (const __attribute__((address_space(1))) void *)(s_hn + s_tile * RCN_BT + lane),
-                (__attribute__((address_space(3))) void *)(bbase + TILEB + w * 256), 4, 0, 0);
+#pragma unroll
+            for (int hp = 0; hp < HNP; ++hp)
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) void *)(s_hn + s_tile * BT + 64 * hp + lane),
+                    (__attribute__((address_space(3))) void *)(bbase + TILEB + w * (BT * 4) + 256 * hp), 4, 0, 0);
             ++staged;
         }
         if (++s_tile == s_nT) { ++s_pair; s_seek(); }
@@ -499,14 +509,17 @@ __global__ __launch_bounds__(512, 2) void k_coarse_top2(CoarseArgs a)
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             const unsigned tile = smem_base + (done % RCN_NBUF) * BUFB;
-            const unsigned hnl = tile + TILEB + w * 256;
-            const unsigned base = (unsigned)(t * RCN_BT);
-            if constexpr (SH == 0) {
-                step(pX0, pX1, pY0, pY1, tile, hnl, 0, base - 32u);   // epilogue of (t-1, rb 1)
-                step(pY0, pY1, pX0, pX1, tile, hnl, 1, base);         // epilogue of (t, rb 0)
-            } else {
-                step16(qX, qY, tile, hnl, 0, base - 32u);
-                step16(qY, qX, tile, hnl, 1, base);
+            const unsigned hnl = tile + TILEB + w * (BT * 4);
+            const unsigned base = (unsigned)(t * BT);
+#pragma unroll
+            for (int rb = 0; rb < BT / 32; rb += 2) {
+                if constexpr (SH == 0) {
+                    step(pX0, pX1, pY0, pY1, tile, hnl, rb, base + 32u * rb - 32u);   // epilogue of the row block before (t, rb)
+                    step(pY0, pY1, pX0, pX1, tile, hnl, rb + 1, base + 32u * rb);     // epilogue of (t, rb)
+                } else {
+                    step16(qX, qY, tile, hnl, rb, base + 32u * rb - 32u);
+                    step16(qY, qX, tile, hnl, rb + 1, base + 32u * rb);
+                }
             }
         }
         if (ABL & 1) {
@@ -517,7 +530,7 @@ __global__ __launch_bounds__(512, 2) void k_coarse_top2(CoarseArgs a)
             }
         }
         {   // drain: epilogue of the pair's last row block
-            const unsigned rowbase = (unsigned)((nT - 1) * RCN_BT + 32);
+            const unsigned rowbase = (unsigned)((nT - 1) * BT + BT - 32);
             if constexpr (SH == 0) {
 #pragma unroll
                 for (int reg = 0; reg < 16; ++reg) {
@@ -1421,7 +1434,7 @@ template <int DP> static hipError_t launch_coarse_w4(rcn_ctx *ctx, const CoarseA
 
 template <int DP, int ABL = 0, int SH = 0> static hipError_t launch_coarse(rcn_ctx *ctx, const CoarseArgs &ca, int blocks)
 {
-    const size_t lds = (size_t)RCN_NBUF * (RCN_BT * DP * 2 + 8 * 256) + RCN_TBL_BYTES;
+    const size_t lds = (size_t)RCN_NBUF * (coarse_bt(DP) * DP * 2 + 8 * coarse_bt(DP) * 4) + RCN_TBL_BYTES;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_coarse_top2<DP, ABL, SH>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
