@@ -662,6 +662,52 @@ def small_d_leg(torch, ctx, dev, kind, Dd, n3=100, K3=1500):
     return out
 
 
+def mixed_magnitude_leg(torch, ctx, dev, n3=100, K3=1500):
+    """What ONE out-of-scale image costs (the fp16 scale is one power of two for all resident images).  The sift128 grid again,
+    with every row of image 50 multiplied by 2^30.  Round 2 let the scale follow the largest row: the other 99 images' fp16
+    copies would underflow, nothing would certify and all 7.4 M rows would go through the exact kernels.  Now the histogram of
+    row norms (fix_scale, match.hip) sets that image's rows aside as BIG rows -- exact kernel as queries, never coarse
+    candidates, a norm bound in everybody else's certificates -- and the scale stays where the other 99 images need it.
+    Results stay exact (the pairs that do not involve image 50 must equal the unscaled run); reported: throughput and the share
+    of rows that went to the exact kernel (expected: image 50's own query rows, 49 x 1500 of 7.4 M)."""
+    from reconstructor_amd import synth
+    from reconstructor_amd.matcher import HipL2Matcher, all_pairs
+    pool3 = synth.world_pool("sift", 4 * K3, seed=1234)
+    loc3 = np.stack([synth.image_descriptors("sift", i, K3, pool3, seed=1234) for i in range(n3)])
+    pr3 = all_pairs(n3)
+    m3 = HipL2Matcher(ctx=ctx)
+    res = {}
+    for name, factor in (("uniform", 1.0), ("image_50_times_2p30", 2.0 ** 30)):
+        x = loc3.copy()
+        x[50] *= np.float32(factor)
+        xd = torch.from_numpy(x).to(dev)
+        m3.clear()
+        m3.upload_batch_device(0, n3, xd.data_ptr(), K3, 128)
+        o3 = torch.empty((len(pr3), K3), dtype=torch.int32, device=dev)
+        c3 = torch.empty((len(pr3),), dtype=torch.int32, device=dev)
+        torch.cuda.synchronize(dev)
+        m3.match_grid_device(pr3, o3.data_ptr(), K3, c3.data_ptr())
+        ctx.check(ctx.lib.rcn_synchronize(ctx.h))
+        t3 = time.perf_counter()
+        for _ in range(3):
+            m3.match_grid_device(pr3, o3.data_ptr(), K3, c3.data_ptr())
+        ctx.check(ctx.lib.rcn_synchronize(ctx.h))
+        dt3 = (time.perf_counter() - t3) / 3
+        st3 = m3.stats()
+        res[name] = {"value": float(st3["pair_distances"]) / dt3, "ms_per_step": 1e3 * dt3, "rows_total": int(st3["rows_total"]),
+                     "rows_reranked": int(st3["rows_reranked"]), "rows_exact_fallback": int(st3["rows_exact_fallback"]),
+                     "fallback_share": float(st3["rows_exact_fallback"]) / max(1, float(st3["rows_total"])), "table": o3.cpu().numpy()}
+        m3.clear()
+        del xd, o3, c3
+    keep = (pr3 != 50).all(1)
+    same = bool(np.array_equal(res["uniform"]["table"][keep], res["image_50_times_2p30"]["table"][keep]))
+    for r in res.values():
+        del r["table"]
+    return {"workload": "sift128 grid (100 x 1500 x 128, 4950 pairs); second run with image 50 scaled by 2^30", "unit": "pair-distances/s",
+            "uniform": res["uniform"], "image_50_times_2p30": res["image_50_times_2p30"], "pairs_without_image_50_identical": same,
+            "slowdown": res["uniform"]["value"] / res["image_50_times_2p30"]["value"]}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -800,6 +846,7 @@ def main():
                 # 100 images), the commented-out one ORB, matched as 32 floats (:19-24): K1 at D = 128 and D = 32 on cfg2-sized grids
                 line["sift128"] = small_d_leg(torch, ctx, dev, "sift", 128)
                 line["orb32"] = small_d_leg(torch, ctx, dev, "orb", 32)
+                line["mixed_magnitudes"] = mixed_magnitude_leg(torch, ctx, dev)
                 shard.reserve(n_img, K, D)         # the clear above dropped the shard's images: nothing is matched through it again
             if not args.no_cpu_baseline:
                 images = [local[i] for i in range(min(local.shape[0], 64))]

@@ -49,11 +49,23 @@ template <int DP> __host__ __device__ __forceinline__ int swz(int row)
 // Row statistics at upload: |x|^2 in fp64 and the running maxima that fix the global
 // power-of-two scale.  One wave per row, coalesced; |x|^2 only feeds error bounds (which carry
 // their own slack), so the summation order is free.
+// g_hist (RCN_HIST_BINS words): rows per octave of |x|^2 (bin = floor(log2 |x|^2) + RCN_HIST_BINS / 2, clamped; zero rows in
+// bin 0), collected in LDS and flushed once per workgroup -- what fix_scale needs to tell a few out-of-scale rows from the rest.
+__device__ __forceinline__ int norm_bin(double n2)
+{
+    if (!(n2 > 0.0)) return 0;
+    if (!(n2 <= 1.7976931348623157e308)) return RCN_HIST_BINS - 1;       // infinity / NaN
+    const int e = ilogb(n2) + RCN_HIST_BINS / 2;
+    return e < 1 ? 1 : (e > RCN_HIST_BINS - 1 ? RCN_HIST_BINS - 1 : e);
+}
 template <bool VEC4>
 __global__ __launch_bounds__(256) void k_rowstats(const float *__restrict__ x, int K, int D, double *__restrict__ nrm2,
                                                   unsigned *__restrict__ g_maxabs_bits,
-                                                  unsigned long long *__restrict__ g_maxnrm2_bits)
+                                                  unsigned long long *__restrict__ g_maxnrm2_bits, unsigned *__restrict__ g_hist)
 {
+    __shared__ unsigned s_hist[RCN_HIST_BINS];
+    for (int i = threadIdx.x; i < RCN_HIST_BINS; i += 256) s_hist[i] = 0u;
+    __syncthreads();
     const int lane = threadIdx.x & 63;
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
     float ma = 0.f;
@@ -76,7 +88,7 @@ __global__ __launch_bounds__(256) void k_rowstats(const float *__restrict__ x, i
                 }
             }
             for (int o = 8; o; o >>= 1) acc += __shfl_xor(acc, o);
-            if (sub == 0 && j < K) nrm2[j] = acc;
+            if (sub == 0 && j < K) { nrm2[j] = acc; atomicAdd(&s_hist[norm_bin(acc)], 1u); }
             mx = fmax(mx, acc);
         }
         for (int o = 32; o >= 16; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o));
@@ -90,7 +102,7 @@ __global__ __launch_bounds__(256) void k_rowstats(const float *__restrict__ x, i
                 acc = fma((double)v, (double)v, acc);
             }
             for (int o = 32; o; o >>= 1) acc += __shfl_xor(acc, o);
-            if (lane == 0) nrm2[j] = acc;
+            if (lane == 0) { nrm2[j] = acc; atomicAdd(&s_hist[norm_bin(acc)], 1u); }
             mx = fmax(mx, acc);
         }
     }
@@ -108,22 +120,45 @@ __global__ __launch_bounds__(256) void k_rowstats(const float *__restrict__ x, i
         if (a > __hip_atomic_load(g_maxabs_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(g_maxabs_bits, a);
         if (m > __hip_atomic_load(g_maxnrm2_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(g_maxnrm2_bits, m);
     }
+    // (the __syncthreads above ordered every wave's LDS histogram updates before this flush)
+    for (int i = threadIdx.x; i < RCN_HIST_BINS; i += 256)
+        if (s_hist[i]) atomicAdd(g_hist + i, s_hist[i]);
+}
+
+// the histogram again from norms already in HBM (n rows, zero = unused slot row): rebuilt when replaced images have left
+// more history in it than there are rows resident (rcn_int_prepare_all)
+__global__ __launch_bounds__(256) void k_norm_hist(const double *__restrict__ nrm2, long n, unsigned *__restrict__ g_hist)
+{
+    __shared__ unsigned s_hist[RCN_HIST_BINS];
+    for (int i = threadIdx.x; i < RCN_HIST_BINS; i += 256) s_hist[i] = 0u;
+    __syncthreads();
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) atomicAdd(&s_hist[norm_bin(nrm2[i])], 1u);
+    __syncthreads();
+    for (int i = threadIdx.x; i < RCN_HIST_BINS; i += 256)
+        if (s_hist[i]) atomicAdd(g_hist + i, s_hist[i]);
 }
 
 // fp32 rows -> scaled fp16 rows (chunk-swizzled) + biased half-norms.
 template <int DP>
 __global__ void k_prepare(const float *__restrict__ x, const double *__restrict__ nrm2, int K,
                           int Kp, int D, const ScaleDev *__restrict__ sc,
-                          _Float16 *__restrict__ f16, float *__restrict__ hn)
+                          _Float16 *__restrict__ f16, float *__restrict__ hn, unsigned long long *__restrict__ bigmin)
 {
     constexpr int CPR = DP / 8;
     const float scale = sc->sf;
-    const double half_s2 = sc->hs2, bias = sc->bias;
+    const double half_s2 = sc->hs2, bias = sc->bias, thr2 = sc->thr2;
     int gid = blockIdx.x * blockDim.x + threadIdx.x;
     int row = gid / CPR, c = gid % CPR;
     if (row >= Kp) return;
+    // a BIG row (|x|^2 >= thr2, fix_scale): no fp16 copy (zeros), never a coarse candidate (half-norm = padding value);
+    // the image remembers the smallest such norm
+    const bool big = row < K && !(nrm2[row] < thr2);
     half8 v;
-    if (row < K && c * 8 + 8 <= D && (D & 3) == 0) {      // whole chunk inside the row, 16-B aligned: two float4 loads
+    if (big) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (_Float16)0.f;
+        if (c == 0) atomicMin(bigmin, (unsigned long long)__double_as_longlong(nrm2[row] == nrm2[row] ? nrm2[row] : 0.0));
+    } else if (row < K && c * 8 + 8 <= D && (D & 3) == 0) {      // whole chunk inside the row, 16-B aligned: two float4 loads
         const float4 lo = *reinterpret_cast<const float4 *>(x + (size_t)row * D + c * 8);
         const float4 hi = *reinterpret_cast<const float4 *>(x + (size_t)row * D + c * 8 + 4);
         v[0] = (_Float16)(lo.x * scale); v[1] = (_Float16)(lo.y * scale); v[2] = (_Float16)(lo.z * scale); v[3] = (_Float16)(lo.w * scale);
@@ -137,7 +172,7 @@ __global__ void k_prepare(const float *__restrict__ x, const double *__restrict_
         }
     }
     *reinterpret_cast<half8 *>(f16 + (size_t)row * DP + ((c ^ swz<DP>(row)) * 8)) = v;
-    if (c == 0) hn[row] = row < K ? (float)(half_s2 * nrm2[row] + bias) : RCN_PAD_HN;
+    if (c == 0) hn[row] = (row < K && !big) ? (float)(half_s2 * nrm2[row] + bias) : RCN_PAD_HN;
 }
 
 // Same for a batch of n equally shaped images ([n][K][D] fp32 -> [n][Kp][DP] fp16).
@@ -145,12 +180,12 @@ template <int DP>
 __global__ void k_prepare_batch(const float *__restrict__ x, const double *__restrict__ nrm2,
                                 int n, int Kslot, int Kp, int D, const ScaleDev *__restrict__ sc,
                                 _Float16 *__restrict__ f16, float *__restrict__ hn,
-                                const int32_t *__restrict__ Ks)
+                                const int32_t *__restrict__ Ks, unsigned long long *__restrict__ bigmin)
 {
     // every image owns a slot of Kslot fp32 rows; Ks (may be NULL = Kslot everywhere) holds the rows in use
     constexpr int CPR = DP / 8;
     const float scale = sc->sf;
-    const double half_s2 = sc->hs2, bias = sc->bias;
+    const double half_s2 = sc->hs2, bias = sc->bias, thr2 = sc->thr2;
     const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const long grow = gid / CPR;
     const int c = (int)(gid % CPR);
@@ -158,8 +193,14 @@ __global__ void k_prepare_batch(const float *__restrict__ x, const double *__res
     const int img = (int)(grow / Kp), row = (int)(grow % Kp);
     const float *xi = x + (size_t)img * Kslot * D;
     const int K = Ks ? Ks[img] : Kslot;
+    const double n2 = row < K ? nrm2[(size_t)img * Kslot + row] : 0.0;
+    const bool big = row < K && !(n2 < thr2);            // BIG row: see k_prepare
     half8 v;
-    if (row < K && c * 8 + 8 <= D && (D & 3) == 0) {      // whole chunk inside the row, 16-B aligned: two float4 loads
+    if (big) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (_Float16)0.f;
+        if (c == 0) atomicMin(bigmin + img, (unsigned long long)__double_as_longlong(n2 == n2 ? n2 : 0.0));
+    } else if (row < K && c * 8 + 8 <= D && (D & 3) == 0) {      // whole chunk inside the row, 16-B aligned: two float4 loads
         const float4 lo = *reinterpret_cast<const float4 *>(xi + (size_t)row * D + c * 8);
         const float4 hi = *reinterpret_cast<const float4 *>(xi + (size_t)row * D + c * 8 + 4);
         v[0] = (_Float16)(lo.x * scale); v[1] = (_Float16)(lo.y * scale); v[2] = (_Float16)(lo.z * scale); v[3] = (_Float16)(lo.w * scale);
@@ -173,17 +214,51 @@ __global__ void k_prepare_batch(const float *__restrict__ x, const double *__res
         }
     }
     *reinterpret_cast<half8 *>(f16 + (size_t)grow * DP + ((c ^ swz<DP>(row)) * 8)) = v;
-    if (c == 0) hn[grow] = row < K ? (float)(half_s2 * nrm2[(size_t)img * Kslot + row] + bias) : RCN_PAD_HN;
+    if (c == 0) hn[grow] = (row < K && !big) ? (float)(half_s2 * n2 + bias) : RCN_PAD_HN;
+}
+
+// +infinity (as bits) into n words: "no BIG row" before a conversion records any
+__global__ void k_fill_inf(unsigned long long *p, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = 0x7FF0000000000000ull;
 }
 
 // The global scale from the row statistics (counters[0]: max |x| as fp32 bits, counters[2..3]: max |x|^2 as fp64
 // bits), on the device: the arithmetic of rcn_int_prepare_all's host path, operation for operation (frexp / ldexp /
 // ceil are exact; sqrt is correctly rounded on both sides), so that every GPU of a sharded grid -- and a one-GPU run
 // through the host path -- arrives at the same constants.
-__host__ __device__ inline void fix_scale(float maxabs, double maxn2, int DPa, ScaleDev *o)
+// Out-of-scale rows.  The scale is one power of two for every resident image, so a handful of rows a few thousand times larger
+// than the rest would push everybody else's fp16 copy towards the subnormals (correct, but nothing certifies any more and
+// every row goes through the exact kernels).  The histogram tells that situation apart: if at most 1 / 8 of the rows lie
+// above some octave and the next occupied octave above it is at least 6 further up (norms 8 times larger), the rows above
+// are BIG rows -- they get no fp16 copy, never become coarse candidates, go to the exact kernel as queries, and bound every
+// other query's certificates through their smallest norm (k_filter) -- and the scale is fixed for the rows below:
+// o->thr2 = 2^(top normal octave + 1), s from sqrt(thr2), |x|^2 bound = thr2.  Without such a split thr2 = +infinity and
+// everything is as it was (same s, same BIAS, bit for bit).
+__host__ __device__ inline void fix_scale(float maxabs, double maxn2, const unsigned *hist, int DPa, ScaleDev *o)
 {
     if (!(maxabs > 0.f && maxabs <= 3.4028234e38f)) maxabs = 1.f;          // zero, NaN, infinity
     if (!(maxn2 > 0.0 && maxn2 <= 1.7976931348623157e308)) maxn2 = 1.0;
+    double thr2 = 1.0e308 * 10.0;                                            // +infinity
+    if (hist) {
+        unsigned long long total = 0;
+        int top = 0;
+        for (int b = 1; b < RCN_HIST_BINS; ++b) { total += hist[b]; if (hist[b]) top = b; }
+        // walk down from the top: `above` = rows in octaves > b
+        unsigned long long above = 0;
+        int lowest_big = top + 1;                                            // lowest occupied octave among the rows above b
+        for (int b = top; b >= 1 && total >= 64; --b) {
+            if (above * 8ull > total) break;
+            if (hist[b] && above > 0 && lowest_big - b >= 6)                 // b is occupied, little lies above it, and far above:
+                thr2 = ldexp(1.0, b - RCN_HIST_BINS / 2 + 1);                // a split (the lowest one within the budget wins)
+            if (hist[b]) { above += hist[b]; lowest_big = b; }
+        }
+    }
+    if (thr2 <= 1.7976931348623157e308) {
+        maxn2 = thr2;                                                        // every normal row has |x|^2 < thr2
+        maxabs = (float)sqrt(thr2);                                          // ... and every element below |x|
+    }
     // s = 2^e with s*maxabs in (2^13, 2^14]  (fp16 max is 65504; the query side is negated only)
     int ex;
     (void)frexp((double)maxabs, &ex);  // maxabs = m * 2^ex, m in [0.5,1)
@@ -202,6 +277,7 @@ __host__ __device__ inline void fix_scale(float maxabs, double maxn2, int DPa, S
     o->n_max = n_max;
     o->hn_max = 0.5 * s * s * n_max * n_max + bias;
     o->rel_slack = 1e-9;
+    o->thr2 = thr2;
     o->sf = (float)s; o->pad = 0.f;
 }
 __global__ void k_fix_scale(const unsigned *__restrict__ counters, int DPa, ScaleDev *__restrict__ out)
@@ -209,7 +285,7 @@ __global__ void k_fix_scale(const unsigned *__restrict__ counters, int DPa, Scal
     if (threadIdx.x || blockIdx.x) return;
     const float maxabs = __uint_as_float(counters[0]);
     const double maxn2 = __longlong_as_double(*reinterpret_cast<const long long *>(counters + 2));
-    fix_scale(maxabs, maxn2, DPa, out);
+    fix_scale(maxabs, maxn2, counters + RCN_HIST_WORD, DPa, out);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -661,6 +737,16 @@ __device__ __forceinline__ double acc_to_d2(const ScaleDev &a, double nq2, doubl
     return nq2 + (2.0 / a.s2) * (acc - a.bias);
 }
 
+// lower bound on the exact squared distance from a query of squared norm nq2 to ANY BIG row of an image: (|t| - |q|)^2 with
+// |t| >= the image's smallest BIG norm, evaluated with a relative slack; +infinity when the image has no BIG row
+__device__ __forceinline__ double big_lower_bound(const unsigned long long *bigmin, double nq2)
+{
+    const double b2 = __longlong_as_double((long long)*bigmin);
+    if (!(b2 <= 1.7976931348623157e308)) return b2;                 // +infinity
+    const double d = sqrt(b2) * (1.0 - 1e-12) - sqrt(nq2) * (1.0 + 1e-12);
+    return d > 0.0 ? d * d * (1.0 - 1e-9) : 0.0;
+}
+
 __device__ __forceinline__ void list_append(unsigned long long *list, unsigned *count, bool want,
                                             unsigned long long entry)
 {
@@ -693,16 +779,20 @@ __global__ __launch_bounds__(RCN_FB) void k_filter(RerankArgs a)
         int32_t *o = a.out + (size_t)pair * a.out_stride + q;
         *o = -1;
         if (ti.K >= 2) {
-            if (a.all_to_fallback) fb = true;
+            const double nq2 = qi.nrm2[q];
+            const uint2 c = a.all_to_fallback ? make_uint2(0u, 0u) : a.cand[(size_t)pair * a.kq_stride + q];
+            // exact kernel at once: no coarse pass at all; a BIG query row (no fp16 copy: fix_scale); fewer than two ordinary train
+            // rows (the second candidate is a padding / BIG row, whose accumulator says nothing about its distance)
+            if (a.all_to_fallback || !(nq2 < S.thr2) || !(__uint_as_float(c.y & ~a.idx_mask) < 1.0e29f)) fb = true;
             else {
-                const uint2 c = a.cand[(size_t)pair * a.kq_stride + q];
-                const double nq2 = qi.nrm2[q];
                 const double eps = coarse_eps(S, nq2);
+                // the train image's BIG rows never were candidates; every one of them is at least this far from the query
+                const double lb_big = big_lower_bound(ti.bigmin, nq2);
                 const double slack = S.rel_slack * (nq2 + S.n_max * S.n_max);
                 // every row has acc >= trunc(best); both candidates have acc < trunc(second)+quantum
                 const double lo = (double)__uint_as_float(c.x & ~a.idx_mask);
                 const double hi = (double)__uint_as_float((c.y & ~a.idx_mask) + a.idx_mask + 1u);
-                double lb0 = acc_to_d2(S, nq2, lo - eps) - slack;
+                double lb0 = fmin(acc_to_d2(S, nq2, lo - eps) - slack, lb_big);
                 const double ub1 = acc_to_d2(S, nq2, hi + eps) + slack;
                 if (lb0 < 0.0) lb0 = 0.0;
                 surv = ratio_pass(lb0, ub1, a.ratio);
@@ -715,7 +805,7 @@ __global__ __launch_bounds__(RCN_FB) void k_filter(RerankArgs a)
                     const double hi0 = (double)__uint_as_float((c.x & ~a.idx_mask) + a.idx_mask + 1u);
                     const double lo1 = (double)__uint_as_float(c.y & ~a.idx_mask);
                     const double ub0 = acc_to_d2(S, nq2, hi0 + eps) + slack;
-                    double lbnc = acc_to_d2(S, nq2, lo1 - eps) - slack;
+                    double lbnc = fmin(acc_to_d2(S, nq2, lo1 - eps) - slack, lb_big);
                     if (lbnc < 0.0) lbnc = 0.0;
                     if (ub0 >= 0.0 && ub0 < lbnc && ratio_pass(ub0, lbnc, a.ratio)) {
                         *o = (int32_t)(c.x & a.idx_mask);
@@ -806,7 +896,7 @@ __global__ __launch_bounds__(64) void k_rerank_lds(RerankArgs a)
             if (ti.K > 2) {
                 const double nq2 = qi.nrm2[q];
                 const double lbacc = (double)__uint_as_float(c.y & ~a.idx_mask);
-                double lbnc = acc_to_d2(S, nq2, lbacc - coarse_eps(S, nq2)) - S.rel_slack * (nq2 + S.n_max * S.n_max);
+                double lbnc = fmin(acc_to_d2(S, nq2, lbacc - coarse_eps(S, nq2)) - S.rel_slack * (nq2 + S.n_max * S.n_max), big_lower_bound(ti.bigmin, nq2));
                 if (lbnc < 0.0) lbnc = 0.0;
                 ok = acc < lbnc && ratio_pass(acc, lbnc, a.ratio);
             }
@@ -837,7 +927,7 @@ __global__ void k_rerank_generic(RerankArgs a)
         if (ti.K > 2) {
             const double nq2 = qi.nrm2[q];
             const double lbacc = (double)__uint_as_float(c.y & ~a.idx_mask);
-            lbnc = acc_to_d2(S, nq2, lbacc - coarse_eps(S, nq2)) - S.rel_slack * (nq2 + S.n_max * S.n_max);
+            lbnc = fmin(acc_to_d2(S, nq2, lbacc - coarse_eps(S, nq2)) - S.rel_slack * (nq2 + S.n_max * S.n_max), big_lower_bound(ti.bigmin, nq2));
         }
         int res = certify(ea, ia, eb, lbnc, a.ratio);
         if (res == -2) {
@@ -1067,11 +1157,12 @@ static int pad_dim(int D)
 
 static hipError_t launch_rowstats(rcn_ctx *ctx, const float *x, int rows, int D, double *nrm2, unsigned *cnt)
 {
+    ctx->hist_rows += rows;
     unsigned long long *mx = reinterpret_cast<unsigned long long *>(cnt + 2);
     if (D % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0)
-        k_rowstats<true><<<std::max(1, std::min((rows + 15) / 16, 4096)), 256, 0, ctx->stream>>>(x, rows, D, nrm2, cnt, mx);
+        k_rowstats<true><<<std::max(1, std::min((rows + 15) / 16, 4096)), 256, 0, ctx->stream>>>(x, rows, D, nrm2, cnt, mx, cnt + RCN_HIST_WORD);
     else
-        k_rowstats<false><<<std::max(1, std::min((rows + 3) / 4, 4096)), 256, 0, ctx->stream>>>(x, rows, D, nrm2, cnt, mx);
+        k_rowstats<false><<<std::max(1, std::min((rows + 3) / 4, 4096)), 256, 0, ctx->stream>>>(x, rows, D, nrm2, cnt, mx, cnt + RCN_HIST_WORD);
     return hipGetLastError();
 }
 
@@ -1082,7 +1173,8 @@ static void free_image(ImgHost &im)
     if (im.f16) (void)hipFree(im.f16);
     if (im.hn) (void)hipFree(im.hn);
     if (im.nrm2) (void)hipFree(im.nrm2);
-    im.f32 = nullptr; im.f16 = nullptr; im.hn = nullptr; im.nrm2 = nullptr;
+    if (im.bigmin) (void)hipFree(im.bigmin);
+    im.f32 = nullptr; im.f16 = nullptr; im.hn = nullptr; im.nrm2 = nullptr; im.bigmin = nullptr;
 }
 
 static void free_slab(Slab &sl)
@@ -1090,6 +1182,7 @@ static void free_slab(Slab &sl)
     if (sl.f16) (void)hipFree(sl.f16);
     if (sl.hn) (void)hipFree(sl.hn);
     if (sl.nrm2) (void)hipFree(sl.nrm2);
+    if (sl.bigmin) (void)hipFree(sl.bigmin);
     sl = Slab();
 }
 
@@ -1119,12 +1212,13 @@ int rcn_match_release(rcn_ctx *ctx)
 static int ensure_counters(rcn_ctx *ctx)
 {
     if (!ctx->counters.p) {
-        RCN_HIP(ctx->counters.reserve(128));
-        RCN_HIP(hipMemsetAsync(ctx->counters.p, 0, 128, ctx->stream));
+        RCN_HIP(ctx->counters.reserve(RCN_COUNTER_BYTES));
+        RCN_HIP(hipMemsetAsync(ctx->counters.p, 0, RCN_COUNTER_BYTES, ctx->stream));
     }
     return RCN_OK;
 }
-// counters layout: [0] u32 maxabs bits, [2..3] u64 max nrm2 bits, [8 + 2c] fallback / [9 + 2c] survivor count of chunk c
+// counters layout (words): [0] u32 maxabs bits, [2..3] u64 max nrm2 bits, [8 + 2c] fallback / [9 + 2c] survivor count of chunk c,
+// [RCN_HIST_WORD .. + RCN_HIST_BINS) rows per octave of |x|^2
 
 // rcn_match_pair keeps two scratch images resident (ids INT32_MIN, INT32_MIN+1) so that the next
 // call can reuse their allocations; they must not pin D when nothing else is resident.
@@ -1183,6 +1277,7 @@ static int upload_common(rcn_ctx *ctx, int32_t img_id, const float *src, bool sr
         RCN_HIP(hipMalloc(&im.f16, (size_t)Kp * DPa * sizeof(_Float16)));
         RCN_HIP(hipMalloc(&im.hn, (size_t)Kp * sizeof(float)));
         RCN_HIP(hipMalloc(&im.nrm2, (size_t)Kp * sizeof(double)));
+        RCN_HIP(hipMalloc(&im.bigmin, sizeof(unsigned long long)));
     }
     if (K > 0) {
         RCN_HIP(hipMemcpyAsync(im.f32, src, (size_t)K * D * sizeof(float),
@@ -1250,6 +1345,7 @@ int rcn_int_slab_attach(rcn_ctx *ctx, int32_t first_id, int32_t n_images, int32_
         RCN_HIP(hipMalloc(&sl.f16, (size_t)n_slots * Kp * DPa * sizeof(_Float16)));
         RCN_HIP(hipMalloc(&sl.hn, (size_t)n_slots * Kp * sizeof(float)));
         RCN_HIP(hipMalloc(&sl.nrm2, (size_t)n_slots * K * sizeof(double)));
+        RCN_HIP(hipMalloc(&sl.bigmin, (size_t)n_slots * sizeof(unsigned long long)));
         for (size_t i = 0; i < ctx->slabs.size() && si < 0; ++i)
             if (!ctx->slabs[i].live) { ctx->slabs[i] = sl; si = (int)i; }      // reuse a retired position
         if (si < 0) { ctx->slabs.push_back(sl); si = (int)ctx->slabs.size() - 1; }
@@ -1273,6 +1369,7 @@ int rcn_int_slab_attach(rcn_ctx *ctx, int32_t first_id, int32_t n_images, int32_
         im.f16 = sl.f16 + (size_t)i * Kp * DPa;
         im.hn = sl.hn + (size_t)i * Kp;
         im.nrm2 = sl.nrm2 + (size_t)i * K;
+        im.bigmin = sl.bigmin + i;
         auto it = ctx->images.find(first_id + i);
         if (it != ctx->images.end()) im.slot = it->second.slot;
         ctx->images[first_id + i] = im;
@@ -1312,16 +1409,18 @@ template <int DP> static void launch_prepare_batch(rcn_ctx *ctx, const Slab &sl)
     if (sl.conv_n <= 0) return;
     const long nthr = (long)sl.conv_n * sl.Kp * (DP / 8);
     const size_t f = sl.conv_first;
+    k_fill_inf<<<(sl.conv_n + 255) / 256, 256, 0, ctx->stream>>>(sl.bigmin + f, sl.conv_n);
     k_prepare_batch<DP><<<(unsigned)((nthr + 255) / 256), 256, 0, ctx->stream>>>(
         sl.f32 + f * sl.K * sl.D, sl.nrm2 + f * sl.K, sl.conv_n, sl.K, sl.Kp, sl.D, ctx->scale_dev.as<ScaleDev>(),
-        sl.f16 + f * sl.Kp * DP, sl.hn + f * sl.Kp, sl.Ks_dev ? sl.Ks_dev + f : nullptr);
+        sl.f16 + f * sl.Kp * DP, sl.hn + f * sl.Kp, sl.Ks_dev ? sl.Ks_dev + f : nullptr, sl.bigmin + f);
 }
 
 template <int DP> static void launch_prepare(rcn_ctx *ctx, const ImgHost &im)
 {
     const int n = im.Kp * (DP / 8);
+    k_fill_inf<<<1, 64, 0, ctx->stream>>>(im.bigmin, 1);
     k_prepare<DP><<<(n + 255) / 256, 256, 0, ctx->stream>>>(im.f32, im.nrm2, im.K, im.Kp, ctx->D, ctx->scale_dev.as<ScaleDev>(),
-                                                            im.f16, im.hn);
+                                                            im.f16, im.hn, im.bigmin);
 }
 
 // Host copies of the scale constants after a device-side fix (k_fix_scale): one small read behind the stream.
@@ -1333,6 +1432,7 @@ int rcn_int_resolve_scale(rcn_ctx *ctx)
     ctx->scale = ctx->scale_host.s;
     ctx->bias = ctx->scale_host.bias;
     ctx->max_norm = ctx->scale_host.n_max;
+    ctx->thr2 = ctx->scale_host.thr2;
     ctx->scale_on_device = false;
     return RCN_OK;
 }
@@ -1358,16 +1458,34 @@ int rcn_int_prepare_all(rcn_ctx *ctx)
         ctx->scale_on_device = true;
     } else {
         { int rcs = rcn_int_resolve_scale(ctx); if (rcs) return rcs; }
-        unsigned hc[4] = {0, 0, 0, 0};
-        RCN_HIP(hipMemcpyAsync(hc, ctx->counters.p, 16, hipMemcpyDeviceToHost, ctx->stream));
+        {   // the histogram counts every row ever uploaded since the last clear: once replaced images (the per-pair plugin call
+            // re-uploads two scratch images every time) outweigh the resident ones, count the resident rows afresh
+            long resident = 0;
+            for (const auto &kv : ctx->images) resident += kv.second.slab < 0 ? kv.second.K : 0;
+            for (const Slab &sl : ctx->slabs) resident += sl.live ? (long)sl.n * sl.K : 0;
+            if (ctx->hist_rows > 2 * resident + 1024) {
+                unsigned *hist = ctx->counters.as<unsigned>() + RCN_HIST_WORD;
+                RCN_HIP(hipMemsetAsync(hist, 0, RCN_HIST_BINS * sizeof(unsigned), ctx->stream));
+                for (const auto &kv : ctx->images)
+                    if (kv.second.slab < 0 && kv.second.K > 0)
+                        k_norm_hist<<<std::min(64, (kv.second.K + 255) / 256), 256, 0, ctx->stream>>>(kv.second.nrm2, kv.second.K, hist);
+                for (const Slab &sl : ctx->slabs)
+                    if (sl.live) k_norm_hist<<<std::min(1024L, ((long)sl.n * sl.K + 255) / 256), 256, 0, ctx->stream>>>(sl.nrm2, (long)sl.n * sl.K, hist);
+                RCN_HIP(hipGetLastError());
+                ctx->hist_rows = resident;
+            }
+        }
+        std::vector<unsigned> hc(RCN_HIST_WORD + RCN_HIST_BINS, 0u);
+        RCN_HIP(hipMemcpyAsync(hc.data(), ctx->counters.p, RCN_COUNTER_BYTES, hipMemcpyDeviceToHost, ctx->stream));
         RCN_HIP(hipStreamSynchronize(ctx->stream));
         float maxabs;
         double maxn2;
         memcpy(&maxabs, &hc[0], 4);
         memcpy(&maxn2, &hc[2], 8);
-        fix_scale(maxabs, maxn2, DPa, &ctx->scale_host);
+        fix_scale(maxabs, maxn2, hc.data() + RCN_HIST_WORD, DPa, &ctx->scale_host);
         const double s = ctx->scale_host.s, bias = ctx->scale_host.bias;
-        moved = s != ctx->scale || bias != ctx->bias;
+        moved = s != ctx->scale || bias != ctx->bias || ctx->scale_host.thr2 != ctx->thr2;
+        ctx->thr2 = ctx->scale_host.thr2;
         ctx->scale = s;
         ctx->max_norm = ctx->scale_host.n_max;
         ctx->bias = bias;
@@ -1393,7 +1511,7 @@ int rcn_int_prepare_all(rcn_ctx *ctx)
             RCN_HIP(hipGetLastError());
         }
         im.dirty = false;
-        table.push_back(ImgDev{im.f32, im.f16, im.hn, im.nrm2, im.K, im.Kp});
+        table.push_back(ImgDev{im.f32, im.f16, im.hn, im.nrm2, im.bigmin, im.K, im.Kp});
     }
     if (ctx->DP)
         for (size_t si = 0; si < ctx->slabs.size(); ++si) {
@@ -1644,7 +1762,11 @@ int rcn_int_match_grid(rcn_ctx *ctx, const int32_t *pairs_host, int32_t n_pairs,
                     switch (ctx->DP) {
                     case 32: e = launch_coarse<32>(ctx, ca, blocks); break;
                     case 64: e = launch_coarse<64>(ctx, ca, blocks); break;
-                    case 128: e = launch_coarse<128>(ctx, ca, blocks); break;
+                    case 128:
+#ifdef RCN_DIAG
+                        if (ctx->ablate == 1) { e = launch_coarse<128, 1, 0>(ctx, ca, blocks); break; }   // timing only: no top-2 fold
+#endif
+                        e = launch_coarse<128>(ctx, ca, blocks); break;
                     default: e = launch_coarse<256>(ctx, ca, blocks); break;
                     }
                 }
@@ -1742,7 +1864,8 @@ int rcn_desc_clear(rcn_ctx *ctx)
     RCN_HIP(hipSetDevice(ctx->device));
     RCN_HIP(hipStreamSynchronize(ctx->stream));
     rcn_match_release(ctx);
-    if (ctx->counters.p) RCN_HIP(hipMemsetAsync(ctx->counters.p, 0, 128, ctx->stream));
+    if (ctx->counters.p) RCN_HIP(hipMemsetAsync(ctx->counters.p, 0, RCN_COUNTER_BYTES, ctx->stream));
+    ctx->hist_rows = 0;
     return RCN_OK;
 }
 
@@ -1877,7 +2000,7 @@ int rcn_match_last_stats(const rcn_ctx *cctx, rcn_match_stats *out)
     if (ctx->last_stats.err_bound_d2 < 0.0 && ctx->scale_dev.p) {
         { int rcs = rcn_int_resolve_scale(ctx); if (rcs) return rcs; }
         ScaleDev m;
-        fix_scale(1.f, 1.0, ctx->DP ? ctx->DP : 32, &m);                 // c_acc only depends on DP
+        fix_scale(1.f, 1.0, nullptr, ctx->DP ? ctx->DP : 32, &m);        // c_acc only depends on DP
         const double s2 = ctx->scale * ctx->scale, nq = ctx->max_norm, u = std::ldexp(1.0, -11);
         const double hn_max = 0.5 * s2 * nq * nq + ctx->bias;
         const double eps = (2 * u + u * u) * s2 * nq * nq + std::ldexp(1.0, -14) * std::sqrt((double)(ctx->DP ? ctx->DP : 32)) * ctx->scale * 2 * nq +

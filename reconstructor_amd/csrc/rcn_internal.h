@@ -44,6 +44,7 @@ struct ImgDev {
     const _Float16 *f16;   // [Kp][DP]    scaled by the global power of two, 16-B chunks XOR-swizzled
     const float *hn;       // [Kp]        0.5*s^2*|t|^2 + BIAS ; padded rows = huge
     const double *nrm2;    // [K]         |x|^2 in fp64
+    const unsigned long long *bigmin;   // bits of the smallest |x|^2 among this image's BIG rows (+infinity: it has none)
     int32_t K, Kp;
 };
 
@@ -52,6 +53,7 @@ struct ImgHost {
     _Float16 *f16 = nullptr;
     float *hn = nullptr;
     double *nrm2 = nullptr;
+    unsigned long long *bigmin = nullptr;
     int32_t K = 0, Kp = 0;
     int32_t slot = -1;  // row in the device image table
     int32_t slab = -1;  // >= 0: buffers are views into ctx->slabs[slab] (batch upload)
@@ -69,8 +71,15 @@ struct Slab {
     _Float16 *f16 = nullptr;
     float *hn = nullptr;
     double *nrm2 = nullptr;
+    unsigned long long *bigmin = nullptr;   // [n] one word per slot
     bool live = false;
 };
+
+// ctx->counters (words): [0] max |x| bits, [2..3] max |x|^2 bits, [8..15] per-chunk list counts, then the histogram of rows per
+// octave of |x|^2 (match.hip, k_rowstats / fix_scale)
+#define RCN_HIST_BINS 512
+#define RCN_HIST_WORD 64
+#define RCN_COUNTER_BYTES ((RCN_HIST_WORD + RCN_HIST_BINS) * 4)
 
 // The global fp16 scale and what follows from it, kept in HBM: fixed either by the host
 // (rcn_int_prepare_all, after reading the row statistics) or by k_fix_scale on the device (the sharded exchange,
@@ -86,6 +95,7 @@ struct ScaleDev {
     double hn_max;      // s^2 Nmax^2 / 2 + BIAS
     double n_max;       // Nmax
     double rel_slack;   // relative slack for the fp64 evaluation of the bound itself
+    double thr2;        // rows with |x|^2 >= thr2 are BIG rows (fix_scale, match.hip); +infinity: none
     float  sf;          // (float)s
     float  pad;
 };
@@ -112,6 +122,8 @@ struct rcn_ctx {
     double scale = 0.0;      // s, power of two (0 = nothing prepared yet)
     double bias = 0.0;       // BIAS in accumulator units
     double max_norm = 0.0;   // max |x| over resident rows
+    long hist_rows = 0;      // rows counted into the norm histogram since it was last cleared / rebuilt
+    double thr2 = 0.0;       // BIG-row threshold in force (part of the scale: a change reconverts everything)
     DevBuf scale_dev;        // one ScaleDev: what the kernels read
     DevBuf desc_bad;         // desc.hip: keypoints outside their descriptor map since the last rcn_desc_sample_errors
     ScaleDev scale_host;     // staging of the host-fixed scale (uploaded asynchronously)

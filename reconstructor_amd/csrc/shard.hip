@@ -387,14 +387,18 @@ int rcn_shard_exchange(rcn_shard *sh, const float *local_desc_dev, const int32_t
     if (ragged)      // now with every image's own row count
         rc = rcn_int_slab_attach(ctx, 0, sh->n_images, world * per, landing, K, D, sh->rank * per, cnt, &sh->slab, sh->all_K.data(), counts);
     if (rc) return rc;
+    // the histogram of row norms describes THIS exchange's rows (the maxima are running ones): cleared, filled by the local
+    // statistics, summed over the ranks
+    unsigned *cw = ctx->counters.as<unsigned>();
+    RCN_HIP(hipMemsetAsync(cw + RCN_HIST_WORD, 0, RCN_HIST_BINS * sizeof(unsigned), st));
     rc = rcn_int_slab_rowstats(ctx, sh->slab, sh->rank * per, cnt);
     if (rc) return rc;
     // global scale statistics: max |x| (fp32 bits) and max |x|^2 (fp64 bits); non-negative floats order like
     // their bit patterns, so an unsigned max is the floating-point max
-    unsigned *cw = ctx->counters.as<unsigned>();
     RCN_NCCL(ncclGroupStart());
     RCN_NCCL(ncclAllReduce(cw, cw, 1, ncclUint32, ncclMax, sh->comm, st));
     RCN_NCCL(ncclAllReduce(cw + 2, cw + 2, 1, ncclUint64, ncclMax, sh->comm, st));
+    RCN_NCCL(ncclAllReduce(cw + RCN_HIST_WORD, cw + RCN_HIST_WORD, RCN_HIST_BINS, ncclUint32, ncclSum, sh->comm, st));
     RCN_NCCL(ncclGroupEnd());
     // the scale is fixed ON THE DEVICE behind the all-reduce (k_fix_scale): the host neither reads the statistics nor
     // waits; converts the local block, builds the image table (uploaded only when it changed)
@@ -411,6 +415,7 @@ int rcn_shard_exchange(rcn_shard *sh, const float *local_desc_dev, const int32_t
     RCN_NCCL(ncclAllGather(f16 + sh->rank * blk16, f16, blk16, ncclChar, sh->comm, st));
     RCN_NCCL(ncclAllGather(hn + sh->rank * blkhn, hn, blkhn, ncclChar, sh->comm, st));
     RCN_NCCL(ncclAllGather(n2 + sh->rank * blkn2, n2, blkn2, ncclChar, sh->comm, st));
+    RCN_NCCL(ncclAllGather(sl.bigmin + (size_t)sh->rank * per, sl.bigmin, (size_t)per, ncclUint64, sh->comm, st));     // smallest BIG-row norm per image
     RCN_NCCL(ncclGroupEnd());
     // fp32 rows: on the side stream with their own communicator, behind the fp16 payload (so the two do
     // not share the links while the coarse kernel is waiting) and hence behind (a) the local block being

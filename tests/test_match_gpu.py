@@ -290,3 +290,39 @@ def test_cfg2_full_grid_equals_the_oracle(matcher):
     assert len(bad) == 0, ("pairs whose table differs from the oracle's", g["pairs"][bad][:8])
     assert int(c.sum()) == int(g["matches_found"])
     matcher.clear()
+
+
+def test_out_of_scale_rows_are_set_aside_not_followed(matcher):
+    """The fp16 scale of the coarse pass is one power of two for every resident image.  Rows far out of scale -- here one image
+    2^30 times larger than the rest, as query and as train image, plus three stray huge rows inside an ordinary image -- are
+    set aside as BIG rows (fix_scale's histogram of row norms): exact kernel as queries, never coarse candidates, a norm bound
+    in everybody else's certificates.  The grid stays equal to the oracle; the pairs that do not involve the large image equal
+    the run without it; and the ordinary rows keep their certificates instead of all falling back (what following the largest
+    row with the scale would cost: every fp16 copy underflows)."""
+    n, K = 40, 120                                         # 4800 rows, 124 of them out of scale (the budget is one row in eight)
+    ims = synth.descriptor_set("sift", n, K, n_world=400, seed=23)
+    pairs = orc.all_pairs(n).astype(np.int32)
+    matcher.clear()
+    for i, im in enumerate(ims):
+        matcher.upload(i, im)
+    base, _ = matcher.match_grid(pairs, K)
+    st0 = matcher.stats()
+    big = [im.copy() for im in ims]
+    big[17] = big[17] * np.float32(2.0 ** 30)              # a whole image out of scale: query in (17, j), train in (i, 17)
+    big[3][[5, 60, 119]] *= np.float32(2.0 ** 28)          # three stray rows of an ordinary image
+    big[3][61] = big[3][60]                                # ... one of them duplicated: a BIG query whose nearest neighbour is BIG
+    matcher.clear()
+    for i, im in enumerate(big):
+        matcher.upload(i, im)
+    out, counts = matcher.match_grid(pairs, K)
+    st1 = matcher.stats()
+    exp, ec = orc.match_grid(big, pairs, threads=0)
+    assert np.array_equal(out, exp) and np.array_equal(counts, ec)
+    keep = ((pairs != 17) & (pairs != 3)).all(1)
+    assert np.array_equal(out[keep], base[keep])
+    # to the exact kernel: BIG query rows (image 17's rows in its 22 pairs as query, image 3's four rows in its 36 pairs) and
+    # every query row of the 17 pairs whose TRAIN image is image 17 (no ordinary train row to propose)
+    assert st1["rows_exact_fallback"] <= st0["rows_exact_fallback"] + (n - 1) * K + 4 * (n - 1 - 3) + 64
+    assert st1["rows_exact_fallback"] >= (n - 1) * K
+    print("fallback rows: uniform %d, with out-of-scale rows %d of %d" % (st0["rows_exact_fallback"], st1["rows_exact_fallback"], st1["rows_total"]))
+    matcher.clear()
