@@ -1064,7 +1064,7 @@ template <int NT> __device__ __forceinline__ void trail_update(double *L, int r0
 }
 
 #ifdef RCN_STAMP   // diagnostic build only (tools/chol_diag_bench.hip): phase time stamps
-__device__ unsigned long long g_stamps[32];
+__device__ unsigned long long g_stamps[64];
 #define STAMP(i) do { __syncthreads(); if (threadIdx.x == 0) g_stamps[i] = clock64(); } while (0)
 #else
 #define STAMP(i)
@@ -1081,9 +1081,8 @@ __global__ __launch_bounds__(64 * CDW) void k_chol_diag(double *S, int ld, int k
     gate_enter(g);
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     double *L = reinterpret_cast<double *>(smem_raw);  // [128][DL]
-    __shared__ double rd[NB + 2 + 64];                  // reciprocals of L's diagonal; [NB] = breakdown flag; [NB+2..] pivot column line
+    __shared__ double rd[NB + 2];                       // reciprocals of L's diagonal; [NB] = breakdown flag
     double *misc = rd + NB;                             // (16-byte multiple keeps the dynamic base aligned)
-    double *colb = rd + NB + 2;
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     double *A = S + ((size_t)kb * NB) * ld + (size_t)kb * NB;
     if (t == 0) misc[0] = 0.0;
@@ -1105,58 +1104,97 @@ __global__ __launch_bounds__(64 * CDW) void k_chol_diag(double *S, int ld, int k
     }
     __syncthreads();
     STAMP(0);
-    // 1a. 16x16 leaf by wave 0 alone: lane l holds row l in registers; the pivot column is
-    //     broadcast through a small LDS line (one ds_write + uniform-address reads per pivot;
-    //     LDS operations of one wave are ordered, so no workgroup barrier inside)
+    // 1a. 16x16 leaf by wave 0 alone, on the matrix pipe.  The block lives in ONE accumulator tile S (all 256 entries,
+    //     kept symmetric) and is eliminated four columns at a time:
+    //       - the 4x4 diagonal block is pulled into wave-uniform values (v_readlane) and factored AND inverted there,
+    //         ~60 scalar-shaped f64 operations; M = (its factor)^-1, padded with zeros, becomes an MFMA A operand;
+    //       - M x S[p] gives the four columns of L for ALL sixteen rows at once, already in operand layout
+    //         (lane (row, k)), and S -= P P^T is one more MFMA;
+    //       - the identity, carried along as extra rows (T2 = its transpose), undergoes the same column operations and
+    //         ends as L^-T: the leaf inverse costs two more MFMAs per step instead of a 136-term substitution.
+    //     Entries of S and T2 left of the active columns turn into rounding residue and are never read for a stored
+    //     value.  (Round 2's leaf kept one row per lane and did all of this on the vector ALU: ~1200 instructions and
+    //     8.6k cycles per leaf, the longest serial stretch of the factorisation's critical chain.)
+    unsigned mk[10];      // slot of M[i][k] (i >= k, row-major over the lower triangle) -> all-ones in the lane (i, k) that holds it
+    {
+        const int c = lane & 15, g = lane >> 4;
+#pragma unroll
+        for (int i = 0, slot = 0; i < 4; ++i)
+#pragma unroll
+            for (int k = 0; k <= i; ++k, ++slot) mk[slot] = (c == i && g == k) ? 0xFFFFFFFFu : 0u;
+    }
     auto leaf_factor = [&](int c0) {
-            const int row = lane & (LB - 1);
-            double a[LB];
+            double *Lb = L + c0 * DL + c0;
+            const int c = lane & 15, g = lane >> 4;
+            f64x4 Sm, T2;
 #pragma unroll
-            for (int c = 0; c < LB; ++c) a[c] = L[(c0 + row) * DL + c0 + c];
-            bool ok = true;
-#pragma unroll
-            for (int j = 0; j < LB; ++j) {
-                colb[lane] = a[j];
-                const double djj = colb[j];
-                if (!(djj > 0.0) || !isfinite(djj)) ok = false;      // wave-uniform
-                // 1/sqrt and sqrt from v_rsq_f64 + Newton steps
-                double inv = __builtin_amdgcn_rsq(djj);
-                inv = inv * (1.5 - 0.5 * djj * inv * inv);
-                double dj = djj * inv;
-                dj = fma(0.5 * inv, fma(-dj, dj, djj), dj);
-                inv = fma(inv, fma(-dj, inv, 1.0), inv);
-                a[j] = row == j ? dj : a[j] * inv;
-                if (lane == 0) rd[c0 + j] = inv;
-                // every lane updates its whole row (entries right of the diagonal are scratch):
-                //   a[c] -= L[row][j] * L[c][j],   L[c][j] = colb[c] * inv
-                const double tj = a[j] * inv;
-#pragma unroll
-                for (int c = j + 1; c < LB; ++c) a[c] = fma(-tj, colb[c], a[c]);
+            for (int r = 0; r < 4; ++r) {
+                const int i = g + 4 * r;
+                Sm[r] = Lb[(i > c ? i : c) * DL + (i > c ? c : i)];
+                T2[r] = i == c ? 1.0 : 0.0;
             }
+            double Lc[4], Yc[4];
+            double last = 0.0;
+            const f64x4 zero4 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                auto pick = [&](int k, int j) {      // S[4p+k][4p+j] as a uniform value
+                    const int src = 4 * p + j + 16 * k;
+                    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(Sm[p]), src),
+                                            __builtin_amdgcn_readlane(__double2loint(Sm[p]), src));
+                };
+                // 1/sqrt(d): v_rsq_f64 is good to 2^-24 (measured over 2^26 arguments), one cubic step
+                // y (1 + e/2 + 3 e^2/8), e = 1 - d y^2, leaves |1 - d y^2| <= 2.8e-16 in four dependent operations.
+                // A pivot that is not positive and finite makes y a NaN, and the NaN reaches every later pivot.
+                auto rsq3 = [&](double d) {
+                    const double y = __builtin_amdgcn_rsq(d);
+                    const double e = fma(-(d * y), y, 1.0);
+                    return fma(y * e, fma(0.375, e, 0.5), y);
+                };
+                // the A operand of the solve, lane (i = c, k = g) = M[i][k], assembled by mask as each value appears
+                // (selects here turn into divergent branches around the scalar chain)
+                unsigned mlo = 0, mhi = 0;
+                auto put = [&](double v, int slot) { mlo |= (unsigned)__double2loint(v) & mk[slot]; mhi |= (unsigned)__double2hiint(v) & mk[slot]; };
+                double d00 = pick(0, 0), d10 = pick(1, 0), d20 = pick(2, 0), d30 = pick(3, 0), d11 = pick(1, 1),
+                       d21 = pick(2, 1), d31 = pick(3, 1), d22 = pick(2, 2), d32 = pick(3, 2), d33 = pick(3, 3);
+                const double i0 = rsq3(d00);
+                put(i0, 0);
+                const double l10 = d10 * i0, l20 = d20 * i0, l30 = d30 * i0;
+                d11 = fma(-l10, l10, d11); d21 = fma(-l20, l10, d21); d31 = fma(-l30, l10, d31);
+                d22 = fma(-l20, l20, d22); d32 = fma(-l30, l20, d32); d33 = fma(-l30, l30, d33);
+                const double i1 = rsq3(d11);
+                put(i1, 2);
+                const double m10 = -i1 * (l10 * i0);
+                put(m10, 1);
+                const double l21 = d21 * i1, l31 = d31 * i1;
+                d22 = fma(-l21, l21, d22); d32 = fma(-l31, l21, d32); d33 = fma(-l31, l31, d33);
+                const double i2 = rsq3(d22);
+                put(i2, 5);
+                const double m21 = -i2 * (l21 * i1), m20 = -i2 * fma(l21, m10, l20 * i0);
+                put(m21, 4); put(m20, 3);
+                const double l32 = d32 * i2;
+                d33 = fma(-l32, l32, d33);
+                const double i3 = rsq3(d33);
+                const double m32 = -i3 * (l32 * i2), m31 = -i3 * fma(l32, m21, l31 * i1);
+                const double m30 = -i3 * fma(l32, m20, fma(l31, m10, l30 * i0));
+                put(i3, 9); put(m32, 8); put(m31, 7); put(m30, 6);
+                last = i3;
+                const double mop = __hiloint2double((int)mhi, (int)mlo);
+                const f64x4 X = __builtin_amdgcn_mfma_f64_16x16x4f64(mop, Sm[p], zero4, 0, 0, 0);   // [0]: lane (j, g) = L[j][4p+g]
+                if (p < 3) Sm = __builtin_amdgcn_mfma_f64_16x16x4f64(-X[0], X[0], Sm, 0, 0, 0);
+                const f64x4 Y = __builtin_amdgcn_mfma_f64_16x16x4f64(mop, T2[p], zero4, 0, 0, 0);   // [0]: lane (e, g) = L^-T[e][4p+g]
+                if (p < 3) T2 = __builtin_amdgcn_mfma_f64_16x16x4f64(-X[0], Y[0], T2, 0, 0, 0);
+                Lc[p] = X[0]; Yc[p] = Y[0];
+            }
+            const bool ok = isfinite(last);
             if (!ok && lane == 0) misc[0] = 1.0;
-            if (lane < LB) {
+            // lane (j, g), column m = 4p + g: the factor at and below the diagonal, the inverse (transposed) above it,
+            // and the reciprocal of the diagonal in rd
 #pragma unroll
-                for (int c = 0; c < LB; ++c)
-                    if (c <= row) L[(c0 + row) * DL + c0 + c] = a[c];
-            }
-            // leaf inverse, lane c -> column c of D^-1 by forward substitution; row r of the
-            // factor comes back as uniform-address LDS reads
-            {
-                const double *Lw = L + c0 * DL + c0;
-                double x[LB];
-#pragma unroll
-                for (int r = 0; r < LB; ++r) {
-                    double s0 = r == row ? 1.0 : 0.0, s1 = 0.0;      // two chains halve the dependent depth
-#pragma unroll
-                    for (int m = 0; m + 1 < r; m += 2) { s0 = fma(-Lw[r * DL + m], x[m], s0); s1 = fma(-Lw[r * DL + m + 1], x[m + 1], s1); }
-                    if (r & 1) s0 = fma(-Lw[r * DL + r - 1], x[r - 1], s0);
-                    x[r] = (s0 + s1) * rd[c0 + r];
-                }
-                if (lane < LB) {
-#pragma unroll
-                    for (int r = 1; r < LB; ++r)
-                        if (r > row) L[(c0 + row) * DL + c0 + r] = x[r];   // transposed, strictly upper
-                }
+            for (int p = 0; p < 4; ++p) {
+                const int m = 4 * p + g;
+                Lb[c * DL + m] = m <= c ? Lc[p] : Yc[p];
+                if (m == c) rd[c0 + c] = Yc[p];
             }
             };
     if (w == 0) leaf_factor(0);
@@ -1188,7 +1226,7 @@ __global__ __launch_bounds__(64 * CDW) void k_chol_diag(double *S, int ld, int k
             }
         }
         __syncthreads();
-        STAMP(2);
+        STAMP(32 + 2 * (c0 / LB));
         // 1c. trailing square -= panel panel^T, lower 16x16 tiles on MFMA: the accumulator starts
         //     as the C tile and the A operand is negated.  LOOKAHEAD: wave 0 takes tile (0,0) -- the next
         //     leaf's diagonal block -- and goes straight on to factor and invert that leaf while waves
@@ -1216,7 +1254,7 @@ __global__ __launch_bounds__(64 * CDW) void k_chol_diag(double *S, int ld, int k
             if (w == 0) leaf_factor(r0);
         }
         __syncthreads();
-        STAMP(3);
+        STAMP(33 + 2 * (c0 / LB));
     }
     STAMP(13);
     // The factor of the diagonal tile itself is read by nobody (panels and triangular solves use its

@@ -25,11 +25,17 @@ int main()
         k_chol_diag<<<1, 64 * CDW, NB * DL * 8>>>(dA, n, 0, dLinv, dflag, rep == 0, Gate{nullptr, 0, nullptr, 0, nullptr, 0, dflag});
         (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
         float ms; (void)hipEventElapsedTime(&ms, e0, e1);
-        unsigned long long st[32];
+        unsigned long long st[64];
         (void)hipMemcpyFromSymbol(st, HIP_SYMBOL(g_stamps), sizeof(st));
         printf("rep %d: %.1f us total; ticks(100MHz?) ", rep, ms * 1e3);
         printf("factor(all leaves+trsm+trail)=%llu | store=", st[13] - st[0]);
         printf("%llu leafinv=%llu blockinv=%llu out=%llu\n", st[14] - st[13], st[15] - st[14], st[16] - st[15], st[17] - st[16]);
+        if (rep == 3) {
+            printf("  first leaf %llu;", st[1] - st[0]);
+            unsigned long long prev = st[1];
+            for (int i = 0; i < 7; ++i) { printf(" [solve %llu, update+leaf %llu]", st[32 + 2 * i] - prev, st[33 + 2 * i] - st[32 + 2 * i]); prev = st[33 + 2 * i]; }
+            printf("\n");
+        }
     }
     // check: L L^T == A and Linv L == I (one more run that stores L)
     (void)hipMemcpy(dA, A.data(), n * n * 8, hipMemcpyHostToDevice);
