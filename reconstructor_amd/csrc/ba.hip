@@ -1028,10 +1028,6 @@ __device__ __forceinline__ double rdlane(double v, int src)
     return __longlong_as_double(((unsigned long long)hi << 32) | lo);
 }
 
-__device__ __forceinline__ double dinv_at(const double *L, const double *rd, int i, int r, int c)
-{
-    return r == c ? rd[LB * i + r] : L[(LB * i + c) * DL + LB * i + r];
-}
 
 template <int NT> __device__ __forceinline__ void trail_update(double *L, int r0, int c0, int t)
 {
@@ -1063,6 +1059,41 @@ template <int NT> __device__ __forceinline__ void trail_update(double *L, int r0
         }
 }
 
+// Pieces of the doubling steps of k_chol_diag (2c): one 16x16 output tile per call, trip counts compile-time.
+// pass 1, T tile (rows rs.., 16-column group CT) of  L_hi,lo * Dinv_lo : Dinv_lo is lower triangular, so k starts at 16 CT
+template <int HALF, int CT>
+__device__ __forceinline__ f64x4 dbl_pass1(const double *L, int lo0, int rs, int lane)
+{
+    f64x4 a4 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int kk = 16 * CT; kk < HALF; kk += 4) {
+        const int k = kk + (lane >> 4), c = 16 * CT + (lane & 15);
+        double bb = L[(lo0 + k) * DL + lo0 + c];
+        if (kk < 16 * (CT + 1)) bb = c <= k ? bb : 0.0;       // only the diagonal 16-block of the operand needs the mask
+        a4 = __builtin_amdgcn_mfma_f64_16x16x4f64(L[(rs + (lane & 15)) * DL + lo0 + k], bb, a4, 0, 0, 0);
+    }
+    return a4;
+}
+// pass 2, X tile (16-row group RT of the hi part, the 16 columns at Tcol) of  -Dinv_hi * T : k ends with the row group
+template <int RT>
+__device__ __forceinline__ f64x4 dbl_pass2(const double *L, const double *Tcol, int hi0, int lane)
+{
+    f64x4 a4 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int kk = 0; kk < 16 * (RT + 1); kk += 4) {
+        const int k = kk + (lane >> 4), r = 16 * RT + (lane & 15);
+        double aa = -L[(hi0 + r) * DL + hi0 + k];
+        if (kk >= 16 * RT) aa = k <= r ? aa : 0.0;
+        a4 = __builtin_amdgcn_mfma_f64_16x16x4f64(aa, Tcol[k * DL + (lane & 15)], a4, 0, 0, 0);
+    }
+    return a4;
+}
+__device__ __forceinline__ void tile_to_lds(double *dst, f64x4 a4, int lane)
+{
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) dst[((lane >> 4) + 4 * reg) * DL + (lane & 15)] = a4[reg];
+}
+
 #ifdef RCN_STAMP   // diagnostic build only (tools/chol_diag_bench.hip): phase time stamps
 __device__ unsigned long long g_stamps[64];
 #define STAMP(i) do { __syncthreads(); if (threadIdx.x == 0) g_stamps[i] = clock64(); } while (0)
@@ -1072,16 +1103,16 @@ __device__ unsigned long long g_stamps[64];
 // ring_done / ring_need: in the chain-bound steps of the factorisation (the host decides) this kernel also does the gate's
 // job on its way out -- by then the bulk update the first trailing column of this step waits for has long finished, so
 // the check is free and the chain loses a 5-us kernel; ring_need < 0: nothing to wait for here.
-#define CDW 4          // waves of the diagonal kernel: wave 0 owns the leaves, the others the matrix work between them.  Four, one
-                       // per SIMD: the unrolled leaf code wants ~340 registers (eight waves at 256 spill 400 bytes per lane), and
-                       // the doubling steps below deal their tiles to exactly four waves
+#define CDW 8          // waves of the diagonal kernel: wave 0 owns the leaves, the others the matrix work between them.  Eight since the
+                       // leaf moved to the matrix pipe (136 registers; the vector-ALU leaf of round 2 wanted ~340 and spilled at
+                       // eight waves); the doubling steps (2c) deal their tiles to exactly eight waves
 __global__ __launch_bounds__(64 * CDW) void k_chol_diag(double *S, int ld, int kb, double *Linv, int *flag, int store_L, Gate g)
 {
     __builtin_amdgcn_s_setprio(3);
     gate_enter(g);
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     double *L = reinterpret_cast<double *>(smem_raw);  // [128][DL]
-    __shared__ double rd[NB + 2];                       // reciprocals of L's diagonal; [NB] = breakdown flag
+    __shared__ double rd[NB + 2];                       // L's diagonal (the leaves hold their inverse in place); [NB] = breakdown flag
     double *misc = rd + NB;                             // (16-byte multiple keeps the dynamic base aligned)
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     double *A = S + ((size_t)kb * NB) * ld + (size_t)kb * NB;
@@ -1188,13 +1219,14 @@ __global__ __launch_bounds__(64 * CDW) void k_chol_diag(double *S, int ld, int k
             }
             const bool ok = isfinite(last);
             if (!ok && lane == 0) misc[0] = 1.0;
-            // lane (j, g), column m = 4p + g: the factor at and below the diagonal, the inverse (transposed) above it,
-            // and the reciprocal of the diagonal in rd
+            // lane (c, g), m = 4p + g: the INVERSE goes in place (entry [m][c], m >= c) -- every later reader of this block
+            // (the solves below, the doubling steps, the output) wants the inverse; the factor itself is only ever stored
+            // on request and waits transposed above the diagonal ([m][c] = L[c][m], m < c), its diagonal in rd
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
                 const int m = 4 * p + g;
-                Lb[c * DL + m] = m <= c ? Lc[p] : Yc[p];
-                if (m == c) rd[c0 + c] = Yc[p];
+                Lb[m * DL + c] = m >= c ? Yc[p] : Lc[p];
+                if (m == c) rd[c0 + c] = Lc[p];
             }
             };
     if (w == 0) leaf_factor(0);
@@ -1218,7 +1250,7 @@ __global__ __launch_bounds__(64 * CDW) void k_chol_diag(double *S, int ld, int k
                 for (int kk = 0; kk < LB; kk += 4) {
                     const int k = kk + (lane >> 4), c = lane & 15;
                     const double a = At[(lane & 15) * DL + k];
-                    const double b = k <= c ? dinv_at(L, rd, leaf, c, k) : 0.0;
+                    const double b = k <= c ? L[(LB * leaf + c) * DL + LB * leaf + k] : 0.0;
                     acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
                 }
 #pragma unroll
@@ -1262,7 +1294,7 @@ __global__ __launch_bounds__(64 * CDW) void k_chol_diag(double *S, int ld, int k
     if (store_L)
         for (int i = t; i < NB * NB; i += 64 * CDW) {
             const int r = i / NB, c = i % NB;
-            if (c <= r) A[(size_t)r * ld + c] = L[r * DL + c];
+            if (c <= r) A[(size_t)r * ld + c] = r / LB != c / LB ? L[r * DL + c] : r == c ? rd[r] : L[c * DL + r];
         }
     STAMP(14);
     // 2a. (leaf inverses were produced by wave 0 right after each leaf factorization)
@@ -1277,7 +1309,7 @@ __global__ __launch_bounds__(64 * CDW) void k_chol_diag(double *S, int ld, int k
 #pragma unroll
         for (int kk = 0; kk < LB; kk += 4) {       // T = L_ij * Dinv_j
             const int k = kk + (lane >> 4), c = lane & 15;
-            const double b = c <= k ? dinv_at(L, rd, j, k, c) : 0.0;
+            const double b = c <= k ? L[(LB * j + k) * DL + LB * j + c] : 0.0;
             acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Bt[(lane & 15) * DL + k], b, acc, 0, 0, 0);
         }
 #pragma unroll
@@ -1286,98 +1318,66 @@ __global__ __launch_bounds__(64 * CDW) void k_chol_diag(double *S, int ld, int k
 #pragma unroll
         for (int kk = 0; kk < LB; kk += 4) {       // X = -Dinv_i * T
             const int k = kk + (lane >> 4), r = lane & 15;
-            const double a = k <= r ? -dinv_at(L, rd, i, r, k) : 0.0;
+            const double a = k <= r ? -L[(LB * i + r) * DL + LB * i + k] : 0.0;
             acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Bt[k * DL + (lane & 15)], acc, 0, 0, 0);
         }
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) Bt[((lane >> 4) + 4 * reg) * DL + (lane & 15)] = acc[reg];
     }
     __syncthreads();
-    // 2c. two more doubling steps, 32 -> 64 -> 128, each  X_hi,lo = -Dinv_hi * (L_hi,lo * Dinv_lo)  in place:
-    //     pass 1 gives every wave whole ROW strips of L_hi,lo (all their columns are read before the strip
-    //     is overwritten by T), pass 2 whole COLUMN strips of T; three workgroup barriers per step.
-    //     An entry of an already inverted diagonal part is dinv_at inside a 16-leaf and in place otherwise.
-    auto inv_at = [&](int r, int c) -> double {   // c <= r, both inside an inverted diagonal part
-        return (r / LB == c / LB) ? dinv_at(L, rd, r / LB, r % LB, c % LB) : L[r * DL + c];
+    // 2c. two more doubling steps, 32 -> 64 -> 128, each  X_hi,lo = -Dinv_hi * (L_hi,lo * Dinv_lo):  T = L_hi,lo * Dinv_lo goes
+    //     to the mirror block ABOVE the diagonal (rows lo.., columns hi..: scratch nobody else reads), so a wave stores its
+    //     tile as soon as it has it; one barrier; X = -Dinv_hi * T is written straight over L_hi,lo (all reads of it ended
+    //     at that barrier); one barrier.  Eight 16x16 tiles at the first level, one per wave; sixteen at the second, two per
+    //     wave, paired so that the triangular operand gives both waves of a strip the same number of k-steps (1+4, 2+3).
+    //     Trip counts are compile-time: a runtime k-range here cost 2.8x.
+    {
+        const int blk = w >> 2, s0 = (w >> 1) & 1, q = w & 1;
+        const int lo0 = 64 * blk, hi0 = lo0 + 32;
+        {
+            const f64x4 a4 = q == 0 ? dbl_pass1<32, 0>(L, lo0, hi0 + 16 * s0, lane) : dbl_pass1<32, 1>(L, lo0, hi0 + 16 * s0, lane);
+            tile_to_lds(L + (lo0 + 16 * s0) * DL + hi0 + 16 * q, a4, lane);
+        }
+        __syncthreads();
+        {
+            const f64x4 a4 = q == 0 ? dbl_pass2<0>(L, L + lo0 * DL + hi0 + 16 * s0, hi0, lane) : dbl_pass2<1>(L, L + lo0 * DL + hi0 + 16 * s0, hi0, lane);
+            tile_to_lds(L + (hi0 + 16 * q) * DL + lo0 + 16 * s0, a4, lane);
+        }
+        __syncthreads();
+    }
+    double *out = Linv + (size_t)kb * NB * NB;
+    // (the strict upper triangle of every Linv tile is zeroed once per solve and never written, except for the zero beside
+    // an odd diagonal entry.)  The two 64x64 diagonal blocks are final here: their stores drain under the last level.
+    auto rows_out = [&](int r_first, int c_first) {      // 64 rows x 64 columns from (r_first, c_first): lane -> 2 columns, 32 lanes a row
+        const int c = c_first + 2 * (lane & 31);
+#pragma unroll 8
+        for (int qq = 0; qq < 64 / (2 * CDW); ++qq) {
+            const int r = r_first + 2 * (w + CDW * qq) + (lane >> 5);
+            const double v0 = L[r * DL + c], v1 = L[r * DL + c + 1];
+            if (c <= r) *reinterpret_cast<f64x2 *>(out + (size_t)r * NB + c) = (f64x2){v0, c + 1 <= r ? v1 : 0.0};
+        }
     };
-#pragma unroll
-    for (int half = 32; half <= 64; half *= 2) {
-        const int nblk2 = NB / (2 * half);                 // off-diagonal blocks at this level: 2, then 1
-        const int strips = half / 16, wpb = 4 / nblk2;     // 16-wide strips per block; waves per block: 2, then 4
-        const int blk = w / wpb, wl = w % wpb;
-        const int lo0 = 2 * half * blk, hi0 = lo0 + half;  // the block is rows hi0.., columns lo0..
-        f64x4 acc[4][4];                                   // [own strip][tile across]; at most 2 x 2 or 1 x 4 used
-        const int own = strips / wpb;                      // strips per wave: 1
-        // pass 1: T = B * Dinv_lo, row strips
-#pragma unroll
-        for (int s0 = 0; s0 < own; ++s0) {
-            const int rs = hi0 + 16 * (wl * own + s0);
-#pragma unroll
-            for (int ct = 0; ct < 4; ++ct) {
-                if (ct >= strips) break;
-                f64x4 a4 = {0.0, 0.0, 0.0, 0.0};
-                for (int kk = 16 * ct; kk < half; kk += 4) {      // Dinv_lo is lower triangular: k >= column
-                    const int k = kk + (lane >> 4), c = 16 * ct + (lane & 15);
-                    const double bb = c <= k ? inv_at(lo0 + k, lo0 + c) : 0.0;
-                    a4 = __builtin_amdgcn_mfma_f64_16x16x4f64(L[(rs + (lane & 15)) * DL + lo0 + k], bb, a4, 0, 0, 0);
-                }
-                acc[s0][ct] = a4;
-            }
+    rows_out(0, 0);
+    rows_out(64, 64);
+    {
+        const int s0 = w >> 1, q = w & 1;
+        {
+            const f64x4 a4 = q == 0 ? dbl_pass1<64, 0>(L, 0, 64 + 16 * s0, lane) : dbl_pass1<64, 1>(L, 0, 64 + 16 * s0, lane);
+            const f64x4 b4 = q == 0 ? dbl_pass1<64, 3>(L, 0, 64 + 16 * s0, lane) : dbl_pass1<64, 2>(L, 0, 64 + 16 * s0, lane);
+            tile_to_lds(L + (16 * s0) * DL + 64 + 16 * q, a4, lane);
+            tile_to_lds(L + (16 * s0) * DL + 64 + 16 * (3 - q), b4, lane);
         }
         __syncthreads();
-#pragma unroll
-        for (int s0 = 0; s0 < own; ++s0) {
-            const int rs = hi0 + 16 * (wl * own + s0);
-#pragma unroll
-            for (int ct = 0; ct < 4; ++ct) {
-                if (ct >= strips) break;
-#pragma unroll
-                for (int reg = 0; reg < 4; ++reg) L[(rs + (lane >> 4) + 4 * reg) * DL + lo0 + 16 * ct + (lane & 15)] = acc[s0][ct][reg];
-            }
-        }
-        __syncthreads();
-        // pass 2: X = -Dinv_hi * T, column strips
-#pragma unroll
-        for (int s0 = 0; s0 < own; ++s0) {
-            const int cs = lo0 + 16 * (wl * own + s0);
-#pragma unroll
-            for (int rt = 0; rt < 4; ++rt) {
-                if (rt >= strips) break;
-                f64x4 a4 = {0.0, 0.0, 0.0, 0.0};
-                for (int kk = 0; kk < 16 * (rt + 1); kk += 4) {   // Dinv_hi is lower triangular: k <= row
-                    const int k = kk + (lane >> 4), r = 16 * rt + (lane & 15);
-                    const double aa = k <= r ? -inv_at(hi0 + r, hi0 + k) : 0.0;
-                    a4 = __builtin_amdgcn_mfma_f64_16x16x4f64(aa, L[(hi0 + k) * DL + cs + (lane & 15)], a4, 0, 0, 0);
-                }
-                acc[s0][rt] = a4;
-            }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int s0 = 0; s0 < own; ++s0) {
-            const int cs = lo0 + 16 * (wl * own + s0);
-#pragma unroll
-            for (int rt = 0; rt < 4; ++rt) {
-                if (rt >= strips) break;
-#pragma unroll
-                for (int reg = 0; reg < 4; ++reg) L[(hi0 + 16 * rt + (lane >> 4) + 4 * reg) * DL + cs + (lane & 15)] = acc[s0][rt][reg];
-            }
+        {
+            const f64x4 a4 = q == 0 ? dbl_pass2<0>(L, L + 64 + 16 * s0, 64, lane) : dbl_pass2<1>(L, L + 64 + 16 * s0, 64, lane);
+            const f64x4 b4 = q == 0 ? dbl_pass2<3>(L, L + 64 + 16 * s0, 64, lane) : dbl_pass2<2>(L, L + 64 + 16 * s0, 64, lane);
+            tile_to_lds(L + (64 + 16 * q) * DL + 16 * s0, a4, lane);
+            tile_to_lds(L + (64 + 16 * (3 - q)) * DL + 16 * s0, b4, lane);
         }
         __syncthreads();
     }
     STAMP(16);
-    double *out = Linv + (size_t)kb * NB * NB;
-    // (the strict upper triangle of every Linv tile is zeroed once per solve and never written, except
-    // for the zero beside an odd diagonal entry.)  A thread moves two neighbouring columns of CDW rows apart.
-    {
-        const int c = 2 * (t & 63);
-        auto at = [&](int r, int cc) -> double {
-            return cc > r ? 0.0 : (r / LB == cc / LB) ? dinv_at(L, rd, r / LB, r % LB, cc % LB) : L[r * DL + cc];   // all off-diagonal entries are in place
-        };
-#pragma unroll 8
-        for (int r = t >> 6; r < NB; r += CDW)
-            if (c <= r) *reinterpret_cast<f64x2 *>(out + (size_t)r * NB + c) = (f64x2){at(r, c), at(r, c + 1)};
-    }
+    rows_out(64, 0);
     STAMP(17);
 }
 
