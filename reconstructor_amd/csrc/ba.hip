@@ -1000,26 +1000,21 @@ __global__ __launch_bounds__(64) void k_ring_gate(Gate g)
 
 // ---------------------------------------------------------------------------------------
 // K7: dense Cholesky of the padded reduced system (npad multiple of 128), lower triangle.
-// Diagonal block (one workgroup, block resident in LDS, ~30 workgroup barriers in total):
-//   1. blocked factorisation with 16-wide leaves: a leaf is factored AND inverted by wave 0 alone (LDS
-//      operations of a wave are ordered, so no workgroup barrier inside; the leaf inverse lives
-//      transposed in the otherwise unused upper triangle of the leaf's diagonal block), rows below
-//      become A Dinv^T and the trailing square is updated as 16x16 v_mfma_f64_16x16x4_f64 tiles.
-//      Lookahead: wave 0 updates the next leaf's diagonal tile first and factors it while waves 1..3
-//      finish the trailing square, so the serial leaf work hides behind the MFMA work;
-//   2. blocked inverse of the factor by doubling, 16 -> 32 -> 64 -> 128, in place:
-//          X_hi,lo = -Dinv_hi * (L_hi,lo * Dinv_lo)
-//      (row strips per wave in the first product, column strips in the second: three barriers a step).
-// Writes L^-1 into Linv[kb] (used by the panel GEMM and the triangular solves) and, on request, L into S.
+// Diagonal block (one workgroup of eight waves, block resident in LDS, 16 workgroup barriers in total):
+//   1. blocked factorisation with 16-wide leaves.  A leaf is factored AND inverted by wave 0 alone, on the matrix pipe
+//      (leaf_factor below); rows below become A Dinv^T and the trailing square is updated as 16x16
+//      v_mfma_f64_16x16x4_f64 tiles.  Lookahead: wave 0 updates the next leaf's diagonal tile first and factors it
+//      while waves 1..7 finish the trailing square, so the serial leaf work hides behind the MFMA work;
+//   2. the inverse of the factor grows a block row per leaf in the same phase, by waves 1..7, also behind the leaf:
+//          Linv[k][j] = -Dinv_k * sum_{m = j .. k-1} L[k][m] Linv[m][j]
+//      (round 2 inverted by doubling, 16 -> 32 -> 64 -> 128, AFTER the factorisation: 11 us of the kernel's 58).
+//      Leaf inverses sit in place on the diagonal (the factor's own leaf blocks wait transposed above it, diagonal in rd);
+//      the other inverse blocks sit in the mirror position above the diagonal, the factor stays below it.
+// Writes L^-1 into Linv[kb] (used by the panel GEMM and the triangular solves) as it appears and, on request, L into S.
 #define DL 129   // LDS row stride of the diagonal block (doubles): row walks are conflict-free
 #define LB 16    // leaf size
 #define NBL (NB / LB)
 
-// leaf inverse element (r,c), c <= r, of leaf i: strictly-lower entries live transposed in the
-// upper triangle of the leaf's own diagonal block; the diagonal is the reciprocal of L's.
-// element (r,c), c <= r, of the inverse of 32x32 leaf i32 once stage 2b has run: inside a 16x16
-// diagonal block it is the 16-leaf inverse, otherwise the off-diagonal block stored in place
-#define DINV32_DECL
 // broadcast of lane `src`'s double (src wave-uniform): two v_readlane_b32
 __device__ __forceinline__ double rdlane(double v, int src)
 {
@@ -1059,41 +1054,6 @@ template <int NT> __device__ __forceinline__ void trail_update(double *L, int r0
         }
 }
 
-// Pieces of the doubling steps of k_chol_diag (2c): one 16x16 output tile per call, trip counts compile-time.
-// pass 1, T tile (rows rs.., 16-column group CT) of  L_hi,lo * Dinv_lo : Dinv_lo is lower triangular, so k starts at 16 CT
-template <int HALF, int CT>
-__device__ __forceinline__ f64x4 dbl_pass1(const double *L, int lo0, int rs, int lane)
-{
-    f64x4 a4 = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int kk = 16 * CT; kk < HALF; kk += 4) {
-        const int k = kk + (lane >> 4), c = 16 * CT + (lane & 15);
-        double bb = L[(lo0 + k) * DL + lo0 + c];
-        if (kk < 16 * (CT + 1)) bb = c <= k ? bb : 0.0;       // only the diagonal 16-block of the operand needs the mask
-        a4 = __builtin_amdgcn_mfma_f64_16x16x4f64(L[(rs + (lane & 15)) * DL + lo0 + k], bb, a4, 0, 0, 0);
-    }
-    return a4;
-}
-// pass 2, X tile (16-row group RT of the hi part, the 16 columns at Tcol) of  -Dinv_hi * T : k ends with the row group
-template <int RT>
-__device__ __forceinline__ f64x4 dbl_pass2(const double *L, const double *Tcol, int hi0, int lane)
-{
-    f64x4 a4 = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int kk = 0; kk < 16 * (RT + 1); kk += 4) {
-        const int k = kk + (lane >> 4), r = 16 * RT + (lane & 15);
-        double aa = -L[(hi0 + r) * DL + hi0 + k];
-        if (kk >= 16 * RT) aa = k <= r ? aa : 0.0;
-        a4 = __builtin_amdgcn_mfma_f64_16x16x4f64(aa, Tcol[k * DL + (lane & 15)], a4, 0, 0, 0);
-    }
-    return a4;
-}
-__device__ __forceinline__ void tile_to_lds(double *dst, f64x4 a4, int lane)
-{
-#pragma unroll
-    for (int reg = 0; reg < 4; ++reg) dst[((lane >> 4) + 4 * reg) * DL + (lane & 15)] = a4[reg];
-}
-
 #ifdef RCN_STAMP   // diagnostic build only (tools/chol_diag_bench.hip): phase time stamps
 __device__ unsigned long long g_stamps[64];
 #define STAMP(i) do { __syncthreads(); if (threadIdx.x == 0) g_stamps[i] = clock64(); } while (0)
@@ -1112,6 +1072,7 @@ __global__ __launch_bounds__(64 * CDW) void k_chol_diag(double *S, int ld, int k
     gate_enter(g);
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     double *L = reinterpret_cast<double *>(smem_raw);  // [128][DL]
+    if (threadIdx.x >= 64) __builtin_amdgcn_s_setprio(2);   // wave 0 carries the serial chain: its few MFMAs go before its SIMD neighbour's
     __shared__ double rd[NB + 2];                       // L's diagonal (the leaves hold their inverse in place); [NB] = breakdown flag
     double *misc = rd + NB;                             // (16-byte multiple keeps the dynamic base aligned)
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
@@ -1146,6 +1107,7 @@ __global__ __launch_bounds__(64 * CDW) void k_chol_diag(double *S, int ld, int k
     //     Entries of S and T2 left of the active columns turn into rounding residue and are never read for a stored
     //     value.  (Round 2's leaf kept one row per lane and did all of this on the vector ALU: ~1200 instructions and
     //     8.6k cycles per leaf, the longest serial stretch of the factorisation's critical chain.)
+    double *out = Linv + (size_t)kb * NB * NB;
     unsigned mk[10];      // slot of M[i][k] (i >= k, row-major over the lower triangle) -> all-ones in the lane (i, k) that holds it
     {
         const int c = lane & 15, g = lane >> 4;
@@ -1232,12 +1194,13 @@ __global__ __launch_bounds__(64 * CDW) void k_chol_diag(double *S, int ld, int k
     if (w == 0) leaf_factor(0);
     __syncthreads();
     STAMP(1);
+    f64x4 tcur = {0.0, 0.0, 0.0, 0.0};       // waves 1..7: T_j of the inverse's next block row (2., below)
     for (int c0 = 0; c0 < NB; c0 += LB) {
         if (misc[0] != 0.0) {
             if (t == 0) *flag = 1;
             return;
         }
-        const int r0 = c0 + LB;
+        const int r0 = c0 + LB, kk = c0 / LB;
         if (r0 >= NB) break;
         // 1b. rows below: X = A * D^-T as 16x16 MFMA tiles (one wave per tile), in place:
         //     X[r][c] = sum_{k<=c} A[r][k] * Dinv[c][k]
@@ -1284,6 +1247,61 @@ __global__ __launch_bounds__(64 * CDW) void k_chol_diag(double *S, int ld, int k
                 for (int reg = 0; reg < 4; ++reg) Ct[((lane >> 4) + 4 * reg) * DL + (lane & 15)] = acc[reg];
             }
             if (w == 0) leaf_factor(r0);
+            else if (w - 1 <= kk) {
+                // 2. the inverse grows a block row per leaf, behind the leaf work of wave 0:  Linv[k][j] = -Dinv_k T_j  with
+                //    T_j = sum_{m = j .. k-1} L[k][m] Linv[m][j].  Wave j + 1 owns tile column j for good: it finishes row kk
+                //    (T_j came with it from the last step, in registers: accumulator layout IS the B-operand layout),
+                //    keeps the block in the mirror position above the diagonal for its own later use, sends it to HBM, and
+                //    builds T_j of row kk + 1 -- whose leaf wave 0 is factoring right now.  Every block it reads is its own
+                //    or a finished leaf's, so there is no synchronisation beyond the barriers of the factorisation.
+                const int j = w - 1, ci = lane & 15, kq = lane >> 4;
+                f64x4 R = {0.0, 0.0, 0.0, 0.0};
+                if (j < kk) {
+#pragma unroll
+                    for (int sx = 0; sx < 4; ++sx) {
+                        const int k = 4 * sx + kq;
+                        const double a = k <= ci ? -L[(c0 + ci) * DL + c0 + k] : 0.0;
+                        R = __builtin_amdgcn_mfma_f64_16x16x4f64(a, tcur[sx], R, 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) {
+                        L[(LB * j + kq + 4 * reg) * DL + c0 + ci] = R[reg];
+                        out[(size_t)(c0 + kq + 4 * reg) * NB + LB * j + ci] = R[reg];
+                    }
+                }
+                f64x4 T = {0.0, 0.0, 0.0, 0.0};
+                const double *Ar = L + (r0 + ci) * DL;          // row of L[kk + 1][.] this lane feeds as A operand
+                {   // m = j: the leaf inverse on the diagonal (lower triangular; above it sits the factor, transposed).  The wave
+                    // that starts a tile column (j == kk) is the first to read that leaf's inverse: it also sends it to HBM.
+#pragma unroll
+                    for (int sx = 0; sx < 4; ++sx) {
+                        const int k = 4 * sx + kq;
+                        const double b = ci <= k ? L[(LB * j + k) * DL + LB * j + ci] : 0.0;
+                        if (j == kk && ci <= k) out[(size_t)(c0 + k) * NB + c0 + ci] = b;
+                        T = __builtin_amdgcn_mfma_f64_16x16x4f64(Ar[LB * j + k], b, T, 0, 0, 0);
+                    }
+                }
+                if (j + 1 < kk) {    // the blocks between, operands of step m + 1 requested before the MFMAs of step m
+                    double an[4], bn[4];
+#pragma unroll
+                    for (int sx = 0; sx < 4; ++sx) { an[sx] = Ar[LB * (j + 1) + 4 * sx + kq]; bn[sx] = L[(LB * j + 4 * sx + kq) * DL + LB * (j + 1) + ci]; }
+                    for (int m = j + 1; m < kk; ++m) {
+                        double ac[4], bc[4];
+#pragma unroll
+                        for (int sx = 0; sx < 4; ++sx) { ac[sx] = an[sx]; bc[sx] = bn[sx]; }
+                        const int mn = m + 1 < kk ? m + 1 : m;
+#pragma unroll
+                        for (int sx = 0; sx < 4; ++sx) { an[sx] = Ar[LB * mn + 4 * sx + kq]; bn[sx] = L[(LB * j + 4 * sx + kq) * DL + LB * mn + ci]; }
+#pragma unroll
+                        for (int sx = 0; sx < 4; ++sx) T = __builtin_amdgcn_mfma_f64_16x16x4f64(ac[sx], bc[sx], T, 0, 0, 0);
+                    }
+                }
+                if (j < kk) {
+#pragma unroll
+                    for (int sx = 0; sx < 4; ++sx) T = __builtin_amdgcn_mfma_f64_16x16x4f64(Ar[c0 + 4 * sx + kq], R[sx], T, 0, 0, 0);
+                }
+                tcur = T;
+            }
         }
         __syncthreads();
         STAMP(33 + 2 * (c0 / LB));
@@ -1297,87 +1315,27 @@ __global__ __launch_bounds__(64 * CDW) void k_chol_diag(double *S, int ld, int k
             if (c <= r) A[(size_t)r * ld + c] = r / LB != c / LB ? L[r * DL + c] : r == c ? rd[r] : L[c * DL + r];
         }
     STAMP(14);
-    // 2a. (leaf inverses were produced by wave 0 right after each leaf factorization)
-    __syncthreads();
-    STAMP(15);
-    // 2b. the 32x32 leaf inverses from the 16x16 ones: in every 32-block the off-diagonal 16x16
-    //     block becomes  -Dinv_hi * (L_hi,lo * Dinv_lo)  in place (one wave per 32-block).
-    if (w < 4) {
-        const int i = 2 * w + 1, j = 2 * w;
-        double *Bt = L + (LB * i) * DL + LB * j;
-        f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+    // the last block row of the inverse: its leaf was the last thing the loop did
+    if (w >= 1) {
+        const int j = w - 1, c0 = NB - LB, ci = lane & 15, kq = lane >> 4;
+        f64x4 R = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int kk = 0; kk < LB; kk += 4) {       // T = L_ij * Dinv_j
-            const int k = kk + (lane >> 4), c = lane & 15;
-            const double b = c <= k ? L[(LB * j + k) * DL + LB * j + c] : 0.0;
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Bt[(lane & 15) * DL + k], b, acc, 0, 0, 0);
+        for (int sx = 0; sx < 4; ++sx) {
+            const int k = 4 * sx + kq;
+            const double a = k <= ci ? -L[(c0 + ci) * DL + c0 + k] : 0.0;
+            R = __builtin_amdgcn_mfma_f64_16x16x4f64(a, tcur[sx], R, 0, 0, 0);
         }
 #pragma unroll
-        for (int reg = 0; reg < 4; ++reg) Bt[((lane >> 4) + 4 * reg) * DL + (lane & 15)] = acc[reg];
-        acc = (f64x4){0.0, 0.0, 0.0, 0.0};       // same wave: LDS order makes T visible
+        for (int reg = 0; reg < 4; ++reg) out[(size_t)(c0 + kq + 4 * reg) * NB + LB * j + ci] = R[reg];
+        if (w == 1) {
 #pragma unroll
-        for (int kk = 0; kk < LB; kk += 4) {       // X = -Dinv_i * T
-            const int k = kk + (lane >> 4), r = lane & 15;
-            const double a = k <= r ? -L[(LB * i + r) * DL + LB * i + k] : 0.0;
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Bt[k * DL + (lane & 15)], acc, 0, 0, 0);
+            for (int sx = 0; sx < 4; ++sx) {
+                const int k = 4 * sx + kq;
+                if (ci <= k) out[(size_t)(c0 + k) * NB + c0 + ci] = L[(c0 + k) * DL + c0 + ci];
+            }
         }
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg) Bt[((lane >> 4) + 4 * reg) * DL + (lane & 15)] = acc[reg];
-    }
-    __syncthreads();
-    // 2c. two more doubling steps, 32 -> 64 -> 128, each  X_hi,lo = -Dinv_hi * (L_hi,lo * Dinv_lo):  T = L_hi,lo * Dinv_lo goes
-    //     to the mirror block ABOVE the diagonal (rows lo.., columns hi..: scratch nobody else reads), so a wave stores its
-    //     tile as soon as it has it; one barrier; X = -Dinv_hi * T is written straight over L_hi,lo (all reads of it ended
-    //     at that barrier); one barrier.  Eight 16x16 tiles at the first level, one per wave; sixteen at the second, two per
-    //     wave, paired so that the triangular operand gives both waves of a strip the same number of k-steps (1+4, 2+3).
-    //     Trip counts are compile-time: a runtime k-range here cost 2.8x.
-    {
-        const int blk = w >> 2, s0 = (w >> 1) & 1, q = w & 1;
-        const int lo0 = 64 * blk, hi0 = lo0 + 32;
-        {
-            const f64x4 a4 = q == 0 ? dbl_pass1<32, 0>(L, lo0, hi0 + 16 * s0, lane) : dbl_pass1<32, 1>(L, lo0, hi0 + 16 * s0, lane);
-            tile_to_lds(L + (lo0 + 16 * s0) * DL + hi0 + 16 * q, a4, lane);
-        }
-        __syncthreads();
-        {
-            const f64x4 a4 = q == 0 ? dbl_pass2<0>(L, L + lo0 * DL + hi0 + 16 * s0, hi0, lane) : dbl_pass2<1>(L, L + lo0 * DL + hi0 + 16 * s0, hi0, lane);
-            tile_to_lds(L + (hi0 + 16 * q) * DL + lo0 + 16 * s0, a4, lane);
-        }
-        __syncthreads();
-    }
-    double *out = Linv + (size_t)kb * NB * NB;
-    // (the strict upper triangle of every Linv tile is zeroed once per solve and never written, except for the zero beside
-    // an odd diagonal entry.)  The two 64x64 diagonal blocks are final here: their stores drain under the last level.
-    auto rows_out = [&](int r_first, int c_first) {      // 64 rows x 64 columns from (r_first, c_first): lane -> 2 columns, 32 lanes a row
-        const int c = c_first + 2 * (lane & 31);
-#pragma unroll 8
-        for (int qq = 0; qq < 64 / (2 * CDW); ++qq) {
-            const int r = r_first + 2 * (w + CDW * qq) + (lane >> 5);
-            const double v0 = L[r * DL + c], v1 = L[r * DL + c + 1];
-            if (c <= r) *reinterpret_cast<f64x2 *>(out + (size_t)r * NB + c) = (f64x2){v0, c + 1 <= r ? v1 : 0.0};
-        }
-    };
-    rows_out(0, 0);
-    rows_out(64, 64);
-    {
-        const int s0 = w >> 1, q = w & 1;
-        {
-            const f64x4 a4 = q == 0 ? dbl_pass1<64, 0>(L, 0, 64 + 16 * s0, lane) : dbl_pass1<64, 1>(L, 0, 64 + 16 * s0, lane);
-            const f64x4 b4 = q == 0 ? dbl_pass1<64, 3>(L, 0, 64 + 16 * s0, lane) : dbl_pass1<64, 2>(L, 0, 64 + 16 * s0, lane);
-            tile_to_lds(L + (16 * s0) * DL + 64 + 16 * q, a4, lane);
-            tile_to_lds(L + (16 * s0) * DL + 64 + 16 * (3 - q), b4, lane);
-        }
-        __syncthreads();
-        {
-            const f64x4 a4 = q == 0 ? dbl_pass2<0>(L, L + 64 + 16 * s0, 64, lane) : dbl_pass2<1>(L, L + 64 + 16 * s0, 64, lane);
-            const f64x4 b4 = q == 0 ? dbl_pass2<3>(L, L + 64 + 16 * s0, 64, lane) : dbl_pass2<2>(L, L + 64 + 16 * s0, 64, lane);
-            tile_to_lds(L + (64 + 16 * q) * DL + 16 * s0, a4, lane);
-            tile_to_lds(L + (64 + 16 * (3 - q)) * DL + 16 * s0, b4, lane);
-        }
-        __syncthreads();
     }
     STAMP(16);
-    rows_out(64, 0);
     STAMP(17);
 }
 
@@ -1399,14 +1357,14 @@ __global__ __launch_bounds__(64 * CDW) void k_chol_diag(double *S, int ld, int k
 // first / m: the tiles kb + 1 + first .. kb + 1 + first + m - 1 of the tile column (the critical tile is first = 0, m = 1)
 template <int MODE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(96)))
-void k_gemm_q(double *S, double *L, int ld, int kb, int first, int m, const double *Linv, Gate g)
+void k_gemm_q(double *S, double *L, int ld, int kb, int first, int m, const double *Linv, Gate g, int dj = 1)
 {
     __builtin_amdgcn_s_setprio(3);      // these waves share SIMDs with the bulk update's: their few MFMAs and loads go first
     gate_enter(g);
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     const int strip = 8 * (slot >> 2) + xcd, qj = slot & 3;      // strip: 32 rows of the tile column, qj: 32 output columns
     if (strip >= 4 * m) return;
-    const int tj = MODE == 0 ? kb : kb + 1;
+    const int tj = MODE == 0 ? kb : kb + dj;      // MODE 1: the tile column that is updated, S(i, kb + dj) -= L(i, kb) L(kb + dj, kb)'
     const size_t row0 = (size_t)(kb + 1 + first) * NB + 32 * (size_t)strip;
     const double *A = (MODE == 0 ? S : L) + row0 * ld + (size_t)kb * NB;
     const double *B = MODE == 0 ? Linv + (size_t)kb * NB * NB + (size_t)(32 * qj) * NB
@@ -1554,16 +1512,21 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt_ring(double *S, const double
 // index known at compile time every wait count below is a literal and the loop has no branch.
 // map: the launch's tiles, one word (row << 16 | column, relative to tile kb + 2; ~0 = none) per workgroup, dealt so that
 // the eight XCDs -- workgroup b runs on XCD b % 8 -- carry equal shares of whole supertiles (build_bulk_maps).
-template <int DBG, int NST>
-__global__ __launch_bounds__(256, 2) void k_gemm_nt_pipe(double *S, const double *L, int ld, int kb, const unsigned *__restrict__ map)
+// MODE 1 is the PANEL product on the same pipeline, L(i, kb) = S(i, kb) Linv_kb' (B = the inverse of the diagonal block, row
+// stride 128; no C tile, the product itself is stored): the rows of a panel below the critical tile, a tile per workgroup.
+// S is the matrix the result is written to (MODE 0: S, updated in place; MODE 1: L), Lm the matrix A is read from.
+template <int DBG, int NST, int MODE = 0>
+__global__ __launch_bounds__(256, 2) void k_gemm_nt_pipe(double *S, const double *Lm, int ld, int kb, const unsigned *__restrict__ map, int toff, int *sig,
+                                                          const double *Linv = nullptr)
 {
     static_assert(NST % 4 == 0 && NST >= 16, "C tiles are folded in during stages 0 .. 15");
     extern __shared__ __attribute__((aligned(16))) char gsm[];
     const unsigned e = map[blockIdx.x];
     if (e == ~0u) return;
-    const int ti = kb + 2 + (int)(e >> 16), tj = kb + 2 + (int)(e & 0xffffu);
-    const double *A = L + ((size_t)ti * NB) * ld + (size_t)kb * NB;
-    const double *B = L + ((size_t)tj * NB) * ld + (size_t)kb * NB;
+    const int ti = kb + toff + (int)(e >> 16), tj = MODE == 1 ? kb : kb + toff + (int)(e & 0xffffu);
+    const double *A = Lm + ((size_t)ti * NB) * ld + (size_t)kb * NB;
+    const double *B = MODE == 1 ? Linv + (size_t)kb * NB * NB : Lm + ((size_t)tj * NB) * ld + (size_t)kb * NB;
+    const int ldb = MODE == 1 ? NB : ld;
     const int t = threadIdx.x, lane = t & 63;
     const int w = __builtin_amdgcn_readfirstlane(t >> 6);      // wave-uniform, and the compiler should know: everything derived
                                                                // from it (ring slots, C descriptor, tile offsets) lives in SGPRs
@@ -1581,7 +1544,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt_pipe(double *S, const double
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f64x4){0.0, 0.0, 0.0, 0.0};
     const double *srcA = A + (size_t)(32 * w + fr) * ld + 2 * fk;
-    const double *srcB = B + (size_t)(32 * w + fr) * ld + 2 * fk;
+    const double *srcB = B + (size_t)(32 * w + fr) * ldb + 2 * fk;
     auto issue = [&](int s) {
         char *buf = gsm + (s % GST) * GSTAGE_BYTES + 2048 * w;
         const int k0 = 8 * s;
@@ -1590,7 +1553,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt_pipe(double *S, const double
         for (int q = 0; q < 2; ++q) {
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(srcA + (size_t)(16 * q) * ld + k0),
                                              (__attribute__((address_space(3))) void *)(buf + 1024 * q), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(srcB + (size_t)(16 * q) * ld + k0),
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(srcB + (size_t)(16 * q) * ldb + k0),
                                              (__attribute__((address_space(3))) void *)(buf + 8192 + 1024 * q), 16, 0, 0);
         }
     };
@@ -1632,7 +1595,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt_pipe(double *S, const double
 #pragma unroll
     for (int s = 0; s < NST; ++s) {
         const int P = s & 1;
-        const bool c_req = (s & 1) == 0 && s < 16, c_fold = (s & 1) == 1 && s < 16;
+        const bool c_req = MODE == 0 && (s & 1) == 0 && s < 16, c_fold = MODE == 0 && (s & 1) == 1 && s < 16;
         const int ci = (s >> 2) & 3, cj = s & 2;       // the pair of tiles of this stage (even) or of the one before (odd)
         // my reads of stage s (requested one stage ago) have returned: the fragments are in their registers and the ring
         // slot is free on my side.  The ONLY LDS wait of the step -- the reads of stage s + 1 requested below stay in flight
@@ -1681,9 +1644,16 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt_pipe(double *S, const double
             for (int reg = 0; reg < 4; ++reg)
                 if (!(DBG & 2) || acc[i][j][reg] == 1.2345e300) {
                     union { v2i r; double d; } u;
-                    u.d = -acc[i][j][reg];                  // C - A B'
+                    u.d = MODE == 1 ? acc[i][j][reg] : -acc[i][j][reg];                  // C - A B'  (MODE 1: A B')
                     __builtin_amdgcn_raw_buffer_store_b64(u.r, crs, cvo + 128 * j, (16 * i + 4 * reg) * ld8, 0);
                 }
+    // A two-panel update tells the other streams when its first two tile columns are done, tile by tile: they are all
+    // the next two diagonal blocks and panels need of it, and they come first in its map (build_bulk_maps).
+    if (sig && (e & 0xffffu) < 2u) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (t == 0) __hip_atomic_fetch_add(sig, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 // forward substitution step kb: y_kb = Linv_kb b_kb ; b_i -= L[i,kb] y_kb for i > kb.
@@ -1918,9 +1888,19 @@ static int build_bulk_maps(rcn_ctx *ctx, int nblk)
 {
     if (ctx->bulk_map_nblk == nblk && ctx->bulk_map.p) return RCN_OK;
     std::vector<unsigned> all;
-    ctx->bulk_map_off.assign((size_t)std::max(nblk, 1), 0);
-    ctx->bulk_map_grid.assign((size_t)std::max(nblk, 1), 0);
-    for (int mt = 1; mt <= nblk - 2; ++mt) {
+    const size_t nm = (size_t)std::max(nblk, 1);
+    ctx->bulk_map_off.assign(nm, 0);
+    ctx->bulk_map_grid.assign(nm, 0);
+    ctx->pair_map_off.assign(nm, 0);
+    ctx->pair_map_grid.assign(nm, 0);
+    // head2: the tiles of the first two columns lead the map, rows dealt to the XCDs eight apart (the two tiles of a row
+    // share its panel rows in that XCD's L2); the rest of the triangle follows in supertiles as before
+    auto make = [&](int mt, bool head2, std::vector<int> &off, std::vector<int> &grid) {
+        std::vector<unsigned> per[8];
+        const int c_first = head2 ? std::min(2, mt) : 0;
+        if (head2)
+            for (int r = 0; r < mt; ++r)
+                for (int c = 0; c < c_first && c <= r; ++c) per[r & 7].push_back(((unsigned)r << 16) | (unsigned)c);
         const int SS = mt >= 24 ? 4 : 2, R = (mt + SS - 1) / SS;
         std::vector<std::vector<unsigned>> st;
         for (int sr = 0; sr < R; ++sr)
@@ -1928,11 +1908,10 @@ static int build_bulk_maps(rcn_ctx *ctx, int nblk)
                 std::vector<unsigned> tl;
                 for (int r = sr * SS; r < std::min(mt, sr * SS + SS); ++r)
                     for (int c = sc * SS; c < sc * SS + SS; ++c)
-                        if (c <= r) tl.push_back(((unsigned)r << 16) | (unsigned)c);
+                        if (c <= r && c >= c_first) tl.push_back(((unsigned)r << 16) | (unsigned)c);
                 if (!tl.empty()) st.push_back(std::move(tl));
             }
         std::stable_sort(st.begin(), st.end(), [](const std::vector<unsigned> &a, const std::vector<unsigned> &b) { return a.size() > b.size(); });
-        std::vector<unsigned> per[8];
         for (auto &tl : st) {
             int x = 0;
             for (int i = 1; i < 8; ++i)
@@ -1941,12 +1920,21 @@ static int build_bulk_maps(rcn_ctx *ctx, int nblk)
         }
         size_t slots = 0;
         for (auto &v : per) slots = std::max(slots, v.size());
-        ctx->bulk_map_off[mt] = (int)all.size();
-        ctx->bulk_map_grid[mt] = (int)(8 * slots);
+        off[mt] = (int)all.size();
+        grid[mt] = (int)(8 * slots);
         for (size_t sl = 0; sl < slots; ++sl)
             for (int x = 0; x < 8; ++x) all.push_back(sl < per[x].size() ? per[x][sl] : ~0u);
+    };
+    for (int mt = 1; mt <= nblk - 2; ++mt) {
+        make(mt, false, ctx->bulk_map_off, ctx->bulk_map_grid);
+        make(mt, true, ctx->pair_map_off, ctx->pair_map_grid);
     }
-    if (all.empty()) all.push_back(~0u);
+    // tile columns for the pipelined kernel on the panel stream: rows 1, 2, .. of column 0 (a panel below its critical tile,
+    // the rest of the first trailing column) and the same rows of columns 0 and 1 side by side (first of a pair)
+    ctx->col_map_off1 = (int)all.size();
+    for (int r = 1; r <= nblk; ++r) all.push_back((unsigned)r << 16);
+    ctx->col_map_off2 = (int)all.size();
+    for (int r = 1; r <= nblk; ++r) { all.push_back((unsigned)r << 16); all.push_back(((unsigned)r << 16) | 1u); }
     RCN_HIP(hipStreamSynchronize(ctx->stream));          // nobody may still read the old maps
     RCN_HIP(ctx->bulk_map.reserve(all.size() * sizeof(unsigned)));
     RCN_HIP(hipMemcpy(ctx->bulk_map.p, all.data(), all.size() * sizeof(unsigned), hipMemcpyHostToDevice));
@@ -2135,6 +2123,8 @@ int rcn_int_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_option
     RCN_HIP(hipMemsetAsync(d.Linv, 0, sizeof(double) * (size_t)nblk * NB * NB, st));   // upper triangles of the tile inverses stay zero
     RCN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_chol_diag), hipFuncAttributeMaxDynamicSharedMemorySize, NB * DL * 8));
     RCN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_nt_pipe<0, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, GST * GSTAGE_BYTES));
+    RCN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_nt_pipe<0, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, GST * GSTAGE_BYTES));
+    RCN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_nt_pipe<0, 16, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, GST * GSTAGE_BYTES));
     { int rcm = build_bulk_maps(ctx, nblk); if (rcm) return rcm; }
     RCN_HIP(hipStreamSynchronize(st));   // host vectors go out of use; timing starts with inputs resident
     const double t_start = now_s();        // the pair lists of the Schur build are part of the solve (only the pack is not)
@@ -2261,47 +2251,91 @@ int rcn_int_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_option
         // and every counter is published by the FIRST thread of the kernel that follows the work on its own stream.
         // A wait that times out (2 s: a runtime that does not let the three streams progress side by side) raises flag 3;
         // the factorisation is then repeated on one stream in plain order, and every later one runs that way (ctx->chol_safe).
+        // TWO-PANEL bulk updates (round 3).  While many tile rows remain (ctx->chol_pair_min), steps go in pairs (p, q = p + 1):
+        //   C(p) also takes the SECOND trailing column, S(i, p+2) -= L(i, p) L(p+2, p)', so that everything steps p and q need
+        //   of panel p is in place without a bulk update; there is no B(p); and B(q) applies panels p and q together,
+        //   K = 256, to columns >= p + 3.  The C tile of the bulk kernel is loaded and stored once per 256 k instead of once
+        //   per 128 (286 us -> 241 us per panel at 77 tile rows).  What the next pair needs of B(q) early are its first two
+        //   tile columns (p+3: D/T/P of step p+2 and p+3; p+4: C(p+2), T(p+3)); they lead its map and every finished tile of
+        //   them bumps a device counter (sig), so the chain never waits for a whole two-panel update except through stream order.
+        // Who has to wait for which bulk kernel is looked up per tile column: lastw[j] names the last bulk-stream kernel that
+        // writes column j -- either "all of kernel #ord" (cB, published by the gate in front of the next bulk kernel) or
+        // "the leading columns of a two-panel kernel" (sig reaching a cumulative tile count).
         auto factorise = [&](bool safe) -> hipError_t {
             hipStream_t sA = st, sB = safe ? st : ctx->panel_stream, sC = safe ? st : ctx->aux_stream;
-            int *cD = d.flag + 2, *cT = d.flag + 3, *cP = d.flag + 4, *cC = d.flag + 5, *cB = d.flag + 6;
+            int *cD = d.flag + 2, *cT = d.flag + 3, *cP = d.flag + 4, *cC = d.flag + 5, *cB = d.flag + 6, *sig = d.flag + 7;
             const Gate none = {nullptr, 0, nullptr, 0, nullptr, 0, d.flag};
-            auto gate = [&](const int *c0, int n0, const int *c1, int n1, int *pub, int pubval) {
-                Gate g = {safe ? nullptr : c0, n0, safe ? nullptr : c1, n1, safe ? nullptr : pub, pubval, d.flag};
+            struct Wr { const int *c; int n; };
+            auto gate = [&](const int *c0, int n0, Wr w, int *pub, int pubval) {
+                Gate g = {safe ? nullptr : c0, n0, safe ? nullptr : w.c, w.n, safe ? nullptr : pub, pubval, d.flag};
                 return g;
             };
+            std::vector<Wr> lastw((size_t)nblk + 4, Wr{nullptr, 0});
+            auto later = [](Wr a, Wr b) { return !a.c ? b : !b.c ? a : (a.c == b.c ? (a.n >= b.n ? a : b) : b); };   // b is the younger lookup on a tie of kinds
+            int bulk_ord = 0, sig_cum = 0;
             if (!safe) {
                 hipError_t e = hipEventRecord(ctx->ba_ev[0], sA);
                 if (e == hipSuccess) e = hipStreamWaitEvent(sB, ctx->ba_ev[0], 0);     // B and C start behind everything queued so far
                 if (e == hipSuccess) e = hipStreamWaitEvent(sC, ctx->ba_ev[0], 0);
                 if (e != hipSuccess) return e;
             }
+            const unsigned *maps = ctx->bulk_map.as<unsigned>();
+            bool pair_open = false;                   // the step before this one was the first of a pair
             for (int kb = 0; kb < nblk; ++kb) {
                 const int m = nblk - kb - 1;          // tiles below the diagonal block
+                const bool second = pair_open;
+                const bool first_of_pair = !second && m - 2 >= ctx->chol_pair_min && m >= 4;
                 // D(kb): publishes "T(kb-1) done"
-                k_chol_diag<<<1, 64 * CDW, NB * DL * 8, sA>>>(d.S, npad, kb, d.Linv, d.flag, kb == nblk - 1, gate(nullptr, 0, nullptr, 0, cT, kb));
+                k_chol_diag<<<1, 64 * CDW, NB * DL * 8, sA>>>(d.S, npad, kb, d.Linv, d.flag, kb == nblk - 1, gate(nullptr, 0, Wr{nullptr, 0}, cT, kb));
                 if (m <= 0) break;
                 const int gq1 = 32;                   // grid of k_gemm_q for one tile: strips 0..3 on 4 of the 8 XCD slots
-                // T(kb), first half: publishes "D(kb) done"; waits for C(kb-1) and B(kb-1)
-                k_gemm_q<0><<<gq1, 256, 0, sA>>>(d.S, d.L, npad, kb, 0, 1, d.Linv, gate(cC, kb, cB, kb, cD, kb + 1));
+                // T(kb), first half: publishes "D(kb) done"; waits for C(kb-1) and the bulk updates of column kb + 1
+                k_gemm_q<0><<<gq1, 256, 0, sA>>>(d.S, d.L, npad, kb, 0, 1, d.Linv, gate(cC, kb, lastw[kb + 1], cD, kb + 1));
                 k_gemm_q<1><<<gq1, 256, 0, sA>>>(d.S, d.L, npad, kb, 0, 1, d.Linv, none);
                 // On B and C the waits are ONE-WAVE gate kernels in front of the work, never inside it: a grid of a thousand
                 // workgroups that spins while it holds its CU slots could keep the very kernel it waits for from becoming resident.
                 if (m > 1) {
                     const int gq = 32 * ((4 * (m - 1) + 7) / 8);
-                    // P(kb): its gate publishes "C(kb-1) done" and waits for D(kb) and B(kb-2)
-                    if (!safe) k_ring_gate<<<1, 64, 0, sB>>>(gate(cD, kb + 1, cB, kb - 1, cC, kb));
-                    k_gemm_q<0><<<gq, 256, 0, sB>>>(d.S, d.L, npad, kb, 1, m - 1, d.Linv, none);
-                    // C(kb): its gate publishes "P(kb) done" and waits for T(kb) and B(kb-1)
-                    if (!safe) k_ring_gate<<<1, 64, 0, sB>>>(gate(cT, kb + 1, cB, kb, cP, kb + 1));
-                    k_gemm_q<1><<<gq, 256, 0, sB>>>(d.S, d.L, npad, kb, 1, m - 1, d.Linv, none);
-                    // B(kb): its gate publishes "B(kb-1) done" and waits for P(kb)
-                    if (!safe) k_ring_gate<<<1, 64, 0, sC>>>(gate(cP, kb + 1, nullptr, 0, cB, kb));
-                    k_gemm_nt_pipe<0, 16><<<ctx->bulk_map_grid[m - 1], 256, GST * GSTAGE_BYTES, sC>>>(d.S, d.L, npad, kb, ctx->bulk_map.as<unsigned>() + ctx->bulk_map_off[m - 1]);
+                    // P(kb): its gate publishes "C(kb-1) done" and waits for D(kb) and the bulk updates of column kb.
+                    // Long tile columns go through the pipelined kernel, a 128x128 tile per workgroup (m - 1 workgroups that
+                    // stage their operands in LDS, where k_gemm_q needs 16 (m - 1) that stream theirs from L2 and crowd the
+                    // bulk update beside them); short ones stay with k_gemm_q, whose single tile finishes in 8 us, not 20.
+                    const bool piped = m - 1 >= ctx->chol_pipe_min;
+                    if (!safe) k_ring_gate<<<1, 64, 0, sB>>>(gate(cD, kb + 1, lastw[kb], cC, kb));
+                    if (piped) k_gemm_nt_pipe<0, 16, 1><<<m - 1, 256, GST * GSTAGE_BYTES, sB>>>(d.L, d.S, npad, kb, maps + ctx->col_map_off1, 1, nullptr, d.Linv);
+                    else k_gemm_q<0><<<gq, 256, 0, sB>>>(d.S, d.L, npad, kb, 1, m - 1, d.Linv, none);
+                    // C(kb): its gate publishes "P(kb) done" and waits for T(kb) and the bulk updates of the column(s) it writes
+                    if (!safe) k_ring_gate<<<1, 64, 0, sB>>>(gate(cT, kb + 1, first_of_pair ? later(lastw[kb + 1], lastw[kb + 2]) : lastw[kb + 1], cP, kb + 1));
+                    if (piped) {
+                        if (first_of_pair) k_gemm_nt_pipe<0, 16><<<2 * (m - 1), 256, GST * GSTAGE_BYTES, sB>>>(d.S, d.L, npad, kb, maps + ctx->col_map_off2, 1, nullptr);
+                        else k_gemm_nt_pipe<0, 16><<<m - 1, 256, GST * GSTAGE_BYTES, sB>>>(d.S, d.L, npad, kb, maps + ctx->col_map_off1, 1, nullptr);
+                    } else {
+                        k_gemm_q<1><<<gq, 256, 0, sB>>>(d.S, d.L, npad, kb, 1, m - 1, d.Linv, none);
+                        if (first_of_pair) k_gemm_q<1><<<gq, 256, 0, sB>>>(d.S, d.L, npad, kb, 1, m - 1, d.Linv, none, 2);
+                    }
+                    if (first_of_pair) {
+                        pair_open = true;             // no bulk kernel at this step
+                    } else if (second) {
+                        // B(kb), two panels: columns >= kb + 2, counted from kb - 1; waits for P(kb)
+                        pair_open = false;
+                        const int mt = m - 1;
+                        ++bulk_ord;
+                        if (!safe) k_ring_gate<<<1, 64, 0, sC>>>(gate(cP, kb + 1, Wr{nullptr, 0}, cB, bulk_ord - 1));
+                        k_gemm_nt_pipe<0, 32><<<ctx->pair_map_grid[mt], 256, GST * GSTAGE_BYTES, sC>>>(d.S, d.L, npad, kb - 1, maps + ctx->pair_map_off[mt], 3, safe ? nullptr : sig);
+                        sig_cum += mt >= 2 ? 2 * mt - 1 : 1;
+                        for (int j = kb + 2; j < nblk; ++j) lastw[j] = j < kb + 4 ? Wr{sig, sig_cum} : Wr{cB, bulk_ord};
+                    } else {
+                        // B(kb), one panel: its gate publishes "the bulk kernel before it is done" and waits for P(kb)
+                        ++bulk_ord;
+                        if (!safe) k_ring_gate<<<1, 64, 0, sC>>>(gate(cP, kb + 1, Wr{nullptr, 0}, cB, bulk_ord - 1));
+                        k_gemm_nt_pipe<0, 16><<<ctx->bulk_map_grid[m - 1], 256, GST * GSTAGE_BYTES, sC>>>(d.S, d.L, npad, kb, maps + ctx->bulk_map_off[m - 1], 2, nullptr);
+                        for (int j = kb + 2; j < nblk; ++j) lastw[j] = Wr{cB, bulk_ord};
+                    }
                 } else if (!safe) {
                     // one tile left below the diagonal block: no panel rest and no bulk update, but T(kb) still waits to hear
-                    // that C(kb-1) and B(kb-1) are done
-                    k_ring_gate<<<1, 64, 0, sB>>>(gate(nullptr, 0, nullptr, 0, cC, kb));
-                    k_ring_gate<<<1, 64, 0, sC>>>(gate(nullptr, 0, nullptr, 0, cB, kb));
+                    // that C(kb-1) and the last bulk kernel are done
+                    k_ring_gate<<<1, 64, 0, sB>>>(gate(nullptr, 0, Wr{nullptr, 0}, cC, kb));
+                    k_ring_gate<<<1, 64, 0, sC>>>(gate(nullptr, 0, Wr{nullptr, 0}, cB, bulk_ord));
                 }
             }
             hipError_t e = hipGetLastError();

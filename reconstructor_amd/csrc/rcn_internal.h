@@ -177,6 +177,10 @@ struct rcn_ctx {
     // tile maps of the bulk trailing update (ba.hip, build_bulk_maps): one per trailing size, balanced over the XCDs
     DevBuf bulk_map;
     std::vector<int> bulk_map_off, bulk_map_grid;
+    std::vector<int> pair_map_off, pair_map_grid;   // the same triangles with their first two tile columns leading (two-panel updates)
+    int col_map_off1 = 0, col_map_off2 = 0;          // tile columns for the pipelined kernel on the panel stream
+    int chol_pipe_min = 32;                          // panel / column kernels go through the pipelined kernel from this many tiles on
+    int chol_pair_min = 24;                          // two-panel bulk updates while at least this many tile rows remain below the pair
     int bulk_map_nblk = 0;
     bool chol_safe = false;             // a device-counter hand-off timed out once: factorise on one stream, in plain order, from then on
     hipEvent_t ba_ev[9];

@@ -29,7 +29,7 @@ int main()
         (void)hipMemcpyFromSymbol(st, HIP_SYMBOL(g_stamps), sizeof(st));
         printf("rep %d: %.1f us total; ticks(100MHz?) ", rep, ms * 1e3);
         printf("factor(all leaves+trsm+trail)=%llu | store=", st[13] - st[0]);
-        printf("%llu leafinv=%llu blockinv=%llu out=%llu\n", st[14] - st[13], st[15] - st[14], st[16] - st[15], st[17] - st[16]);
+        printf("%llu last inverse row=%llu\n", st[14] - st[13], st[16] - st[14]);
         if (rep == 3) {
             printf("  first leaf %llu;", st[1] - st[0]);
             unsigned long long prev = st[1];

@@ -36,3 +36,15 @@ for name in ('k_chol_diag', 'void k_gemm_q<0>', 'void k_gemm_q<1>', 'void k_gemm
     s2 = [k for k in sel if k[2].startswith(name)]
     if s2:
         print("%-18s n=%d sum %.2f ms avg %.1f us" % (name, len(s2), sum(k[1] - k[0] for k in s2) / 1e6, sum(k[1] - k[0] for k in s2) / 1e3 / len(s2)))
+# the bulk stream: duration of every bulk update and the idle time in front of it
+bulk = [k for k in sel if k[2].startswith('void k_gemm_nt')]
+if bulk:
+    print("bulk updates: start(us) dur(us) idle-before(us) grid")
+    idle = 0.0
+    for i, k in enumerate(bulk):
+        gap = (k[0] - bulk[i - 1][1]) / 1e3 if i else (k[0] - t0) / 1e3
+        idle += gap if i else 0.0
+        if i % max(1, len(bulk) // 24) == 0 or i == len(bulk) - 1:
+            print("  %8.0f %7.1f %7.1f %6d" % ((k[0] - t0) / 1e3, (k[1] - k[0]) / 1e3, gap, k[5] // 256))
+    print("bulk busy %.2f ms, idle between bulk kernels %.2f ms, first starts at %.0f us, last ends %.0f us before the end" % (
+        sum(k[1] - k[0] for k in bulk) / 1e6, idle / 1e3, (bulk[0][0] - t0) / 1e3, (t1 - bulk[-1][1]) / 1e3))

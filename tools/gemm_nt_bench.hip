@@ -42,7 +42,7 @@ int main()
         for (int rep = 0; rep < 2; ++rep) {                                                                                \
             float m;                                                                                                       \
             (void)hipEventRecord(e0);                                                                                      \
-            k_gemm_nt_pipe<D, N><<<pgrid, 256, GST * GSTAGE_BYTES>>>(S0, L, npad, 0, map);                        \
+            k_gemm_nt_pipe<D, N><<<pgrid, 256, GST * GSTAGE_BYTES>>>(S0, L, npad, 0, map, 2, nullptr);                        \
             (void)hipEventRecord(e1); (void)hipEventSynchronize(e1); (void)hipEventElapsedTime(&m, e0, e1);                 \
             if (rep) printf("  pipe K = %4d %s: %.1f us (%.1f TF)   %s\n", 8 * N, what, m * 1e3, flop * (N / 16.0) / m * 1e-9, hipGetErrorString(hipGetLastError())); \
         }
@@ -54,8 +54,8 @@ int main()
             for (size_t i = 0; i < c0.size(); ++i) c0[i] = (double)((i * 2654435761u) % 1000) * 1e-3;
             (void)hipMemset(S1, 0, N * 8);
             (void)hipMemcpy(S1 + (size_t)5 * 128 * npad, c0.data(), c0.size() * 8, hipMemcpyHostToDevice);
-            if (two) k_gemm_nt_pipe<0, 32><<<pgrid, 256, GST * GSTAGE_BYTES>>>(S1, L, npad, 0, map);
-            else k_gemm_nt_pipe<0, 16><<<pgrid, 256, GST * GSTAGE_BYTES>>>(S1, L, npad, 0, map);
+            if (two) k_gemm_nt_pipe<0, 32><<<pgrid, 256, GST * GSTAGE_BYTES>>>(S1, L, npad, 0, map, 2, nullptr);
+            else k_gemm_nt_pipe<0, 16><<<pgrid, 256, GST * GSTAGE_BYTES>>>(S1, L, npad, 0, map, 2, nullptr);
             std::vector<double> c2((size_t)128 * npad);
             (void)hipMemcpy(c2.data(), S1 + (size_t)5 * 128 * npad, c2.size() * 8, hipMemcpyDeviceToHost);
             double md2 = 0;
