@@ -2285,6 +2285,7 @@ int rcn_int_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_option
                 const int m = nblk - kb - 1;          // tiles below the diagonal block
                 const bool second = pair_open;
                 const bool first_of_pair = !second && m - 2 >= ctx->chol_pair_min && m >= 4;
+                const bool two_cols = first_of_pair;
                 // D(kb): publishes "T(kb-1) done"
                 k_chol_diag<<<1, 64 * CDW, NB * DL * 8, sA>>>(d.S, npad, kb, d.Linv, d.flag, kb == nblk - 1, gate(nullptr, 0, Wr{nullptr, 0}, cT, kb));
                 if (m <= 0) break;
@@ -2305,13 +2306,13 @@ int rcn_int_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_option
                     if (piped) k_gemm_nt_pipe<0, 16, 1><<<m - 1, 256, GST * GSTAGE_BYTES, sB>>>(d.L, d.S, npad, kb, maps + ctx->col_map_off1, 1, nullptr, d.Linv);
                     else k_gemm_q<0><<<gq, 256, 0, sB>>>(d.S, d.L, npad, kb, 1, m - 1, d.Linv, none);
                     // C(kb): its gate publishes "P(kb) done" and waits for T(kb) and the bulk updates of the column(s) it writes
-                    if (!safe) k_ring_gate<<<1, 64, 0, sB>>>(gate(cT, kb + 1, first_of_pair ? later(lastw[kb + 1], lastw[kb + 2]) : lastw[kb + 1], cP, kb + 1));
+                    if (!safe) k_ring_gate<<<1, 64, 0, sB>>>(gate(cT, kb + 1, two_cols ? later(lastw[kb + 1], lastw[kb + 2]) : lastw[kb + 1], cP, kb + 1));
                     if (piped) {
-                        if (first_of_pair) k_gemm_nt_pipe<0, 16><<<2 * (m - 1), 256, GST * GSTAGE_BYTES, sB>>>(d.S, d.L, npad, kb, maps + ctx->col_map_off2, 1, nullptr);
+                        if (two_cols) k_gemm_nt_pipe<0, 16><<<2 * (m - 1), 256, GST * GSTAGE_BYTES, sB>>>(d.S, d.L, npad, kb, maps + ctx->col_map_off2, 1, nullptr);
                         else k_gemm_nt_pipe<0, 16><<<m - 1, 256, GST * GSTAGE_BYTES, sB>>>(d.S, d.L, npad, kb, maps + ctx->col_map_off1, 1, nullptr);
                     } else {
                         k_gemm_q<1><<<gq, 256, 0, sB>>>(d.S, d.L, npad, kb, 1, m - 1, d.Linv, none);
-                        if (first_of_pair) k_gemm_q<1><<<gq, 256, 0, sB>>>(d.S, d.L, npad, kb, 1, m - 1, d.Linv, none, 2);
+                        if (two_cols) k_gemm_q<1><<<gq, 256, 0, sB>>>(d.S, d.L, npad, kb, 1, m - 1, d.Linv, none, 2);
                     }
                     if (first_of_pair) {
                         pair_open = true;             // no bulk kernel at this step
@@ -2325,7 +2326,7 @@ int rcn_int_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_option
                         sig_cum += mt >= 2 ? 2 * mt - 1 : 1;
                         for (int j = kb + 2; j < nblk; ++j) lastw[j] = j < kb + 4 ? Wr{sig, sig_cum} : Wr{cB, bulk_ord};
                     } else {
-                        // B(kb), one panel: its gate publishes "the bulk kernel before it is done" and waits for P(kb)
+                        // B(kb), one panel, columns >= kb + 2: its gate publishes "the bulk kernel before it is done" and waits for P(kb)
                         ++bulk_ord;
                         if (!safe) k_ring_gate<<<1, 64, 0, sC>>>(gate(cP, kb + 1, Wr{nullptr, 0}, cB, bulk_ord - 1));
                         k_gemm_nt_pipe<0, 16><<<ctx->bulk_map_grid[m - 1], 256, GST * GSTAGE_BYTES, sC>>>(d.S, d.L, npad, kb, maps + ctx->bulk_map_off[m - 1], 2, nullptr);

@@ -37,7 +37,8 @@ for name in ('k_chol_diag', 'void k_gemm_q<0>', 'void k_gemm_q<1>', 'void k_gemm
     if s2:
         print("%-18s n=%d sum %.2f ms avg %.1f us" % (name, len(s2), sum(k[1] - k[0] for k in s2) / 1e6, sum(k[1] - k[0] for k in s2) / 1e3 / len(s2)))
 # the bulk stream: duration of every bulk update and the idle time in front of it
-bulk = [k for k in sel if k[2].startswith('void k_gemm_nt')]
+bulk_stream = max(set(k[3] for k in sel if k[2].startswith('void k_gemm_nt')), key=lambda q: sum(k[1] - k[0] for k in sel if k[3] == q and k[2].startswith('void k_gemm_nt')), default=None)
+bulk = [k for k in sel if k[2].startswith('void k_gemm_nt') and k[3] == bulk_stream]
 if bulk:
     print("bulk updates: start(us) dur(us) idle-before(us) grid")
     idle = 0.0
@@ -48,3 +49,13 @@ if bulk:
             print("  %8.0f %7.1f %7.1f %6d" % ((k[0] - t0) / 1e3, (k[1] - k[0]) / 1e3, gap, k[5] // 256))
     print("bulk busy %.2f ms, idle between bulk kernels %.2f ms, first starts at %.0f us, last ends %.0f us before the end" % (
         sum(k[1] - k[0] for k in bulk) / 1e6, idle / 1e3, (bulk[0][0] - t0) / 1e3, (t1 - bulk[-1][1]) / 1e3))
+# everything that ran during a few chosen steps, all streams (start..end us from the step's diagonal start, stream, grid in workgroups)
+import os
+for si in [int(x) for x in os.environ.get("TIMELINE_STEPS", "").split(",") if x]:
+    if si + 1 >= len(out):
+        continue
+    a, b = out[si][0][0], out[si + 1][0][0]
+    print("step %d, all streams:" % si)
+    for k in sel:
+        if k[1] > a and k[0] < b:
+            print("   s%s %-22s grid %5d  %7.1f .. %7.1f" % (k[3], k[2].split('(')[0].replace('void ', '')[:22], k[5] // max(1, (256 if 'gemm' in k[2] else 64 if 'gate' in k[2] else 512)), (k[0] - a) / 1e3, (k[1] - a) / 1e3))

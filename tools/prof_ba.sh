@@ -8,6 +8,6 @@ rm -rf "$O"; mkdir -p "$O"
 rocprofv3 --kernel-trace --stats -d $O/trace -o t --output-format csv -- python3 tools/ba_run.py $NC $NP 2 > $O/trace.log 2>&1
 grep "^run" $O/trace.log
 find $O -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} gpurun_out/${TAG}_kernel_stats.csv
-python3 tools/chol_timeline2.py $(find $O -name "*kernel_trace.csv" | head -1) $NBLK
+TIMELINE_STEPS=${TIMELINE_STEPS:-} python3 tools/chol_timeline2.py $(find $O -name "*kernel_trace.csv" | head -1) $NBLK
 find $O -name "*kernel_trace.csv" -size +8M -delete
 head -12 gpurun_out/${TAG}_kernel_stats.csv | cut -c1-120

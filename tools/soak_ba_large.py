@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""tools/soak_ba_large.py [seconds] [seed] -- bundle adjustment at sizes where the factorisation runs its two-stream
-schedule (reduced systems of 3 .. 24 blocks of 128: 40 .. 300 cameras): every random problem is solved twice on the GPU
+"""tools/soak_ba_large.py [seconds] [seed] [min_cams max_cams] -- bundle adjustment at sizes where the factorisation runs its
+three-stream schedule (default 40 .. 300 cameras: reduced systems of 3 .. 24 blocks of 128; from 27 blocks, ~340 cameras, on the
+two-panel bulk updates with their tile-level hand-off take part): every random problem is solved twice on the GPU
 and the two results must be equal bit for bit (a race in the stream hand-offs would show as a difference or a failed
 step); every fifth is also solved by the CPU oracle and must agree on the iteration count and on the final RMS to 1e-5 px.
 Not part of the test-suite; run on the MI355X box."""
@@ -17,13 +18,14 @@ sys.path.insert(0, ROOT)
 def main():
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    lo, hi = (int(sys.argv[3]), int(sys.argv[4])) if len(sys.argv) > 4 else (40, 300)
     from oracle import orc_ba
     from reconstructor_amd import _lib, ba, synth_ba
     ctx = _lib.Context(0)
     rng = np.random.default_rng(seed)
     t0, n, checked, blocks = time.time(), 0, 0, set()
     while time.time() - t0 < budget:
-        nc = int(rng.integers(40, 300))
+        nc = int(rng.integers(lo, hi))
         npts = int(rng.integers(8, 30)) * nc
         k = int(rng.integers(3, 9))
         sc = synth_ba.make_scene(nc, npts, obs_per_point=k, seed=int(rng.integers(1 << 30)))
