@@ -1,4 +1,5 @@
-"""tools/pmc_report.py <prof dir> <out dir> -- condense the raw output of tools/profile_r02.sh into the files under profiles/:
+"""tools/pmc_report.py <prof dir> <out dir> [tag] -- condense the raw output of tools/profile_round.sh into the files under profiles/
+(named <tag>_*, tag = r03 by default):
 per-kernel counter means, the derived figures (effective clock, MFMA-pipe busy share, VALU per MFMA, fabric bytes per
 launch corrected as MI355X_MICROARCH.md prescribes) and the traffic JSON bench.py quotes.  Everything is stamped with
 the hash of the sources the profiled binary was built from (bench.source_hash) and the git HEAD of the build tree."""
@@ -32,6 +33,7 @@ def kernel_stats(d):
 
 def main():
     prof, outd = sys.argv[1], sys.argv[2]
+    tag = sys.argv[3] if len(sys.argv) > 3 else "r03"
     import bench
     stamp = {"source_hash": bench.source_hash()}
     try:
@@ -40,10 +42,10 @@ def main():
     except Exception:
         pass
     traffic = dict(stamp)
-    traffic["_comment"] = ("fabric-side bytes per launch of K1 from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/profile_r02.sh): counters in KiB; "
+    traffic["_comment"] = ("fabric-side bytes per launch of K1 from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/profile_round.sh): counters in KiB; "
                            "on gfx950 FETCH_SIZE reports half the bytes of wide coalesced streaming reads, so it is doubled; WRITE_SIZE is exact; Infinity-Cache hits are "
                            "counted by these counters, so this is an upper bound on DRAM bytes (MI355X_MICROARCH.md, HBM section)")
-    lines = ["# condensed by tools/pmc_report.py from gpurun_out/prof_r02 (tools/profile_r02.sh); source_hash %s git %s%s" %
+    lines = ["# condensed by tools/pmc_report.py from gpurun_out/prof_" + tag + " (tools/profile_round.sh); source_hash %s git %s%s" %
              (stamp["source_hash"], stamp.get("git_head", "?")[:12], " +uncommitted" if stamp.get("git_dirty") else "")]
     for shape, label in (("100_2048_256_6", "100x2048"), ("100_1500_128_6", "sift 100x1500x128"), ("1000_4096_256", "1000x4096")):
         sq = counters(os.path.join(prof, "k1_sq_" + shape))
@@ -82,13 +84,13 @@ def main():
         for tab in (sq, lds, fe, wr):
             for (kn2, c), (v, n) in sorted(tab.items()):
                 lines.append("%-44s %-28s n=%d mean=%.5g" % (kn2[:44], c, n, v))
-    json.dump(traffic, open(os.path.join(outd, "r02_match_traffic.json"), "w"), indent=1)
-    open(os.path.join(outd, "r02_match_pmc_summary.txt"), "w").write("\n".join(lines) + "\n")
+    json.dump(traffic, open(os.path.join(outd, tag + "_match_traffic.json"), "w"), indent=1)
+    open(os.path.join(outd, tag + "_match_pmc_summary.txt"), "w").write("\n".join(lines) + "\n")
     # kernel-trace summaries
-    for name, sub in (("r02_bench_kernel_stats.csv", "trace_bench"), ("r02_ba_cfg5_kernel_stats.csv", "trace_ba5")):
+    for name, sub in ((tag + "_bench_kernel_stats.csv", "trace_bench"), (tag + "_ba_cfg5_kernel_stats.csv", "trace_ba5"), (tag + "_ba_cfg4_kernel_stats.csv", "trace_ba4"), (tag + "_k1_cfg3_kernel_stats.csv", "trace_k1_cfg3")):
         st = kernel_stats(os.path.join(prof, sub))
         with open(os.path.join(outd, name), "w") as f:
-            f.write("# rocprofv3 --kernel-trace --stats (tools/profile_r02.sh, %s); source_hash %s git %s\n" % (sub, stamp["source_hash"], stamp.get("git_head", "?")[:12]))
+            f.write("# rocprofv3 --kernel-trace --stats (tools/profile_round.sh, %s); source_hash %s git %s\n" % (sub, stamp["source_hash"], stamp.get("git_head", "?")[:12]))
             f.write("kernel,calls,avg_us,total_ms,percent\n")
             for k, v in sorted(st.items(), key=lambda kv: -kv[1]["total_ms"]):
                 f.write('"%s",%d,%.3f,%.3f,%.2f\n' % (k, v["calls"], v["avg_us"], v["total_ms"], v["pct"]))
@@ -96,12 +98,19 @@ def main():
     sq, fe, wr = counters(os.path.join(prof, "ba5_sq")), counters(os.path.join(prof, "ba5_fetch")), counters(os.path.join(prof, "ba5_write"))
     bl = ["# BA cfg 5 (1000 cams / 100k pts / 1M obs), tools/ba_run.py 1000 100000 1, rocprofv3 --pmc passes; source_hash %s git %s" % (stamp["source_hash"], stamp.get("git_head", "?")[:12]),
           "# FETCH_SIZE / WRITE_SIZE in KiB per launch (FETCH to be doubled for wide streaming reads); MFMA share = SQ_VALU_MFMA_BUSY_CYCLES / (1024 x GRBM_GUI_ACTIVE / 8)"]
+    bl.append("# derived, per launch: fabric bytes = 1024 x (2 x FETCH_SIZE + WRITE_SIZE); MFMA-pipe busy share")
+    for k in sorted(set(kk for (kk, c) in fe)):
+        f, w = fe.get((k, "FETCH_SIZE"), (float("nan"), 0))[0], wr.get((k, "WRITE_SIZE"), (float("nan"), 0))[0]
+        cyc = sq.get((k, "GRBM_GUI_ACTIVE"), (float("nan"), 0))[0] / 8.0
+        busy = sq.get((k, "SQ_VALU_MFMA_BUSY_CYCLES"), (float("nan"), 0))[0]
+        bl.append("%-44s fabric_bytes=%.4g  mfma_busy_share=%.3f  cycles=%.4g" % (k[:44], 1024.0 * (2.0 * f + w), busy / (1024.0 * cyc) if cyc == cyc and cyc > 0 else float("nan"), cyc))
+    bl.append("# raw counter means")
     for (k, c), (v, n) in sorted(sq.items()):
         bl.append("%-44s %-28s n=%d mean=%.5g" % (k[:44], c, n, v))
     for tab in (fe, wr):
         for (k, c), (v, n) in sorted(tab.items()):
             bl.append("%-44s %-28s n=%d mean=%.5g" % (k[:44], c, n, v))
-    open(os.path.join(outd, "r02_ba_pmc_summary.txt"), "w").write("\n".join(bl) + "\n")
+    open(os.path.join(outd, tag + "_ba_pmc_summary.txt"), "w").write("\n".join(bl) + "\n")
     print("wrote", outd)
 
 

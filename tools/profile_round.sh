@@ -1,14 +1,17 @@
 #!/bin/bash
-# tools/profile_r02.sh -- every rocprofv3 pass behind profiles/r02_* (run on the MI355X box from the repo root:
-#   gpurun -- 'bash tools/profile_r02.sh').  Counter passes are separate runs with --pmc only (no trace domains),
-# the program directly after `--`.  Raw output goes to gpurun_out/prof_r02/, tools/pmc_report.py condenses it.
+# tools/profile_round.sh [TAG] -- every rocprofv3 pass behind profiles/<TAG>_* (TAG = r03 by default; run on the MI355X box from
+# the repo root:  gpurun -- 'bash tools/profile_round.sh r03').  Counter passes are separate runs with --pmc only (no trace domains),
+# the program directly after `--`.  Raw output goes to gpurun_out/prof_<TAG>/, tools/pmc_report.py condenses it.
 set -o pipefail
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
-O=gpurun_out/prof_r02
+R=${1:-r03}
+O=gpurun_out/prof_$R
 rm -rf "$O"; mkdir -p "$O"
 run() { echo "== $*"; "$@" || echo "   (rc=$?)"; }
 # ---- kernel time: the whole default bench (cfg3 headline + cfg2 + BA legs), no CPU baseline
 run rocprofv3 --kernel-trace --stats -d $O/trace_bench -o t --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > $O/trace_bench.log 2>&1
+# ---- kernel time of the dominant kernel at the headline shape alone (cfg3: every launch in this trace is a 1000 x 4096 x 256 launch)
+run rocprofv3 --kernel-trace --stats -d $O/trace_k1_cfg3 -o t --output-format csv -- python3 tools/k1_run.py 1000 4096 256 2 > $O/trace_k1_cfg3.log 2>&1
 # ---- K1 counters at cfg2 shape (100 x 2048 x 256) and at the SIFT shape (100 x 1500 x 128)
 for shape in "100 2048 256 6" "100 1500 128 6"; do
   tag=$(echo $shape | tr ' ' '_')
@@ -23,9 +26,11 @@ run rocprofv3 --pmc WRITE_SIZE -d $O/k1_write_1000_4096_256 -o p --output-format
 run rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_INSTS_MFMA SQ_WAVE_CYCLES -d $O/k1_sq_1000_4096_256 -o p --output-format csv -- python3 tools/k1_run.py 1000 4096 256 1 > $O/k1_sq_cfg3.log 2>&1
 # ---- BA cfg 5: kernel time and the factorisation chain's counters
 run rocprofv3 --kernel-trace --stats -d $O/trace_ba5 -o t --output-format csv -- python3 tools/ba_run.py 1000 100000 2 > $O/trace_ba5.log 2>&1
+run rocprofv3 --kernel-trace --stats -d $O/trace_ba4 -o t --output-format csv -- python3 tools/ba_run.py 200 20000 2 > $O/trace_ba4.log 2>&1
 run rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_INSTS_MFMA SQ_WAVE_CYCLES SQ_BUSY_CYCLES -d $O/ba5_sq -o p --output-format csv -- python3 tools/ba_run.py 1000 100000 1 > $O/ba5_sq.log 2>&1
 run rocprofv3 --pmc FETCH_SIZE -d $O/ba5_fetch -o p --output-format csv -- python3 tools/ba_run.py 1000 100000 1 > $O/ba5_fetch.log 2>&1
 run rocprofv3 --pmc WRITE_SIZE -d $O/ba5_write -o p --output-format csv -- python3 tools/ba_run.py 1000 100000 1 > $O/ba5_write.log 2>&1
 # keep what the report needs small: counter CSVs and the *_kernel_stats.csv of the traces
 find $O -name "*kernel_trace.csv" -size +4M -delete
 du -sh $O
+mkdir -p gpurun_out/profiles_$R && python3 tools/pmc_report.py $O gpurun_out/profiles_$R $R && ls -la gpurun_out/profiles_$R
