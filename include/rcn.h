@@ -292,7 +292,9 @@ typedef struct {
     double  cost_trace[160];    /* cost after each iteration, [0] = initial */
     double  jacobian_seconds;   /* HIP-event time of the residual + Jacobian kernel (k_ba_eval<true>: 224 B written per observation), summed */
     int32_t jacobian_evals;     /* launches summed into jacobian_seconds */
-    int32_t reserved2;
+    int32_t factor_schedule;    /* 0: the factorisations ran on three streams; 1: on one stream in program order (a cross-stream
+                                   wait gave up -- a runtime that does not run the streams side by side -- and the context
+                                   latched the one-stream schedule; same bits either way) */
 } rcn_ba_summary;
 
 int rcn_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *problem, const rcn_ba_options *options,

@@ -106,7 +106,7 @@ class BaSummary(C.Structure):
                 ("solve_seconds", C.c_double), ("schur_seconds", C.c_double),
                 ("cholesky_seconds", C.c_double), ("trisolve_seconds", C.c_double),
                 ("cost_trace", C.c_double * 160),
-                ("jacobian_seconds", C.c_double), ("jacobian_evals", C.c_int32), ("reserved2", C.c_int32)]
+                ("jacobian_seconds", C.c_double), ("jacobian_evals", C.c_int32), ("factor_schedule", C.c_int32)]
 
 
 _LIB = None

@@ -2291,7 +2291,8 @@ int rcn_int_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_option
                 if (m <= 0) break;
                 const int gq1 = 32;                   // grid of k_gemm_q for one tile: strips 0..3 on 4 of the 8 XCD slots
                 // T(kb), first half: publishes "D(kb) done"; waits for C(kb-1) and the bulk updates of column kb + 1
-                k_gemm_q<0><<<gq1, 256, 0, sA>>>(d.S, d.L, npad, kb, 0, 1, d.Linv, gate(cC, kb, lastw[kb + 1], cD, kb + 1));
+                // (diagnostic build, RCN_CHOL_BREAK=1: step 1 waits for a count that never comes -- the test of the fallback)
+                k_gemm_q<0><<<gq1, 256, 0, sA>>>(d.S, d.L, npad, kb, 0, 1, d.Linv, gate(cC, ctx->chol_break && kb == 1 ? 1 << 30 : kb, lastw[kb + 1], cD, kb + 1));
                 k_gemm_q<1><<<gq1, 256, 0, sA>>>(d.S, d.L, npad, kb, 0, 1, d.Linv, none);
                 // On B and C the waits are ONE-WAVE gate kernels in front of the work, never inside it: a grid of a thousand
                 // workgroups that spins while it holds its CU slots could keep the very kernel it waits for from becoming resident.
@@ -2481,6 +2482,7 @@ int rcn_int_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_option
         else (void)hipGetLastError();
     }
     sum->iterations = iter;
+    sum->factor_schedule = ctx->chol_safe ? 1 : 0;
     sum->termination = termination;
     sum->final_cost = cost;
     sum->final_rms_px = std::sqrt(2.0 * cost / std::max(no, 1));

@@ -258,3 +258,35 @@ def test_rejected_steps_follow_the_oracle(gpu_ctx):
     n = min(len(s0["cost_trace"]), len(s1["cost_trace"]), 12)
     assert np.allclose(s1["cost_trace"][:n], s0["cost_trace"][:n], rtol=1e-6)       # the early trace; 50 chaotic iterations amplify rounding
     assert abs(s1["final_rms_px"] - s0["final_rms_px"]) <= 1e-3 * s0["final_rms_px"]
+
+
+def test_a_broken_stream_hand_off_falls_back_to_one_stream_with_the_same_bits(gpu_ctx):
+    """a cross-stream wait of the factorisation that gives up must cost time, not the result.  The diagnostic
+    build can break one hand-off on purpose (RCN_CHOL_BREAK=1: step 1 of every three-stream factorisation waits for a count
+    that never comes); the wait times out after 2 s, the context latches the one-stream schedule, the linear solve of that
+    iteration is redone -- and poses, intrinsics and points equal the shipping library's, bit for bit."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from reconstructor_amd import ba
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    diag = os.path.join(root, "tools", "librcn_diag.so")
+    assert os.path.exists(diag), "tools/librcn_diag.so missing: run __graft_entry__.build()"
+    sc = synth_ba.make_scene(70, 1500, obs_per_point=6, seed=77)         # 6 blocks of 128: every kind of step occurs
+    P1, I1, X1, s1 = ba.solve_scene(gpu_ctx, sc)
+    assert s1["factor_schedule"] == 0
+    code = ("import sys, json, hashlib; sys.path.insert(0, %r)\n"
+            "from reconstructor_amd import _lib, ba, synth_ba\n"
+            "sc = synth_ba.make_scene(70, 1500, obs_per_point=6, seed=77)\n"
+            "P, I, X, s = ba.solve_scene(_lib.Context(0), sc)\n"
+            "print(json.dumps({'h': hashlib.sha256(P.tobytes() + I.tobytes() + X.tobytes()).hexdigest(), 'sched': s['factor_schedule'],\n"
+            "                  'it': s['iterations'], 'cost': s['final_cost'], 'sec': s['solve_seconds'], 'invalid': s['invalid_steps']}))\n" % root)
+    env = dict(os.environ, RCN_LIB=diag, RCN_CHOL_BREAK="1")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    import hashlib
+    assert d["sched"] == 1 and d["sec"] > 1.5 and d["invalid"] == 0
+    assert d["it"] == s1["iterations"] and d["cost"] == s1["final_cost"]
+    assert d["h"] == hashlib.sha256(P1.tobytes() + I1.tobytes() + X1.tobytes()).hexdigest()
