@@ -1515,6 +1515,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt_ring(double *S, const double
 // MODE 1 is the PANEL product on the same pipeline, L(i, kb) = S(i, kb) Linv_kb' (B = the inverse of the diagonal block, row
 // stride 128; no C tile, the product itself is stored): the rows of a panel below the critical tile, a tile per workgroup.
 // S is the matrix the result is written to (MODE 0: S, updated in place; MODE 1: L), Lm the matrix A is read from.
+#define PIPE_PRIO 0x200      // flag in toff: raise the wave priority (launches on the panel stream: they share SIMDs with the bulk update)
 template <int DBG, int NST, int MODE = 0>
 __global__ __launch_bounds__(256, 2) void k_gemm_nt_pipe(double *S, const double *Lm, int ld, int kb, const unsigned *__restrict__ map, int toff, int *sig,
                                                           const double *Linv = nullptr)
@@ -1523,6 +1524,8 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt_pipe(double *S, const double
     extern __shared__ __attribute__((aligned(16))) char gsm[];
     const unsigned e = map[blockIdx.x];
     if (e == ~0u) return;
+    if (toff & PIPE_PRIO) __builtin_amdgcn_s_setprio(2);
+    toff &= 0xff;
     const int ti = kb + toff + (int)(e >> 16), tj = MODE == 1 ? kb : kb + toff + (int)(e & 0xffffu);
     const double *A = Lm + ((size_t)ti * NB) * ld + (size_t)kb * NB;
     const double *B = MODE == 1 ? Linv + (size_t)kb * NB * NB : Lm + ((size_t)tj * NB) * ld + (size_t)kb * NB;
@@ -2304,13 +2307,13 @@ int rcn_int_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_option
                     // bulk update beside them); short ones stay with k_gemm_q, whose single tile finishes in 8 us, not 20.
                     const bool piped = m - 1 >= ctx->chol_pipe_min;
                     if (!safe) k_ring_gate<<<1, 64, 0, sB>>>(gate(cD, kb + 1, lastw[kb], cC, kb));
-                    if (piped) k_gemm_nt_pipe<0, 16, 1><<<m - 1, 256, GST * GSTAGE_BYTES, sB>>>(d.L, d.S, npad, kb, maps + ctx->col_map_off1, 1, nullptr, d.Linv);
+                    if (piped) k_gemm_nt_pipe<0, 16, 1><<<m - 1, 256, GST * GSTAGE_BYTES, sB>>>(d.L, d.S, npad, kb, maps + ctx->col_map_off1, 1 | PIPE_PRIO, nullptr, d.Linv);
                     else k_gemm_q<0><<<gq, 256, 0, sB>>>(d.S, d.L, npad, kb, 1, m - 1, d.Linv, none);
                     // C(kb): its gate publishes "P(kb) done" and waits for T(kb) and the bulk updates of the column(s) it writes
                     if (!safe) k_ring_gate<<<1, 64, 0, sB>>>(gate(cT, kb + 1, two_cols ? later(lastw[kb + 1], lastw[kb + 2]) : lastw[kb + 1], cP, kb + 1));
                     if (piped) {
-                        if (two_cols) k_gemm_nt_pipe<0, 16><<<2 * (m - 1), 256, GST * GSTAGE_BYTES, sB>>>(d.S, d.L, npad, kb, maps + ctx->col_map_off2, 1, nullptr);
-                        else k_gemm_nt_pipe<0, 16><<<m - 1, 256, GST * GSTAGE_BYTES, sB>>>(d.S, d.L, npad, kb, maps + ctx->col_map_off1, 1, nullptr);
+                        if (two_cols) k_gemm_nt_pipe<0, 16><<<2 * (m - 1), 256, GST * GSTAGE_BYTES, sB>>>(d.S, d.L, npad, kb, maps + ctx->col_map_off2, 1 | PIPE_PRIO, nullptr);
+                        else k_gemm_nt_pipe<0, 16><<<m - 1, 256, GST * GSTAGE_BYTES, sB>>>(d.S, d.L, npad, kb, maps + ctx->col_map_off1, 1 | PIPE_PRIO, nullptr);
                     } else {
                         k_gemm_q<1><<<gq, 256, 0, sB>>>(d.S, d.L, npad, kb, 1, m - 1, d.Linv, none);
                         if (two_cols) k_gemm_q<1><<<gq, 256, 0, sB>>>(d.S, d.L, npad, kb, 1, m - 1, d.Linv, none, 2);
