@@ -962,12 +962,12 @@ __global__ void k_ring_signal(int *counter, int value)
 }
 
 // one thread: relaxed poll (an sc1 load) with a 2-second limit (100 MHz wall clock, independent of the shader clock)
-__device__ __forceinline__ void ring_wait(const int *counter, int need, int *flag)
+__device__ __forceinline__ void ring_wait(const int *counter, int need, int *flag, int code = 3)
 {
     const unsigned long long t0 = wall_clock64();
     while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
         __builtin_amdgcn_s_sleep(8);
-        if (wall_clock64() - t0 > 200000000ull) { *flag = 3; break; }
+        if (wall_clock64() - t0 > 200000000ull) { *flag = code; break; }
     }
 }
 
@@ -1709,6 +1709,73 @@ __global__ __launch_bounds__(512) void k_trsv_bwd(const double *S /* = L: sub-di
     if (g == 0) y[(size_t)j * NB + t] -= (part[0][t] + part[1][t]) + (part[2][t] + part[3][t]);
 }
 
+// The same backward substitution as ONE launch (round 3): 79 dependent launches of ~8 us each were 0.6 ms of a cfg-5 iteration.
+// Workgroup j owns block row j: it holds Linv_j in registers from the start, takes every x_i (i > j) as it appears, subtracts
+// L(i, j)' x_i from its right-hand side (the tile L(i, j) is already in registers by then), then publishes x_j = Linv_j' y_j.
+// The hand-off is the DATA itself: x is preset to a sentinel (all-ones bit pattern, a NaN no arithmetic produces), written with
+// agent-coherent stores and polled element by element with agent-coherent loads -- one memory round trip per step instead of
+// three (store acknowledged, flag stored, flag seen, data loaded), no L2-wide release / acquire.  The sums are grouped exactly as
+// in k_trsv_bwd (four partial sums of 32, combined pairwise, block rows in descending order), so the bits are the same.
+// All nblk workgroups must be resident at once (the host takes this path only while nblk <= half the CUs); an element that does
+// not come within 2 s raises *flag = 4 and the host repeats the substitution with the per-step kernels.
+#define TRSV_SENTINEL 0xFFFFFFFFFFFFFFFFull
+__global__ __launch_bounds__(512) void k_trsv_bwd_chain(const double *Lm, int ld, int nblk, const double *Linv, const double *y, double *x, int *flag)
+{
+    __shared__ double xk[NB], part[4][NB];
+    const int t = threadIdx.x & 127, g = threadIdx.x >> 7;
+    const int j = nblk - 1 - (int)blockIdx.x;             // the head of the chain is dispatched first
+    double li[32], cur[32], nxt[32];
+    {
+        const double *Lk = Linv + (size_t)j * NB * NB;
+#pragma unroll
+        for (int m = 0; m < 32; ++m) li[m] = Lk[(size_t)(32 * g + m) * NB + t];
+    }
+    double yj = g == 0 ? y[(size_t)j * NB + t] : 0.0;
+    auto fetch = [&](int i, double (&dst)[32]) {
+        const double *blk = Lm + ((size_t)i * NB) * ld + (size_t)j * NB;      // L[i, j] tile: rows m, column t
+#pragma unroll
+        for (int m = 0; m < 32; ++m) dst[m] = blk[(size_t)(32 * g + m) * ld + t];
+    };
+    if (nblk - 1 > j) fetch(nblk - 1, nxt);
+    unsigned long long *xb = reinterpret_cast<unsigned long long *>(x);
+    for (int i = nblk - 1; i > j; --i) {
+#pragma unroll
+        for (int m = 0; m < 32; ++m) cur[m] = nxt[m];
+        if (i - 1 > j) fetch(i - 1, nxt);
+        if (g == 0) {
+            unsigned long long v = __hip_atomic_load(xb + (size_t)i * NB + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (v == TRSV_SENTINEL) {
+                const unsigned long long t0 = wall_clock64();
+                do {
+                    __builtin_amdgcn_s_sleep(2);
+                    v = __hip_atomic_load(xb + (size_t)i * NB + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (wall_clock64() - t0 > 200000000ull) { *flag = 4; break; }
+                } while (v == TRSV_SENTINEL);
+            }
+            xk[t] = __longlong_as_double((long long)v);
+        }
+        __syncthreads();
+        double u = 0.0;
+#pragma unroll
+        for (int m = 0; m < 32; ++m) u += cur[m] * xk[32 * g + m];
+        part[g][t] = u;
+        __syncthreads();
+        if (g == 0) yj -= (part[0][t] + part[1][t]) + (part[2][t] + part[3][t]);
+    }
+    __syncthreads();
+    if (g == 0) xk[t] = yj;
+    __syncthreads();
+    double s = 0.0;
+#pragma unroll
+    for (int m = 0; m < 32; ++m) s += li[m] * xk[32 * g + m];      // zeros above the diagonal
+    part[g][t] = s;
+    __syncthreads();
+    if (g == 0) {
+        const double xv = (part[0][t] + part[1][t]) + (part[2][t] + part[3][t]);
+        __hip_atomic_store(xb + (size_t)j * NB + t, (unsigned long long)__double_as_longlong(xv), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 // ---------------------------------------------------------------------------------------
 // K8: point back-substitution, scaled step = -y.  Two passes: per observation  t_o = W_o' y_c  out of the W plane (a
 // wave's 64 rows of 240 B staged through LDS as one contiguous block), then per point  -Vinv (g_p - sum_o t_o)  over the
@@ -2214,7 +2281,7 @@ int rcn_int_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_option
         }
         const double ir = 1.0 / radius;
         RCN_HIP(hipEventRecord(ctx->ba_tev[0], st));
-        RCN_HIP(hipMemsetAsync(d.flag, 0, 8 * sizeof(int), st));      // [0] breakdown / gate flag, [2..6] progress counters of the factorisation's streams
+        RCN_HIP(hipMemsetAsync(d.flag, 0, 8 * sizeof(int), st));      // [0] breakdown / gate flag, [2..7] progress counters of the factorisation's streams
         if (!gather) RCN_HIP(hipMemsetAsync(Sb, 0, sizeof(double) * 100 * (size_t)nc * nc, st));
         if (npad > n) RCN_HIP(hipMemsetAsync(d.S + (size_t)n * npad, 0, sizeof(double) * (size_t)(npad - n) * npad, st));
         RCN_HIP(hipMemsetAsync(d.rhs, 0, sizeof(double) * npad, st));
@@ -2356,7 +2423,11 @@ int rcn_int_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_option
         RCN_HIP(hipEventRecord(ctx->ba_tev[2], st));
         if (rhs_row) k_ba_y_from_row<<<(npad + 255) / 256, 256, 0, st>>>(d);
         else for (int kb = 0; kb < nblk; ++kb) k_trsv_fwd<<<nblk - kb, 128, 0, st>>>(d.L, npad, kb, d.Linv, d.rhs, d.yc);
-        for (int kb = nblk - 1; kb >= 0; --kb) k_trsv_bwd<<<kb + 1, 512, 0, st>>>(d.L, npad, kb, d.Linv, d.yc, d.rhs);
+        if (ctx->trsv_chain && 2 * nblk <= ctx->prop.multiProcessorCount) {
+            RCN_HIP(hipMemsetAsync(d.rhs, 0xFF, sizeof(double) * npad, st));      // the sentinel (the right-hand side itself went into the system's last row)
+            k_trsv_bwd_chain<<<nblk, 512, 0, st>>>(d.L, npad, nblk, d.Linv, d.yc, d.rhs, d.flag);
+        }
+        else for (int kb = nblk - 1; kb >= 0; --kb) k_trsv_bwd<<<kb + 1, 512, 0, st>>>(d.L, npad, kb, d.Linv, d.yc, d.rhs);
         RCN_HIP(hipGetLastError());
         RCN_HIP(hipMemcpyAsync(d.yc, d.rhs, sizeof(double) * npad, hipMemcpyDeviceToDevice, st));
         if (no > 0) k_ba_backsub_obs<<<ebj, 128, 0, st>>>(d);
@@ -2379,6 +2450,13 @@ int rcn_int_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_option
             RCN_HIP(hipEventElapsedTime(&ms, ctx->ba_tev[0], ctx->ba_tev[1])); sum->schur_seconds += 1e-3 * ms;
             RCN_HIP(hipEventElapsedTime(&ms, ctx->ba_tev[1], ctx->ba_tev[2])); sum->cholesky_seconds += 1e-3 * ms;
             RCN_HIP(hipEventElapsedTime(&ms, ctx->ba_tev[2], ctx->ba_tev[3])); sum->trisolve_seconds += 1e-3 * ms;
+        }
+        if (hflag == 4 && ctx->trsv_chain) {
+            // the one-launch backward substitution gave up on a flag (its workgroups were not all resident): per-step kernels from now on
+            ctx->trsv_chain = false;
+            --iter;
+            reuse_diag = true;
+            continue;
         }
         if (hflag == 3 && !ctx->chol_safe) {
             // a cross-stream wait of the factorisation gave up: this runtime does not run the three streams side by side.

@@ -93,6 +93,8 @@ int rcn_create(int device_id, rcn_ctx **out)
     ctx->ba_trsv_fwd = btf && btf[0] == '1';
     const char *cs = std::getenv("RCN_CHOL_SAFE");
     ctx->chol_safe = cs && cs[0] == '1';
+    const char *tch = std::getenv("RCN_TRSV_CHAIN");
+    if (tch) ctx->trsv_chain = tch[0] != '0';
     const char *cbk = std::getenv("RCN_CHOL_BREAK");
     ctx->chol_break = cbk && cbk[0] == '1';
     const char *cpm = std::getenv("RCN_CHOL_PAIR_MIN");

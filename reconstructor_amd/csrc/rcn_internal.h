@@ -180,6 +180,7 @@ struct rcn_ctx {
     std::vector<int> pair_map_off, pair_map_grid;   // the same triangles with their first two tile columns leading (two-panel updates)
     int col_map_off1 = 0, col_map_off2 = 0;          // tile columns for the pipelined kernel on the panel stream
     int chol_pipe_min = 32;                          // panel / column kernels go through the pipelined kernel from this many tiles on
+    bool trsv_chain = true;                          // backward substitution as one launch (k_trsv_bwd_chain); off after a flag timeout
     bool chol_break = false;                         // diagnostic build: break one cross-stream hand-off (forces the one-stream fallback)
     int chol_pair_min = 24;                          // two-panel bulk updates while at least this many tile rows remain below the pair
     int bulk_map_nblk = 0;

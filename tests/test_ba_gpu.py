@@ -290,3 +290,10 @@ def test_a_broken_stream_hand_off_falls_back_to_one_stream_with_the_same_bits(gp
     assert d["sched"] == 1 and d["sec"] > 1.5 and d["invalid"] == 0
     assert d["it"] == s1["iterations"] and d["cost"] == s1["final_cost"]
     assert d["h"] == hashlib.sha256(P1.tobytes() + I1.tobytes() + X1.tobytes()).hexdigest()
+    # the backward substitution as one launch (x handed from block row to block row through the data itself) against the
+    # per-step kernels it falls back to: the same bits
+    env = dict(os.environ, RCN_LIB=diag, RCN_TRSV_CHAIN="0")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["sched"] == 0 and d["invalid"] == 0 and d["h"] == hashlib.sha256(P1.tobytes() + I1.tobytes() + X1.tobytes()).hexdigest()
