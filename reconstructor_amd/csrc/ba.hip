@@ -1716,8 +1716,9 @@ __global__ __launch_bounds__(512) void k_trsv_bwd(const double *S /* = L: sub-di
 // agent-coherent stores and polled element by element with agent-coherent loads -- one memory round trip per step instead of
 // three (store acknowledged, flag stored, flag seen, data loaded), no L2-wide release / acquire.  The sums are grouped exactly as
 // in k_trsv_bwd (four partial sums of 32, combined pairwise, block rows in descending order), so the bits are the same.
-// All nblk workgroups must be resident at once (the host takes this path only while nblk <= half the CUs); an element that does
-// not come within 2 s raises *flag = 4 and the host repeats the substitution with the per-step kernels.
+// Workgroup j waits only for workgroups dispatched BEFORE it (larger j = smaller block index, and dispatch is in order), so the
+// launch cannot deadlock whatever share of it is resident; the host still keeps it to nblk <= half the CUs.  An element that
+// does not come within 2 s raises *flag = 4 and the host repeats the substitution with the per-step kernels.
 #define TRSV_SENTINEL 0xFFFFFFFFFFFFFFFFull
 __global__ __launch_bounds__(512) void k_trsv_bwd_chain(const double *Lm, int ld, int nblk, const double *Linv, const double *y, double *x, int *flag)
 {
