@@ -962,6 +962,19 @@ __global__ void k_ring_signal(int *counter, int value)
 }
 
 // one thread: relaxed poll (an sc1 load) with a 2-second limit (100 MHz wall clock, independent of the shader clock)
+#ifdef RCN_DIAG
+// Diagnostic build only: a device-side timeline of the factorisation's kernels (tools/chol_device_timeline.py).  rocprofv3's kernel
+// trace stretches dependent launches and cross-stream hand-offs by tens of microseconds, which is the very thing to be measured.
+// Slot 3 * id: first workgroup entered; + 1: its gate passed; + 2: last workgroup left.  id = 8 * block step + kind.
+__device__ unsigned long long *g_tl = nullptr;
+#define TL_MARK(id, w) do { if (g_tl && threadIdx.x == 0 && (blockIdx.x == 0 || (w) == 2)) atomicMax(&g_tl[3 * (id) + (w)], (unsigned long long)wall_clock64()); } while (0)
+extern "C" int rcn_diag_timeline_set(unsigned long long *dev_buf)
+{
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_tl), &dev_buf, sizeof(dev_buf)) == hipSuccess ? 0 : -1;
+}
+#else
+#define TL_MARK(id, w)
+#endif
 __device__ __forceinline__ void ring_wait(const int *counter, int need, int *flag, int code = 3)
 {
     const unsigned long long t0 = wall_clock64();
@@ -1069,7 +1082,9 @@ __device__ unsigned long long g_stamps[64];
 __global__ __launch_bounds__(64 * CDW) void k_chol_diag(double *S, int ld, int kb, double *Linv, int *flag, int store_L, Gate g)
 {
     __builtin_amdgcn_s_setprio(3);
+    TL_MARK(8 * kb, 0);
     gate_enter(g);
+    TL_MARK(8 * kb, 1);
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     double *L = reinterpret_cast<double *>(smem_raw);  // [128][DL]
     if (threadIdx.x >= 64) __builtin_amdgcn_s_setprio(2);   // wave 0 carries the serial chain: its few MFMAs go before its SIMD neighbour's
@@ -1337,6 +1352,7 @@ __global__ __launch_bounds__(64 * CDW) void k_chol_diag(double *S, int ld, int k
     }
     STAMP(16);
     STAMP(17);
+    TL_MARK(8 * kb, 2);
 }
 
 // Dense blocked Cholesky, GEMM side.  S holds the reduced system and its trailing updates; the
@@ -1360,7 +1376,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(96)))
 void k_gemm_q(double *S, double *L, int ld, int kb, int first, int m, const double *Linv, Gate g, int dj = 1)
 {
     __builtin_amdgcn_s_setprio(3);      // these waves share SIMDs with the bulk update's: their few MFMAs and loads go first
+    [[maybe_unused]] const int tl_id = 8 * kb + (MODE == 0 ? (first == 0 ? 1 : 3) : (first == 0 ? 2 : (dj == 2 ? 5 : 4)));
+    TL_MARK(tl_id, 0);
     gate_enter(g);
+    TL_MARK(tl_id, 1);
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     const int strip = 8 * (slot >> 2) + xcd, qj = slot & 3;      // strip: 32 rows of the tile column, qj: 32 output columns
     if (strip >= 4 * m) return;
@@ -1394,6 +1413,7 @@ void k_gemm_q(double *S, double *L, int ld, int kb, int first, int m, const doub
     }
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) C[(size_t)(wr + fk + 4 * reg) * ld + wc + fr] = acc[reg];
+    TL_MARK(tl_id, 2);
 }
 
 // Tile mapping of the bulk update: the lower triangle of the mt x mt trailing tiles is cut into
@@ -1526,6 +1546,8 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt_pipe(double *S, const double
     if (e == ~0u) return;
     if (toff & PIPE_PRIO) __builtin_amdgcn_s_setprio(2);
     toff &= 0xff;
+    [[maybe_unused]] const int tl_id = 8 * kb + (MODE == 1 ? 3 : toff == 1 ? 4 : 6);
+    TL_MARK(tl_id, 0);
     const int ti = kb + toff + (int)(e >> 16), tj = MODE == 1 ? kb : kb + toff + (int)(e & 0xffffu);
     const double *A = Lm + ((size_t)ti * NB) * ld + (size_t)kb * NB;
     const double *B = MODE == 1 ? Linv + (size_t)kb * NB * NB : Lm + ((size_t)tj * NB) * ld + (size_t)kb * NB;
@@ -1656,7 +1678,11 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt_pipe(double *S, const double
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (t == 0) __hip_atomic_fetch_add(sig, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+#ifdef RCN_DIAG
+        if (g_tl && t == 0) atomicMax(&g_tl[3 * tl_id + 1], (unsigned long long)wall_clock64());      // a head tile finished
+#endif
     }
+    TL_MARK(tl_id, 2);
 }
 
 // forward substitution step kb: y_kb = Linv_kb b_kb ; b_i -= L[i,kb] y_kb for i > kb.
