@@ -13,9 +13,9 @@
 //      gathers over per-block observation-pair lists built once per solve (k_pair_*), written
 //      straight into the dense reduced system; bit-reproducible                      [L2 gathers / f64 MFMA]
 //      (k_ba_schur + k_ba_S_assemble + k_ba_cam_rhs: the atomic form, RCN_BA_SCHUR_ATOMICS=1)
-//   K7 k_chol_diag -> k_gemm_q<0> -> k_gemm_q<1> (latency chain) beside k_gemm_nt_ring (bulk, second
-//      stream): blocked right-looking Cholesky with lookahead, v_mfma_f64_16x16x4_f64       [f64 MFMA]
-//      k_trsv_bwd (k_trsv_fwd only when the rhs does not ride through the factorisation)
+//   K7 k_chol_diag -> k_gemm_q<0> -> k_gemm_q<1> (latency chain) beside k_gemm_nt_pipe (panels and columns on a second
+//      stream, bulk updates on a third): blocked right-looking Cholesky, v_mfma_f64_16x16x4_f64   [f64 MFMA]
+//      k_trsv_bwd_chain (k_trsv_bwd per step as its fallback; k_trsv_fwd only when the rhs does not ride through the factorisation)
 //   K8 k_ba_backsub, k_ba_model, k_ba_plus, reductions                                       [HBM]
 // The LM control flow on the host follows Ceres' TrustRegionMinimizer / LevenbergMarquardt
 // strategy step by step (same order of tests as the CPU restatement used for parity).
@@ -946,21 +946,6 @@ __global__ __launch_bounds__(64) void k_ba_cam_rhs(BaDev d)
         for (int a = 0; a < dc; ++a) d.rhs[off + a] = d.gcraw[10 * (size_t)c + a] * d.sc[off + a] - acc[a];
 }
 
-// Hand-off from the bulk stream to the chain inside one factorisation without a cross-stream event wait on the chain.
-// k_ring_signal runs on the bulk stream behind trailing update kb and publishes kb + 1; k_ring_gate runs on the chain
-// stream as ONE wave and returns once the counter has reached the step it needs.  Measured against the event pair
-// (kernel trace, cfg 5): the wait itself is only ~1 us shorter (4.9 us gate vs ~6 us of event wait; the 6.6 us of the
-// chain's own event record stay), but the first trailing column (k_gemm_q<1>) now starts within 1 us of the gate while
-// the bulk kernel of the same step is still being released by the event machinery, so it runs alone instead of beside
-// a starting bulk kernel: 17 us instead of 39 us on average, factorisation -3 % (cfg 5) / -5 % (cfg 4).
-// Safety: the bulk kernels never wait for the chain beyond work that is already complete when the gate is launched,
-// one spinning wave cannot starve them of resources, and the gate gives up after ~2 s (flag 3: the solve reports a
-// failed step) -- it cannot hang the queue.
-__global__ void k_ring_signal(int *counter, int value)
-{
-    __hip_atomic_store(counter, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-}
-
 // one thread: relaxed poll (an sc1 load) with a 2-second limit (100 MHz wall clock, independent of the shader clock)
 #ifdef RCN_DIAG
 // Diagnostic build only: a device-side timeline of the factorisation's kernels (tools/chol_device_timeline.py).  rocprofv3's kernel
@@ -1026,47 +1011,6 @@ __global__ __launch_bounds__(64) void k_ring_gate(Gate g)
 // Writes L^-1 into Linv[kb] (used by the panel GEMM and the triangular solves) as it appears and, on request, L into S.
 #define DL 129   // LDS row stride of the diagonal block (doubles): row walks are conflict-free
 #define LB 16    // leaf size
-#define NBL (NB / LB)
-
-// broadcast of lane `src`'s double (src wave-uniform): two v_readlane_b32
-__device__ __forceinline__ double rdlane(double v, int src)
-{
-    const unsigned long long b = __double_as_longlong(v);
-    const unsigned lo = __builtin_amdgcn_readlane((unsigned)b, src), hi = __builtin_amdgcn_readlane((unsigned)(b >> 32), src);
-    return __longlong_as_double(((unsigned long long)hi << 32) | lo);
-}
-
-
-template <int NT> __device__ __forceinline__ void trail_update(double *L, int r0, int c0, int t)
-{
-    const int ty = t >> 4, tx = t & 15;
-    double acc[NT][NT];
-#pragma unroll
-    for (int u = 0; u < NT; ++u)
-#pragma unroll
-        for (int v = 0; v < NT; ++v) acc[u][v] = 0.0;
-#pragma unroll 4
-    for (int m = 0; m < LB; ++m) {
-        double a[NT], b[NT];
-#pragma unroll
-        for (int u = 0; u < NT; ++u) {
-            a[u] = L[(r0 + ty + 16 * u) * DL + c0 + m];
-            b[u] = L[(r0 + tx + 16 * u) * DL + c0 + m];
-        }
-#pragma unroll
-        for (int u = 0; u < NT; ++u)
-#pragma unroll
-            for (int v = 0; v < NT; ++v) acc[u][v] += a[u] * b[v];
-    }
-#pragma unroll
-    for (int u = 0; u < NT; ++u)
-#pragma unroll
-        for (int v = 0; v < NT; ++v) {
-            const int i = r0 + ty + 16 * u, c = r0 + tx + 16 * v;
-            if (c <= i) L[i * DL + c] -= acc[u][v];
-        }
-}
-
 #ifdef RCN_STAMP   // diagnostic build only (tools/chol_diag_bench.hip): phase time stamps
 __device__ unsigned long long g_stamps[64];
 #define STAMP(i) do { __syncthreads(); if (threadIdx.x == 0) g_stamps[i] = clock64(); } while (0)
@@ -1368,8 +1312,8 @@ __global__ __launch_bounds__(64 * CDW) void k_chol_diag(double *S, int ld, int k
 // and + 1 of every 8-wide group g, so a load instruction covers 16 rows x one 64-B line), then 16
 // v_mfma_f64_16x16x4_f64.  The four workgroups that share a 32-row A strip carry the same
 // (blockIdx & 7), i.e. run on the same XCD and share the strip in its L2.
-// k_gemm_nt_ring (the rest of the trailing update, S[i,j] -= L[i,kb] L[j,kb]^T for kb+1 < j <= i)
-// runs beside them on a second stream (lookahead) and is built for throughput.
+// k_gemm_nt_pipe (the rest of the trailing update, S[i,j] -= L[i,kb] L[j,kb]^T for kb+1 < j <= i)
+// runs beside them on its own stream and is built for throughput.
 // first / m: the tiles kb + 1 + first .. kb + 1 + first + m - 1 of the tile column (the critical tile is first = 0, m = 1)
 template <int MODE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(96)))
@@ -1416,15 +1360,7 @@ void k_gemm_q(double *S, double *L, int ld, int kb, int first, int m, const doub
     TL_MARK(tl_id, 2);
 }
 
-// Tile mapping of the bulk update: the lower triangle of the mt x mt trailing tiles is cut into
-// 8x8-tile super-tiles and every super-tile belongs to ONE XCD (workgroups go round-robin to the 8
-// XCDs, so blockIdx & 7 names the XCD): its 64 workgroups read only 16 panel tiles (2 MB), which
-// stay in that XCD's 4-MB L2.
-#define ST 8
-__host__ __device__ inline int gemm_nt_grid(int mt) { const int R = (mt + ST - 1) / ST, ns = R * (R + 1) / 2; return 8 * ((ns + 7) / 8) * ST * ST; }
-
-// Bulk trailing update, LDS-DMA form:  S[i,j] -= L[i, kb..] L[j, kb..]^T  over nst 8-wide k-stages
-// (K = 8 nst: 128 for one panel).  Operands reach LDS by LDS-DMA only -- no staging registers --
+// Bulk trailing update, LDS-DMA ring:  S[i,j] -= L[i, kb..] L[j, kb..]^T  over 8-wide k-stages.  Operands reach LDS by LDS-DMA only -- no staging registers --
 // through a 4-stage ring, three stages (24 k) ahead of the MFMAs, behind counted vmcnt waits and one
 // raw s_barrier per stage.  A stage holds, per operand, 128 rows x 8 doubles as eight 1-KiB
 // row groups in PIECE-MAJOR order (slot = piece * 16 + row, 16 B per slot): each DMA lane picks
@@ -1433,90 +1369,7 @@ __host__ __device__ inline int gemm_nt_grid(int mt) { const int R = (mt + ST - 1
 // MFMA steps (lane group fk supplies k = 2 fk and 2 fk + 1).
 #define GST 4
 #define GSTAGE_BYTES (2 * 128 * 8 * 8)   // A + B, 16 KiB
-template <int DBG>   // DBG != 0: timing experiments of tools/gemm_nt_bench only (1: no C load, 2: no C store, 4: no operand DMA)
-__global__ __launch_bounds__(256, 2) void k_gemm_nt_ring(double *S, const double *L, int ld, int kb, int mt, int nst)
-{
-    extern __shared__ __attribute__((aligned(16))) char gsm[];
-    int ti, tj;
-    {
-        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-        const int sidx = (slot / (ST * ST)) * 8 + xcd, within = slot % (ST * ST);
-        int sr = (int)((sqrt(8.0 * sidx + 1.0) - 1.0) * 0.5);
-        while ((sr + 1) * (sr + 2) / 2 <= sidx) ++sr;
-        while (sr * (sr + 1) / 2 > sidx) --sr;
-        const int sc = sidx - sr * (sr + 1) / 2;
-        const int r = sr * ST + within / ST, c = sc * ST + within % ST;
-        if (r >= mt || c > r) return;
-        ti = kb + 2 + r; tj = kb + 2 + c;
-    }
-    const double *A = L + ((size_t)ti * NB) * ld + (size_t)kb * NB;
-    const double *B = L + ((size_t)tj * NB) * ld + (size_t)kb * NB;
-    double *C = S + ((size_t)ti * NB) * ld + (size_t)tj * NB;
-    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-    const int wr = (w >> 1) * 64, wc = (w & 1) * 64;
-    const int fr = lane & 15, fk = lane >> 4;
-    f64x4 acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int reg = 0; reg < 4; ++reg)
-                acc[i][j][reg] = (DBG & 1) ? 0.0 : C[(size_t)(wr + 16 * i + fk + 4 * reg) * ld + wc + 16 * j + fr];
-    // wave w copies row groups 2w, 2w+1 of both operands: 4 DMA instructions per stage
-    const double *srcA = A + (size_t)(32 * w + fr) * ld + 2 * fk;
-    const double *srcB = B + (size_t)(32 * w + fr) * ld + 2 * fk;
-    auto issue = [&](int s) {
-        char *buf = gsm + (s % GST) * GSTAGE_BYTES + 2048 * w;
-        const int k0 = 8 * s;
-        if (DBG & 4) return;
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(srcA + (size_t)(16 * q) * ld + k0),
-                                             (__attribute__((address_space(3))) void *)(buf + 1024 * q), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(srcB + (size_t)(16 * q) * ld + k0),
-                                             (__attribute__((address_space(3))) void *)(buf + 8192 + 1024 * q), 16, 0, 0);
-        }
-    };
-    auto lds_read = [&](unsigned addr) -> f64x2 {
-        f64x2 v;
-        asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr));
-        return v;
-    };
-    const unsigned base = (unsigned)(size_t)(const __attribute__((address_space(3))) char *)gsm;
-    const unsigned offA = (unsigned)((wr >> 4) * 1024 + fk * 256 + fr * 16);
-    const unsigned offB = (unsigned)(8192 + (wc >> 4) * 1024 + fk * 256 + fr * 16);
-    for (int s = 0; s < GST - 1 && s < nst; ++s) issue(s);
-    for (int s = 0; s < nst; ++s) {
-        const int ahead = min(nst - 1 - s, GST - 2);   // stages issued after stage s
-        if (ahead >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else if (ahead == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();            // stage s landed for every wave; everyone is done with stage s-1
-        if (s + GST - 1 < nst) issue(s + GST - 1);   // into the buffer of stage s-1
-        const unsigned st = base + (unsigned)((s % GST) * GSTAGE_BYTES);
-        f64x2 a0 = lds_read(st + offA), a1 = lds_read(st + offA + 1024), a2 = lds_read(st + offA + 2048), a3 = lds_read(st + offA + 3072);
-        f64x2 b0 = lds_read(st + offB), b1 = lds_read(st + offB + 1024), b2 = lds_read(st + offB + 2048), b3 = lds_read(st + offB + 3072);
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3));
-        const f64x2 a[4] = {-a0, -a1, -a2, -a3}, b[4] = {b0, b1, b2, b3};
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i][h], b[j][h], acc[i][j], 0, 0, 0);
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int reg = 0; reg < 4; ++reg)
-                if (!(DBG & 2) || acc[i][j][reg] == 1.2345e300) C[(size_t)(wr + 16 * i + fk + 4 * reg) * ld + wc + 16 * j + fr] = acc[i][j][reg];
-}
-
-// Bulk trailing update, second form (round 3).  Same tile, ring and operand layout as k_gemm_nt_ring; what changes is
+// The bulk kernel (round 3; round 2's k_gemm_nt_ring, same tile, ring and operand layout, waited for LDS inside every stage and read its C tile up front).  What changed is
 // where a wave waits.  Measured on the ring form (tools/gemm_nt_bench, tools/mfma_f64_peak): the bare
 // v_mfma_f64_16x16x4_f64 loop sustains 77 TFLOP/s on this chip (64 cycles per MFMA at ~2.36 GHz: f64 is not
 // clock-limited), the ring form's loop alone 58 (operands + barrier exposed once per 8-k stage) and a K = 128 pass 37:
@@ -2339,7 +2192,7 @@ int rcn_int_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_option
         //         -- all D(k+1) needs of panel k                                                 k_gemm_q<0/1>    chain A
         //   P(k)  the rest of the panel, rows >= k + 2                                           k_gemm_q<0>      panels B
         //   C(k)  the rest of the first trailing column, S(i, k+1) -= L(i, k) L(k+1, k)'         k_gemm_q<1>      panels B
-        //   B(k)  the bulk update of columns >= k + 2                                            k_gemm_nt_ring   bulk C
+        //   B(k)  the bulk update of columns >= k + 2                                            k_gemm_nt_pipe   bulk C
         // The serial chain is D(k) T(k) D(k+1) T(k+1) ...: two small launches between two diagonal blocks where round 2 had the
         // whole panel, a gate and the whole first column (131 us per step, of which 83 the diagonal block).  Cross-stream
         // dependencies travel through five device counters (Gate, above):
@@ -2368,7 +2221,8 @@ int rcn_int_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_option
                 return g;
             };
             std::vector<Wr> lastw((size_t)nblk + 4, Wr{nullptr, 0});
-            auto later = [](Wr a, Wr b) { return !a.c ? b : !b.c ? a : (a.c == b.c ? (a.n >= b.n ? a : b) : b); };   // b is the younger lookup on a tie of kinds
+            // the younger of two lookups: kernels counted by cB (one panel) only ever follow those that signal through sig (two panels)
+            auto later = [&](Wr a, Wr b) { return !a.c ? b : !b.c ? a : (a.c == b.c ? (a.n >= b.n ? a : b) : (a.c == cB ? a : b)); };
             int bulk_ord = 0, sig_cum = 0;
             if (!safe) {
                 hipError_t e = hipEventRecord(ctx->ba_ev[0], sA);

@@ -1,4 +1,4 @@
-// tools/gemm_nt_bench.hip -- diagnostic: the bulk trailing-update kernels on a synthetic 10112^2 system (kb = 0).
+// tools/gemm_nt_bench.hip -- diagnostic: the bulk trailing-update kernel on a synthetic 10112^2 system (kb = 0).
 #include "../reconstructor_amd/csrc/ba.hip"
 #include <cstdio>
 #include <vector>
@@ -12,23 +12,9 @@ int main()
     double *S0, *S1, *L;
     (void)hipMalloc(&S0, N * 8); (void)hipMalloc(&S1, N * 8); (void)hipMalloc(&L, N * 8);
     (void)hipMemcpy(L, h.data(), N * 8, hipMemcpyHostToDevice);
-#define SETA(D) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_nt_ring<D>), hipFuncAttributeMaxDynamicSharedMemorySize, GST * GSTAGE_BYTES)
-    SETA(0); SETA(1); SETA(2); SETA(3); SETA(4); SETA(7);
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     const double flop = 2.0 * 128 * 128 * 128 * (double)mt * (mt + 1) / 2;
-    for (int rep = 0; rep < 4; ++rep) {
-        float ms0, ms1;
-        (void)hipMemset(S0, 0, N * 8); (void)hipMemset(S1, 0, N * 8);
-        ms0 = 0.f;
-        (void)hipEventRecord(e0);
-        k_gemm_nt_ring<0><<<gemm_nt_grid(mt), 256, GST * GSTAGE_BYTES>>>(S1, L, npad, 0, mt, 16);
-        (void)hipEventRecord(e1); (void)hipEventSynchronize(e1); (void)hipEventElapsedTime(&ms1, e0, e1);
-        if (rep == 3) {
-#define RUNV(D) { float m; (void)hipEventRecord(e0); k_gemm_nt_ring<D><<<gemm_nt_grid(mt), 256, GST * GSTAGE_BYTES>>>(S0, L, npad, 0, mt, 16); (void)hipEventRecord(e1); (void)hipEventSynchronize(e1); (void)hipEventElapsedTime(&m, e0, e1); printf("  variant %d: %.1f us (%.1f TF)\n", D, m * 1e3, flop / m * 1e-9); }
-            RUNV(1) RUNV(2) RUNV(3) RUNV(4) RUNV(7)
-        }
-        printf("rep %d: ring %.1f us (%.1f TF)   %s\n", rep, ms1 * 1e3, flop / ms1 * 1e-9, hipGetErrorString(hipGetLastError()));
-    }
+    float ms0 = 0.f; (void)ms0;
     // the pipelined form (k_gemm_nt_pipe) over the balanced tile map of this trailing size
     {
         rcn_ctx *bc = new rcn_ctx();
@@ -68,28 +54,5 @@ int main()
             printf("max |pipe(K = %d) - host| on tile (5,3) = %.3e\n", two ? 256 : 128, md2);
         }
     }
-    // the loop on its own: K = 8 nst per pass for longer and longer passes (per-tile prologue / epilogue amortised)
-    for (int nst : {16, 32, 64, 128})
-        for (int v = 0; v < 2; ++v) {
-            float m;
-            (void)hipEventRecord(e0);
-            if (v == 0) k_gemm_nt_ring<0><<<gemm_nt_grid(mt), 256, GST * GSTAGE_BYTES>>>(S0, L, npad, 0, mt, nst);
-            else k_gemm_nt_ring<7><<<gemm_nt_grid(mt), 256, GST * GSTAGE_BYTES>>>(S0, L, npad, 0, mt, nst);
-            (void)hipEventRecord(e1); (void)hipEventSynchronize(e1); (void)hipEventElapsedTime(&m, e0, e1);
-            printf("  K = %4d variant %d: %.1f us (%.1f TF)\n", 8 * nst, v ? 7 : 0, m * 1e3, flop * (nst / 16.0) / m * 1e-9);
-        }
-    // check one tile (ti = 5, tj = 3) against the host: S1 = 0 - A B^T
-    (void)hipMemset(S1, 0, N * 8);
-    k_gemm_nt_ring<0><<<gemm_nt_grid(mt), 256, GST * GSTAGE_BYTES>>>(S1, L, npad, 0, mt, 16);
-    std::vector<double> c((size_t)128 * npad);
-    (void)hipMemcpy(c.data(), S1 + (size_t)5 * 128 * npad, c.size() * 8, hipMemcpyDeviceToHost);
-    double md = 0;
-    for (int i = 0; i < 128; ++i)
-        for (int j = 0; j < 128; ++j) {
-            double sref = 0;
-            for (int k = 0; k < 128; ++k) sref -= h[((size_t)5 * 128 + i) * npad + k] * h[((size_t)3 * 128 + j) * npad + k];
-            md = fmax(md, fabs(sref - c[(size_t)i * npad + 3 * 128 + j]));
-        }
-    printf("max |ring - host| on tile (5,3) = %.3e\n", md);
     return 0;
 }
