@@ -2139,19 +2139,30 @@ int rcn_int_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_option
     sum->cost_trace[0] = cost;
 
     double radius = opt->initial_trust_region_radius, decrease = 2.0;
-    bool reuse_diag = false, need_gradient = true;
+    bool reuse_diag = false, need_gradient = true, grad_pending = false;
     int invalid_run = 0, termination = 0, iter = 0;
     for (;;) {
         if (need_gradient) {
-            RCN_HIP(hipMemsetAsync(d.scal + 6, 0, sizeof(double), st));
-            k_ba_gradmax<<<std::max(1, std::min(1024, (std::max(nc, 3 * np) + 255) / 256)), 256, 0, st>>>(d, d.scal + 6);
+            // max |gradient| at the new point.  Its test comes BEFORE the next step in Ceres' loop; here the kernel is queued
+            // and the value rides home with the scalars of the step that follows (one host synchronisation per iteration
+            // instead of two: a quarter of a small problem's iteration).  If it was below the tolerance after all, that step
+            // is dropped unseen -- it has only written candidate buffers -- and the loop ends where Ceres' would have.
+            RCN_HIP(hipMemsetAsync(d.scal + 12, 0, sizeof(double), st));
+            k_ba_gradmax<<<std::max(1, std::min(1024, (std::max(nc, 3 * np) + 255) / 256)), 256, 0, st>>>(d, d.scal + 12);
             RCN_HIP(hipGetLastError());
-            RCN_HIP(read_scal(8));
             need_gradient = false;
-            if (hs[6] <= opt->gradient_tolerance) { termination = RCN_BA_CONVERGENCE_GRADIENT; break; }
+            grad_pending = true;
         }
-        if (iter >= opt->max_iterations) { termination = RCN_BA_NO_CONVERGENCE; break; }
-        if (radius <= opt->min_trust_region_radius) { termination = RCN_BA_CONVERGENCE_RADIUS; break; }
+        if (iter >= opt->max_iterations || radius <= opt->min_trust_region_radius) {
+            // no step follows: the gradient test still comes first
+            if (grad_pending) {
+                RCN_HIP(read_scal(13));
+                grad_pending = false;
+                if (hs[12] <= opt->gradient_tolerance) { termination = RCN_BA_CONVERGENCE_GRADIENT; break; }
+            }
+            termination = iter >= opt->max_iterations ? RCN_BA_NO_CONVERGENCE : RCN_BA_CONVERGENCE_RADIUS;
+            break;
+        }
         ++iter;
 
         // ---- LM step
@@ -2300,7 +2311,8 @@ int rcn_int_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_option
             if (e == hipSuccess) e = hipStreamWaitEvent(sA, ctx->ba_ev[2], 0);
             return e;
         };
-        RCN_HIP(factorise(ctx->chol_safe));
+        // (up to two blocks there is no panel rest, no column rest and no bulk update: nothing for the other two streams to do)
+        RCN_HIP(factorise(ctx->chol_safe || nblk <= 2));
         RCN_HIP(hipEventRecord(ctx->ba_tev[2], st));
         if (rhs_row) k_ba_y_from_row<<<(npad + 255) / 256, 256, 0, st>>>(d);
         else for (int kb = 0; kb < nblk; ++kb) k_trsv_fwd<<<nblk - kb, 128, 0, st>>>(d.L, npad, kb, d.Linv, d.rhs, d.yc);
@@ -2325,7 +2337,15 @@ int rcn_int_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_option
         int hflag = 0;
         RCN_HIP(hipMemcpyAsync(&hflag, d.flag, sizeof(int), hipMemcpyDeviceToHost, st));
         RCN_HIP(hipEventRecord(ctx->ba_tev[3], st));
-        RCN_HIP(read_scal(10));
+        RCN_HIP(read_scal(13));
+        if (grad_pending) {
+            grad_pending = false;
+            if (hs[12] <= opt->gradient_tolerance) {      // converged before this step: it does not count and is not looked at
+                --iter;
+                termination = RCN_BA_CONVERGENCE_GRADIENT;
+                break;
+            }
+        }
         {
             float ms = 0.f;
             RCN_HIP(hipEventElapsedTime(&ms, ctx->ba_tev[0], ctx->ba_tev[1])); sum->schur_seconds += 1e-3 * ms;
