@@ -19,10 +19,14 @@
 // Failure: a rank whose local step fails still enters rcn_shard_exchange, whose status vote ends the collective
 // phase on every rank together (include/rcn.h, rcn_shard_fail); the driver then throws -- it cannot hang.
 #pragma once
+#include <algorithm>
 #include <atomic>
 #include <stdexcept>
 #include <string>
 #include <thread>
+#include <vector>
+#include <unordered_map>
+#include <memory>
 
 #include "../../include/rcn.h"
 #include "rcn_types.h"
@@ -66,6 +70,71 @@ public:
 
     int world() const { return world_; }
     rcn_ctx *context(int rank = 0) { return ctx_[rank]; }
+
+    // The features / matches cache the reference lists as a TODO (README.md:39): everything matchFeatures consumed and
+    // produced, in one checksummed file (rcn_store_save: written to <path>.tmp, then renamed).  Pure host code.
+    static void saveStore(const std::string &path, std::unordered_map<int, std::vector<FeaturePtr<>>> &features, const FeatureMatches &featureMatches)
+    {
+        const int n = (int)features.size();
+        std::vector<int32_t> ids(n), Ks(n);
+        std::vector<std::vector<float>> desc(n);
+        std::vector<std::vector<int32_t>> xy(n);
+        std::vector<const float *> dp(n);
+        std::vector<const int32_t *> cp(n);
+        int D = 0;
+        for (int i = 0; i < n; ++i) {
+            const auto &f = features.at(i);
+            ids[i] = i; Ks[i] = (int32_t)f.size();
+            if (!f.empty()) D = (int)f[0]->featDesc.desc.size();
+            desc[i].reserve(f.size() * (size_t)D);
+            xy[i].reserve(2 * f.size());
+            for (const auto &ft : f) {
+                desc[i].insert(desc[i].end(), ft->featDesc.desc.begin(), ft->featDesc.desc.end());
+                xy[i].push_back(ft->featCoord.x); xy[i].push_back(ft->featCoord.y);
+            }
+            dp[i] = desc[i].data(); cp[i] = xy[i].data();
+        }
+        std::vector<std::pair<int, int>> keys;
+        for (const auto &kv : featureMatches) keys.push_back(kv.first);
+        std::sort(keys.begin(), keys.end());
+        std::vector<int32_t> pairs, qt;
+        std::vector<int64_t> offs(1, 0);
+        for (const auto &k : keys) {
+            const auto &m = featureMatches.at(k);
+            std::vector<std::pair<int, int>> e(m.begin(), m.end());
+            std::sort(e.begin(), e.end());
+            pairs.push_back(k.first); pairs.push_back(k.second);
+            for (const auto &p : e) { qt.push_back(p.first); qt.push_back(p.second); }
+            offs.push_back((int64_t)qt.size() / 2);
+        }
+        rcn_store_contents c{};
+        c.n_images = n; c.D = D; c.has_coords = 1; c.n_pairs = (int32_t)keys.size();
+        c.img_ids = ids.data(); c.img_K = Ks.data(); c.desc = dp.data(); c.coords = cp.data();
+        c.pairs = pairs.data(); c.offsets = offs.data(); c.qt = qt.data();
+        if (rcn_store_save(path.c_str(), &c) != RCN_OK) throw std::runtime_error("HipPairGridDriver::saveStore: rcn_store_save failed for " + path);
+    }
+    // ... and back: the containers the rest of the reference's pipeline reads, as matchFeatures left them
+    static void loadStore(const std::string &path, std::unordered_map<int, std::vector<FeaturePtr<>>> &features, FeatureMatches &featureMatches)
+    {
+        rcn_store *st = nullptr;
+        if (rcn_store_open(path.c_str(), &st) != RCN_OK) throw std::runtime_error("HipPairGridDriver::loadStore: cannot open or verify " + path);
+        rcn_store_contents c{};
+        if (rcn_store_contents_of(st, &c) != RCN_OK) { rcn_store_close(st); throw std::runtime_error("HipPairGridDriver::loadStore: no contents"); }
+        features.clear(); featureMatches.clear();
+        for (int i = 0; i < c.n_images; ++i) {
+            auto &f = features[c.img_ids[i]];
+            for (int k = 0; k < c.img_K[i]; ++k) {
+                const float *row = c.desc[i] + (size_t)k * c.D;
+                const FeatCoord<> xy = c.has_coords ? FeatCoord<>(c.coords[i][2 * k], c.coords[i][2 * k + 1]) : FeatCoord<>();
+                f.push_back(std::make_shared<Feature<>>(xy, FeatDesc(row, row + c.D)));
+            }
+        }
+        for (int p = 0; p < c.n_pairs; ++p) {
+            auto &m = featureMatches[{c.pairs[2 * p], c.pairs[2 * p + 1]}];
+            for (int64_t e = c.offsets[p]; e < c.offsets[p + 1]; ++e) m[c.qt[2 * e]] = c.qt[2 * e + 1];
+        }
+        rcn_store_close(st);
+    }
 
     // features[imgId] for imgId = 0 .. n-1 (SequentialReconstructor.h:205); fills featureMatches (:226).
     // filter = the argument of SequentialReconstructor::matchFeatures(bool filter): pairs with at least 7 matches keep

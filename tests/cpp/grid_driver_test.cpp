@@ -56,6 +56,28 @@ int main(int argc, char **argv)
         fprintf(stderr, "%s\n", e.what());
         return 1;
     }
+    if (argc > 6) {
+        // shard + filter + store in one C++ run: everything the loop consumed and produced goes to the store file and comes
+        // back equal -- descriptors and coordinates bit for bit, every map entry
+        HipPairGridDriver::saveStore(argv[6], features, featureMatches);
+        std::unordered_map<int, std::vector<FeaturePtr<>>> f2;
+        FeatureMatches m2;
+        HipPairGridDriver::loadStore(argv[6], f2, m2);
+        bool same = f2.size() == features.size() && m2.size() == featureMatches.size();
+        for (int i = 0; same && i < n; ++i) {
+            same = f2[i].size() == features[i].size();
+            for (size_t k = 0; same && k < features[i].size(); ++k)
+                same = f2[i][k]->featDesc.desc == features[i][k]->featDesc.desc && f2[i][k]->featCoord.x == features[i][k]->featCoord.x &&
+                       f2[i][k]->featCoord.y == features[i][k]->featCoord.y;
+        }
+        for (const auto &kv : featureMatches) {
+            if (!same) break;
+            auto it = m2.find(kv.first);
+            same = it != m2.end() && it->second == kv.second;
+        }
+        if (!same) { fprintf(stderr, "the store file does not give back what was saved\n"); return 4; }
+        printf("store round trip ok: %s\n", argv[6]);
+    }
     std::vector<std::pair<int, int>> keys;
     for (const auto &kv : featureMatches) keys.push_back(kv.first);
     std::sort(keys.begin(), keys.end());

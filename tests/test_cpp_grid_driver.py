@@ -96,7 +96,15 @@ def test_cpp_grid_driver_whole_pair_loop_with_the_filter(tmp_path):
     # between two implementations
     ims, coords, _ = synth.scene_set("sift", 7, [300, 320, 280, 310, 12, 300, 0], n_world=900, seed=5)
     coords[5][:] = 91          # every sample of a pair with image 5 is degenerate: no model -> nothing stored -> reverse pass
-    got, _ = _run_driver(tmp_path, ims, coords, 128, 0, 1)
+    store_path = tmp_path / "loop.rcnstore"
+    got, r = _run_driver(tmp_path, ims, coords, 128, 0, 1, -1, store_path)      # ... and shard + filter + STORE in the same C++ run
+    assert "store round trip ok" in r.stdout and store_path.exists()
+    from reconstructor_amd import store as rstore
+    with rstore.Store(store_path) as back:                                      # the Python side reads the same file
+        assert back.n_images == len(ims) and back.has_coords and back.n_pairs == len(got)
+        assert all(np.array_equal(back.images[i], ims[i]) and np.array_equal(back.coords[i], coords[i]) for i in range(len(ims)))
+        stored = {(int(a), int(b)): {int(q): int(t) for q, t in back.qt[int(back.offsets[p]):int(back.offsets[p + 1])]} for p, (a, b) in enumerate(back.pairs)}
+        assert stored == got
     exp = reference_loop(ims, coords)
     plain = reference_loop(ims)
     assert not any(8 <= len(v) <= 13 for v in plain.values())
