@@ -79,6 +79,18 @@ int rcn_desc_sample_device(rcn_ctx *ctx, const float *desc_map_dev, int64_t stri
  * written as zeros and counted.  rcn_desc_sample_errors waits for the ctx stream and returns RCN_ERR_ARG (count in
  * *n_out_of_range, may be NULL) when any keypoint of the calls since the last read was outside; the count is cleared. */
 int rcn_desc_sample_errors(rcn_ctx *ctx, int32_t *n_out_of_range);
+/* Host-side batch ingest: n_images images with their own row counts K[i] >= 0, each a dense row-major K[i] x D
+ * fp32 matrix in HOST memory (rows[i]; what featDescToCV packs per call, FeatureMatcher.cpp:11-25 -- here for every
+ * image of the loop at once), become ids first_img_id .. first_img_id + n_images - 1.  One device block of
+ * [n][max K][D] owned by the ctx (tails zeroed), one asynchronous copy per image straight out of the caller's rows
+ * (pinned rows -- rcn_host_alloc -- travel at the link rate; pageable rows are staged by the runtime), ONE stats
+ * launch, ONE conversion launch at the next grid call, ONE host synchronisation before the call returns: the host
+ * rows are borrowed for the call only.  Calling it again with the same (first id, n, max K, D) reuses every
+ * allocation.  Replaces n synchronous rcn_desc_upload calls (each of which waits for its own copy). */
+int rcn_desc_upload_batch(rcn_ctx *ctx, int32_t first_img_id, int32_t n_images, const float *const *rows_host,
+                          const int32_t *K, int32_t D);
+/* Forget one image (no-op when the id is not resident).  Other resident images, and their D, stay. */
+int rcn_desc_remove(rcn_ctx *ctx, int32_t img_id);
 int rcn_desc_clear(rcn_ctx *ctx);
 int rcn_desc_count(const rcn_ctx *ctx);
 

@@ -17,7 +17,7 @@ ERRORS = {-1: "RCN_ERR_ARG", -2: "RCN_ERR_HIP", -3: "RCN_ERR_NO_DEVICE",
 # every symbol include/rcn.h declares (tests check the library exports exactly these)
 SYMBOLS = [
     "rcn_create", "rcn_destroy", "rcn_last_error", "rcn_version", "rcn_set_stream",
-    "rcn_synchronize", "rcn_desc_upload", "rcn_desc_upload_device", "rcn_desc_upload_batch_device", "rcn_desc_sample_device", "rcn_desc_sample_errors", "rcn_desc_clear",
+    "rcn_synchronize", "rcn_desc_upload", "rcn_desc_upload_device", "rcn_desc_upload_batch_device", "rcn_desc_upload_batch", "rcn_desc_remove", "rcn_desc_sample_device", "rcn_desc_sample_errors", "rcn_desc_clear",
     "rcn_desc_count", "rcn_match_pair", "rcn_match_grid", "rcn_match_grid_device",
     "rcn_match_last_stats", "rcn_match_profile", "rcn_ba_default_options", "rcn_ba_solve",
     "rcn_landmark_validity", "rcn_landmark_validity_device",
@@ -146,6 +146,10 @@ def load():
     L.rcn_desc_upload_device.argtypes = [vp, i32, vp, i32, i32]
     L.rcn_desc_upload_batch_device.restype = C.c_int
     L.rcn_desc_upload_batch_device.argtypes = [vp, i32, i32, vp, i32, i32]
+    L.rcn_desc_upload_batch.restype = C.c_int
+    L.rcn_desc_upload_batch.argtypes = [vp, i32, i32, vp, vp, i32]
+    L.rcn_desc_remove.restype = C.c_int
+    L.rcn_desc_remove.argtypes = [vp, i32]
     L.rcn_desc_sample_device.restype = C.c_int
     L.rcn_desc_sample_device.argtypes = [vp, vp, i64, i64, i64, i32, i32, vp, i32, i32, vp]
     L.rcn_desc_sample_errors.restype = C.c_int

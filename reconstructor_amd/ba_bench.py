@@ -7,13 +7,19 @@ FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X FP64 matrix, vendor figure quoted in SUR
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 
 
-def run_config(ctx, n_cams, n_points, seed=2024, repeats=2):
-    sc = synth_ba.make_scene(n_cams, n_points, obs_per_point=10, seed=seed)
-    best = None
-    for _ in range(repeats):                       # first call also sizes the workspace
+def run_config(ctx, n_cams, n_points, seed=2024, repeats=3, perturb=None):
+    """One warm-up solve (it also sizes the workspace), then `repeats` timed solves of the same scene; the figures quoted are
+    those of the MEDIAN solve by wall time (one 3-iteration solve moved with every clock transient)."""
+    kw = {} if perturb is None else {"perturb": perturb}
+    sc = synth_ba.make_scene(n_cams, n_points, obs_per_point=10, seed=seed, **kw)
+    ba.solve_scene(ctx, sc)
+    runs = []
+    for _ in range(max(1, repeats)):
         P, I, X, s = ba.solve_scene(ctx, sc)
-        if best is None or s["solve_seconds"] < best["solve_seconds"]:
-            best = s
+        runs.append(s)
+    runs.sort(key=lambda r: r["solve_seconds"] / max(1, r["iterations"]))
+    best = runs[len(runs) // 2]
+    rates = [r["iterations"] / r["solve_seconds"] for r in runs]
     n = best["reduced_dim"]
     npad = (n + 127) // 128 * 128
     chol_flop = npad ** 3 / 3.0
@@ -31,6 +37,9 @@ def run_config(ctx, n_cams, n_points, seed=2024, repeats=2):
         "workload": "%d cams / %d points / %d observations" % (n_cams, n_points, sc["obs_cam"].shape[0]),
         "lm_iterations": best["iterations"], "solve_seconds": best["solve_seconds"],
         "lm_iterations_per_s": best["iterations"] / best["solve_seconds"],
+        "timed_solves": len(runs), "lm_iterations_per_s_all": sorted(rates), "statistic": "median of the timed solves (one untimed warm-up solve first)",
+        "successful_steps": best["successful_steps"], "unsuccessful_steps": best["unsuccessful_steps"], "invalid_steps": best["invalid_steps"],
+        "line_search_backtracks": best["line_search_backtracks"],
         "initial_rms_px": best["initial_rms_px"], "final_rms_px": best["final_rms_px"],
         "termination": ba.TERMINATION.get(best["termination"], "?"), "reduced_dim": n,
         "cholesky_flop_per_iteration": chol_flop,
@@ -43,10 +52,22 @@ def run_config(ctx, n_cams, n_points, seed=2024, repeats=2):
     }
 
 
+FAR_START = (0.35, 1.75, 1.75)  # 35 times the perturbation of the headline scene (rotation rad, translation, points): at cfg-4 size the
+                                # oracle runs into the 50-iteration cap with a rejected step and 45 line-search backtracks on the way
+
+
 def run(ctx, with_cfg5=True):
     """GPU timings only; bench.py adds the CPU baseline (the oracle is not importable from here)."""
     out = {}
     sc4, out["cfg4"] = run_config(ctx, 200, 20000)
     if with_cfg5:
-        _, out["cfg5"] = run_config(ctx, 1000, 100000, repeats=1)
+        _, out["cfg5"] = run_config(ctx, 1000, 100000, repeats=3)
+        # the same scene from 35 times as far: a long solve (rejected steps and the bounds line search included where
+        # they occur), so that iterations/s is not the figure of three easy iterations
+        _, far = run_config(ctx, 1000, 100000, repeats=3, perturb=FAR_START)
+        out["cfg5_far_start"] = {k: far[k] for k in ("workload", "lm_iterations", "solve_seconds", "lm_iterations_per_s", "timed_solves",
+                                                     "lm_iterations_per_s_all", "statistic", "successful_steps", "unsuccessful_steps", "invalid_steps",
+                                                     "line_search_backtracks", "initial_rms_px", "final_rms_px", "termination", "phase_seconds",
+                                                     "cholesky_roofline")}
+        out["cfg5_far_start"]["perturbation"] = "rotation %.2f rad, translation %.2f, points %.2f (x35 the headline scene)" % FAR_START
     return sc4, out

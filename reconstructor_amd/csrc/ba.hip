@@ -756,14 +756,20 @@ __device__ __forceinline__ f64x4 schur_mfma_chunk(const double *__restrict__ Wt,
 // one wave per strictly-lower block (c, c2 < c), written straight into the dense reduced system
 __global__ __launch_bounds__(256) void k_ba_schur_mfma(BaDev d, const int *off, const unsigned long long *list)
 {
+    // Block row c (the blocks (c, c2 < c): they all gather Y rows of camera c's observations, each about as often as its
+    // landmark has other observations) runs on ONE XCD -- workgroup b sits on XCD b % 8 (observed, speed only) and takes four
+    // consecutive blocks of the sequence of rows c = x, x + 8, x + 16, ... of its XCD x -- so that a Y row is fetched into
+    // that XCD's L2 once instead of once per XCD (round 3 dealt the blocks round-robin: 3.2 GB at the fabric per launch).
+    // Row x + 8 t starts at block x t + 4 t (t - 1) of the XCD's sequence.
     const int lane = threadIdx.x & 63;
-    const int blk = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int nlow = d.nc * (d.nc - 1) / 2;
-    if (blk >= nlow) return;
-    int c = (int)((sqrt(8.0 * blk + 1.0) + 1.0) * 0.5);
-    while (c * (c + 1) / 2 <= blk) ++c;
-    while (c * (c - 1) / 2 > blk) --c;
-    const int c2 = blk - c * (c - 1) / 2, key = c * d.nc + c2;
+    const int x = blockIdx.x & 7, q = (blockIdx.x >> 3) * 4 + (threadIdx.x >> 6);
+    auto row_start = [x](int t) { return x * t + 4 * t * (t - 1); };
+    int t = (int)((sqrt((double)(x - 4) * (x - 4) + 16.0 * q) - (x - 4)) * 0.125);
+    while (row_start(t + 1) <= q) ++t;
+    while (t > 0 && row_start(t) > q) --t;
+    const int c = x + 8 * t, c2 = q - row_start(t);
+    if (c >= d.nc || c2 >= c) return;
+    const int key = c * d.nc + c2;
     const int dc = d.cam_dim[c], dc2 = d.cam_dim[c2];
     if (dc == 0 || dc2 == 0) return;
     f64x4 acc = {0.0, 0.0, 0.0, 0.0};
@@ -960,12 +966,21 @@ extern "C" int rcn_diag_timeline_set(unsigned long long *dev_buf)
 #else
 #define TL_MARK(id, w)
 #endif
+// The flag word is STICKY: the first event of a factorisation owns it (0 -> code by compare-and-swap), so a gate timeout (3) is
+// never overwritten by the non-finite pivot (1) that the kernels behind it may then meet on half-updated tiles -- the host must
+// see the 3 to switch schedules -- and a wait that finds the flag already raised returns at once: the result is discarded
+// anyway, and every later hand-off of the same factorisation would otherwise burn its own 2 s.
+__device__ __forceinline__ void flag_raise(int *flag, int code)
+{
+    (void)atomicCAS(flag, 0, code);
+}
 __device__ __forceinline__ void ring_wait(const int *counter, int need, int *flag, int code = 3)
 {
     const unsigned long long t0 = wall_clock64();
     while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
+        if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
         __builtin_amdgcn_s_sleep(8);
-        if (wall_clock64() - t0 > 200000000ull) { *flag = code; break; }
+        if (wall_clock64() - t0 > 200000000ull) { flag_raise(flag, code); break; }
     }
 }
 
@@ -995,6 +1010,13 @@ __global__ __launch_bounds__(64) void k_ring_gate(Gate g)
 {
     gate_enter(g);
 }
+#ifdef RCN_DIAG
+// RCN_CHOL_BREAK=2 (diagnostic build): what a broken hand-off does to the numbers -- the diagonal block behind it holds garbage
+__global__ void k_diag_poison(double *S, int ld, int kb)
+{
+    S[((size_t)kb * NB) * ld + (size_t)kb * NB] = __longlong_as_double(0x7ff8000000000000ll);
+}
+#endif
 
 // ---------------------------------------------------------------------------------------
 // K7: dense Cholesky of the padded reduced system (npad multiple of 128), lower triangle.
@@ -1156,7 +1178,7 @@ __global__ __launch_bounds__(64 * CDW) void k_chol_diag(double *S, int ld, int k
     f64x4 tcur = {0.0, 0.0, 0.0, 0.0};       // waves 1..7: T_j of the inverse's next block row (2., below)
     for (int c0 = 0; c0 < NB; c0 += LB) {
         if (misc[0] != 0.0) {
-            if (t == 0) *flag = 1;
+            if (t == 0) flag_raise(flag, 1);
             return;
         }
         const int r0 = c0 + LB, kk = c0 / LB;
@@ -1448,7 +1470,8 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt_pipe(double *S, const double
         case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
         case 16: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
         case 20: asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); break;
-        default: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
+        case 24: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;      // a count this list does not know: wait for everything
         }
     };
     // "=&v": an LDS read writes its destination when the data returns -- it must not share a register with an address
@@ -1460,52 +1483,67 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt_pipe(double *S, const double
                      : "v"(offA + so), "v"(offB + so) : "memory");
     };
     for (int s = 0; s < GST; ++s) issue(s);
-    wait_vm(12);
-    __builtin_amdgcn_s_barrier();
-    read_stage(0, 0);
     // Stage s sits in register buffer s & 1.  Per stage: make stage s + 1 visible (its DMA pieces have landed for every
-    // wave) and refill the ring slot stage s has just left; even stage s < 16: request C tiles (i, j) = (s / 4, s % 4 and + 1);
-    // request the operands of stage s + 1; odd stage s < 16: fold the two tiles requested one stage ago in; the 32 MFMAs.
-    // Pending operations YOUNGER than the DMA of stage s + 1, which the barrier's wait allows for: the DMA of stages
-    // s + 2 and s + 3 (where they exist) and, at an odd stage, the 8 loads of C requested at the stage before.
+    // wave) and refill the ring slot stage s has just left; fold C tile s in; request C tile s + 2; request the operands of
+    // stage s + 1; the 32 MFMAs.  The sixteen 16x16 tiles of C are requested ONE at a time, tiles 0 and 1 behind the ring's
+    // prologue and tile s + 2 at stage s, and folded in TWO stages after their request (round 3 requested two tiles at the
+    // even stages and folded them one stage later: the same sixteen registers, half the time for the load -- and a stage
+    // lasts ~1.9 us with two workgroups on the CU, which is what a read from HBM takes under load: the fold waited at every
+    // odd stage).
+    // Vector-memory operations of a wave in issue order:  D0 D1 D2 D3 C0 C1 | D4 C2 | D5 C3 | ... (D = 4 DMA pieces, C = 4 loads);
+    // every wait below counts the operations YOUNGER than the one it needs, which may stay pending.
     typedef int v2i __attribute__((ext_vector_type(2)));
     v2i craw[2][4];
+    constexpr int NCT = MODE == 0 ? 16 : 0;            // C tiles
+    const bool with_c = NCT > 0 && !(DBG & 1);
+    auto c_req = [&](int tile) {
+        // inline asm: a load the compiler issues itself it also waits for itself, with vmcnt(0) -- the counter is in-order and
+        // it cannot tell the DMA pieces behind the load from the load -- which would drain the ring at every stage
+        const int ci = tile >> 2, cj = tile & 3;
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg)
+            asm volatile("buffer_load_dwordx2 %0, %1, %2, %3 offen" : "=&v"(craw[tile & 1][reg]) : "v"(cvo + 128 * cj), "s"(crs), "s"((16 * ci + 4 * reg) * ld8) : "memory");
+    };
+    auto fold = [&](int tile) {
+        const int ci = tile >> 2, cj = tile & 3, B = tile & 1;
+        asm volatile("" : "+v"(craw[B][0]), "+v"(craw[B][1]), "+v"(craw[B][2]), "+v"(craw[B][3]));
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            union { v2i r; double d; } u;
+            u.r = craw[B][reg];
+            acc[ci][cj][reg] -= u.d;          // the accumulators hold A B' - C: the sign turns at the store
+        }
+    };
+    // C loads among the tiles lo .. hi (those that exist)
+    auto n_c = [&](int lo, int hi) { int n = 0; for (int j = lo; j <= hi; ++j) n += (with_c && j >= 0 && j < NCT) ? 1 : 0; return n; };
+    if (with_c) { c_req(0); c_req(1); }
+    wait_vm(12 + 4 * n_c(0, 1));
+    __builtin_amdgcn_s_barrier();
+    read_stage(0, 0);
 #pragma unroll
     for (int s = 0; s < NST; ++s) {
         const int P = s & 1;
-        const bool c_req = MODE == 0 && (s & 1) == 0 && s < 16, c_fold = MODE == 0 && (s & 1) == 1 && s < 16;
-        const int ci = (s >> 2) & 3, cj = s & 2;       // the pair of tiles of this stage (even) or of the one before (odd)
         // my reads of stage s (requested one stage ago) have returned: the fragments are in their registers and the ring
         // slot is free on my side.  The ONLY LDS wait of the step -- the reads of stage s + 1 requested below stay in flight
         // behind this step's MFMAs (a wait in front of the MFMAs would wait for them too: the counter is in-order)
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ra[P][0]), "+v"(ra[P][1]), "+v"(ra[P][2]), "+v"(ra[P][3]), "+v"(rb[P][0]), "+v"(rb[P][1]), "+v"(rb[P][2]), "+v"(rb[P][3]) :: "memory");
         if (s + 1 < NST) {
-            wait_vm(4 * ((s + 2 < NST) + (s + 3 < NST)) + (c_fold ? 8 : 0));
+            // needs D(s+1).  Younger: D(s+2), D(s+3); the C loads issued behind D(s+1): C0, C1 behind the prologue (all of
+            // D0 .. D3 precede them), C(t+2) behind D(t+4) at stage t, i.e. C(s-1) .. C(s+1) for s >= 3
+            const int c_younger = s + 1 <= 3 ? n_c(0, s + 1) : n_c(s - 1, s + 1);
+            wait_vm(4 * ((s + 2 < NST) + (s + 3 < NST)) + 4 * c_younger);
             __builtin_amdgcn_s_barrier();
             if (s + GST < NST) issue(s + GST);                      // into the slot of stage s
         }
-        if (c_req && !(DBG & 1)) {
-            // inline asm: a load the compiler issues itself it also waits for itself, with vmcnt(0) -- the counter is in-order and
-            // it cannot tell the DMA pieces behind the load from the load -- which would drain the ring at every second stage
-#pragma unroll
-            for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-                for (int reg = 0; reg < 4; ++reg)
-                    asm volatile("buffer_load_dwordx2 %0, %1, %2, %3 offen" : "=&v"(craw[jj][reg]) : "v"(cvo + 128 * (cj + jj)), "s"(crs), "s"((16 * ci + 4 * reg) * ld8) : "memory");
+        if (with_c && s < NCT) {
+            // needs C(s), requested two stages ago (tiles 0, 1: behind the prologue).  Younger: C(s+1), and every D issued
+            // behind C(s): D(s+3) and D(s+4) for s >= 2, D4 and D5 for s = 1, D4 for s = 0 -- those that exist
+            const int d_younger = s >= 2 ? (s + 3 < NST) + (s + GST < NST) : (s == 1 ? (4 < NST) + (5 < NST) : (4 < NST));
+            wait_vm(4 * d_younger + 4 * n_c(s + 1, s + 1));
+            fold(s);
+            if (s + 2 < NCT) c_req(s + 2);
         }
         if (s + 1 < NST) read_stage(1 - P, s + 1);
-        if (c_fold && !(DBG & 1)) {
-            wait_vm(4 * (s + GST < NST));                           // younger than the C loads: this stage's DMA
-            asm volatile("" : "+v"(craw[0][0]), "+v"(craw[0][1]), "+v"(craw[0][2]), "+v"(craw[0][3]), "+v"(craw[1][0]), "+v"(craw[1][1]), "+v"(craw[1][2]), "+v"(craw[1][3]));
-#pragma unroll
-            for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-                for (int reg = 0; reg < 4; ++reg) {
-                    union { v2i r; double d; } u;
-                    u.r = craw[jj][reg];
-                    acc[ci][cj + jj][reg] -= u.d;          // the accumulators hold A B' - C: the sign turns at the store
-                }
-        }
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -1629,7 +1667,7 @@ __global__ __launch_bounds__(512) void k_trsv_bwd_chain(const double *Lm, int ld
                 do {
                     __builtin_amdgcn_s_sleep(2);
                     v = __hip_atomic_load(xb + (size_t)i * NB + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (wall_clock64() - t0 > 200000000ull) { *flag = 4; break; }
+                    if (wall_clock64() - t0 > 200000000ull || __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { flag_raise(flag, 4); break; }
                 } while (v == TRSV_SENTINEL);
             }
             xk[t] = __longlong_as_double((long long)v);
@@ -2182,7 +2220,15 @@ int rcn_int_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_option
             if (nc > 1) {
                 const int nlow = nc * (nc - 1) / 2;
                 if (npairs_lower / (size_t)nlow > 128) k_ba_schur_mfma_wg<<<nlow, 512, 0, st>>>(d, pk_off, pk_list);   // long lists: a workgroup per block
-                else k_ba_schur_mfma<<<(nlow + 3) / 4, 256, 0, st>>>(d, pk_off, pk_list);
+                else {
+                    // the longest per-XCD sequence of blocks is XCD 7's (or the last XCD that still owns a row): rows 7, 15, ...
+                    int qmax = 0;
+                    for (int xx = 0; xx < 8; ++xx) {
+                        const int T = nc > xx ? (nc - 1 - xx) / 8 + 1 : 0;      // rows of this XCD
+                        qmax = std::max(qmax, xx * T + 4 * T * (T - 1));
+                    }
+                    k_ba_schur_mfma<<<8 * ((qmax + 3) / 4), 256, 0, st>>>(d, pk_off, pk_list);
+                }
             }
             if (csplit > 1) k_ba_schur_diag_mfma<12><<<nc * csplit, 1024, 0, st>>>(d, pk_off, pk_list, ir, csplit);
             else k_ba_schur_diag_mfma<4><<<nc, 1024, 0, st>>>(d, pk_off, pk_list, ir, 1);
@@ -2256,6 +2302,9 @@ int rcn_int_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_option
                 // (diagnostic build, RCN_CHOL_BREAK=1: step 1 waits for a count that never comes -- the test of the fallback)
                 k_gemm_q<0><<<gq1, 256, 0, sA>>>(d.S, d.L, npad, kb, 0, 1, d.Linv, gate(cC, ctx->chol_break && kb == 1 ? 1 << 30 : kb, lastw[kb + 1], cD, kb + 1));
                 k_gemm_q<1><<<gq1, 256, 0, sA>>>(d.S, d.L, npad, kb, 0, 1, d.Linv, none);
+#ifdef RCN_DIAG
+                if (ctx->chol_break == 2 && kb == 1 && !safe) k_diag_poison<<<1, 1, 0, sA>>>(d.S, npad, kb + 1);      // the next diagonal kernel meets a NaN pivot AFTER the timeout
+#endif
                 // On B and C the waits are ONE-WAVE gate kernels in front of the work, never inside it: a grid of a thousand
                 // workgroups that spins while it holds its CU slots could keep the very kernel it waits for from becoming resident.
                 if (m > 1) {

@@ -96,7 +96,7 @@ int rcn_create(int device_id, rcn_ctx **out)
     const char *tch = std::getenv("RCN_TRSV_CHAIN");
     if (tch) ctx->trsv_chain = tch[0] != '0';
     const char *cbk = std::getenv("RCN_CHOL_BREAK");
-    ctx->chol_break = cbk && cbk[0] == '1';
+    ctx->chol_break = cbk ? std::atoi(cbk) : 0;
     const char *cpm = std::getenv("RCN_CHOL_PAIR_MIN");
     if (cpm) ctx->chol_pair_min = std::atoi(cpm);
     const char *cpi = std::getenv("RCN_CHOL_PIPE_MIN");

@@ -1183,6 +1183,8 @@ static void free_slab(Slab &sl)
     if (sl.hn) (void)hipFree(sl.hn);
     if (sl.nrm2) (void)hipFree(sl.nrm2);
     if (sl.bigmin) (void)hipFree(sl.bigmin);
+    if (sl.own_f32) (void)hipFree(sl.own_f32);
+    if (sl.own_Ks) (void)hipFree(sl.own_Ks);
     sl = Slab();
 }
 
@@ -1401,6 +1403,46 @@ static int upload_batch(rcn_ctx *ctx, int32_t first_id, int32_t n, const float *
     int rc = rcn_int_slab_attach(ctx, first_id, n, n, src, K, D, 0, n, &si, nullptr, nullptr);
     if (rc || si < 0) return rc;
     return rcn_int_slab_rowstats(ctx, si, 0, n);
+}
+
+// rcn_desc_upload_batch: ragged host images into one ctx-owned block.  The slab machinery above does the rest (one stats
+// launch here, one conversion launch at the next prepare); what this adds is the block itself and the copies.
+static int upload_batch_host(rcn_ctx *ctx, int32_t first_id, int32_t n, const float *const *rows, const int32_t *Ks, int32_t D)
+{
+    if (n < 0 || D <= 0 || (n > 0 && (!rows || !Ks))) { ctx->set_error("rcn_desc_upload_batch: bad argument"); return RCN_ERR_ARG; }
+    if (n == 0) return RCN_OK;
+    int32_t Kmax = 1;
+    for (int i = 0; i < n; ++i) {
+        if (Ks[i] < 0 || (Ks[i] > 0 && !rows[i])) { ctx->set_error("rcn_desc_upload_batch: bad row count or NULL rows"); return RCN_ERR_ARG; }
+        Kmax = std::max(Kmax, Ks[i]);
+    }
+    if ((int64_t)n * Kmax > 0x7fffffffLL) { ctx->set_error("rcn_desc_upload_batch: batch too large"); return RCN_ERR_ARG; }
+    RCN_HIP(hipSetDevice(ctx->device));
+    // a block of this shape from an earlier call is reused; otherwise the new one is handed to the slab once it is attached
+    float *blk = nullptr;
+    int32_t *ksd = nullptr;
+    for (const Slab &sl : ctx->slabs)
+        if (sl.live && sl.own_f32 && sl.first_id == first_id && sl.n == n && sl.K == Kmax && sl.D == D) { blk = sl.own_f32; ksd = sl.own_Ks; }
+    const bool fresh = !blk;
+    const size_t bytes = (size_t)n * Kmax * D * sizeof(float);
+    if (fresh) {
+        RCN_HIP(hipMalloc(&blk, bytes));
+        if (hipMalloc(&ksd, (size_t)n * sizeof(int32_t)) != hipSuccess) { (void)hipFree(blk); ctx->set_error("rcn_desc_upload_batch: out of device memory"); return RCN_ERR_HIP; }
+    }
+    auto fail = [&](int rc) { if (fresh) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(blk); (void)hipFree(ksd); } return rc; };
+    hipError_t e = hipMemsetAsync(blk, 0, bytes, ctx->stream);                     // tails must be zero: they take part in the row statistics
+    for (int i = 0; i < n && e == hipSuccess; ++i)
+        if (Ks[i] > 0) e = hipMemcpyAsync(blk + (size_t)i * Kmax * D, rows[i], (size_t)Ks[i] * D * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(ksd, Ks, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream);
+    if (e != hipSuccess) { ctx->set_error(std::string("rcn_desc_upload_batch: ") + hipGetErrorString(e)); return fail(RCN_ERR_HIP); }
+    int si = -1;
+    int rc = rcn_int_slab_attach(ctx, first_id, n, n, blk, Kmax, D, 0, n, &si, Ks, ksd);
+    if (rc || si < 0) return fail(rc ? rc : RCN_ERR_ARG);
+    ctx->slabs[si].own_f32 = blk;
+    ctx->slabs[si].own_Ks = ksd;
+    rc = rcn_int_slab_rowstats(ctx, si, 0, n);
+    RCN_HIP(hipStreamSynchronize(ctx->stream));       // the host rows are borrowed for the call only
+    return rc;
 }
 
 template <int DP> static void launch_prepare_batch(rcn_ctx *ctx, const Slab &sl)
@@ -1855,6 +1897,30 @@ int rcn_desc_upload_batch_device(rcn_ctx *ctx, int32_t first_img_id, int32_t n_i
     if (!ctx) return RCN_ERR_ARG;
     std::lock_guard<std::mutex> lk(ctx->mu);
     return upload_batch(ctx, first_img_id, n_images, desc_dev, K, D);
+}
+
+int rcn_desc_upload_batch(rcn_ctx *ctx, int32_t first_img_id, int32_t n_images, const float *const *rows_host,
+                          const int32_t *K, int32_t D)
+{
+    if (!ctx) return RCN_ERR_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    return upload_batch_host(ctx, first_img_id, n_images, rows_host, K, D);
+}
+
+int rcn_desc_remove(rcn_ctx *ctx, int32_t img_id)
+{
+    if (!ctx) return RCN_ERR_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    auto it = ctx->images.find(img_id);
+    if (it == ctx->images.end()) return RCN_OK;
+    RCN_HIP(hipSetDevice(ctx->device));
+    RCN_HIP(hipStreamSynchronize(ctx->stream));      // a grid call may still read its rows
+    free_image(it->second);
+    ctx->images.erase(it);
+    retire_unreferenced_slabs(ctx);
+    ctx->prepared = false;
+    if (ctx->images.empty()) ctx->D = ctx->DP = 0;   // nothing left to pin the descriptor length
+    return RCN_OK;
 }
 
 int rcn_desc_clear(rcn_ctx *ctx)

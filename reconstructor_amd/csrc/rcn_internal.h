@@ -68,6 +68,8 @@ struct Slab {
     int32_t conv_first = 0, conv_n = 0;   // slots this ctx converts to fp16 itself (the rest arrives by all-gather)
     const float *f32 = nullptr;   // borrowed from the caller
     const int32_t *Ks_dev = nullptr;   // borrowed: rows in use per slot when the images are ragged (NULL = K everywhere)
+    float *own_f32 = nullptr;          // rcn_desc_upload_batch: the block of fp32 rows belongs to the slab (f32 points into it)
+    int32_t *own_Ks = nullptr;         // ... and so do the per-slot row counts (Ks_dev points at them)
     _Float16 *f16 = nullptr;
     float *hn = nullptr;
     double *nrm2 = nullptr;
@@ -181,7 +183,7 @@ struct rcn_ctx {
     int col_map_off1 = 0, col_map_off2 = 0;          // tile columns for the pipelined kernel on the panel stream
     int chol_pipe_min = 32;                          // panel / column kernels go through the pipelined kernel from this many tiles on
     bool trsv_chain = true;                          // backward substitution as one launch (k_trsv_bwd_chain); off after a flag timeout
-    bool chol_break = false;                         // diagnostic build: break one cross-stream hand-off (forces the one-stream fallback)
+    int chol_break = 0;                              // diagnostic build: 1 = break one cross-stream hand-off (forces the one-stream fallback); 2 = and put a NaN pivot behind it
     int chol_pair_min = 24;                          // two-panel bulk updates while at least this many tile rows remain below the pair
     int bulk_map_nblk = 0;
     bool chol_safe = false;             // a device-counter hand-off timed out once: factorise on one stream, in plain order, from then on

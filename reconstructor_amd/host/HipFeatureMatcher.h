@@ -11,12 +11,17 @@
 // `auto features1 = features[imgId1]` copies the vector of shared pointers for every pair
 // (SequentialReconstructor.cpp:213-214), so image i crosses this boundary N - 1 times -- and FlannMatcher
 // re-packs both images on every call (featDescToCV, FeatureMatcher.cpp:11-25).  Here an image is recognised by
-// the Feature objects its shared pointers name (first, last, count, descriptor length, plus a signature of three
-// descriptor rows against in-place edits), packed and uploaded ONCE, and kept resident in the ctx (fp32 rows,
-// fp16 copy, norms) under an id of the plugin's own range; a pair call then is one rcn_match_grid over two
-// resident ids.  Least recently used images are replaced beyond `capacity` images.  Descriptors are written once
-// by the detector and never edited afterwards in the reference; a caller that does edit them calls invalidate().
+// the Feature objects its shared pointers name (first, last, count, descriptor length) plus a signature over the
+// address of EVERY row's descriptor storage and the contents of up to 64 evenly spaced rows -- a feature vector that
+// was freed and re-detected into recycled Feature objects still moves its descriptor allocations or their sampled
+// contents -- packed and uploaded ONCE, and kept resident in the ctx (fp32 rows, fp16 copy, norms) under an id of
+// the plugin's own range; a pair call then is one rcn_match_grid over two resident ids.  Least recently used images
+// are replaced beyond `capacity` images.  Descriptors are written once by the detector and never edited afterwards
+// in the reference; a caller that edits rows IN PLACE (same storage, rows outside the sample) MUST call invalidate().
 #pragma once
+#include <atomic>
+#include <cstdint>
+#include <cstring>
 #include <mutex>
 #include <stdexcept>
 #include <string>
@@ -72,6 +77,8 @@ public:
                        const std::pair<int, int> /*imgShape1*/, const std::pair<int, int> /*imgShape2*/) override
     {
         if (features1.empty() || features2.empty()) return;   // the reference asserts here (:39)
+        // one descriptor length per call (featDescToCV would build two matrices knnMatch then refuses)
+        if (features1[0]->featDesc.desc.size() != features2[0]->featDesc.desc.size()) throw std::runtime_error("descriptor lengths differ");
         std::lock_guard<std::mutex> lk(mu_);                  // the cache and the pair of ids it hands out belong to one caller at a time
         const int32_t pr[2] = {resident(features1), resident(features2)};
         std::vector<int32_t> out(features1.size(), -1);
@@ -81,6 +88,7 @@ public:
             // an image against itself (the loop never asks for it): not a grid pair of two residents -- the uncached call
             int D1 = 0, D2 = 0;
             const std::vector<float> q = featDescToDense(features1, D1), t = featDescToDense(features2, D2);
+            if (D1 != D2) throw std::runtime_error("descriptor lengths differ");
             rc = rcn_match_pair(ctx_, q.data(), (int32_t)features1.size(), t.data(), (int32_t)features2.size(), D1, ratioThresh, out.data(), &count);
         }
         if (rc != RCN_OK) throw std::runtime_error(std::string("HipL2Matcher::matchFeatures: ") + rcn_last_error(ctx_));
@@ -98,7 +106,7 @@ public:
         std::vector<int32_t> out(features1.size(), -1);
         int32_t count = 0;
         std::lock_guard<std::mutex> lk(mu_);
-        if (!cache_.empty()) { rcn_desc_clear(ctx_); cache_.clear(); }        // rcn_match_pair needs the ctx's D to itself
+        dropOwn();                                                             // rcn_match_pair needs the ctx's D to itself (only the plugin's own ids go)
         const int rc = rcn_match_pair(ctx_, q.data(), (int32_t)features1.size(), t.data(), (int32_t)features2.size(), D1, ratioThresh, out.data(), &count);
         if (rc != RCN_OK) throw std::runtime_error(std::string("rcn_match_pair: ") + rcn_last_error(ctx_));
         for (size_t i = 0; i < out.size(); ++i)
@@ -111,7 +119,7 @@ public:
         cache_.clear();
     }
     void setCapacity(size_t images) { std::lock_guard<std::mutex> lk(mu_); capacity_ = images < 2 ? 2 : images; }
-    size_t uploads() const { return uploads_; }               // images packed + uploaded so far (a 25-image loop: 25, not 600)
+    size_t uploads() const { return uploads_.load(); }        // images packed + uploaded so far (a 25-image loop: 25, not 600)
     rcn_ctx *context() { return ctx_; }
 
 private:
@@ -126,23 +134,32 @@ private:
     static uint64_t signature(const std::vector<FeaturePtr<>> &f)
     {
         uint64_t h = 1469598103934665603ull;
-        const size_t rows[3] = {0, f.size() / 2, f.size() - 1};
-        for (size_t r : rows) {
-            const std::vector<float> &d = f[r]->featDesc.desc;
-            const unsigned char *b = reinterpret_cast<const unsigned char *>(d.data());
-            for (size_t i = 0; i < d.size() * sizeof(float); ++i) { h ^= b[i]; h *= 1099511628211ull; }
+        auto mix = [&h](uint64_t v) { h ^= v; h *= 1099511628211ull; h ^= h >> 29; };
+        for (const FeaturePtr<> &p : f) {                       // where every row lives, and how long it is
+            mix(reinterpret_cast<uintptr_t>(p->featDesc.desc.data()));
+            mix(p->featDesc.desc.size());
         }
+        const size_t n = f.size(), step = n > 64 ? n / 64 : 1;  // what up to 64 evenly spaced rows (first and last among them) hold
+        auto row = [&](size_t r) { for (float v : f[r]->featDesc.desc) { uint32_t u; std::memcpy(&u, &v, 4); mix(u); } };
+        for (size_t r = 0; r < n; r += step) row(r);
+        row(n - 1);
         return h;
+    }
+    // the plugin's own images out of the ctx (a shared ctx keeps everybody else's descriptors)
+    void dropOwn()
+    {
+        for (const Entry &e : cache_)
+            if (rcn_desc_remove(ctx_, e.id) != RCN_OK) throw std::runtime_error(std::string("rcn_desc_remove: ") + rcn_last_error(ctx_));
+        cache_.clear();
     }
     // id under which the image is resident in the ctx, uploading it first when it is not (mu_ held)
     int32_t resident(const std::vector<FeaturePtr<>> &f)
     {
         const int D = (int)f[0]->featDesc.desc.size();
         const uint64_t sig = signature(f);
-        if (!cache_.empty() && cache_[0].D != D) {            // another descriptor kind: the ctx holds one D at a time
-            if (rcn_desc_clear(ctx_) != RCN_OK) throw std::runtime_error(std::string("rcn_desc_clear: ") + rcn_last_error(ctx_));
-            cache_.clear();
-        }
+        if (!cache_.empty() && cache_[0].D != D) dropOwn();   // another descriptor kind: the ctx holds one D at a time.  Only the plugin's
+                                                              // own ids go; if other users of a shared ctx still hold the old length, the upload
+                                                              // below fails with "all resident images must share D" instead of wiping them
         for (Entry &e : cache_)
             if (e.first == f.front().get() && e.last == f.back().get() && e.K == f.size() && e.D == D && e.sig == sig) {
                 e.stamp = ++clock_;
@@ -174,7 +191,8 @@ private:
     bool owned_ = true;
     std::mutex mu_;
     std::vector<Entry> cache_;
-    size_t capacity_ = 64, uploads_ = 0;
+    size_t capacity_ = 64;
+    std::atomic<size_t> uploads_{0};
     uint64_t clock_ = 0;
     const float ratioThresh = 0.7;   // FeatureMatcher.h:45
 };

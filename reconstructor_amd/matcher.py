@@ -98,6 +98,24 @@ class HipL2Matcher(FeatureMatcher):
         self.ctx.check(self.ctx.lib.rcn_desc_upload_batch_device(
             self.ctx.h, int(first_id), int(n_images), C.c_void_p(dev_ptr), K, D))
 
+    def upload_batch(self, first_id, images):
+        """Ragged host images (a list of K_i x D arrays) as ids first_id ..: one call, one synchronisation
+        (rcn_desc_upload_batch) instead of one synchronous upload per image."""
+        arrs = [_as_desc(im) for im in images]
+        D = next((a.shape[1] for a in arrs if a.ndim == 2 and a.shape[0] and a.shape[1]), self._D)
+        if D <= 0:
+            raise ValueError("no image of the batch has a descriptor length")
+        if any(a.shape[0] and a.shape[1] != D for a in arrs):
+            raise ValueError("descriptor lengths differ")
+        self._D = D
+        n = len(arrs)
+        rows = (C.c_void_p * max(n, 1))(*[a.ctypes.data if a.shape[0] else None for a in arrs])
+        Ks = np.array([a.shape[0] for a in arrs], np.int32)
+        self.ctx.check(self.ctx.lib.rcn_desc_upload_batch(self.ctx.h, int(first_id), n, rows, Ks.ctypes.data, D))
+
+    def remove(self, img_id):
+        self.ctx.check(self.ctx.lib.rcn_desc_remove(self.ctx.h, int(img_id)))
+
     def clear(self):
         self.ctx.check(self.ctx.lib.rcn_desc_clear(self.ctx.h))
         self.ctx.check(self.ctx.lib.rcn_coords_clear(self.ctx.h))

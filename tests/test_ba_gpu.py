@@ -260,6 +260,22 @@ def test_rejected_steps_follow_the_oracle(gpu_ctx):
     assert abs(s1["final_rms_px"] - s0["final_rms_px"]) <= 1e-3 * s0["final_rms_px"]
 
 
+def test_far_start_at_cfg4_size_follows_the_oracle(gpu_ctx):
+    """The bench's far-start variant (ba_bench.FAR_START) at cfg-4 size, where the oracle finishes in seconds: 50 iterations
+    into the cap, the bounds line search on most of them, a rejected step on the way.  Same accept / reject decisions and
+    the same early cost trace; 50 badly conditioned iterations amplify rounding, so the end is compared loosely."""
+    from reconstructor_amd import ba, ba_bench
+    sc = synth_ba.make_scene(200, 20000, obs_per_point=10, seed=2024, perturb=ba_bench.FAR_START)
+    P0, I0, X0, s0 = orc_ba.solve(sc, threads=6)
+    P1, I1, X1, s1 = ba.solve_scene(gpu_ctx, sc)
+    assert s0["iterations"] >= 10 and s0["line_search_backtracks"] > 0, "the scene is meant to be a long, line-searched solve"
+    assert s1["iterations"] == s0["iterations"] and s1["termination"] == s0["termination"]
+    assert s1["successful_steps"] == s0["successful_steps"] and s1["unsuccessful_steps"] == s0["unsuccessful_steps"]
+    n = min(len(s0["cost_trace"]), len(s1["cost_trace"]), 12)
+    assert np.allclose(s1["cost_trace"][:n], s0["cost_trace"][:n], rtol=1e-6)
+    assert abs(s1["final_rms_px"] - s0["final_rms_px"]) <= 1e-2 * s0["final_rms_px"]
+
+
 def test_a_broken_stream_hand_off_falls_back_to_one_stream_with_the_same_bits(gpu_ctx):
     """a cross-stream wait of the factorisation that gives up must cost time, not the result.  The diagnostic
     build can break one hand-off on purpose (RCN_CHOL_BREAK=1: step 1 of every three-stream factorisation waits for a count
@@ -290,6 +306,16 @@ def test_a_broken_stream_hand_off_falls_back_to_one_stream_with_the_same_bits(gp
     assert d["sched"] == 1 and d["sec"] > 1.5 and d["invalid"] == 0
     assert d["it"] == s1["iterations"] and d["cost"] == s1["final_cost"]
     assert d["h"] == hashlib.sha256(P1.tobytes() + I1.tobytes() + X1.tobytes()).hexdigest()
+    # the kernels behind a timed-out hand-off run on half-updated tiles and may meet a non-finite pivot.  The
+    # timeout must stay in the flag word (RCN_CHOL_BREAK=2 puts a NaN on the next diagonal block behind the broken wait): the
+    # context still switches schedules instead of counting a failed step, and every later wait of that factorisation returns
+    # at once -- ONE 2-s timeout in the whole solve, not one per hand-off.
+    env = dict(os.environ, RCN_LIB=diag, RCN_CHOL_BREAK="2")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["sched"] == 1 and d["invalid"] == 0 and 1.5 < d["sec"] < 4.0, d
+    assert d["it"] == s1["iterations"] and d["h"] == hashlib.sha256(P1.tobytes() + I1.tobytes() + X1.tobytes()).hexdigest()
     # the backward substitution as one launch (x handed from block row to block row through the data itself) against the
     # per-step kernels it falls back to: the same bits
     env = dict(os.environ, RCN_LIB=diag, RCN_TRSV_CHAIN="0")

@@ -326,3 +326,58 @@ def test_out_of_scale_rows_are_set_aside_not_followed(matcher):
     assert st1["rows_exact_fallback"] >= (n - 1) * K
     print("fallback rows: uniform %d, with out-of-scale rows %d of %d" % (st0["rows_exact_fallback"], st1["rows_exact_fallback"], st1["rows_total"]))
     matcher.clear()
+
+
+def test_host_batch_ingest_equals_one_upload_per_image(matcher):
+    """rcn_desc_upload_batch: ragged [n][K_i][D] host images in one call (one block, one stats launch, one
+    synchronisation) -- the tables equal the one-upload-per-image path's and the oracle's; a second batch of the same
+    shape reuses the block; an empty image in the middle and an image of one row are part of it."""
+    ks = [300, 0, 513, 1, 256, 777]
+    ims = synth.descriptor_set("sift", len(ks), [max(k, 1) for k in ks], seed=91)
+    ims = [im[:k] for im, k in zip(ims, ks)]
+    pairs = [(0, 2), (0, 4), (2, 5), (4, 5), (3, 5), (5, 0), (1, 2), (2, 1)]
+    exp, ec = orc.match_grid(ims, pairs, threads=2)
+    matcher.clear()
+    matcher.upload_batch(10, ims)
+    shifted = [(a + 10, b + 10) for a, b in pairs]
+    out, counts = matcher.match_grid(shifted, max(ks))
+    assert np.array_equal(out, exp) and np.array_equal(counts, ec)
+    # same shape again, other contents: allocations reused, results follow the new rows
+    ims2 = [im[::-1].copy() for im in ims]
+    exp2, ec2 = orc.match_grid(ims2, pairs, threads=2)
+    matcher.upload_batch(10, ims2)
+    out, counts = matcher.match_grid(shifted, max(ks))
+    assert np.array_equal(out, exp2) and np.array_equal(counts, ec2)
+    # one image replaced on its own, one removed: the others stay
+    matcher.upload(12, ims[2])
+    matcher.remove(15)
+    assert matcher.ctx.lib.rcn_desc_count(matcher.ctx.h) == len(ks) - 1
+    ims3 = list(ims2)
+    ims3[2] = ims[2]
+    exp3, ec3 = orc.match_grid(ims3, [(0, 2), (0, 4), (2, 4)], threads=2)
+    out, counts = matcher.match_grid([(10, 12), (10, 14), (12, 14)], max(ks))
+    assert np.array_equal(out, exp3) and np.array_equal(counts, ec3)
+    matcher.clear()
+    assert matcher.ctx.lib.rcn_desc_count(matcher.ctx.h) == 0
+
+
+def test_remove_frees_the_descriptor_length(matcher):
+    """rcn_desc_remove of the last image lets the ctx take another D (what the plugin's cache does on a shared ctx
+    instead of rcn_desc_clear, which would wipe everybody's descriptors)."""
+    from reconstructor_amd import _lib
+    matcher.clear()
+    a = synth.descriptor_set("sift", 2, 200, seed=5)
+    b = synth.descriptor_set("orb", 2, 200, seed=6)
+    matcher.upload(1, a[0])
+    matcher.upload(2, a[1])
+    with pytest.raises(_lib.RcnError):
+        matcher.upload(3, b[0])                 # D = 32 beside D = 128
+    matcher.remove(1)
+    matcher.remove(2)
+    matcher.remove(2)                           # not resident any more: a no-op
+    matcher.upload(3, b[0])
+    matcher.upload(4, b[1])
+    out, counts = matcher.match_grid([(3, 4)], 200)
+    exp, ec = orc.match_grid(b, [(0, 1)], threads=1)
+    assert np.array_equal(out, exp) and np.array_equal(counts, ec)
+    matcher.clear()

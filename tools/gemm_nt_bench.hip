@@ -23,17 +23,19 @@ int main()
         const int pgrid = bc->bulk_map_grid[mt];
         printf("  map: %d workgroups for %d tiles (the busiest XCD carries %d)\n", pgrid, mt * (mt + 1) / 2, pgrid / 8);
 #define PSET(D, N) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_nt_pipe<D, N>), hipFuncAttributeMaxDynamicSharedMemorySize, GST * GSTAGE_BYTES)
-        PSET(0, 16); PSET(4, 16); PSET(7, 16); PSET(0, 32); PSET(4, 32); PSET(7, 32);
+        PSET(0, 16); PSET(4, 16); PSET(7, 16); PSET(0, 32); PSET(4, 32); PSET(7, 32); PSET(1, 16); PSET(2, 16); PSET(3, 16); PSET(1, 32); PSET(2, 32); PSET(3, 32);
 #define PRUN(D, N, what)                                                                                                   \
-        for (int rep = 0; rep < 2; ++rep) {                                                                                \
+        for (int rep = 0; rep < 5; ++rep) {                                                                                \
             float m;                                                                                                       \
             (void)hipEventRecord(e0);                                                                                      \
             k_gemm_nt_pipe<D, N><<<pgrid, 256, GST * GSTAGE_BYTES>>>(S0, L, npad, 0, map, 2, nullptr);                        \
             (void)hipEventRecord(e1); (void)hipEventSynchronize(e1); (void)hipEventElapsedTime(&m, e0, e1);                 \
-            if (rep) printf("  pipe K = %4d %s: %.1f us (%.1f TF)   %s\n", 8 * N, what, m * 1e3, flop * (N / 16.0) / m * 1e-9, hipGetErrorString(hipGetLastError())); \
+            if (rep == 4) printf("  pipe K = %4d %s: %.1f us (%.1f TF)   %s\n", 8 * N, what, m * 1e3, flop * (N / 16.0) / m * 1e-9, hipGetErrorString(hipGetLastError())); \
         }
         PRUN(0, 16, "full") PRUN(4, 16, "no operand DMA") PRUN(7, 16, "loop only")
         PRUN(0, 32, "full") PRUN(4, 32, "no operand DMA") PRUN(7, 32, "loop only")
+        PRUN(1, 16, "no C loads") PRUN(2, 16, "no C stores") PRUN(3, 16, "no C at all")
+        PRUN(1, 32, "no C loads") PRUN(2, 32, "no C stores") PRUN(3, 32, "no C at all") PRUN(0, 32, "full again")
         // correctness of the pipelined form on one tile, against a non-zero C, for both pass lengths
         for (int two = 0; two < 2; ++two) {
             std::vector<double> c0((size_t)128 * npad);
