@@ -195,14 +195,30 @@ int rcn_shard_put_image(rcn_shard *sh, int32_t img_id, const float *desc_host, i
 /* Collective.  local_desc_dev: this rank's [count][K][D] fp32 block in HBM (copied), or NULL when the rows are
  * already in the slot.  local_K: rows in use per owned image (count entries, each <= K; tails are zeroed), or
  * NULL = what rcn_shard_put_image recorded, K for untouched slots.  Afterwards ids 0 .. n_images-1 are resident
- * in the shard's ctx, image i with its own row count. */
+ * in the shard's ctx, image i with its own row count.  One host wait when every slot of every rank is full, two
+ * when some rank's images are ragged (the row counts are then gathered too). */
 int rcn_shard_exchange(rcn_shard *sh, const float *local_desc_dev, const int32_t *local_K);
 /* This rank's share of the canonical grid (rcn_shard_pairs order); out_dev / counts_dev as rcn_match_grid_device
  * (out_stride >= K).  Both NULL: the tables stay in buffers owned by the ctx, for rcn_shard_lists. */
 int rcn_shard_match(rcn_shard *sh, float ratio, int32_t *out_dev, int64_t out_stride, int32_t *counts_dev);
-/* Host lists of the last rcn_shard_match(sh, ratio, NULL, 0, NULL): rcn_match_compact_begin + _wait on the ctx's
+/* Host lists of the last rcn_shard_match(sh, ratio, NULL, 0, NULL): rcn_match_compact_begin + _wait on the shard's
  * own tables (same arguments and the same behaviour when capacity is too small: *total_out tells how many). */
 int rcn_shard_lists(rcn_shard *sh, int64_t *offsets_host, int32_t *qt_host, int64_t capacity, int64_t *total_out);
+
+/* The lists of EVERY rank on one rank: the single featureMatches map the reference keeps
+ * (SequentialReconstructor.cpp:224,264,274).  Collective.  table_dev / stride / counts_dev: this rank's tables of the last
+ * rcn_shard_match (all three NULL / 0: the shard's own tables, after rcn_shard_match(sh, ratio, NULL, 0, NULL), filtered
+ * or not).  Every rank compacts its tables on the GPU; the totals and the per-pair counts are all-gathered (one bounded host
+ * wait); the lists travel to `root` device to device (ncclSend / ncclRecv over xGMI), are put in canonical pair order on
+ * the root's GPU (pair number p of the row-major i < j list: offsets_host[p] .. offsets_host[p + 1]) and reach the root's
+ * host memory in ONE copy.  offsets_host (n(n-1)/2 + 1 entries), qt_host, capacity and *total_out are read on the root only
+ * (other ranks may pass NULL / 0); a capacity that is too small fails on every rank together with *total_out set on the
+ * root.  rcn_shard_merge_lists is the same merge for lists that are already in host memory (per-rank results of
+ * rcn_shard_lists, gathered by whatever the host has): pure host code, no GPU, no communicator. */
+int rcn_shard_gather_lists(rcn_shard *sh, int32_t root, const int32_t *table_dev, int64_t stride, const int32_t *counts_dev,
+                           int64_t *offsets_host, int32_t *qt_host, int64_t capacity, int64_t *total_out);
+int rcn_shard_merge_lists(int32_t n_images, int32_t world, const int64_t *const *offsets_per_rank, const int32_t *const *qt_per_rank,
+                          int64_t *offsets_out, int32_t *qt_out, int64_t capacity, int64_t *total_out);
 
 typedef struct {
     int32_t rank, world, n_images, images_per_rank;
@@ -214,14 +230,23 @@ typedef struct {
 } rcn_shard_stats;
 int rcn_shard_info(const rcn_shard *sh, rcn_shard_stats *out);
 
-/* Failure handling.  rcn_shard_exchange is the only collective after rcn_shard_create, and it opens with a status vote:
- * an all-gather of one word per rank next to the row counts, in front of its single host synchronisation.  A failure
- * that only THIS rank saw -- rcn_shard_reserve could not allocate, rcn_shard_put_image was refused, or the host driver
- * reports one of its own through rcn_shard_fail -- is remembered in the shard; the rank must still call
- * rcn_shard_exchange, which then returns an error on EVERY rank (the failing rank its own code, the others RCN_ERR_COMM
- * naming it) before any further collective is entered, so no peer is left waiting.  rcn_shard_match refuses to run until
- * an exchange has gone through again. */
+/* Failure handling.  The collectives after rcn_shard_create are rcn_shard_exchange and rcn_shard_gather_lists, and both open
+ * with a status vote: an all-gather of a few words per rank (status, shape, "my block is ragged") in front of the first
+ * host wait.  Every allocation of the call happens BEFORE the vote.  A failure that only THIS rank saw -- rcn_shard_reserve
+ * could not allocate, rcn_shard_put_image was refused, or the host driver reports one of its own through rcn_shard_fail --
+ * is remembered in the shard; the rank must still call rcn_shard_exchange, which then returns an error on EVERY rank (the
+ * failing rank its own code, the others RCN_ERR_COMM naming it) before any further collective is entered, so no peer is
+ * left waiting.  Ranks that reserved different shapes fail the same way.  rcn_shard_match refuses to run until an exchange
+ * has gone through again.
+ *   Behind the vote nothing allocates and nothing returns early: a HIP error there is recorded, the remaining collectives
+ * are still entered, the call returns the error to this caller and the peers hear of it in the NEXT vote.  An RCCL call that
+ * refuses to queue leaves the peers without a partner; the communicators are then aborted (ncclCommAbort).
+ *   The host never waits for a collective without a limit: every wait of the shard API polls, watches
+ * ncclCommGetAsyncError and gives up after rcn_shard_set_timeout seconds (default 600) -- it then aborts both communicators,
+ * and the shard is dead: every later call returns RCN_ERR_COMM at once (destroy it and create a new one).  A peer that
+ * crashed or walked away therefore costs a timeout, never a hang. */
 int rcn_shard_fail(rcn_shard *sh, int32_t code /* negative RCN_ERR_* */);
+int rcn_shard_set_timeout(rcn_shard *sh, double seconds);
 
 /* Phase times of the sharded step, HIP events on the streams the work runs on: enable, run steps (at most 64 are
  * kept), read the sums (waits for the shard's streams; clears them). */

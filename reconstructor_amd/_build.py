@@ -16,7 +16,7 @@ SO_DIAG = os.path.join(ROOT, "tools", "librcn_diag.so")
 SOURCES = ["ctx.hip", "match.hip", "ba.hip", "ba_session.hip", "validity.hip", "fmat.hip", "shard.hip", "store.hip", "desc.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
-LIBS = ["-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib"]
+LIBS = ["-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib", "-Wl,-z,defs"]      # -z defs: an unresolved symbol fails the build, not the first dlopen
 
 
 def _stale(so):

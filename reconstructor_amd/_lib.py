@@ -27,7 +27,7 @@ SYMBOLS = [
     "rcn_shard_owned_images", "rcn_shard_pair_count", "rcn_shard_pairs", "rcn_shard_unique_id",
     "rcn_shard_create", "rcn_shard_destroy", "rcn_shard_ctx", "rcn_shard_reserve", "rcn_shard_put_image", "rcn_shard_exchange",
     "rcn_shard_match", "rcn_shard_lists", "rcn_shard_info", "rcn_device_count",
-    "rcn_shard_fail", "rcn_shard_profile", "rcn_shard_profile_read", "rcn_shard_filter", "rcn_match_grid_filtered",
+    "rcn_shard_fail", "rcn_shard_set_timeout", "rcn_shard_gather_lists", "rcn_shard_merge_lists", "rcn_shard_profile", "rcn_shard_profile_read", "rcn_shard_filter", "rcn_match_grid_filtered",
     "rcn_ba_session_create", "rcn_ba_session_destroy", "rcn_ba_session_add_camera", "rcn_ba_session_cameras",
     "rcn_ba_session_add_points", "rcn_ba_session_add_observations", "rcn_ba_session_counts", "rcn_ba_session_graph",
     "rcn_ba_session_solve", "rcn_ba_session_read_points", "rcn_ba_session_points_device", "rcn_ba_session_validity",
@@ -228,6 +228,12 @@ def load():
     L.rcn_match_grid_filtered.argtypes = [vp, vp, i32, f32, i32, vp, i64, vp, vp]
     L.rcn_shard_fail.restype = C.c_int
     L.rcn_shard_fail.argtypes = [vp, i32]
+    L.rcn_shard_set_timeout.restype = C.c_int
+    L.rcn_shard_set_timeout.argtypes = [vp, C.c_double]
+    L.rcn_shard_gather_lists.restype = C.c_int
+    L.rcn_shard_gather_lists.argtypes = [vp, i32, vp, i64, vp, vp, vp, i64, C.POINTER(i64)]
+    L.rcn_shard_merge_lists.restype = C.c_int
+    L.rcn_shard_merge_lists.argtypes = [i32, i32, vp, vp, vp, vp, i64, C.POINTER(i64)]
     L.rcn_shard_profile.restype = C.c_int
     L.rcn_shard_profile.argtypes = [vp, C.c_int]
     L.rcn_shard_profile_read.restype = C.c_int

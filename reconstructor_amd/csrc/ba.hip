@@ -756,20 +756,17 @@ __device__ __forceinline__ f64x4 schur_mfma_chunk(const double *__restrict__ Wt,
 // one wave per strictly-lower block (c, c2 < c), written straight into the dense reduced system
 __global__ __launch_bounds__(256) void k_ba_schur_mfma(BaDev d, const int *off, const unsigned long long *list)
 {
-    // Block row c (the blocks (c, c2 < c): they all gather Y rows of camera c's observations, each about as often as its
-    // landmark has other observations) runs on ONE XCD -- workgroup b sits on XCD b % 8 (observed, speed only) and takes four
-    // consecutive blocks of the sequence of rows c = x, x + 8, x + 16, ... of its XCD x -- so that a Y row is fetched into
-    // that XCD's L2 once instead of once per XCD (round 3 dealt the blocks round-robin: 3.2 GB at the fabric per launch).
-    // Row x + 8 t starts at block x t + 4 t (t - 1) of the XCD's sequence.
+    // (Round 4 tried dealing whole block rows to one XCD -- row c on XCD c % 8, so that camera c's Y rows are fetched into one
+    // L2 instead of eight: 547 us against 515 us per cfg-5 launch.  The gathers are 8 bytes per lane out of 240-byte rows; the
+    // kernel is bound by the address rate of the gather path, not by what is behind it.  Removed.)
     const int lane = threadIdx.x & 63;
-    const int x = blockIdx.x & 7, q = (blockIdx.x >> 3) * 4 + (threadIdx.x >> 6);
-    auto row_start = [x](int t) { return x * t + 4 * t * (t - 1); };
-    int t = (int)((sqrt((double)(x - 4) * (x - 4) + 16.0 * q) - (x - 4)) * 0.125);
-    while (row_start(t + 1) <= q) ++t;
-    while (t > 0 && row_start(t) > q) --t;
-    const int c = x + 8 * t, c2 = q - row_start(t);
-    if (c >= d.nc || c2 >= c) return;
-    const int key = c * d.nc + c2;
+    const int blk = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int nlow = d.nc * (d.nc - 1) / 2;
+    if (blk >= nlow) return;
+    int c = (int)((sqrt(8.0 * blk + 1.0) + 1.0) * 0.5);
+    while (c * (c + 1) / 2 <= blk) ++c;
+    while (c * (c - 1) / 2 > blk) --c;
+    const int c2 = blk - c * (c - 1) / 2, key = c * d.nc + c2;
     const int dc = d.cam_dim[c], dc2 = d.cam_dim[c2];
     if (dc == 0 || dc2 == 0) return;
     f64x4 acc = {0.0, 0.0, 0.0, 0.0};
@@ -2220,15 +2217,7 @@ int rcn_int_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_option
             if (nc > 1) {
                 const int nlow = nc * (nc - 1) / 2;
                 if (npairs_lower / (size_t)nlow > 128) k_ba_schur_mfma_wg<<<nlow, 512, 0, st>>>(d, pk_off, pk_list);   // long lists: a workgroup per block
-                else {
-                    // the longest per-XCD sequence of blocks is XCD 7's (or the last XCD that still owns a row): rows 7, 15, ...
-                    int qmax = 0;
-                    for (int xx = 0; xx < 8; ++xx) {
-                        const int T = nc > xx ? (nc - 1 - xx) / 8 + 1 : 0;      // rows of this XCD
-                        qmax = std::max(qmax, xx * T + 4 * T * (T - 1));
-                    }
-                    k_ba_schur_mfma<<<8 * ((qmax + 3) / 4), 256, 0, st>>>(d, pk_off, pk_list);
-                }
+                else k_ba_schur_mfma<<<(nlow + 3) / 4, 256, 0, st>>>(d, pk_off, pk_list);
             }
             if (csplit > 1) k_ba_schur_diag_mfma<12><<<nc * csplit, 1024, 0, st>>>(d, pk_off, pk_list, ir, csplit);
             else k_ba_schur_diag_mfma<4><<<nc, 1024, 0, st>>>(d, pk_off, pk_list, ir, 1);

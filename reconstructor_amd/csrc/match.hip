@@ -152,7 +152,7 @@ __global__ void k_prepare(const float *__restrict__ x, const double *__restrict_
     if (row >= Kp) return;
     // a BIG row (|x|^2 >= thr2, fix_scale): no fp16 copy (zeros), never a coarse candidate (half-norm = padding value);
     // the image remembers the smallest such norm
-    const bool big = row < K && !(nrm2[row] < thr2);
+    const bool big = row < K && thr2 <= 1.7976931348623157e308 && !(nrm2[row] < thr2);      // only a finite threshold splits (a NaN norm is not a BIG row)
     half8 v;
     if (big) {
 #pragma unroll
@@ -194,7 +194,7 @@ __global__ void k_prepare_batch(const float *__restrict__ x, const double *__res
     const float *xi = x + (size_t)img * Kslot * D;
     const int K = Ks ? Ks[img] : Kslot;
     const double n2 = row < K ? nrm2[(size_t)img * Kslot + row] : 0.0;
-    const bool big = row < K && !(n2 < thr2);            // BIG row: see k_prepare
+    const bool big = row < K && thr2 <= 1.7976931348623157e308 && !(n2 < thr2);            // BIG row: see k_prepare
     half8 v;
     if (big) {
 #pragma unroll
@@ -783,7 +783,7 @@ __global__ __launch_bounds__(RCN_FB) void k_filter(RerankArgs a)
             const uint2 c = a.all_to_fallback ? make_uint2(0u, 0u) : a.cand[(size_t)pair * a.kq_stride + q];
             // exact kernel at once: no coarse pass at all; a BIG query row (no fp16 copy: fix_scale); fewer than two ordinary train
             // rows (the second candidate is a padding / BIG row, whose accumulator says nothing about its distance)
-            if (a.all_to_fallback || !(nq2 < S.thr2) || !(__uint_as_float(c.y & ~a.idx_mask) < 1.0e29f)) fb = true;
+            if (a.all_to_fallback || !(nq2 < S.thr2) /* also a NaN norm: the exact kernel restates the oracle's arithmetic for it */ || !(__uint_as_float(c.y & ~a.idx_mask) < 1.0e29f)) fb = true;
             else {
                 const double eps = coarse_eps(S, nq2);
                 // the train image's BIG rows never were candidates; every one of them is at least this far from the query
@@ -1470,7 +1470,7 @@ int rcn_int_resolve_scale(rcn_ctx *ctx)
 {
     if (!ctx->scale_on_device) return RCN_OK;
     RCN_HIP(hipMemcpyAsync(&ctx->scale_host, ctx->scale_dev.p, sizeof(ScaleDev), hipMemcpyDeviceToHost, ctx->stream));
-    RCN_HIP(hipStreamSynchronize(ctx->stream));
+    RCN_HIP(rcn_int_stream_wait(ctx));
     ctx->scale = ctx->scale_host.s;
     ctx->bias = ctx->scale_host.bias;
     ctx->max_norm = ctx->scale_host.n_max;
@@ -1519,7 +1519,7 @@ int rcn_int_prepare_all(rcn_ctx *ctx)
         }
         std::vector<unsigned> hc(RCN_HIST_WORD + RCN_HIST_BINS, 0u);
         RCN_HIP(hipMemcpyAsync(hc.data(), ctx->counters.p, RCN_COUNTER_BYTES, hipMemcpyDeviceToHost, ctx->stream));
-        RCN_HIP(hipStreamSynchronize(ctx->stream));
+        RCN_HIP(rcn_int_stream_wait(ctx));
         float maxabs;
         double maxn2;
         memcpy(&maxabs, &hc[0], 4);
@@ -1572,7 +1572,7 @@ int rcn_int_prepare_all(rcn_ctx *ctx)
     const bool same = table.size() == ctx->table_host.size() && ctx->img_table.p &&
                       (table.empty() || memcmp(table.data(), ctx->table_host.data(), table.size() * sizeof(ImgDev)) == 0);
     if (!same) {
-        RCN_HIP(hipStreamSynchronize(ctx->stream));       // a previous upload may still read the staging vector
+        RCN_HIP(rcn_int_stream_wait(ctx));       // a previous upload may still read the staging vector
         ctx->table_host.swap(table);
         RCN_HIP(ctx->img_table.reserve(std::max<size_t>(1, ctx->table_host.size()) * sizeof(ImgDev)));
         if (!ctx->table_host.empty())

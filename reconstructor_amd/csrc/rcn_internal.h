@@ -191,8 +191,23 @@ struct rcn_ctx {
     hipEvent_t ba_tev[6];            // phase timing of rcn_ba_solve ([4], [5]: around k_ba_eval<true>)
     bool ba_ev_made = false;
 
+    // Host waits inside rcn_int_prepare_all.  A sharded exchange (shard.hip) installs a BOUNDED wait for the duration of
+    // its call -- the ctx stream then carries collectives, and a peer that died would otherwise keep this host thread in
+    // hipStreamSynchronize for ever; NULL: plain hipStreamSynchronize.
+    int (*wait_hook)(void *arg, hipStream_t st) = nullptr;
+    void *wait_arg = nullptr;
+    // match tables owned by the ctx (out_tmp / cnt_tmp): bumped by every entry point that writes them, so that a shard can tell
+    // whether the tables its rcn_shard_match left there are still the ones it is about to filter / compact
+    uint64_t own_table_gen = 0;
+
     void set_error(const std::string &s) { err = s; }
 };
+// RCN_HIP-compatible wait for everything queued on ctx->stream (the hook, or hipStreamSynchronize)
+inline hipError_t rcn_int_stream_wait(rcn_ctx *ctx)
+{
+    if (ctx->wait_hook) return ctx->wait_hook(ctx->wait_arg, ctx->stream) == RCN_OK ? hipSuccess : hipErrorUnknown;
+    return hipStreamSynchronize(ctx->stream);
+}
 
 // Device-resident part of a bundle-adjustment problem (rcn_ba_session, ba_session.hip -> rcn_int_ba_solve, ba.hip)
 struct BaResident {
@@ -207,6 +222,8 @@ int rcn_match_release(rcn_ctx *ctx);
 int rcn_int_compact_begin(rcn_ctx *ctx, const int32_t *table_dev, int64_t stride, const int32_t *counts_dev,
                           int32_t n_pairs, int64_t *offsets_host, int32_t *qt_host, int64_t capacity, int64_t *total_out);
 int rcn_int_compact_wait(rcn_ctx *ctx);
+// store.hip: the ordered compaction kernel alone (rcn_shard_gather_lists: the lists stay in HBM)
+void rcn_int_launch_cmp_fill(hipStream_t st, const int32_t *table_dev, int64_t stride, const int32_t *counts_dev, const long long *off, int32_t n_pairs, int2 *qt);
 // fmat.hip: rcn_match_table_filter_device with ctx->mu already held
 int rcn_int_table_filter(rcn_ctx *ctx, const int32_t *pairs_host, int32_t n_pairs, int32_t *table_dev,
                          int64_t stride, int32_t *counts_dev, int32_t *out_status_dev);

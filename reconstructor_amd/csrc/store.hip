@@ -101,6 +101,12 @@ int rcn_match_compact_wait(rcn_ctx *ctx)
 
 }  // extern "C"
 
+// shard.hip (rcn_shard_gather_lists): the ordered compaction alone, no copy to the host
+void rcn_int_launch_cmp_fill(hipStream_t st, const int32_t *table_dev, int64_t stride, const int32_t *counts_dev, const long long *off, int32_t n_pairs, int2 *qt)
+{
+    k_cmp_fill<<<n_pairs, 256, 0, st>>>(table_dev, stride, counts_dev, off, qt);
+}
+
 // the two above with ctx->mu held by the caller (rcn_shard_lists keeps it across table lookup, compaction and wait)
 int rcn_int_compact_begin(rcn_ctx *ctx, const int32_t *table_dev, int64_t stride, const int32_t *counts_dev,
                           int32_t n_pairs, int64_t *offsets_host, int32_t *qt_host, int64_t capacity, int64_t *total_out)

@@ -17,7 +17,8 @@
 //            with at least 7 matches (rcn_shard_filter: the match table never leaves HBM); the recommended binding
 //            for the whole loop.
 // Failure: a rank whose local step fails still enters rcn_shard_exchange, whose status vote ends the collective
-// phase on every rank together (include/rcn.h, rcn_shard_fail); the driver then throws -- it cannot hang.
+// phase on every rank together (include/rcn.h, rcn_shard_fail); the driver then throws -- it cannot hang.  The library's
+// own waits are bounded as well (rcn_shard_set_timeout): a rank that died costs its peers a timeout, not a hang.
 #pragma once
 #include <algorithm>
 #include <atomic>
@@ -55,10 +56,14 @@ public:
         if (rcn_shard_unique_id(id) != RCN_OK) throw std::runtime_error("HipPairGridDriver: rcn_shard_unique_id failed");
         ctx_.assign(world_, nullptr);
         shard_.assign(world_, nullptr);
-        // rcn_shard_create is collective: one thread per rank
+        // Two phases, joined in between: every ctx first (local: a device that cannot be had is known here, and then NO rank
+        // goes on), only then rcn_shard_create, which is collective -- a rank that skipped it would leave the others inside
+        // ncclCommInitRank for ever.
         std::vector<std::string> err(world_);
+        run([&](int r) { if (rcn_create(r, &ctx_[r]) != RCN_OK) err[r] = "rcn_create failed on device " + std::to_string(r); });
+        for (const auto &e : err)
+            if (!e.empty()) { release(); throw std::runtime_error("HipPairGridDriver: " + e); }
         run([&](int r) {
-            if (rcn_create(r, &ctx_[r]) != RCN_OK) { err[r] = "rcn_create failed"; return; }
             if (rcn_shard_create(ctx_[r], r, world_, id, &shard_[r]) != RCN_OK) err[r] = std::string("rcn_shard_create: ") + rcn_last_error(ctx_[r]);
         });
         for (const auto &e : err)

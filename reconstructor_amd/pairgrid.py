@@ -45,6 +45,25 @@ def merge_shards(shards, world):
     return out
 
 
+def merge_lists(n_images, world, per_rank):
+    """rcn_shard_merge_lists: per_rank[r] = (offsets, qt) as Shard.lists() returns them on rank r -> (offsets[P+1], qt[total, 2]) of
+    the whole canonical grid (pair number p of the row-major i < j list came from rank p % world).  Pure host code."""
+    L = _lib.load()
+    P = n_images * (n_images - 1) // 2
+    offs = [np.ascontiguousarray(o, np.int64) for o, _ in per_rank]
+    qts = [np.ascontiguousarray(q, np.int32).reshape(-1, 2) for _, q in per_rank]
+    op = (C.c_void_p * world)(*[o.ctypes.data for o in offs])
+    qp = (C.c_void_p * world)(*[q.ctypes.data if len(q) else None for q in qts])
+    out_off = np.zeros(P + 1, np.int64)
+    total = C.c_int64(0)
+    cap = int(sum(int(o[-1]) for o in offs))
+    out_qt = np.zeros((max(cap, 1), 2), np.int32)
+    rc = L.rcn_shard_merge_lists(n_images, world, op, qp, out_off.ctypes.data, out_qt.ctypes.data, cap, C.byref(total))
+    if rc:
+        raise _lib.RcnError(rc, "rcn_shard_merge_lists")
+    return out_off, out_qt[:total.value]
+
+
 def unique_id():
     """ncclGetUniqueId as 128 bytes (one rank draws it, every rank passes it to Shard)."""
     buf = (C.c_uint8 * _lib.SHARD_ID_BYTES)()
@@ -97,6 +116,31 @@ class Shard:
         if total.value:
             self.ctx.check(self.ctx.lib.rcn_shard_lists(self.h, offs.ctypes.data, qt.ctypes.data, total.value, C.byref(total)))
         return offs, qt[:total.value]
+
+    def gather_lists(self, root=0, table_dev_ptr=None, stride=0, counts_dev_ptr=None, capacity=None):
+        """Collective (rcn_shard_gather_lists): the lists of every rank in canonical pair order on `root`, moved device to device
+        over RCCL.  Returns (offsets, qt) on the root and (None, None) elsewhere.  capacity: entries the root's buffer holds
+        (None: sized by a first call that reports the total -- every rank must then pass None as well)."""
+        P = self.info()["n_images"] * (self.info()["n_images"] - 1) // 2
+        is_root = self.rank == root
+        t = C.c_void_p(table_dev_ptr) if table_dev_ptr else None
+        c = C.c_void_p(counts_dev_ptr) if counts_dev_ptr else None
+        offs = np.zeros(P + 1, np.int64) if is_root else None
+        total = C.c_int64(0)
+        if capacity is None:
+            rc = self.ctx.lib.rcn_shard_gather_lists(self.h, root, t, stride, c, offs.ctypes.data if is_root else None, None, 0, C.byref(total))
+            if rc == 0:                # nothing matched anywhere
+                return (offs, np.zeros((0, 2), np.int32)) if is_root else (None, None)
+            if not (rc == -1 and (not is_root or total.value > 0)):
+                self.ctx.check(rc)
+            capacity = total.value
+        qt = np.zeros((max(1, capacity), 2), np.int32) if is_root else None
+        self.ctx.check(self.ctx.lib.rcn_shard_gather_lists(self.h, root, t, stride, c, offs.ctypes.data if is_root else None,
+                                                           qt.ctypes.data if is_root else None, capacity if is_root else 0, C.byref(total)))
+        return (offs, qt[:total.value]) if is_root else (None, None)
+
+    def set_timeout(self, seconds):
+        self.ctx.check(self.ctx.lib.rcn_shard_set_timeout(self.h, float(seconds)))
 
     def info(self):
         s = _lib.ShardStats()

@@ -48,12 +48,25 @@ mine = pairgrid.shard_pairs(n, world, rank)            # the C partition (rcn_sh
 out, counts = orc.match_grid(ims, mine, threads=1)          # stand-in for the per-rank GPU grid call
 rows = [None] * world
 dist.all_gather_object(rows, out)
+def lists_of(table):                 # what rcn_shard_lists hands back for a table: offsets + (query, train) in ascending query order
+    offs, qt = [0], []
+    for row in table:
+        q = np.nonzero(row >= 0)[0]
+        qt.append(np.stack([q, row[q]], 1))
+        offs.append(offs[-1] + len(q))
+    return np.array(offs, np.int64), (np.concatenate(qt) if qt else np.zeros((0, 2))).astype(np.int32)
+per_rank = [None] * world
+dist.all_gather_object(per_rank, lists_of(out))      # the control plane carries the per-rank lists here; on GPUs rcn_shard_gather_lists does (RCCL)
 if rank == 0:
     merged = pairgrid.merge_shards(rows, world)
     full = [synth.image_descriptors("orb", i, K, pool, seed=7) for i in range(n)]
     exp, _ = orc.match_grid(full, all_pairs(n), threads=1)
     assert np.array_equal(merged, exp)
-    print("OK", merged.shape, int((merged >= 0).sum()))
+    # the host half of the gather (rcn_shard_merge_lists): the single featureMatches map in canonical pair order
+    goff, gqt = pairgrid.merge_lists(n, world, per_rank)
+    eoff, eqt = lists_of(exp)
+    assert np.array_equal(goff, eoff) and np.array_equal(gqt, eqt)
+    print("OK", merged.shape, int((merged >= 0).sum()), len(gqt))
 dist.destroy_process_group()
 '''
 
@@ -67,3 +80,23 @@ def test_two_ranks_gloo(tmp_path):
                        capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "OK" in r.stdout
+
+
+def test_merge_lists_is_the_inverse_of_the_deal():
+    """rcn_shard_merge_lists on random per-rank lists, worlds 1 .. 8, against a direct construction."""
+    rng = np.random.default_rng(5)
+    for n in (2, 3, 7, 20):
+        P = n * (n - 1) // 2
+        cnt = rng.integers(0, 5, P)
+        cnt[rng.random(P) < 0.3] = 0
+        full_off = np.concatenate([[0], np.cumsum(cnt)]).astype(np.int64)
+        full_qt = rng.integers(0, 1000, (int(full_off[-1]), 2)).astype(np.int32)
+        for world in (1, 2, 3, 8):
+            per = []
+            for r in range(world):
+                idx = np.arange(r, P, world)
+                off = np.concatenate([[0], np.cumsum(cnt[idx])]).astype(np.int64)
+                qt = np.concatenate([full_qt[full_off[p]:full_off[p + 1]] for p in idx]) if len(idx) else np.zeros((0, 2), np.int32)
+                per.append((off, qt.astype(np.int32).reshape(-1, 2)))
+            off, qt = pairgrid.merge_lists(n, world, per)
+            assert np.array_equal(off, full_off) and np.array_equal(qt, full_qt)

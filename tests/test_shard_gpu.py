@@ -248,3 +248,105 @@ def test_device_side_scale_equals_the_host_side_scale(shard, gpu_ctx):
     assert np.array_equal(out.cpu().numpy(), tab) and np.array_equal(cnt.cpu().numpy(), c2)
     for k in ("rows_reranked", "rows_exact_fallback", "err_bound_d2", "rows_total"):
         assert st_dev[k] == st_host[k], k
+
+
+def test_gather_lists_at_world_one_equals_the_lists(shard):
+    """rcn_shard_gather_lists is collective; at world size 1 the root receives nothing over RCCL, but every other step --
+    totals + per-pair counts all-gathered, the bounded waits, the votes, the canonical interleave on the device, the one
+    copy to the host -- is the code every rank runs at N > 1.  Own tables (ragged, some pairs empty) and caller's tables."""
+    import torch
+    from reconstructor_amd.matcher import all_pairs
+    Ks = [300, 64, 0, 513, 2, 97]
+    ims = synth.descriptor_set("sift", len(Ks), Ks, n_world=800, seed=15)
+    n, Kmax, D = len(Ks), max(Ks), 128
+    exp, ec = orc.match_grid(ims, all_pairs(n), threads=4)
+    shard.ctx.check(shard.ctx.lib.rcn_desc_clear(shard.ctx.h))
+    shard.reserve(n, Kmax, D)
+    for i, im in enumerate(ims):
+        shard.put_image(i, im)
+    shard.exchange(None, None)
+    shard.match(0.7)
+    offs, qt = shard.lists()
+    goffs, gqt = shard.gather_lists(0)
+    assert np.array_equal(goffs, offs) and np.array_equal(gqt, qt) and np.array_equal(np.diff(goffs), ec)
+    # a root buffer that is too small: an error with the total, and the shard stays usable
+    total = C.c_int64(0)
+    small = np.zeros((max(1, len(qt) - 1), 2), np.int32)
+    rc = shard.ctx.lib.rcn_shard_gather_lists(shard.h, 0, None, 0, None, goffs.ctypes.data, small.ctypes.data, len(qt) - 1, C.byref(total))
+    assert rc == -1 and total.value == len(qt)
+    # the caller's own tables
+    P = n * (n - 1) // 2
+    out = torch.full((P, Kmax + 3), -7, dtype=torch.int32, device="cuda")
+    cnt = torch.full((P,), -7, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    shard.match(0.7, out.data_ptr(), Kmax + 3, cnt.data_ptr())
+    goffs2, gqt2 = shard.gather_lists(0, out.data_ptr(), Kmax + 3, cnt.data_ptr())
+    assert np.array_equal(goffs2, offs) and np.array_equal(gqt2, qt)
+    shard.set_timeout(600.0)
+
+
+_FAULT = r"""
+import sys, json, ctypes as C
+import numpy as np
+sys.path.insert(0, %r)
+import torch
+from reconstructor_amd import _lib, pairgrid, synth
+from reconstructor_amd.matcher import all_pairs
+L = _lib.load()
+assert b"DIAGNOSTIC" in L.rcn_version()
+L.rcn_diag_shard_fault.argtypes = [C.c_void_p, C.c_int]
+ctx = _lib.Context(0)
+sh = pairgrid.Shard(ctx, 0, 1, pairgrid.unique_id())
+ims = synth.descriptor_set("sift", 4, 200, n_world=500, seed=77)
+dev = torch.from_numpy(np.ascontiguousarray(np.stack(ims))).cuda()
+torch.cuda.synchronize()
+res = {}
+def call(name, f):
+    try:
+        f(); res[name] = 0
+    except _lib.RcnError as e:
+        res[name] = e.code; res[name + "_text"] = str(e)
+sh.reserve(4, 200, 128)
+call("clean0", lambda: sh.exchange(dev.data_ptr()))
+kind = int(sys.argv[1])
+assert L.rcn_diag_shard_fault(sh.h, kind) == 0
+call("faulty", lambda: sh.exchange(dev.data_ptr()))
+call("match", lambda: sh.match(0.7))
+call("lists", lambda: sh.lists())
+call("gather", lambda: sh.gather_lists(0))
+call("next", lambda: sh.exchange(dev.data_ptr()))          # kind 1: the vote carries last call's error; kind 2: the shard is dead
+call("after", lambda: sh.exchange(dev.data_ptr()))
+call("match2", lambda: sh.match(0.7))
+call("reserve", lambda: sh.reserve(4, 200, 128))
+sh.close()
+print(json.dumps(res))
+"""
+
+
+@pytest.mark.parametrize("kind", [1, 2])
+def test_failure_behind_the_vote_reaches_every_entry_point(kind):
+    """an error AFTER the status vote must neither strand the peers inside a collective nor go unreported.
+    The diagnostic build injects one (rcn_diag_shard_fault) in a child process.  kind 1, a HIP error behind the vote: the
+    exchange still enters every remaining collective, returns the error, match / lists / gather refuse to run on it, the NEXT
+    exchange's vote reports it once more (that is how the peers hear of it) and the one after is clean.  kind 2, an RCCL call
+    that refuses to queue: the communicators are aborted and every later entry point returns RCN_ERR_COMM at once."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    diag = os.path.join(root, "tools", "librcn_diag.so")
+    assert os.path.exists(diag), "tools/librcn_diag.so missing: run __graft_entry__.build()"
+    r = subprocess.run([sys.executable, "-c", _FAULT % root, str(kind)], capture_output=True, text=True, timeout=300, env=dict(os.environ, RCN_LIB=diag))
+    assert r.returncode == 0, r.stdout + r.stderr
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["clean0"] == 0
+    if kind == 1:
+        assert d["faulty"] == -2 and "behind the vote" in d["faulty_text"]                 # RCN_ERR_HIP, reported at once
+        assert d["match"] != 0 and d["lists"] != 0 and d["gather"] != 0                      # nothing runs on the abandoned exchange
+        assert d["next"] == -2                                                              # the vote of the next exchange carries it
+        assert d["after"] == 0 and d["match2"] == 0 and d["reserve"] == 0                   # and then the shard is clean again
+    else:
+        assert d["faulty"] == -7 and "aborted" in d["faulty_text"]                          # RCN_ERR_COMM
+        for k in ("match", "lists", "gather", "next", "after", "match2", "reserve"):
+            assert d[k] == -7, (k, d)
