@@ -275,7 +275,33 @@ def cfg1_leg(ctx, with_cpu):
             m.upload(i, ims[i])
             m.upload_coords(i, coords[i])
         sync()
+        t_up_each = time.perf_counter() - t0
+        # the batched host ingest (rcn_desc_upload_batch + rcn_coords_upload_batch: one synchronisation each), from pageable rows
+        # as a detector's std::vector would be and from pinned rows (rcn_host_alloc); the second call of a shape reuses the block
+        m.clear()
+        m.upload_batch(0, ims); m.upload_coords_batch(0, coords); sync()
+        t0 = time.perf_counter()
+        m.upload_batch(0, ims)
+        m.upload_coords_batch(0, coords)
+        sync()
         t_up = time.perf_counter() - t0
+        pin = C.c_void_p()
+        nbytes = sum(im.nbytes for im in ims)
+        ctx.check(ctx.lib.rcn_host_alloc(C.byref(pin), nbytes))
+        pinned, o = [], 0
+        for im in ims:
+            v = np.ctypeslib.as_array((C.c_float * im.size).from_address(pin.value + o)).reshape(im.shape)
+            v[...] = im
+            pinned.append(v)
+            o += im.nbytes
+        m.upload_batch(0, pinned); sync()
+        t0 = time.perf_counter()
+        m.upload_batch(0, pinned)
+        m.upload_coords_batch(0, coords)
+        sync()
+        t_up_pinned = time.perf_counter() - t0
+        m.upload_batch(0, ims); sync()          # the pinned block goes away below: the resident rows are the pageable ones' copy
+        ctx.lib.rcn_host_free(pin)
         tab = torch.empty((P, stride), dtype=torch.int32, device="cuda")
         cnt = torch.empty((P,), dtype=torch.int32, device="cuda")
         ver = torch.empty((P,), dtype=torch.int32, device="cuda")
@@ -300,7 +326,7 @@ def cfg1_leg(ctx, with_cpu):
         loop(False)                                   # warm (workspaces)
         ts = loop(True)
         t_all = min((lambda r: r[-1] - r[0])(loop(False)) for _ in range(3))
-        g = {"upload_seconds": t_up, "match_seconds": ts[1] - ts[0], "filter_seconds": ts[2] - ts[1], "lists_seconds": ts[3] - ts[2],
+        g = {"upload_seconds": t_up, "upload_seconds_pinned_rows": t_up_pinned, "upload_seconds_one_call_per_image": t_up_each, "match_seconds": ts[1] - ts[0], "filter_seconds": ts[2] - ts[1], "lists_seconds": ts[3] - ts[2],
              "gpu_seconds": t_all, "matches_kept": int(total.value), "pairs_per_s": P / t_all,
              "note": "gpu_seconds = match + filter + host lists back to back (no synchronisation in between); the three stage times are one run with a synchronisation after each"}
         if with_cpu:
@@ -478,9 +504,53 @@ def parity_cfg3(world, rank):
     return check
 
 
-def run_grid(torch, dist, dev, shard, n_img, K, local_dev, steps, warmup, world, materialise=True, check=None):
+def gather_leg(torch, dist, dev, shard, out, counts, K, P, n_img, world, rank, fence, reps=2):
+    """After the timed steps: the lists of EVERY rank on rank 0 -- the reference's single featureMatches map
+    (SequentialReconstructor.cpp:224,264,274) -- through rcn_shard_gather_lists: compaction on every GPU, RCCL send / receive
+    device to device, canonical interleave on the root's GPU, one copy into pinned host memory.  Timed on its own (max over
+    ranks), bounded by the shard's timeout; a failure is reported in the line, never raised: the step figures stand without it."""
+    import ctypes as C
+    ctx = shard.ctx
+    res = {"root": 0}
+    try:
+        shard.set_timeout(180.0)
+        mine = int(counts[:P].sum().item()) if P else 0
+        tot = torch.tensor([float(mine)], dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(tot)
+        total = int(tot.item())
+        Ptot = n_img * (n_img - 1) // 2
+        hp, offs = C.c_void_p(), None
+        if rank == 0:
+            ctx.check(ctx.lib.rcn_host_alloc(C.byref(hp), 8 * max(1, total)))
+            offs = np.zeros(Ptot + 1, np.int64)
+        got = C.c_int64(0)
+        times = []
+        for _ in range(reps):
+            fence()
+            t0 = time.perf_counter()
+            ctx.check(ctx.lib.rcn_shard_gather_lists(shard.h, 0, C.c_void_p(out.data_ptr()), K, C.c_void_p(counts.data_ptr()),
+                                                     offs.ctypes.data if rank == 0 else None, hp if rank == 0 else None, total if rank == 0 else 0, C.byref(got)))
+            fence()
+            times.append(time.perf_counter() - t0)
+        t = torch.tensor([min(times)], dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        res.update({"gather_ms": 1e3 * float(t.item()), "entries": int(got.value), "bytes_to_root_host": 8 * int(got.value)})
+        if rank == 0:
+            # the root's own pairs sit at numbers 0, world, 2 world, ... of the merged list
+            own = counts[:P].cpu().numpy()
+            res["consistent"] = bool(got.value == total and offs[-1] == total and np.array_equal(np.diff(offs)[0::world][:P], own))
+            ctx.lib.rcn_host_free(hp)
+    except Exception as e:      # noqa: BLE001 -- the bench line must still come out
+        res["gather_error"] = str(e)[:300]
+    return res
+
+
+def run_grid(torch, dist, dev, shard, n_img, K, local_dev, steps, warmup, world, materialise=True, check=None, gather_rank=None):
     """warmup + `steps` timed steps of exchange -> match -> materialise through the sharded-grid ABI.
-    Returns (seconds of the timed region on this rank, stats of the timed steps, matches found, lists bytes)."""
+    Returns (seconds of the timed region on this rank, stats of the timed steps, matches found, lists bytes).
+    gather_rank: this process's rank when the gather leg is to run behind the timed region (st["gather"])."""
     ctx = shard.ctx
     shard.reserve(n_img, K, D)
     info0 = shard.info()
@@ -536,7 +606,9 @@ def run_grid(torch, dist, dev, shard, n_img, K, local_dev, steps, warmup, world,
     if lists is not None:
         lists.close()
     st["parity"] = check(out, counts) if check is not None else None      # outside the timed region: the table is still in HBM
-    return dt, st, n_matches, list_bytes, shard.info()
+    info = shard.info()
+    st["gather"] = gather_leg(torch, dist, dev, shard, out, counts, K, P, n_img, world, gather_rank, fence) if gather_rank is not None else None
+    return dt, st, n_matches, list_bytes, info
 
 
 def host_boundary_leg(torch, dev, shard, images, steps=5):
@@ -774,7 +846,7 @@ def main():
 
     is_cfg = (n_img, K) == WORKLOADS[args.workload]
     main_check = parity_cfg3(world, rank) if (is_cfg and args.workload == "cfg3") else (parity_cfg2 if (is_cfg and args.workload == "cfg2" and world == 1) else None)
-    dt, st, n_matches, list_bytes, info = run_grid(torch, dist, dev, shard, n_img, K, local_dev, args.steps, args.warmup, world, check=main_check)
+    dt, st, n_matches, list_bytes, info = run_grid(torch, dist, dev, shard, n_img, K, local_dev, args.steps, args.warmup, world, check=main_check, gather_rank=rank)
     par = st.get("parity") or {"equal_to_cpu": None, "pairs_compared": 0}
 
     tm = st["shard_times"]
@@ -821,6 +893,14 @@ def main():
             "rccl": {"ranks": int(info["comm_ranks"]), "exchange_ms": phase[0], "f32_gather_ms_side_stream": phase[1], "match_ms": phase[2],
                      "host_syncs_per_exchange": 1},
         }
+        # SURVEY 8(e) "per-pair match lists gathered to rank 0": measured behind the timed steps (rcn_shard_gather_lists, max over
+        # ranks); `value` keeps every rank's lists on that rank, value_with_gather adds the gather to every step
+        g = st.get("gather") or {}
+        line["rccl"].update({k: g[k] for k in ("gather_ms", "entries", "bytes_to_root_host", "consistent", "gather_error", "root") if k in g})
+        if "gather_ms" in g:
+            line["rccl"]["value_with_gather"] = float(n_pairs_total) * K * K / (1e-3 * (ms_step + g["gather_ms"]))
+            line["rccl"]["gather_note"] = ("all ranks' (query, train) lists in canonical pair order in rank 0's pinned host memory: compaction on every GPU, ncclSend / ncclRecv "
+                                           "device to device, interleave on the root's GPU, one D2H copy; `value` is quoted without it (each rank's lists in its own host memory)")
         if world == 1:
             if not args.no_cfg2 and args.workload != "cfg2":
                 # BASELINE configs[1] on the same GPU, same path (exchange + match + materialise)

@@ -143,7 +143,8 @@ int  rcn_match_compact_wait(rcn_ctx *ctx);
 typedef struct {
     int64_t rows_total;
     int64_t rows_reranked;        /* query rows whose two candidates were re-computed exactly (fp64) */
-    int64_t rows_exact_fallback;  /* query rows the coarse pass could not certify: exact brute force */
+    int64_t rows_exact_fallback;  /* query rows the coarse pass and the re-rank could not certify: middle tier (fp32 sweep shared by the rows
+                                     of a train image -> a handful of candidates -> fp64 chain), K2b (every train row in fp64) behind it */
     int64_t pair_distances;       /* sum of K1*K2 */
     double  err_bound_d2;         /* largest certified bound on |coarse - exact| squared distance */
     int32_t used_mfma_path;       /* 1 = fp16 MFMA coarse pass + exact re-rank, 0 = exact kernel only */
@@ -151,6 +152,9 @@ typedef struct {
     double  coarse_ms;            /* HIP-event time of k_coarse_top2 launches, summed */
     double  rerank_ms;            /* k_rerank + k_exact_rows */
     double  unique_ms;            /* k_unique_claim + k_unique_emit */
+    int64_t rows_brute_force;     /* of rows_exact_fallback: rows that went through K2b after all (candidate list overflowed, budget exceeded, D % 4 != 0) */
+    int32_t chunks;               /* pipeline chunks of the last grid call (candidate table / row lists are sized per chunk) */
+    int32_t coarse_launches;      /* coarse-kernel launches summed into coarse_ms (chunks x profiled calls) */
 } rcn_match_stats;
 int rcn_match_last_stats(const rcn_ctx *ctx, rcn_match_stats *out);
 /* enable != 0: bracket the kernels of every following grid call with HIP events on the ctx
@@ -440,6 +444,8 @@ int rcn_fmat_filter_grid_device(rcn_ctx *ctx, int32_t n_pairs, const int32_t *pa
  * the pair loop for every pair, no host round trip.  Needs the integer pixel coordinates of the
  * keypoints of every image involved (Feature<int>::featCoord, K x 2), uploaded once per image. */
 int rcn_coords_upload(rcn_ctx *ctx, int32_t img_id, const int32_t *xy_host, int32_t K);
+/* n images in one call: one asynchronous copy per image, one host synchronisation (the coordinates' rcn_desc_upload_batch) */
+int rcn_coords_upload_batch(rcn_ctx *ctx, int32_t first_img_id, int32_t n_images, const int32_t *const *xy_host, const int32_t *K);
 int rcn_coords_clear(rcn_ctx *ctx);
 /* pairs_host / table_dev / stride / counts_dev exactly as given to and left by rcn_match_grid_device.
  * The table is filtered in place: in a pair with >= 7 matches only the inliers stay (none when no

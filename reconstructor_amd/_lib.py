@@ -22,7 +22,7 @@ SYMBOLS = [
     "rcn_match_last_stats", "rcn_match_profile", "rcn_ba_default_options", "rcn_ba_solve",
     "rcn_landmark_validity", "rcn_landmark_validity_device",
     "rcn_fmat_filter", "rcn_fmat_filter_grid", "rcn_fmat_filter_grid_device",
-    "rcn_coords_upload", "rcn_coords_clear", "rcn_match_table_filter_device",
+    "rcn_coords_upload", "rcn_coords_upload_batch", "rcn_coords_clear", "rcn_match_table_filter_device",
     "rcn_host_alloc", "rcn_host_free", "rcn_match_compact_begin", "rcn_match_compact_wait",
     "rcn_shard_owned_images", "rcn_shard_pair_count", "rcn_shard_pairs", "rcn_shard_unique_id",
     "rcn_shard_create", "rcn_shard_destroy", "rcn_shard_ctx", "rcn_shard_reserve", "rcn_shard_put_image", "rcn_shard_exchange",
@@ -47,7 +47,8 @@ class MatchStats(C.Structure):
     _fields_ = [("rows_total", C.c_int64), ("rows_reranked", C.c_int64), ("rows_exact_fallback", C.c_int64),
                 ("pair_distances", C.c_int64), ("err_bound_d2", C.c_double),
                 ("used_mfma_path", C.c_int32), ("profiled_calls", C.c_int32),
-                ("coarse_ms", C.c_double), ("rerank_ms", C.c_double), ("unique_ms", C.c_double)]
+                ("coarse_ms", C.c_double), ("rerank_ms", C.c_double), ("unique_ms", C.c_double),
+                ("rows_brute_force", C.c_int64), ("chunks", C.c_int32), ("coarse_launches", C.c_int32)]
 
 
 class ShardStats(C.Structure):
@@ -182,6 +183,8 @@ def load():
         fn.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp]
     L.rcn_coords_upload.restype = C.c_int
     L.rcn_coords_upload.argtypes = [vp, i32, vp, i32]
+    L.rcn_coords_upload_batch.restype = C.c_int
+    L.rcn_coords_upload_batch.argtypes = [vp, i32, i32, vp, vp]
     L.rcn_coords_clear.restype = C.c_int
     L.rcn_coords_clear.argtypes = [vp]
     L.rcn_match_table_filter_device.restype = C.c_int

@@ -101,8 +101,10 @@ int rcn_create(int device_id, rcn_ctx **out)
     if (cpm) ctx->chol_pair_min = std::atoi(cpm);
     const char *cpi = std::getenv("RCN_CHOL_PIPE_MIN");
     if (cpi) ctx->chol_pipe_min = std::atoi(cpi);
-    const char *ch = std::getenv("RCN_MATCH_CHUNKS");
-    ctx->chunks = ch ? std::atoi(ch) : 1;
+    const char *ch = std::getenv("RCN_CHUNK_ROWS");
+    if (ch && std::atoll(ch) > 0) ctx->chunk_rows = std::atoll(ch);
+    const char *mr = std::getenv("RCN_MID_ROWS");
+    if (mr && std::atoll(mr) >= 0) ctx->mid_rows = std::max<long long>(1, std::atoll(mr));
 #endif
     memset(&ctx->last_stats, 0, sizeof(ctx->last_stats));
     *out = ctx;
@@ -125,8 +127,10 @@ void rcn_destroy(rcn_ctx *ctx)
     ctx->fm_csr.release(); ctx->fm_pairs.release();
     for (auto &kv : ctx->coords) kv.second.first.release();
     if (ctx->ev_made)
-        for (auto &row : ctx->ev)
-            for (auto &e : row) (void)hipEventDestroy(e);
+        for (auto &call : ctx->ev_c)
+            for (auto &row : call)
+                for (auto &e : row) (void)hipEventDestroy(e);
+    ctx->mid_ws.release();
     if (ctx->ba_ev_made)
         { for (auto &e : ctx->ba_ev) (void)hipEventDestroy(e); for (auto &e : ctx->ba_tev) (void)hipEventDestroy(e); }
     if (ctx->copy_stream) {

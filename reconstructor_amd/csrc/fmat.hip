@@ -21,6 +21,7 @@ namespace {
 #define FM_NLDS 1024       // points kept in LDS; larger pairs read them from global memory
 #define FM_MAX_ITERS 1000
 #define FM_MAX_ATTEMPTS 10000
+#define FM_FUSED_MAX_PAIRS 1024      // up to this many pairs the whole search of a pair runs in one workgroup of one launch (k_fm_pair)
 
 struct FmatArgs {
     const int32_t *off, *xy1, *xy2;
@@ -351,6 +352,32 @@ __device__ void draw_round(const FmState &st, int pair, int n, const Pts &pts, i
     }
 }
 
+// the pair's points into LDS (when they fit): every sample costs an LDS read, not a trip to L2
+__device__ __forceinline__ Pts load_points(const FmatArgs &a, int o0, int n, float2 *P1, float2 *P2, int t, int nthreads)
+{
+    Pts pts;
+    pts.g1 = a.xy1 + 2 * (size_t)o0; pts.g2 = a.xy2 + 2 * (size_t)o0;
+    pts.l1 = n <= FM_NLDS ? P1 : nullptr; pts.l2 = n <= FM_NLDS ? P2 : nullptr;
+    if (n <= FM_NLDS)
+        for (int i = t; i < n; i += nthreads) {
+            P1[i] = make_float2((float)pts.g1[2 * i], (float)pts.g1[2 * i + 1]);
+            P2[i] = make_float2((float)pts.g2[2 * i], (float)pts.g2[2 * i + 1]);
+        }
+    return pts;
+}
+// the state of a pair before its first round (one lane)
+__device__ __forceinline__ void begin_state(const FmState &st, int pair, int n)
+{
+    st.base[pair] = 0; st.max_good[pair] = 0; st.done[pair] = 0; st.have[pair] = 0; st.fail[pair] = 0; st.drawn[pair] = 0;
+    st.min_med[pair] = DBL_MAX;
+    st.rng[pair] = ~0ull;
+    int ni = FM_MAX_ITERS;
+    if (n < 15) { ni = update_num_iters(0.99, 0.45, 7, FM_MAX_ITERS); if (ni < 3) ni = 3; }
+    if (n == 7) ni = 1;
+    if (n < 7) ni = 0;
+    st.niters[pair] = ni; st.stop[pair] = n < 7 ? 1 : 0;
+}
+
 // one wave per pair
 __global__ __launch_bounds__(64) void k_fm_begin(FmatArgs a, FmState st)
 {
@@ -358,43 +385,21 @@ __global__ __launch_bounds__(64) void k_fm_begin(FmatArgs a, FmState st)
     const int pair = blockIdx.x, lane = threadIdx.x;
     const int o0 = a.off[pair], n = a.off[pair + 1] - o0;
     if (lane == 0) {
-        st.base[pair] = 0; st.max_good[pair] = 0; st.done[pair] = 0; st.have[pair] = 0; st.fail[pair] = 0; st.drawn[pair] = 0;
-        st.min_med[pair] = DBL_MAX;
-        st.rng[pair] = ~0ull;
-        int ni = FM_MAX_ITERS;
-        if (n < 15) { ni = update_num_iters(0.99, 0.45, 7, FM_MAX_ITERS); if (ni < 3) ni = 3; }
-        if (n == 7) ni = 1;
-        if (n < 7) ni = 0;
-        st.niters[pair] = ni; st.stop[pair] = n < 7 ? 1 : 0;
+        begin_state(st, pair, n);
         if (n >= 7) atomicAdd(st.active, 1);
     }
     if (n < 7) return;
     __syncthreads();
-    __shared__ float2 P1[FM_NLDS], P2[FM_NLDS];   // the pair's points: every sample costs an LDS read, not a trip to L2
-    Pts pts;
-    pts.g1 = a.xy1 + 2 * (size_t)o0; pts.g2 = a.xy2 + 2 * (size_t)o0;
-    pts.l1 = n <= FM_NLDS ? P1 : nullptr; pts.l2 = n <= FM_NLDS ? P2 : nullptr;
-    if (n <= FM_NLDS) {
-        for (int i = lane; i < n; i += 64) {
-            P1[i] = make_float2((float)pts.g1[2 * i], (float)pts.g1[2 * i + 1]);
-            P2[i] = make_float2((float)pts.g2[2 * i], (float)pts.g2[2 * i + 1]);
-        }
-        __syncthreads();
-    }
+    __shared__ float2 P1[FM_NLDS], P2[FM_NLDS];
+    const Pts pts = load_points(a, o0, n, P1, P2, lane, 64);
+    __syncthreads();
     draw_round(st, pair, n, pts, lane, sp);
 }
 
-// one lane per hypothesis: FM_B lanes = one pair, two pairs per workgroup
-__global__ __launch_bounds__(64) void k_fm_solve(FmatArgs a, FmState st)
+// one lane per hypothesis (lane: position inside a 64-lane block of LDS columns, h: hypothesis of the pair)
+__device__ __forceinline__ void solve_body(const FmatArgs &a, const FmState &st, int pair, int h, int lane, double *sA)
 {
 #pragma clang fp contract(off)
-    __shared__ double sA[63 * 64];
-    if (*st.active == 0) return;
-    const int lane = threadIdx.x, h = lane & (FM_B - 1);
-    const int pair = blockIdx.x * (64 / FM_B) + lane / FM_B;
-    const bool live = pair < a.n_pairs && !st.stop[pair];
-    const int drawn = live ? st.drawn[pair] : 0;
-    if (h >= drawn) return;
     const int o0 = a.off[pair];
     const int32_t *g1 = a.xy1 + 2 * (size_t)o0, *g2 = a.xy2 + 2 * (size_t)o0;
     const int *ix = st.idx + ((size_t)pair * FM_B + h) * 7;
@@ -407,28 +412,24 @@ __global__ __launch_bounds__(64) void k_fm_solve(FmatArgs a, FmState st)
     }
     st.nm[(size_t)pair * FM_B + h] = run_7point(s1, s2, sA, lane, st.F + ((size_t)pair * FM_B + h) * 27);
 }
+// FM_B lanes = one pair, two pairs per workgroup
+__global__ __launch_bounds__(64) void k_fm_solve(FmatArgs a, FmState st)
+{
+    __shared__ double sA[63 * 64];
+    if (*st.active == 0) return;
+    const int lane = threadIdx.x, h = lane & (FM_B - 1);
+    const int pair = blockIdx.x * (64 / FM_B) + lane / FM_B;
+    const bool live = pair < a.n_pairs && !st.stop[pair];
+    const int drawn = live ? st.drawn[pair] : 0;
+    if (h >= drawn) return;
+    solve_body(a, st, pair, h, lane, sA);
+}
 
-__global__ __launch_bounds__(256) void k_fm_score(FmatArgs a, FmState st)
+// one workgroup of 256 threads per pair; sCnt: 3 FM_B ints of LDS (RANSAC's bound of the round)
+__device__ __forceinline__ void score_body(const FmState &st, int pair, int n, int drawn, const Pts &pts, int t, int *sCnt)
 {
 #pragma clang fp contract(off)
-    __shared__ float2 P1[FM_NLDS], P2[FM_NLDS];
-    if (*st.active == 0) return;
-    const int t = threadIdx.x, lane = t & 63, w = t >> 6, pair = blockIdx.x;
-    if (st.stop[pair]) return;
-    const int drawn = st.drawn[pair];
-    if (drawn == 0) return;
-    const int o0 = a.off[pair], n = a.off[pair + 1] - o0;
-    if (n == 7) return;
-    Pts pts;
-    pts.g1 = a.xy1 + 2 * (size_t)o0; pts.g2 = a.xy2 + 2 * (size_t)o0;
-    pts.l1 = n <= FM_NLDS ? P1 : nullptr; pts.l2 = n <= FM_NLDS ? P2 : nullptr;
-    if (n <= FM_NLDS) {
-        for (int i = t; i < n; i += 256) {
-            P1[i] = make_float2((float)pts.g1[2 * i], (float)pts.g1[2 * i + 1]);
-            P2[i] = make_float2((float)pts.g2[2 * i], (float)pts.g2[2 * i + 1]);
-        }
-        __syncthreads();
-    }
+    const int lane = t & 63, w = t >> 6;
     const double *Fp = st.F + (size_t)pair * FM_B * 27;
     const int *nm = st.nm + (size_t)pair * FM_B;
     if (n >= 15) {
@@ -439,7 +440,6 @@ __global__ __launch_bounds__(256) void k_fm_score(FmatArgs a, FmState st)
         // ... and the same holds for the counts of EARLIER matrices of this round: whichever of them
         // are finished when this matrix starts (sCnt, written by the four waves as they go) raise the
         // bound.  Later matrices must not: the reference may stop before it reaches them.
-        __shared__ int sCnt[3 * FM_B];
         for (int i = t; i < 3 * FM_B; i += 256) sCnt[i] = -1;
         __syncthreads();
         const int mg = st.max_good[pair], bound0 = mg > 6 ? mg : 6;
@@ -489,12 +489,60 @@ __global__ __launch_bounds__(256) void k_fm_score(FmatArgs a, FmState st)
         }
     }
 }
+__global__ __launch_bounds__(256) void k_fm_score(FmatArgs a, FmState st)
+{
+    __shared__ float2 P1[FM_NLDS], P2[FM_NLDS];
+    __shared__ int sCnt[3 * FM_B];
+    if (*st.active == 0) return;
+    const int t = threadIdx.x, pair = blockIdx.x;
+    if (st.stop[pair]) return;
+    const int drawn = st.drawn[pair];
+    if (drawn == 0) return;
+    const int o0 = a.off[pair], n = a.off[pair + 1] - o0;
+    if (n == 7) return;
+    const Pts pts = load_points(a, o0, n, P1, P2, t, 256);
+    __syncthreads();
+    score_body(st, pair, n, drawn, pts, t, sCnt);
+}
 
-// one wave per pair: lane 0 replays the reference's sequential accept / shrink logic over the finished
-// round, then the wave draws the next round's samples
-__global__ __launch_bounds__(64) void k_fm_accept(FmatArgs a, FmState st)
+// the reference's sequential accept / shrink-the-budget logic over a finished round of one pair (ONE lane); returns "stop"
+__device__ __forceinline__ bool accept_round(const FmState &st, int pair, int n)
 {
 #pragma clang fp contract(off)
+    const bool ransac = n >= 15;
+    const int drawn = st.drawn[pair], base = st.base[pair];
+    int niters = st.niters[pair], max_good = st.max_good[pair], done = st.done[pair];
+    bool have_best = st.have[pair] != 0;
+    double min_median = st.min_med[pair];
+    bool stop = st.fail[pair] != 0 || drawn == 0;
+    const int *nm = st.nm + (size_t)pair * FM_B, *gd = st.good + (size_t)pair * 3 * FM_B;
+    const double *md = st.med + (size_t)pair * 3 * FM_B, *Fp = st.F + (size_t)pair * FM_B * 27;
+    for (int h = 0; h < drawn; ++h) {
+        if (base + h >= niters) { stop = true; break; }
+        done = base + h + 1;
+        for (int k = 0; k < nm[h]; ++k) {
+            const int m = 3 * h + k;
+            bool take = false;
+            if (n == 7) { take = !have_best; max_good = 7; }
+            else if (ransac) {
+                const int good = gd[m];
+                if (good > (max_good > 6 ? max_good : 6)) {
+                    take = true; max_good = good;
+                    niters = update_num_iters(0.99, (double)(n - good) / n, 7, niters);
+                }
+            } else if (md[m] < min_median) { take = true; min_median = md[m]; }
+            if (take) { have_best = true; for (int i = 0; i < 9; ++i) st.bestF[9 * (size_t)pair + i] = Fp[27 * h + 9 * k + i]; }
+        }
+    }
+    if (base + drawn >= niters) stop = true;
+    st.niters[pair] = niters; st.max_good[pair] = max_good; st.done[pair] = done; st.have[pair] = have_best ? 1 : 0;
+    st.min_med[pair] = min_median; st.base[pair] = base + FM_B;
+    if (stop) { st.stop[pair] = 1; st.drawn[pair] = 0; }
+    return stop;
+}
+// one wave per pair: lane 0 replays the accept logic, then the wave draws the next round's samples
+__global__ __launch_bounds__(64) void k_fm_accept(FmatArgs a, FmState st)
+{
     __shared__ float sp[28];
     __shared__ int sStop;
     if (*st.active == 0) return;
@@ -502,59 +550,23 @@ __global__ __launch_bounds__(64) void k_fm_accept(FmatArgs a, FmState st)
     if (st.stop[pair]) return;
     const int o0 = a.off[pair], n = a.off[pair + 1] - o0;
     if (lane == 0) {
-        const bool ransac = n >= 15;
-        const int drawn = st.drawn[pair], base = st.base[pair];
-        int niters = st.niters[pair], max_good = st.max_good[pair], done = st.done[pair];
-        bool have_best = st.have[pair] != 0;
-        double min_median = st.min_med[pair];
-        bool stop = st.fail[pair] != 0 || drawn == 0;
-        const int *nm = st.nm + (size_t)pair * FM_B, *gd = st.good + (size_t)pair * 3 * FM_B;
-        const double *md = st.med + (size_t)pair * 3 * FM_B, *Fp = st.F + (size_t)pair * FM_B * 27;
-        for (int h = 0; h < drawn; ++h) {
-            if (base + h >= niters) { stop = true; break; }
-            done = base + h + 1;
-            for (int k = 0; k < nm[h]; ++k) {
-                const int m = 3 * h + k;
-                bool take = false;
-                if (n == 7) { take = !have_best; max_good = 7; }
-                else if (ransac) {
-                    const int good = gd[m];
-                    if (good > (max_good > 6 ? max_good : 6)) {
-                        take = true; max_good = good;
-                        niters = update_num_iters(0.99, (double)(n - good) / n, 7, niters);
-                    }
-                } else if (md[m] < min_median) { take = true; min_median = md[m]; }
-                if (take) { have_best = true; for (int i = 0; i < 9; ++i) st.bestF[9 * (size_t)pair + i] = Fp[27 * h + 9 * k + i]; }
-            }
-        }
-        if (base + drawn >= niters) stop = true;
-        st.niters[pair] = niters; st.max_good[pair] = max_good; st.done[pair] = done; st.have[pair] = have_best ? 1 : 0;
-        st.min_med[pair] = min_median; st.base[pair] = base + FM_B;
-        if (stop) { st.stop[pair] = 1; st.drawn[pair] = 0; atomicSub(st.active, 1); }
+        const bool stop = accept_round(st, pair, n);
+        if (stop) atomicSub(st.active, 1);
         sStop = stop;
     }
     __syncthreads();
     if (sStop) return;
-    __shared__ float2 P1[FM_NLDS], P2[FM_NLDS];   // the pair's points: every sample costs an LDS read, not a trip to L2
-    Pts pts;
-    pts.g1 = a.xy1 + 2 * (size_t)o0; pts.g2 = a.xy2 + 2 * (size_t)o0;
-    pts.l1 = n <= FM_NLDS ? P1 : nullptr; pts.l2 = n <= FM_NLDS ? P2 : nullptr;
-    if (n <= FM_NLDS) {
-        for (int i = lane; i < n; i += 64) {
-            P1[i] = make_float2((float)pts.g1[2 * i], (float)pts.g1[2 * i + 1]);
-            P2[i] = make_float2((float)pts.g2[2 * i], (float)pts.g2[2 * i + 1]);
-        }
-        __syncthreads();
-    }
+    __shared__ float2 P1[FM_NLDS], P2[FM_NLDS];
+    const Pts pts = load_points(a, o0, n, P1, P2, lane, 64);
+    __syncthreads();
     draw_round(st, pair, n, pts, lane, sp);
 }
 
-__global__ __launch_bounds__(256) void k_fm_finish(FmatArgs a, FmState st)
+// one workgroup of 256 threads per pair: mask of the winning matrix, verdict, iterations
+__device__ __forceinline__ void finish_body(const FmatArgs &a, const FmState &st, int pair, int o0, int n, int t, int *sGood)
 {
 #pragma clang fp contract(off)
-    __shared__ int sGood[4];
-    const int t = threadIdx.x, lane = t & 63, w = t >> 6, pair = blockIdx.x;
-    const int o0 = a.off[pair], n = a.off[pair + 1] - o0;
+    const int lane = t & 63, w = t >> 6;
     uint8_t *mask = a.mask + o0;
     if (n < 7) {   // not filtered by the reference (SequentialReconstructor.cpp:237)
         for (int i = t; i < n; i += 256) mask[i] = 1;
@@ -591,6 +603,51 @@ __global__ __launch_bounds__(256) void k_fm_finish(FmatArgs a, FmState st)
     if (verdict < 0) for (int i = t; i < n; i += 256) mask[i] = 0;
     if (a.F && t < 9) a.F[9 * (size_t)pair + t] = verdict < 0 ? 0.0 : st.bestF[9 * (size_t)pair + t];
 }
+__global__ __launch_bounds__(256) void k_fm_finish(FmatArgs a, FmState st)
+{
+    __shared__ int sGood[4];
+    const int pair = blockIdx.x;
+    const int o0 = a.off[pair], n = a.off[pair + 1] - o0;
+    finish_body(a, st, pair, o0, n, threadIdx.x, sGood);
+}
+
+// The whole search of ONE pair in ONE workgroup (256 threads): begin, then rounds of solve (FM_B lanes) -> score (all four
+// waves) -> accept + next draw (wave 0) until the pair stops, then finish -- the same device functions as the
+// round-synchronous kernels above, phase by phase behind workgroup barriers, so the masks are the same bits.  One launch
+// instead of 98: for the grids of the reference's own size (300 pairs: every launch of the round-synchronous form is
+// shorter than its launch overhead) this is what the filter costs; large grids keep the round-synchronous form, whose
+// solve phase packs two pairs per wave instead of idling seven of eight lanes (fmat_launch chooses).
+__global__ __launch_bounds__(256) void k_fm_pair(FmatArgs a, FmState st)
+{
+    __shared__ double sA[63 * 64];
+    __shared__ float2 P1[FM_NLDS], P2[FM_NLDS];
+    __shared__ float sp[28];
+    __shared__ int sCnt[3 * FM_B];
+    __shared__ int sGood[4];
+    __shared__ int sStop;
+    const int pair = blockIdx.x, t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int o0 = a.off[pair], n = a.off[pair + 1] - o0;
+    if (t == 0) begin_state(st, pair, n);
+    Pts pts = load_points(a, o0, n, P1, P2, t, 256);
+    __syncthreads();
+    if (n >= 7) {
+        if (w == 0) draw_round(st, pair, n, pts, lane, sp);
+        for (int round = 0; round < (FM_MAX_ITERS + FM_B - 1) / FM_B; ++round) {
+            __syncthreads();                                   // the draw's indices (global, same CU) are visible to the workgroup
+            const int drawn = st.drawn[pair];
+            if (t < drawn) solve_body(a, st, pair, t, t, sA);
+            __syncthreads();
+            if (drawn > 0 && n != 7) score_body(st, pair, n, drawn, pts, t, sCnt);
+            __syncthreads();
+            if (t == 0) sStop = accept_round(st, pair, n) ? 1 : 0;
+            __syncthreads();
+            if (sStop) break;
+            if (w == 0) draw_round(st, pair, n, pts, lane, sp);
+        }
+        __syncthreads();
+    }
+    finish_body(a, st, pair, o0, n, t, sGood);
+}
 
 }  // namespace
 
@@ -620,8 +677,14 @@ static int fmat_launch(rcn_ctx *ctx, int32_t n_pairs, const int32_t *off, const 
     st.good = (int *)take(4 * P * 3 * FM_B); st.med = (double *)take(8 * P * 3 * FM_B);
     st.active = (int *)take(4);
     hipStream_t s = ctx->stream;
-    RCN_HIP(hipMemsetAsync(st.active, 0, 4, s));
     RCN_HIP(hipMemsetAsync(st.bestF, 0, 72 * P, s));
+    if (n_pairs <= FM_FUSED_MAX_PAIRS) {
+        // few pairs: one launch, a workgroup walks its pair through every round (k_fm_pair)
+        k_fm_pair<<<n_pairs, 256, 0, s>>>(a, st);
+        RCN_HIP(hipGetLastError());
+        return RCN_OK;
+    }
+    RCN_HIP(hipMemsetAsync(st.active, 0, 4, s));
     k_fm_begin<<<n_pairs, 64, 0, s>>>(a, st);
     for (int round = 0; round < (FM_MAX_ITERS + FM_B - 1) / FM_B; ++round) {
         k_fm_solve<<<(n_pairs + 64 / FM_B - 1) / (64 / FM_B), 64, 0, s>>>(a, st);
@@ -745,6 +808,25 @@ extern "C" int rcn_coords_upload(rcn_ctx *ctx, int32_t img_id, const int32_t *xy
         RCN_HIP(hipStreamSynchronize(ctx->stream));        // the host rows are borrowed
     }
     e.second = K;
+    return RCN_OK;
+}
+
+// n images at once: one asynchronous copy per image, ONE host synchronisation for the batch (rcn_desc_upload_batch's counterpart)
+extern "C" int rcn_coords_upload_batch(rcn_ctx *ctx, int32_t first_img_id, int32_t n_images, const int32_t *const *xy_host, const int32_t *K)
+{
+    if (!ctx) return RCN_ERR_ARG;
+    if (n_images < 0 || (n_images > 0 && (!xy_host || !K))) { ctx->set_error("rcn_coords_upload_batch: bad argument"); return RCN_ERR_ARG; }
+    for (int i = 0; i < n_images; ++i)
+        if (K[i] < 0 || (K[i] > 0 && !xy_host[i])) { ctx->set_error("rcn_coords_upload_batch: bad row count or NULL coordinates"); return RCN_ERR_ARG; }
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    RCN_HIP(hipSetDevice(ctx->device));
+    for (int i = 0; i < n_images; ++i) {
+        auto &e = ctx->coords[first_img_id + i];
+        RCN_HIP(e.first.reserve(std::max<size_t>(8 * (size_t)K[i], 8)));
+        if (K[i] > 0) RCN_HIP(hipMemcpyAsync(e.first.p, xy_host[i], 8 * (size_t)K[i], hipMemcpyHostToDevice, ctx->stream));
+        e.second = K[i];
+    }
+    RCN_HIP(hipStreamSynchronize(ctx->stream));        // the host rows are borrowed
     return RCN_OK;
 }
 

@@ -30,7 +30,7 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #define RCN_TBL_BYTES ((RCN_GROUP * 24 + 127) / 128 * 128)   // LDS table of the group's train-image records
 #define RCN_NBUF 4          // LDS ring depth (train tiles)
 #define RCN_PD 2            // prefetch distance, tiles
-#define RCN_CHUNKS 4        // pair-list chunks: coarse(c+1) overlaps re-rank(c)
+#define RCN_CHUNK_ROWS (1ll << 27)   // query-row slots of the candidate table per pipeline chunk (1 GiB of candidates; the row lists are at most as long)
 #define RCN_BT 64           // train rows per LDS tile (k_coarse_w4; k_coarse_top2: coarse_bt)
 #define RCN_PAD_HN 1.0e30f  // half-norm of padded train rows: never a candidate
 
@@ -959,13 +959,13 @@ __global__ __launch_bounds__(256) void k_exact_rows(const ImgDev *__restrict__ i
                                                      const unsigned long long *__restrict__ list,
                                                      const unsigned *__restrict__ count, int D,
                                                      float ratio, int32_t *__restrict__ out,
-                                                     int64_t out_stride)
+                                                     int64_t out_stride, unsigned skip = 0)
 {
     __shared__ double sb[4][2];
     __shared__ int si[4][2];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const unsigned n = *count;
-    for (unsigned it = blockIdx.x; it < n; it += gridDim.x) {
+    for (unsigned it = skip + blockIdx.x; it < n; it += gridDim.x) {
         const unsigned long long e = list[it];
         const int pair = (int)(e >> 32), q = (int)(e & 0xFFFFFFFFu);
         const ImgDev qi = imgs[pairs[2 * pair]];
@@ -1005,7 +1005,7 @@ __global__ __launch_bounds__(64 * EX_WAVES) void k_exact_rows_lds(const ImgDev *
                                                          const unsigned long long *__restrict__ list,
                                                          const unsigned *__restrict__ count, int D,
                                                          float ratio, int32_t *__restrict__ out,
-                                                         int64_t out_stride)
+                                                         int64_t out_stride, unsigned skip = 0)
 {
     __shared__ __attribute__((aligned(16))) float tile[EX_WAVES][65 * EX_LD];
     __shared__ double sb[EX_WAVES][2];
@@ -1014,7 +1014,7 @@ __global__ __launch_bounds__(64 * EX_WAVES) void k_exact_rows_lds(const ImgDev *
     const unsigned n = *count;
     const int nchunk = (D + 31) / 32;
     float *tw = tile[w];
-    for (unsigned it = blockIdx.x; it < n; it += gridDim.x) {
+    for (unsigned it = skip + blockIdx.x; it < n; it += gridDim.x) {      // skip: the leading entries went through the middle tier
         const unsigned long long e = list[it];
         const int pair = (int)(e >> 32), q = (int)(e & 0xFFFFFFFFu);
         const ImgDev qi = imgs[pairs[2 * pair]];
@@ -1072,6 +1072,273 @@ __global__ __launch_bounds__(64 * EX_WAVES) void k_exact_rows_lds(const ImgDev *
             for (int k = 1; k < EX_WAVES; ++k) merge_top2(b0, i0, b1, i1, sb[k][0], si[k][0], sb[k][1], si[k][1]);
             out[(size_t)pair * out_stride + q] = ratio_pass(b0, b1, ratio) ? i0 : -1;
         }
+    }
+}
+
+// ---- middle tier (round 4): the rows K2 could not certify, between "one candidate" and "every train row in fp64" -------
+// An uncertified row needs its EXACT two nearest neighbours.  Round 3 sent it straight to K2b: one workgroup per row, all
+// K2 train rows through the fp64 chain -- and, what costs more, all K2 x D x 4 bytes of the train image read for ONE query
+// (cfg 3: 114 476 rows x 4 MB = 480 GB per step through L2 / Infinity Cache: 68.8 ms).  Here the rows are binned by TRAIN
+// image, so that sixteen of them share one sweep over that image, and the sweep runs in fp32 (sub + fma per element, eight
+// times the fp64 chain's rate).  fp32 values cannot decide anything, but they can EXCLUDE: with
+//     g = (D + 8) 2^-23   (relative error of a D-term fp32 sum of squares of fp32 differences, with room)
+// every row whose exact distance is <= U has fp32 value <= U (1 + g) + tiny, so the rows with value <= thr = U (1 + g) + tiny
+// are a superset of the rows within U.  U = an upper bound of the exact SECOND-nearest distance:
+//   * from the coarse pass when the row has one (the second candidate's accumulator + quantum + eps, as k_filter's ub1):
+//     known before the sweep -- one sweep, candidates emitted on the way;
+//   * otherwise (BIG query rows, train images with fewer than two ordinary rows, grids without a coarse pass): the second
+//     smallest fp32 value of a first sweep, inflated by the same error model -- two sweeps.
+// The candidates (a handful per row; the list holds RCN_MIDCAP) then go through the canonical fp64 chain and the
+// (value, index)-ordered top-2 of THOSE is the top-2 of all rows: same bits as K2b.  A list that overflows, and whatever
+// exceeds the tier's row budget, still goes to K2b.
+#define RCN_MIDCAP 32          // candidates kept per row
+#define RCN_MIDQ 16            // query rows per sweep of a train image
+#define RCN_MIDROWS (1 << 21)  // rows per pipeline chunk the tier takes (the rest: K2b)
+struct MidArgs {
+    const ImgDev *imgs;
+    const int32_t *pairs;
+    const uint2 *cand;                     // coarse candidates (NULL / all_to_fallback: none)
+    const unsigned long long *fb_list;     // (pair << 32 | query) in discovery order
+    const unsigned *fb_count;
+    unsigned long long *sorted;            // the same entries binned by train image
+    float *thr;                            // per sorted row: fp32 threshold, +infinity = not known before the sweep
+    unsigned *ccount;                      // per sorted row: candidates found
+    int32_t *clist;                        // [rows][RCN_MIDCAP] train rows
+    unsigned *hist, *offs, *cursor;        // per image slot
+    int4 *items;                           // (train slot, first sorted row, rows, 0)
+    unsigned *n_items;
+    unsigned long long *fb2_list;          // overflowed rows -> K2b
+    unsigned *fb2_count;
+    int32_t *out;
+    int64_t out_stride;
+    const ScaleDev *sc;
+    int32_t n_slots, kq_stride, D, all_to_fallback;
+    uint32_t idx_mask, midrows;            // midrows: rows per pipeline chunk the tier takes
+    float ratio;
+};
+__device__ __forceinline__ unsigned mid_rows(const MidArgs &a) { const unsigned n = *a.fb_count; return n < a.midrows ? n : a.midrows; }
+
+__global__ __launch_bounds__(256) void k_mid_hist(MidArgs a)
+{
+    const unsigned n = mid_rows(a);
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int pair = (int)(a.fb_list[i] >> 32);
+        atomicAdd(a.hist + a.pairs[2 * pair + 1], 1u);
+    }
+}
+// one workgroup: exclusive scan of the bins, the work items (a train image x up to RCN_MIDQ rows), cursors and bins reset
+__global__ __launch_bounds__(1024) void k_mid_bins(MidArgs a)
+{
+    __shared__ unsigned s1[1024], s2[1024];
+    const int t = threadIdx.x, per = (a.n_slots + 1023) / 1024;
+    const int lo = min(a.n_slots, t * per), hi = min(a.n_slots, lo + per);
+    unsigned rows = 0, its = 0;
+    for (int i = lo; i < hi; ++i) { const unsigned h = a.hist[i]; rows += h; its += (h + RCN_MIDQ - 1) / RCN_MIDQ; }
+    s1[t] = rows; s2[t] = its;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+        const unsigned v1 = t >= o ? s1[t - o] : 0u, v2 = t >= o ? s2[t - o] : 0u;
+        __syncthreads();
+        s1[t] += v1; s2[t] += v2;
+        __syncthreads();
+    }
+    unsigned r = s1[t] - rows, k = s2[t] - its;
+    for (int i = lo; i < hi; ++i) {
+        const unsigned h = a.hist[i];
+        a.offs[i] = r; a.cursor[i] = 0u; a.hist[i] = 0u;
+        for (unsigned f = 0; f < h; f += RCN_MIDQ) a.items[k++] = make_int4(i, (int)(r + f), (int)min((unsigned)RCN_MIDQ, h - f), 0);
+        r += h;
+    }
+    if (t == 1023) *a.n_items = s2[1023];
+}
+__global__ __launch_bounds__(256) void k_mid_scatter(MidArgs a)
+{
+    const unsigned n = mid_rows(a);
+    const ScaleDev S = *a.sc;
+    const double g = (double)(a.D + 8) * 1.1920928955078125e-7;
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const unsigned long long e = a.fb_list[i];
+        const int pair = (int)(e >> 32), q = (int)(e & 0xFFFFFFFFu);
+        const int ts = a.pairs[2 * pair + 1];
+        const unsigned pos = a.offs[ts] + atomicAdd(a.cursor + ts, 1u);
+        float thr = INFINITY;
+        if (!a.all_to_fallback) {
+            const ImgDev qi = a.imgs[a.pairs[2 * pair]];
+            const double nq2 = qi.nrm2[q];
+            const uint2 c = a.cand[(size_t)pair * a.kq_stride + q];
+            if (nq2 < S.thr2 && __uint_as_float(c.y & ~a.idx_mask) < 1.0e29f) {
+                // two ordinary rows (the coarse candidates) are within ub1 of the query: so is the exact second neighbour
+                const double hi = (double)__uint_as_float((c.y & ~a.idx_mask) + a.idx_mask + 1u);
+                const double ub1 = acc_to_d2(S, nq2, hi + coarse_eps(S, nq2)) + S.rel_slack * (nq2 + S.n_max * S.n_max);
+                if (ub1 >= 0.0) {
+                    const double tv = (ub1 * (1.0 + g) + 1.0e-30) * (1.0 + 1.0e-6);
+                    thr = tv < 3.0e38 ? (float)tv : INFINITY;      // a threshold that does not fit fp32 decides nothing: two sweeps
+                }
+            }
+        }
+        a.sorted[pos] = e;
+        a.thr[pos] = thr;
+        a.ccount[pos] = 0u;
+    }
+}
+// One workgroup (256 threads) per work item.  A sweep: the train image in tiles of 256 rows (one per thread), every tile in
+// 32-float chunks through LDS with whole 128-byte global segments, the item's query rows beside them; thread t accumulates
+// sum (x - y)^2 of ITS train row against each query in fp32.  EMIT: rows under the query's threshold join its candidate list;
+// otherwise the thread keeps the two smallest values it saw per query.
+#define MID_LD 36
+template <bool EMIT>
+__device__ __forceinline__ void mid_sweep(const MidArgs &a, const ImgDev &ti, const float *const *qptr, int nq, int first, const float *thr,
+                                          float *tt, float *tq, float (&m1)[RCN_MIDQ], float (&m2)[RCN_MIDQ])
+{
+    const int t = threadIdx.x, D = a.D, nchunk = (D + 31) / 32;
+    for (int base = 0; base < ti.K; base += 256) {
+        float acc[RCN_MIDQ];
+#pragma unroll
+        for (int q = 0; q < RCN_MIDQ; ++q) acc[q] = 0.f;
+        for (int ch = 0; ch < nchunk; ++ch) {
+            const int col = ch * 32 + (t & 7) * 4;
+            float4 v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int r = base + i * 32 + (t >> 3);
+                v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (col < D && r < ti.K) v[i] = *reinterpret_cast<const float4 *>(ti.f32 + (size_t)r * D + col);
+            }
+            float4 vq = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (t < 8 * RCN_MIDQ && (t >> 3) < nq && col < D) vq = *reinterpret_cast<const float4 *>(qptr[t >> 3] + col);
+            __syncthreads();                                    // the previous chunk's LDS reads are done
+#pragma unroll
+            for (int i = 0; i < 8; ++i) *reinterpret_cast<float4 *>(tt + (i * 32 + (t >> 3)) * MID_LD + (t & 7) * 4) = v[i];
+            if (t < 8 * RCN_MIDQ) *reinterpret_cast<float4 *>(tq + (t >> 3) * MID_LD + (t & 7) * 4) = vq;
+            __syncthreads();
+            float y[32];
+#pragma unroll
+            for (int k4 = 0; k4 < 8; ++k4) {
+                const float4 w4 = *reinterpret_cast<const float4 *>(tt + t * MID_LD + 4 * k4);
+                y[4 * k4] = w4.x; y[4 * k4 + 1] = w4.y; y[4 * k4 + 2] = w4.z; y[4 * k4 + 3] = w4.w;
+            }
+#pragma unroll
+            for (int q = 0; q < RCN_MIDQ; ++q) {
+                if (q >= nq) break;                               // nq is uniform over the workgroup
+                float s = acc[q];
+#pragma unroll
+                for (int k4 = 0; k4 < 8; ++k4) {
+                    const float4 x = *reinterpret_cast<const float4 *>(tq + q * MID_LD + 4 * k4);      // one address for the whole wave: a broadcast
+                    float d;
+                    d = x.x - y[4 * k4]; s = fmaf(d, d, s);
+                    d = x.y - y[4 * k4 + 1]; s = fmaf(d, d, s);
+                    d = x.z - y[4 * k4 + 2]; s = fmaf(d, d, s);
+                    d = x.w - y[4 * k4 + 3]; s = fmaf(d, d, s);
+                }
+                acc[q] = s;
+            }
+        }
+        const int j = base + t;
+        if (j < ti.K) {
+#pragma unroll
+            for (int q = 0; q < RCN_MIDQ; ++q) {
+                if (q >= nq) break;
+                const float v = acc[q];
+                if (EMIT) {
+                    if (v <= thr[q]) {
+                        const unsigned pos = atomicAdd(a.ccount + first + q, 1u);
+                        if (pos < (unsigned)RCN_MIDCAP) a.clist[(size_t)(first + q) * RCN_MIDCAP + pos] = j;
+                    }
+                } else if (v < m1[q]) { m2[q] = m1[q]; m1[q] = v; }
+                else if (v < m2[q]) m2[q] = v;
+            }
+        }
+    }
+}
+__global__ __launch_bounds__(256) void k_mid_eval(MidArgs a)
+{
+    __shared__ __attribute__((aligned(16))) float tt[256 * MID_LD];
+    __shared__ __attribute__((aligned(16))) float tq[RCN_MIDQ * MID_LD];
+    __shared__ const float *qptr[RCN_MIDQ];
+    __shared__ float thr[RCN_MIDQ];
+    __shared__ float red[4][RCN_MIDQ][2];
+    __shared__ int s_need2;
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const unsigned n_items = *a.n_items;
+    for (unsigned it = blockIdx.x; it < n_items; it += gridDim.x) {
+        const int4 item = a.items[it];
+        const int first = item.y, nq = item.z;
+        const ImgDev ti = a.imgs[item.x];
+        __syncthreads();                                        // the previous item's readers of qptr / thr are done
+        if (t == 0) s_need2 = 0;
+        __syncthreads();
+        if (t < nq) {
+            const unsigned long long e = a.sorted[first + t];
+            const int pair = (int)(e >> 32), q = (int)(e & 0xFFFFFFFFu);
+            qptr[t] = a.imgs[a.pairs[2 * pair]].f32 + (size_t)q * a.D;
+            const float th = a.thr[first + t];
+            thr[t] = th;
+            if (!(th < INFINITY)) s_need2 = 1;
+        }
+        __syncthreads();
+        float m1[RCN_MIDQ], m2[RCN_MIDQ];
+        if (s_need2) {
+            // no bound on the second neighbour before the sweep: the second smallest fp32 value is one after it
+#pragma unroll
+            for (int q = 0; q < RCN_MIDQ; ++q) { m1[q] = INFINITY; m2[q] = INFINITY; }
+            mid_sweep<false>(a, ti, qptr, nq, first, thr, tt, tq, m1, m2);
+#pragma unroll
+            for (int q = 0; q < RCN_MIDQ; ++q) {
+                float b1 = m1[q], b2 = m2[q];
+                for (int o = 32; o; o >>= 1) {
+                    const float c1 = __shfl_xor(b1, o), c2 = __shfl_xor(b2, o);
+                    const float lo = fminf(b1, c1), hi = fmaxf(b1, c1);
+                    b2 = fminf(hi, fminf(b2, c2)); b1 = lo;
+                }
+                if (lane == 0) { red[w][q][0] = b1; red[w][q][1] = b2; }
+            }
+            __syncthreads();
+            if (t < nq) {
+                float b1 = red[0][t][0], b2 = red[0][t][1];
+                for (int k = 1; k < 4; ++k) {
+                    const float c1 = red[k][t][0], c2 = red[k][t][1];
+                    const float lo = fminf(b1, c1), hi = fmaxf(b1, c1);
+                    b2 = fminf(hi, fminf(b2, c2)); b1 = lo;
+                }
+                // exact second neighbour <= (b2 + tiny) / (1 - g); rows within that have fp32 value <= b2 (1 + 3 g) + tiny
+                const double g = (double)(a.D + 8) * 1.1920928955078125e-7;
+                const double tv = ((double)b2 * (1.0 + 3.0 * g) + 3.0e-30) * (1.0 + 1.0e-6);
+                const float mine = tv < 3.0e38 ? (float)tv : INFINITY;
+                thr[t] = fminf(thr[t], mine);                   // a bound known before the sweep stays if it is the tighter one
+            }
+            __syncthreads();
+        }
+        mid_sweep<true>(a, ti, qptr, nq, first, thr, tt, tq, m1, m2);
+    }
+}
+// one wave per row of the tier: the canonical fp64 chain of its candidates, (value, index)-ordered top-2, ratio test
+__global__ __launch_bounds__(256) void k_mid_exact(MidArgs a)
+{
+    const unsigned n = mid_rows(a);
+    const int lane = threadIdx.x & 63;
+    for (unsigned r = blockIdx.x * 4 + (threadIdx.x >> 6); r < n; r += gridDim.x * 4) {
+        const unsigned long long e = a.sorted[r];
+        const int pair = (int)(e >> 32), q = (int)(e & 0xFFFFFFFFu);
+        const unsigned cnt = a.ccount[r];
+        if (cnt > (unsigned)RCN_MIDCAP) {                       // more rows under the threshold than the list holds: every train row, K2b
+            if (lane == 0) a.fb2_list[atomicAdd(a.fb2_count, 1u)] = e;
+            continue;
+        }
+        const ImgDev qi = a.imgs[a.pairs[2 * pair]];
+        const ImgDev ti = a.imgs[a.pairs[2 * pair + 1]];
+        double b0 = INFINITY, b1 = INFINITY;
+        int i0 = 0x7FFFFFFF, i1 = 0x7FFFFFFF;
+        if (lane < (int)cnt) {
+            i0 = a.clist[(size_t)r * RCN_MIDCAP + lane];
+            b0 = exact_d2<true>(qi.f32 + (size_t)q * a.D, ti.f32 + (size_t)i0 * a.D, a.D);
+            if (!(b0 < INFINITY)) { b0 = INFINITY; i0 = 0x7FFFFFFF; }      // K2b never selects a row whose distance is not below +infinity
+        }
+        for (int o = 32; o; o >>= 1) {
+            const double c0 = __shfl_xor(b0, o), c1 = __shfl_xor(b1, o);
+            const int j0 = __shfl_xor(i0, o), j1 = __shfl_xor(i1, o);
+            merge_top2(b0, i0, b1, i1, c0, j0, c1, j1);
+        }
+        if (lane == 0) a.out[(size_t)pair * a.out_stride + q] = ratio_pass(b0, b1, a.ratio) ? i0 : -1;
     }
 }
 
@@ -1141,6 +1408,16 @@ __global__ __launch_bounds__(256) void k_unique_pair(const ImgDev *__restrict__ 
     if ((t & 63) == 0) wsum[t >> 6] = kept;
     __syncthreads();
     if (t == 0) counts[pair] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+// per pipeline chunk: the chunk's counts into the totals of the call.  c[0] rows past the re-rank, c[1] survivors, c[2] rows the
+// middle tier passed on; c[4..6]: fallback rows, re-ranked rows, rows that went through K2b
+__global__ void k_stats_acc(unsigned *c, int mid, unsigned midrows)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    c[4] += c[0];
+    c[5] += c[1];
+    c[6] += mid ? c[2] + (c[0] > midrows ? c[0] - midrows : 0u) : c[0];
 }
 
 // =========================================================================================
@@ -1430,9 +1707,27 @@ static int upload_batch_host(rcn_ctx *ctx, int32_t first_id, int32_t n, const fl
         if (hipMalloc(&ksd, (size_t)n * sizeof(int32_t)) != hipSuccess) { (void)hipFree(blk); ctx->set_error("rcn_desc_upload_batch: out of device memory"); return RCN_ERR_HIP; }
     }
     auto fail = [&](int rc) { if (fresh) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(blk); (void)hipFree(ksd); } return rc; };
+    // The copies alternate between the ctx stream and the ctx's copy stream: one stream's copies run on one DMA engine
+    // (~27 GB/s measured from pinned rows), two streams' on two.  The side stream starts behind the zero fill and joins
+    // before the statistics.
     hipError_t e = hipMemsetAsync(blk, 0, bytes, ctx->stream);                     // tails must be zero: they take part in the row statistics
+    hipStream_t side = nullptr;
+    if (e == hipSuccess && n > 1) {
+        if (!ctx->copy_stream) {
+            e = hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking);
+            for (auto &ev : ctx->cmp_ev) if (e == hipSuccess) e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->cmp_filled, hipEventDisableTiming);
+        }
+        side = ctx->copy_stream;
+        if (e == hipSuccess) e = hipEventRecord(ctx->cmp_filled, ctx->stream);
+        if (e == hipSuccess) e = hipStreamWaitEvent(side, ctx->cmp_filled, 0);
+    }
     for (int i = 0; i < n && e == hipSuccess; ++i)
-        if (Ks[i] > 0) e = hipMemcpyAsync(blk + (size_t)i * Kmax * D, rows[i], (size_t)Ks[i] * D * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
+        if (Ks[i] > 0) e = hipMemcpyAsync(blk + (size_t)i * Kmax * D, rows[i], (size_t)Ks[i] * D * sizeof(float), hipMemcpyHostToDevice, (side && (i & 1)) ? side : ctx->stream);
+    if (e == hipSuccess && side) {
+        e = hipEventRecord(ctx->cmp_filled, side);
+        if (e == hipSuccess) e = hipStreamWaitEvent(ctx->stream, ctx->cmp_filled, 0);
+    }
     if (e == hipSuccess) e = hipMemcpyAsync(ksd, Ks, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream);
     if (e != hipSuccess) { ctx->set_error(std::string("rcn_desc_upload_batch: ") + hipGetErrorString(e)); return fail(RCN_ERR_HIP); }
     int si = -1;
@@ -1682,33 +1977,6 @@ int rcn_int_match_grid(rcn_ctx *ctx, const int32_t *pairs_host, int32_t n_pairs,
     const uint32_t idx_mask = (1u << idx_bits) - 1u;
     const int owner_stride = std::max(1, kt_max);
 
-    RCN_HIP(ctx->pairs_dev.reserve(slots.size() * sizeof(int32_t)));
-    RCN_HIP(ctx->cand.reserve((size_t)n_pairs * kq_stride * sizeof(uint2)));
-    const bool uniq_lds = kt_max <= RCN_UNIQ_LDS;     // owner table of a pair fits LDS: one fused launch
-    if (!uniq_lds) RCN_HIP(ctx->owner.reserve((size_t)n_pairs * owner_stride * sizeof(int32_t)));
-    RCN_HIP(ctx->fb_list.reserve(std::max<int64_t>(1, rows) * sizeof(unsigned long long)));
-    RCN_HIP(ctx->sv_list.reserve(std::max<int64_t>(1, rows) * sizeof(unsigned long long)));
-    RCN_HIP(hipMemcpyAsync(ctx->pairs_dev.p, slots.data(), slots.size() * sizeof(int32_t),
-                           hipMemcpyHostToDevice, ctx->stream));
-    if (!uniq_lds) RCN_HIP(hipMemsetAsync(ctx->owner.p, 0x7f, (size_t)n_pairs * owner_stride * sizeof(int32_t), ctx->stream));
-    RCN_HIP(hipMemsetAsync(counts_dev, 0, (size_t)n_pairs * sizeof(int32_t), ctx->stream));
-
-    const ImgDev *imgs = ctx->img_table.as<ImgDev>();
-    const int32_t *pairs = ctx->pairs_dev.as<int32_t>();
-    const bool vec4 = (ctx->D % 4) == 0;
-
-    const int evi = ctx->ev_n % 64;
-    const bool prof = ctx->profile && ctx->ev_made;
-
-    RerankArgs ra;
-    memset(&ra, 0, sizeof(ra));
-    ra.imgs = imgs; ra.pairs = pairs; ra.cand = ctx->cand.as<uint2>();
-    ra.out = out_dev; ra.out_stride = out_stride;
-    ra.n_pairs = n_pairs; ra.kq_stride = kq_stride; ra.D = ctx->D; ra.idx_mask = idx_mask;
-    ra.ratio = ratio;
-    ra.sc = ctx->scale_dev.as<ScaleDev>();
-    ra.all_to_fallback = mfma ? 0 : 1;
-
     // groups: runs of consecutive pairs that share the query image, cut at RCN_GROUP
     std::vector<int2> &groups = ctx->groups_host;
     groups.clear();
@@ -1718,54 +1986,132 @@ int rcn_int_match_grid(rcn_ctx *ctx, const int32_t *pairs_host, int32_t n_pairs,
         groups.push_back(make_int2(p, cnt));
         p += cnt;
     }
-    // Chunks of the pair list: the MFMA-bound coarse kernel of chunk c+1 (main stream) runs
-    // beside the memory-bound filter / exact re-rank / uniqueness of chunk c (auxiliary stream).
     const int n_groups = (int)groups.size();
-    const int n_chunks = (mfma && n_groups >= 64 && kq_max > 0) ? std::max(1, std::min(RCN_CHUNKS, ctx->chunks)) : 1;
-    // Order of the work items (single-chunk launches): every XCD walks its own contiguous range of the
+    // Pipeline chunks (round 4): the candidate table and the two row lists are sized for at most RCN_CHUNK_ROWS query-row slots
+    // and REUSED by consecutive ranges of the pair list, in stream order -- coarse(c), filter(c), re-rank(c), uniqueness(c),
+    // coarse(c+1), ...  Round 3 sized them for the whole grid: 16.4 GB each at cfg 3, three of them, and a 2000-image grid
+    // would not have fitted the device at all.  A chunk never exceeds the budget (the lists can therefore not overflow) and
+    // ends at a group boundary; a small grid is one chunk and runs exactly as before.  (The two-stream overlap of chunks that
+    // the diagnostic build once had measured slower in rounds 1 and 2 and is gone.)
+    std::vector<int> chunk_g0;      // first group of every chunk, then n_groups
+    int64_t cap_slots = 0, cap_rows = 0;
+    {
+        int64_t slots_c = 0, rows_c = 0;
+        chunk_g0.push_back(0);
+        for (int g = 0; g < n_groups; ++g) {
+            int64_t gs = (int64_t)groups[g].y * kq_stride, gr = 0;
+            for (int r = 0; r < groups[g].y; ++r) gr += lookup(pairs_host[2 * (groups[g].x + r)])->K;
+            if (slots_c > 0 && slots_c + gs > ctx->chunk_rows) {
+                chunk_g0.push_back(g);
+                cap_slots = std::max(cap_slots, slots_c); cap_rows = std::max(cap_rows, rows_c);
+                slots_c = 0; rows_c = 0;
+            }
+            slots_c += gs; rows_c += gr;
+        }
+        cap_slots = std::max(cap_slots, slots_c); cap_rows = std::max(cap_rows, rows_c);
+        chunk_g0.push_back(n_groups);
+    }
+    const int n_chunks = (int)chunk_g0.size() - 1;
+    const bool vec4 = (ctx->D % 4) == 0;
+    const bool mid = vec4 && kt_max >= 2;            // the middle tier reads rows as float4
+    const int n_slots = (int)ctx->table_host.size();
+
+    RCN_HIP(ctx->pairs_dev.reserve(slots.size() * sizeof(int32_t)));
+    RCN_HIP(ctx->cand.reserve((size_t)std::max<int64_t>(1, cap_slots) * sizeof(uint2)));
+    const bool uniq_lds = kt_max <= RCN_UNIQ_LDS;     // owner table of a pair fits LDS: one fused launch
+    if (!uniq_lds) RCN_HIP(ctx->owner.reserve((size_t)n_pairs * owner_stride * sizeof(int32_t)));
+    RCN_HIP(ctx->fb_list.reserve(std::max<int64_t>(1, cap_rows) * sizeof(unsigned long long)));
+    RCN_HIP(ctx->sv_list.reserve(std::max<int64_t>(1, cap_rows) * sizeof(unsigned long long)));
+    // middle tier: binned rows, thresholds, candidate lists, work items, the overflow list, three words per image slot
+    const size_t mid_rows_cap = (size_t)std::min<int64_t>(std::max<int64_t>(1, cap_rows), ctx->mid_rows);
+    auto al = [](size_t b) { return (b + 255) / 256 * 256; };
+    // (the bins come FIRST: their place must not move with the row count of the grid, they carry state -- zeros -- from call to call)
+    const size_t mo_bins = 0, mo_sorted = mo_bins + al(4 * 3 * ((size_t)n_slots + 1)), mo_thr = mo_sorted + al(8 * mid_rows_cap), mo_cc = mo_thr + al(4 * mid_rows_cap),
+                 mo_cl = mo_cc + al(4 * mid_rows_cap), mo_items = mo_cl + al(4 * mid_rows_cap * RCN_MIDCAP),
+                 mo_fb2 = mo_items + al(16 * (mid_rows_cap + (size_t)n_slots + 1)), mo_end = mo_fb2 + al(8 * mid_rows_cap);
+    if (mid) {
+        const bool fresh = mo_end > ctx->mid_ws.cap;
+        RCN_HIP(ctx->mid_ws.reserve(mo_end));
+        if (fresh || ctx->mid_bins_slots != n_slots) {       // the bins are left zeroed by every pass (k_mid_bins); a new buffer, or another slot count, is not
+            RCN_HIP(hipMemsetAsync(ctx->mid_ws.as<char>() + mo_bins, 0, mo_sorted - mo_bins, ctx->stream));
+            ctx->mid_bins_slots = n_slots;
+        }
+    }
+    RCN_HIP(hipMemcpyAsync(ctx->pairs_dev.p, slots.data(), slots.size() * sizeof(int32_t),
+                           hipMemcpyHostToDevice, ctx->stream));
+    if (!uniq_lds) RCN_HIP(hipMemsetAsync(ctx->owner.p, 0x7f, (size_t)n_pairs * owner_stride * sizeof(int32_t), ctx->stream));
+    RCN_HIP(hipMemsetAsync(counts_dev, 0, (size_t)n_pairs * sizeof(int32_t), ctx->stream));
+
+    const ImgDev *imgs = ctx->img_table.as<ImgDev>();
+    const int32_t *pairs = ctx->pairs_dev.as<int32_t>();
+
+    const int evi = ctx->ev_n % 64;
+    const bool prof = ctx->profile && ctx->ev_made;
+
+    RerankArgs ra;
+    memset(&ra, 0, sizeof(ra));
+    ra.imgs = imgs; ra.pairs = pairs;
+    ra.out = out_dev; ra.out_stride = out_stride;
+    ra.n_pairs = n_pairs; ra.kq_stride = kq_stride; ra.D = ctx->D; ra.idx_mask = idx_mask;
+    ra.ratio = ratio;
+    ra.sc = ctx->scale_dev.as<ScaleDev>();
+    ra.all_to_fallback = mfma ? 0 : 1;
+
+    // Order of the work items of a coarse launch: every XCD walks its own contiguous range of the chunk's
     // group list, heaviest groups first, so that the last items to start are the short ones (the tail
     // of a launch is one item long: 5 % of a cfg-2 grid for a four-pair group, 1 % for a one-pair group).
     // Groups are dealt to the XCD ranges round-robin in descending weight; unused slots hold empty groups.
     // (Measured and dropped in round 2: a train-block-major order -- every XCD runs the query tiles of ~8 query
     // images against the SAME four train images at a time, so that all but one of them hit in its L2 -- is 0.5-1.5 %
     // slower: the kernel is power-limited, not fabric-limited, and the order above has the shorter tail.)
-    int n_groups_dev = n_groups;
+    std::vector<int> chunk_off((size_t)n_chunks, 0), chunk_ng((size_t)n_chunks, 0);
     {
         std::vector<int2> &arr = ctx->groups_arranged;
-        if (n_chunks == 1 && mfma && n_groups >= 64 && !ctx->no_item_order) {
-            std::vector<std::pair<int64_t, int>> order((size_t)n_groups);
-            for (int g = 0; g < n_groups; ++g) {
-                int64_t wgt = 0;
-                for (int r = 0; r < groups[g].y; ++r) wgt += lookup(pairs_host[2 * (groups[g].x + r) + 1])->K;
-                order[g] = std::make_pair(-wgt, g);
+        arr.clear();
+        std::vector<std::pair<int64_t, int>> order;
+        for (int c = 0; c < n_chunks; ++c) {
+            const int g0 = chunk_g0[c], g1 = chunk_g0[c + 1], ng = g1 - g0;
+            chunk_off[c] = (int)arr.size();
+            if (mfma && ng >= 64 && !ctx->no_item_order) {
+                order.resize((size_t)ng);
+                for (int g = 0; g < ng; ++g) {
+                    int64_t wgt = 0;
+                    for (int r = 0; r < groups[g0 + g].y; ++r) wgt += lookup(pairs_host[2 * (groups[g0 + g].x + r) + 1])->K;
+                    order[g] = std::make_pair(-wgt, g0 + g);
+                }
+                std::stable_sort(order.begin(), order.end());
+                const int gpx = (ng + 7) / 8;
+                const size_t base = arr.size();
+                arr.resize(base + (size_t)8 * gpx, make_int2(0, 0));
+                for (int k = 0; k < ng; ++k) arr[base + (size_t)(k % 8) * gpx + k / 8] = groups[order[k].second];
+                chunk_ng[c] = 8 * gpx;
+            } else {
+                arr.insert(arr.end(), groups.begin() + g0, groups.begin() + g1);
+                chunk_ng[c] = ng;
             }
-            std::stable_sort(order.begin(), order.end());
-            const int gpx = (n_groups + 7) / 8;
-            arr.assign((size_t)8 * gpx, make_int2(0, 0));
-            for (int k = 0; k < n_groups; ++k) arr[(size_t)(k % 8) * gpx + k / 8] = groups[order[k].second];
-            n_groups_dev = 8 * gpx;
-        } else arr = groups;
-        RCN_HIP(ctx->groups_dev.reserve(arr.size() * sizeof(int2)));
+        }
+        RCN_HIP(ctx->groups_dev.reserve(std::max<size_t>(1, arr.size()) * sizeof(int2)));
         RCN_HIP(hipMemcpyAsync(ctx->groups_dev.p, arr.data(), arr.size() * sizeof(int2), hipMemcpyHostToDevice, ctx->stream));
     }
-    hipStream_t sa = ctx->stream, sb = n_chunks > 1 ? ctx->aux_stream : ctx->stream;
-    unsigned *ccnt = ctx->counters.as<unsigned>() + 8;     // per chunk: [2c] fallback count, [2c+1] survivor count
-    RCN_HIP(hipMemsetAsync(ccnt, 0, 2 * RCN_CHUNKS * sizeof(unsigned), sa));
-    if (n_chunks > 1) {
-        RCN_HIP(hipEventRecord(ctx->ba_ev[0], sa));
-        RCN_HIP(hipStreamWaitEvent(sb, ctx->ba_ev[0], 0));
-    }
-    if (prof) RCN_HIP(hipEventRecord(ctx->ev[evi][0], sa));
-    int64_t row_prefix = 0;
+    hipStream_t st = ctx->stream;
+    // counters (words from +8): [0] fallback rows of the chunk, [1] survivors, [2] rows past the middle tier, [3] its work items;
+    // [4..6] the same three summed over the chunks of the call (rcn_match_last_stats)
+    unsigned *ccnt = ctx->counters.as<unsigned>() + 8;
+    RCN_HIP(hipMemsetAsync(ccnt, 0, 8 * sizeof(unsigned), st));
+    ctx->ev_chunks[evi] = 0;
     for (int c = 0; c < n_chunks; ++c) {
-        const int g0 = (int)((int64_t)n_groups * c / n_chunks), g1 = (int)((int64_t)n_groups * (c + 1) / n_chunks);
+        const int g0 = chunk_g0[c], g1 = chunk_g0[c + 1];
         if (g1 <= g0) continue;
         const int p0 = groups[g0].x, p1 = g1 < n_groups ? groups[g1].x : n_pairs, np_c = p1 - p0;
+        // the chunk's candidates sit at the START of the buffer; the kernels index by grid-wide pair number
+        uint2 *cand_c = ctx->cand.as<uint2>() - (size_t)p0 * kq_stride;
+        const bool tm = prof && c < RCN_EV_CHUNKS;
+        if (tm) { RCN_HIP(hipEventRecord(ctx->ev_c[evi][c][0], st)); ctx->ev_chunks[evi] = c + 1; }
         if (mfma) {
             CoarseArgs ca;
-            ca.imgs = imgs; ca.pairs = pairs; ca.cand = ctx->cand.as<uint2>();
-            const int ng_c = n_chunks == 1 ? n_groups_dev : g1 - g0;
-            ca.groups = ctx->groups_dev.as<int2>() + g0;
+            ca.imgs = imgs; ca.pairs = pairs; ca.cand = cand_c;
+            const int ng_c = chunk_ng[c];
+            ca.groups = ctx->groups_dev.as<int2>() + chunk_off[c];
             ca.n_groups = ng_c; ca.tiles_per_pair = tiles; ca.kq_stride = kq_stride;
             const int64_t items = (int64_t)ng_c * tiles;
             ca.items_per_xcd = (int)((items + 7) / 8);
@@ -1815,55 +2161,72 @@ int rcn_int_match_grid(rcn_ctx *ctx, const int32_t *pairs_host, int32_t n_pairs,
             }
             RCN_HIP(e);
         }
-        if (prof && c == n_chunks - 1) RCN_HIP(hipEventRecord(ctx->ev[evi][1], sa));
-        if (n_chunks > 1) {
-            RCN_HIP(hipEventRecord(ctx->ba_ev[1 + (c & 3)], sa));
-            RCN_HIP(hipStreamWaitEvent(sb, ctx->ba_ev[1 + (c & 3)], 0));
-        }
-        int64_t rows_c = 0;
-        for (int p = p0; p < p1; ++p) rows_c += lookup(pairs_host[2 * p])->K;
+        if (tm) RCN_HIP(hipEventRecord(ctx->ev_c[evi][c][1], st));
+        ra.cand = cand_c;
         ra.pair_base = p0;
-        ra.fb_list = ctx->fb_list.as<unsigned long long>() + row_prefix; ra.fb_count = ccnt + 2 * c;
-        ra.sv_list = ctx->sv_list.as<unsigned long long>() + row_prefix; ra.sv_count = ccnt + 2 * c + 1;
-        row_prefix += rows_c;
+        ra.fb_list = ctx->fb_list.as<unsigned long long>(); ra.fb_count = ccnt;
+        ra.sv_list = ctx->sv_list.as<unsigned long long>(); ra.sv_count = ccnt + 1;
+        if (c > 0) RCN_HIP(hipMemsetAsync(ccnt, 0, 4 * sizeof(unsigned), st));
         if (kq_max > 0) {
             const int qblocks = (kq_max + 255) / 256;
             dim3 g((unsigned)qblocks * (unsigned)np_c);
             ra.qblocks = (kq_max + RCN_FB - 1) / RCN_FB;
-            k_filter<<<(unsigned)ra.qblocks * (unsigned)np_c, RCN_FB, 0, sb>>>(ra);
+            k_filter<<<(unsigned)ra.qblocks * (unsigned)np_c, RCN_FB, 0, st>>>(ra);
             RCN_HIP(hipGetLastError());
             // sharded grid: the fp32 rows of the other ranks' images travel on a side stream while the
             // coarse pass runs on the fp16 payload; the exact stages are the first to read them
-            if (ctx->f32_ready) RCN_HIP(hipStreamWaitEvent(sb, ctx->f32_ready, 0));
+            if (ctx->f32_ready) RCN_HIP(hipStreamWaitEvent(st, ctx->f32_ready, 0));
             if (mfma) {
-                if (vec4) k_rerank_lds<<<ctx->prop.multiProcessorCount * 16, 64, 0, sb>>>(ra);
-                else k_rerank_generic<<<ctx->prop.multiProcessorCount * 8, 256, 0, sb>>>(ra);
+                if (vec4) k_rerank_lds<<<ctx->prop.multiProcessorCount * 16, 64, 0, st>>>(ra);
+                else k_rerank_generic<<<ctx->prop.multiProcessorCount * 8, 256, 0, st>>>(ra);
                 RCN_HIP(hipGetLastError());
             }
             const int fb_blocks = ctx->prop.multiProcessorCount * 8;
-            if (vec4) k_exact_rows_lds<<<fb_blocks, 64 * EX_WAVES, 0, sb>>>(imgs, pairs, ra.fb_list, ra.fb_count, ctx->D, ratio, out_dev, out_stride);
-            else k_exact_rows<false><<<fb_blocks, 256, 0, sb>>>(imgs, pairs, ra.fb_list, ra.fb_count, ctx->D, ratio, out_dev, out_stride);
+            const unsigned long long *brute = ra.fb_list;
+            const unsigned *brute_n = ccnt;
+            if (mid) {
+                // the middle tier takes the first RCN_MIDROWS rows of the list; what overflows its candidate lists lands in fb2
+                char *mw = ctx->mid_ws.as<char>();
+                MidArgs ma;
+                memset(&ma, 0, sizeof(ma));
+                ma.imgs = imgs; ma.pairs = pairs; ma.cand = cand_c; ma.fb_list = ra.fb_list; ma.fb_count = ccnt;
+                ma.sorted = (unsigned long long *)(mw + mo_sorted); ma.thr = (float *)(mw + mo_thr); ma.ccount = (unsigned *)(mw + mo_cc);
+                ma.clist = (int32_t *)(mw + mo_cl); ma.items = (int4 *)(mw + mo_items); ma.fb2_list = (unsigned long long *)(mw + mo_fb2);
+                ma.hist = (unsigned *)(mw + mo_bins); ma.offs = ma.hist + (n_slots + 1); ma.cursor = ma.offs + (n_slots + 1);
+                ma.n_items = ccnt + 3; ma.fb2_count = ccnt + 2;
+                ma.out = out_dev; ma.out_stride = out_stride; ma.sc = ra.sc; ma.n_slots = n_slots; ma.kq_stride = kq_stride; ma.D = ctx->D;
+                ma.all_to_fallback = ra.all_to_fallback; ma.idx_mask = idx_mask; ma.ratio = ratio; ma.midrows = (uint32_t)ctx->mid_rows;
+                const int mb = ctx->prop.multiProcessorCount * 4;
+                k_mid_hist<<<mb, 256, 0, st>>>(ma);
+                k_mid_bins<<<1, 1024, 0, st>>>(ma);
+                k_mid_scatter<<<mb, 256, 0, st>>>(ma);
+                k_mid_eval<<<ctx->prop.multiProcessorCount * 4, 256, 0, st>>>(ma);
+                k_mid_exact<<<mb, 256, 0, st>>>(ma);
+                RCN_HIP(hipGetLastError());
+                // K2b: the overflow list, then the rows beyond the tier's budget (none unless a chunk leaves more than RCN_MIDROWS rows)
+                if (vec4) k_exact_rows_lds<<<fb_blocks, 64 * EX_WAVES, 0, st>>>(imgs, pairs, ma.fb2_list, ma.fb2_count, ctx->D, ratio, out_dev, out_stride);
+                RCN_HIP(hipGetLastError());
+                if (cap_rows > ctx->mid_rows) k_exact_rows_lds<<<fb_blocks, 64 * EX_WAVES, 0, st>>>(imgs, pairs, brute, brute_n, ctx->D, ratio, out_dev, out_stride, (unsigned)ctx->mid_rows);
+            } else if (vec4) k_exact_rows_lds<<<fb_blocks, 64 * EX_WAVES, 0, st>>>(imgs, pairs, brute, brute_n, ctx->D, ratio, out_dev, out_stride);
+            else k_exact_rows<false><<<fb_blocks, 256, 0, st>>>(imgs, pairs, brute, brute_n, ctx->D, ratio, out_dev, out_stride);
             RCN_HIP(hipGetLastError());
-            if (prof && c == n_chunks - 1) RCN_HIP(hipEventRecord(ctx->ev[evi][2], sb));
-            if (!uniq_lds) k_unique_claim<<<g, 256, 0, sb>>>(imgs, pairs, out_dev, out_stride, ctx->owner.as<int32_t>(), owner_stride, qblocks, p0);
+            k_stats_acc<<<1, 64, 0, st>>>(ccnt, mid ? 1 : 0, (unsigned)ctx->mid_rows);
+            if (tm) RCN_HIP(hipEventRecord(ctx->ev_c[evi][c][2], st));
+            if (!uniq_lds) k_unique_claim<<<g, 256, 0, st>>>(imgs, pairs, out_dev, out_stride, ctx->owner.as<int32_t>(), owner_stride, qblocks, p0);
             RCN_HIP(hipGetLastError());
         }
-        if (uniq_lds) k_unique_pair<<<np_c, 256, 0, sb>>>(imgs, pairs, out_dev, out_stride, counts_dev, p0);
+        if (uniq_lds) k_unique_pair<<<np_c, 256, 0, st>>>(imgs, pairs, out_dev, out_stride, counts_dev, p0);
         else {
             const int eblocks = (int)((out_stride + 255) / 256);
             dim3 g((unsigned)eblocks * (unsigned)np_c);
-            k_unique_emit<<<g, 256, 0, sb>>>(imgs, pairs, out_dev, out_stride, ctx->owner.as<int32_t>(), owner_stride, counts_dev, eblocks, p0);
+            k_unique_emit<<<g, 256, 0, st>>>(imgs, pairs, out_dev, out_stride, ctx->owner.as<int32_t>(), owner_stride, counts_dev, eblocks, p0);
         }
         RCN_HIP(hipGetLastError());
+        if (tm) RCN_HIP(hipEventRecord(ctx->ev_c[evi][c][kq_max > 0 ? 3 : 2], st));
+        if (tm && kq_max <= 0) RCN_HIP(hipEventRecord(ctx->ev_c[evi][c][3], st));
     }
-    if (prof && kq_max > 0) {
-        RCN_HIP(hipEventRecord(ctx->ev[evi][3], sb));
-        ctx->ev_n++;
-    }
-    if (n_chunks > 1) {   // the caller's stream continues behind the auxiliary stream's tail
-        RCN_HIP(hipEventRecord(ctx->ba_ev[5], sb));
-        RCN_HIP(hipStreamWaitEvent(sa, ctx->ba_ev[5], 0));
-    }
+    if (prof) ctx->ev_n++;
+    ctx->last_chunks = n_chunks;
     ctx->last_kq_stride = kq_stride; ctx->last_idx_mask = idx_mask; ctx->last_n_pairs = n_pairs;
     // stats: the fallback count is read back lazily in rcn_match_last_stats
     ctx->last_stats.rows_total = rows;
@@ -2056,12 +2419,12 @@ int rcn_match_last_stats(const rcn_ctx *cctx, rcn_match_stats *out)
     if (!ctx || !out) return RCN_ERR_ARG;
     std::lock_guard<std::mutex> lk(ctx->mu);
     if (ctx->last_stats.rows_exact_fallback < 0 && ctx->counters.p) {
-        unsigned n[2 * RCN_CHUNKS];
-        RCN_HIP(hipMemcpyAsync(n, ctx->counters.as<unsigned>() + 8, sizeof(n), hipMemcpyDeviceToHost, ctx->stream));
+        unsigned n[3];
+        RCN_HIP(hipMemcpyAsync(n, ctx->counters.as<unsigned>() + 8 + 4, sizeof(n), hipMemcpyDeviceToHost, ctx->stream));
         RCN_HIP(hipStreamSynchronize(ctx->stream));
-        ctx->last_stats.rows_exact_fallback = 0;
-        ctx->last_stats.rows_reranked = 0;
-        for (int c = 0; c < RCN_CHUNKS; ++c) { ctx->last_stats.rows_exact_fallback += n[2 * c]; ctx->last_stats.rows_reranked += n[2 * c + 1]; }
+        ctx->last_stats.rows_exact_fallback = n[0];
+        ctx->last_stats.rows_reranked = n[1];
+        ctx->last_stats.rows_brute_force = n[2];
     }
     if (ctx->last_stats.err_bound_d2 < 0.0 && ctx->scale_dev.p) {
         { int rcs = rcn_int_resolve_scale(ctx); if (rcs) return rcs; }
@@ -2077,16 +2440,21 @@ int rcn_match_last_stats(const rcn_ctx *cctx, rcn_match_stats *out)
         RCN_HIP(hipStreamSynchronize(ctx->stream));
         const int n = ctx->ev_n < 64 ? ctx->ev_n : 64;
         double c = 0, r = 0, u = 0;
-        for (int i = 0; i < n; ++i) {
-            float ms = 0.f;
-            RCN_HIP(hipEventElapsedTime(&ms, ctx->ev[i][0], ctx->ev[i][1])); c += ms;
-            RCN_HIP(hipEventElapsedTime(&ms, ctx->ev[i][1], ctx->ev[i][2])); r += ms;
-            RCN_HIP(hipEventElapsedTime(&ms, ctx->ev[i][2], ctx->ev[i][3])); u += ms;
-        }
+        int launches = 0;
+        for (int i = 0; i < n; ++i)
+            for (int k = 0; k < ctx->ev_chunks[i]; ++k) {
+                float ms = 0.f;
+                RCN_HIP(hipEventElapsedTime(&ms, ctx->ev_c[i][k][0], ctx->ev_c[i][k][1])); c += ms;
+                RCN_HIP(hipEventElapsedTime(&ms, ctx->ev_c[i][k][1], ctx->ev_c[i][k][2])); r += ms;
+                RCN_HIP(hipEventElapsedTime(&ms, ctx->ev_c[i][k][2], ctx->ev_c[i][k][3])); u += ms;
+                ++launches;
+            }
         ctx->last_stats.profiled_calls = n;
+        ctx->last_stats.coarse_launches = launches;
         ctx->last_stats.coarse_ms = c; ctx->last_stats.rerank_ms = r; ctx->last_stats.unique_ms = u;
         ctx->ev_n = 0;
     }
+    ctx->last_stats.chunks = ctx->last_chunks;
     *out = ctx->last_stats;
     return RCN_OK;
 }
@@ -2099,6 +2467,7 @@ int rcn_match_last_stats(const rcn_ctx *cctx, rcn_match_stats *out)
 int rcn_diag_coarse_table(rcn_ctx *ctx, uint32_t *cand_host, int64_t capacity_words, double *model)
 {
     if (!ctx || !model) return RCN_ERR_ARG;
+    if (ctx->last_chunks != 1) { ctx->set_error("rcn_diag_coarse_table: the last grid ran in several pipeline chunks; the table holds only the last one"); return RCN_ERR_UNSUPPORTED; }
     std::lock_guard<std::mutex> lk(ctx->mu);
     const int64_t words = 2 * (int64_t)ctx->last_n_pairs * ctx->last_kq_stride;
     { int rcs = rcn_int_resolve_scale(ctx); if (rcs) return rcs; }
@@ -2120,8 +2489,9 @@ int rcn_match_profile(rcn_ctx *ctx, int enable)
     std::lock_guard<std::mutex> lk(ctx->mu);
     RCN_HIP(hipSetDevice(ctx->device));
     if (enable && !ctx->ev_made) {
-        for (auto &row : ctx->ev)
-            for (auto &e : row) RCN_HIP(hipEventCreate(&e));
+        for (auto &call : ctx->ev_c)
+            for (auto &row : call)
+                for (auto &e : row) RCN_HIP(hipEventCreate(&e));
         ctx->ev_made = true;
     }
     ctx->profile = enable != 0;

@@ -144,7 +144,14 @@ struct rcn_ctx {
     uint32_t last_idx_mask = 0;
     rcn_match_stats last_stats;
     bool profile = false;
-    hipEvent_t ev[64][4];
+#define RCN_EV_CHUNKS 64
+    hipEvent_t ev_c[64][RCN_EV_CHUNKS][4];   // per kept call and pipeline chunk: before coarse / after coarse / after the exact stages / after uniqueness
+    int ev_chunks[64] = {0};                 // chunks of that call that carry events (further chunks are not timed)
+    int last_chunks = 1;                     // pipeline chunks of the last grid call
+    int64_t chunk_rows = 1ll << 27;          // query-row slots of the candidate table per pipeline chunk (diagnostic build: RCN_CHUNK_ROWS)
+    int64_t mid_rows = 1ll << 21;            // rows per chunk the middle tier takes (diagnostic build: RCN_MID_ROWS)
+    DevBuf mid_ws;                           // middle tier of the exact stages (match.hip): binned rows, thresholds, candidate lists, bins
+    int mid_bins_slots = -1;                 // image slots the zeroed bins of mid_ws were laid out for
     bool ev_made = false;
     int ev_n = 0;          // recorded calls since the last stats read (<= 64)
     // Ablations / alternative device paths exist only in the diagnostic build (-DRCN_DIAG,
@@ -154,7 +161,6 @@ struct rcn_ctx {
     bool coarse_w4 = false;    // RCN_COARSE_W4=1: the one-wave-per-SIMD form of K1 (k_coarse_w4, coarse_w4.h) instead of k_coarse_top2
     int coarse_shape = -1;     // RCN_COARSE_S16=0/1: force k_coarse_top2's MFMA shape (0: 32x32x16, 1: 16x16x32) at every D; -1: the shipping choice
     int ablate = 0;            // RCN_COARSE_ABL
-    int chunks = 1;            // RCN_MATCH_CHUNKS: >1 overlaps re-rank(c) with coarse(c+1) on two streams
     bool force_exact = false;  // RCN_FORCE_EXACT=1: skip the MFMA coarse pass
     bool no_item_order = false;   // RCN_MATCH_NO_ORDER=1: work items in pair order instead of heaviest-first per XCD
     bool ba_atomics = false;   // RCN_BA_SCHUR_ATOMICS=1: atomic Schur accumulation instead of the gather form
@@ -162,7 +168,7 @@ struct rcn_ctx {
 #else
     static constexpr bool coarse_w4 = false;
     static constexpr int coarse_shape = -1;
-    static constexpr int ablate = 0, chunks = 1;
+    static constexpr int ablate = 0;
     static constexpr bool force_exact = false, no_item_order = false, ba_atomics = false, ba_trsv_fwd = false;
 #endif
 

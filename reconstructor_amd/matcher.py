@@ -150,6 +150,14 @@ class HipL2Matcher(FeatureMatcher):
         xy = np.ascontiguousarray(xy, np.int32).reshape(-1, 2)
         self.ctx.check(self.ctx.lib.rcn_coords_upload(self.ctx.h, int(img_id), xy.ctypes.data, len(xy)))
 
+    def upload_coords_batch(self, first_id, coords):
+        """Pixel coordinates of n images (a list of K_i x 2 arrays) in one call, one synchronisation."""
+        arrs = [np.ascontiguousarray(c, np.int32).reshape(-1, 2) for c in coords]
+        n = len(arrs)
+        ptrs = (C.c_void_p * max(n, 1))(*[a.ctypes.data if len(a) else None for a in arrs])
+        Ks = np.array([len(a) for a in arrs], np.int32)
+        self.ctx.check(self.ctx.lib.rcn_coords_upload_batch(self.ctx.h, int(first_id), n, ptrs, Ks.ctypes.data))
+
     def filter_table_device(self, pairs, table_dev_ptr, out_stride, counts_dev_ptr, status_dev_ptr=None):
         """Epipolar filter of a device match table in place (SequentialReconstructor.cpp:237-269 for every
         pair); asynchronous on the ctx stream."""

@@ -333,7 +333,7 @@ def test_host_batch_ingest_equals_one_upload_per_image(matcher):
     synchronisation) -- the tables equal the one-upload-per-image path's and the oracle's; a second batch of the same
     shape reuses the block; an empty image in the middle and an image of one row are part of it."""
     ks = [300, 0, 513, 1, 256, 777]
-    ims = synth.descriptor_set("sift", len(ks), [max(k, 1) for k in ks], seed=91)
+    ims = synth.descriptor_set("sift", len(ks), [max(k, 1) for k in ks], n_world=1200, seed=91)
     ims = [im[:k] for im, k in zip(ims, ks)]
     pairs = [(0, 2), (0, 4), (2, 5), (4, 5), (3, 5), (5, 0), (1, 2), (2, 1)]
     exp, ec = orc.match_grid(ims, pairs, threads=2)
@@ -366,8 +366,8 @@ def test_remove_frees_the_descriptor_length(matcher):
     instead of rcn_desc_clear, which would wipe everybody's descriptors)."""
     from reconstructor_amd import _lib
     matcher.clear()
-    a = synth.descriptor_set("sift", 2, 200, seed=5)
-    b = synth.descriptor_set("orb", 2, 200, seed=6)
+    a = synth.descriptor_set("sift", 2, 200, n_world=400, seed=5)
+    b = synth.descriptor_set("orb", 2, 200, n_world=400, seed=6)
     matcher.upload(1, a[0])
     matcher.upload(2, a[1])
     with pytest.raises(_lib.RcnError):
