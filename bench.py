@@ -599,6 +599,8 @@ def run_grid(torch, dist, dev, shard, n_img, K, local_dev, steps, warmup, world,
     dt = time.perf_counter() - t0
     st = m.stats()
     m.profile(False)
+    free_b, total_b = torch.cuda.mem_get_info(dev)
+    st["hbm_used_bytes"] = int(total_b - free_b)          # everything this process holds on the device right after the timed steps
     st["shard_times"] = shard.times()
     shard.profile(False)
     n_matches = int(counts[:P].sum().item()) if P else 0
@@ -660,15 +662,20 @@ def grid_line(K, n_img, n_pairs_total, dt, steps, st, world, my_pairs):
     """value / roofline of one measured grid (pair-distances of the whole job per second; K1 against the f16 MFMA peak)."""
     pd_job = float(n_pairs_total) * K * K
     calls = max(1, st["profiled_calls"])
-    coarse_ms = st["coarse_ms"] / calls
-    flops = 2.0 * D * float(st["pair_distances"])      # SURVEY 8(d): 2*D flop per pair-distance, this rank's launch
+    launches = max(1, st.get("coarse_launches", 0) or calls)        # pipeline chunks: several launches of K1 per step on large grids
+    coarse_ms = st["coarse_ms"] / launches                           # average launch duration (what rocprofv3's kernel stats show)
+    flops_per_launch = 2.0 * D * float(st["pair_distances"]) * calls / launches
+    flops = flops_per_launch                            # SURVEY 8(d): 2*D flop per pair-distance x the pair-distances of one launch (this rank)
     achieved = flops / (coarse_ms * 1e-3) / 1e12 if coarse_ms > 0 else 0.0
     traffic, tnote = measured_traffic("k_coarse_top2<256>@%dx%d" % (n_img, K)) if world == 1 else (None, "PMC passes are single-GPU")
     roof = {"bound": "mfma", "kernel": "k_coarse_top2<256, 0, 1> (v_mfma_f32_16x16x32_f16)", "achieved": achieved, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": achieved / MFMA_F16_PEAK_TFLOPS, "traffic": traffic,
             "traffic_note": "HBM bytes per launch from rocprofv3 --pmc passes on this exact source (profiles/r03_match_traffic.json); " + str(tnote),
             "algorithmic_hbm_bytes_per_launch": float(n_img) * K * D * 2 + 8.0 * float(st["rows_total"]),
-            "launch_ms": coarse_ms, "rerank_ms": st["rerank_ms"] / calls, "unique_ms": st["unique_ms"] / calls,
+            "launch_ms": coarse_ms, "launches_per_step": launches / calls, "k1_ms_per_step": st["coarse_ms"] / calls,
+            "algorithmic_flop_per_launch": flops_per_launch,
+            "rerank_ms": st["rerank_ms"] / calls, "unique_ms": st["unique_ms"] / calls,
+            "rows_brute_force": int(st.get("rows_brute_force", 0)),
             "source_hash": source_hash()}
     return pd_job * steps / dt, dt / steps * 1e3, roof
 
@@ -767,7 +774,7 @@ def mixed_magnitude_leg(torch, ctx, dev, n3=100, K3=1500):
         dt3 = (time.perf_counter() - t3) / 3
         st3 = m3.stats()
         res[name] = {"value": float(st3["pair_distances"]) / dt3, "ms_per_step": 1e3 * dt3, "rows_total": int(st3["rows_total"]),
-                     "rows_reranked": int(st3["rows_reranked"]), "rows_exact_fallback": int(st3["rows_exact_fallback"]),
+                     "rows_reranked": int(st3["rows_reranked"]), "rows_exact_fallback": int(st3["rows_exact_fallback"]), "rows_brute_force": int(st3["rows_brute_force"]),
                      "fallback_share": float(st3["rows_exact_fallback"]) / max(1, float(st3["rows_total"])), "table": o3.cpu().numpy()}
         m3.clear()
         del xd, o3, c3
@@ -883,6 +890,7 @@ def main():
                        "matches_found": n_matches, "host_list_bytes_per_step": list_bytes,
                        "exchange_bytes_f16_payload": int(info["exchange_bytes_f16"]), "exchange_bytes_f32_side_stream": int(info["exchange_bytes_f32"]),
                        "rows_reranked": rows[0], "rows_exact_fallback": rows[1], "rows_total": rows[2],
+                       "hbm_used_gb_rank0": st.get("hbm_used_bytes", 0) / 1e9, "pipeline_chunks": int(st.get("chunks", 1)),
                        # the table of the LAST timed step against the CPU oracle (outside the timed region): cfg3 = 512 sampled
                        # pairs by row hash + count, 64 per residue of the pair number mod 8, over all ranks; cfg2 = all 4950 pairs
                        "equal_to_cpu": par["equal_to_cpu"], "pairs_compared_with_cpu": par["pairs_compared"]},

@@ -30,7 +30,9 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #define RCN_TBL_BYTES ((RCN_GROUP * 24 + 127) / 128 * 128)   // LDS table of the group's train-image records
 #define RCN_NBUF 4          // LDS ring depth (train tiles)
 #define RCN_PD 2            // prefetch distance, tiles
-#define RCN_CHUNK_ROWS (1ll << 27)   // query-row slots of the candidate table per pipeline chunk (1 GiB of candidates; the row lists are at most as long)
+#define RCN_CHUNK_ROWS (1ll << 27)   // default query-row slots of the candidate table per pipeline chunk (ctx->chunk_rows: 1 GiB of candidates; the row lists are at most as long).
+                                     // cfg 3 on one box (tools/chunk_sweep.py): 1 chunk 3104 ms per call, library holds 57.8 GB; 8 chunks 3104 ms, 9.8 GB; 16 chunks (this
+                                     // setting) 3116 ms, 6.2 GB; 31 chunks 3135 ms, 4.4 GB
 #define RCN_BT 64           // train rows per LDS tile (k_coarse_w4; k_coarse_top2: coarse_bt)
 #define RCN_PAD_HN 1.0e30f  // half-norm of padded train rows: never a candidate
 
@@ -1104,8 +1106,7 @@ struct MidArgs {
     float *thr;                            // per sorted row: fp32 threshold, +infinity = not known before the sweep
     unsigned *ccount;                      // per sorted row: candidates found
     int32_t *clist;                        // [rows][RCN_MIDCAP] train rows
-    unsigned *hist, *offs, *cursor;        // per image slot
-    int4 *items;                           // (train slot, first sorted row, rows, 0)
+    unsigned *hist, *offs, *cursor, *ibase; // per image slot (+ 1): rows, first sorted row, fill cursor, first work item
     unsigned *n_items;
     unsigned long long *fb2_list;          // overflowed rows -> K2b
     unsigned *fb2_count;
@@ -1118,15 +1119,37 @@ struct MidArgs {
 };
 __device__ __forceinline__ unsigned mid_rows(const MidArgs &a) { const unsigned n = *a.fb_count; return n < a.midrows ? n : a.midrows; }
 
+// one atomic per distinct key of a wave (the list comes in runs of one pair: a wave usually holds ONE train image, and a single
+// word takes only ~88 atomics per microsecond): returns the value of the counter before this wave's rows + the lane's rank
+__device__ __forceinline__ unsigned wave_count(unsigned *counters, int key, bool live)
+{
+    unsigned res = 0;
+    unsigned long long todo = __ballot(live);
+    const int lane = threadIdx.x & 63;
+    while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const int k = __shfl(key, leader);
+        const unsigned long long peers = __ballot(live && key == k) & todo;
+        unsigned base = 0;
+        if (lane == leader) base = atomicAdd(counters + k, (unsigned)__popcll(peers));
+        base = __shfl(base, leader);
+        if (peers >> lane & 1ull) res = base + (unsigned)__popcll(peers & ((1ull << lane) - 1ull));
+        todo &= ~peers;
+    }
+    return res;
+}
 __global__ __launch_bounds__(256) void k_mid_hist(MidArgs a)
 {
     const unsigned n = mid_rows(a);
-    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const int pair = (int)(a.fb_list[i] >> 32);
-        atomicAdd(a.hist + a.pairs[2 * pair + 1], 1u);
+    for (unsigned i0 = blockIdx.x * blockDim.x; i0 < n; i0 += gridDim.x * blockDim.x) {
+        const unsigned i = i0 + threadIdx.x;
+        const bool live = i < n;
+        const int ts = live ? a.pairs[2 * (int)(a.fb_list[i] >> 32) + 1] : 0;
+        (void)wave_count(a.hist, ts, live);
     }
 }
-// one workgroup: exclusive scan of the bins, the work items (a train image x up to RCN_MIDQ rows), cursors and bins reset
+// one workgroup: exclusive scans of the bins -- rows (offs) and work items (ibase: a train image x up to RCN_MIDQ rows is one item;
+// k_mid_eval finds the bin of item number i by bisection) -- cursors and bins reset
 __global__ __launch_bounds__(1024) void k_mid_bins(MidArgs a)
 {
     __shared__ unsigned s1[1024], s2[1024];
@@ -1145,22 +1168,25 @@ __global__ __launch_bounds__(1024) void k_mid_bins(MidArgs a)
     unsigned r = s1[t] - rows, k = s2[t] - its;
     for (int i = lo; i < hi; ++i) {
         const unsigned h = a.hist[i];
-        a.offs[i] = r; a.cursor[i] = 0u; a.hist[i] = 0u;
-        for (unsigned f = 0; f < h; f += RCN_MIDQ) a.items[k++] = make_int4(i, (int)(r + f), (int)min((unsigned)RCN_MIDQ, h - f), 0);
-        r += h;
+        a.offs[i] = r; a.ibase[i] = k; a.cursor[i] = 0u; a.hist[i] = 0u;
+        r += h; k += (h + RCN_MIDQ - 1) / RCN_MIDQ;
     }
-    if (t == 1023) *a.n_items = s2[1023];
+    if (t == 1023) { *a.n_items = s2[1023]; a.offs[a.n_slots] = s1[1023]; a.ibase[a.n_slots] = s2[1023]; }
 }
 __global__ __launch_bounds__(256) void k_mid_scatter(MidArgs a)
 {
     const unsigned n = mid_rows(a);
     const ScaleDev S = *a.sc;
     const double g = (double)(a.D + 8) * 1.1920928955078125e-7;
-    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const unsigned long long e = a.fb_list[i];
+    for (unsigned i0 = blockIdx.x * blockDim.x; i0 < n; i0 += gridDim.x * blockDim.x) {
+        const unsigned i = i0 + threadIdx.x;
+        const bool live = i < n;
+        const unsigned long long e = live ? a.fb_list[i] : 0ull;
         const int pair = (int)(e >> 32), q = (int)(e & 0xFFFFFFFFu);
-        const int ts = a.pairs[2 * pair + 1];
-        const unsigned pos = a.offs[ts] + atomicAdd(a.cursor + ts, 1u);
+        const int ts = live ? a.pairs[2 * pair + 1] : 0;
+        const unsigned rank = wave_count(a.cursor, ts, live);
+        if (!live) continue;
+        const unsigned pos = a.offs[ts] + rank;
         float thr = INFINITY;
         if (!a.all_to_fallback) {
             const ImgDev qi = a.imgs[a.pairs[2 * pair]];
@@ -1182,133 +1208,186 @@ __global__ __launch_bounds__(256) void k_mid_scatter(MidArgs a)
     }
 }
 // One workgroup (256 threads) per work item.  A sweep: the train image in tiles of 256 rows (one per thread), every tile in
-// 32-float chunks through LDS with whole 128-byte global segments, the item's query rows beside them; thread t accumulates
-// sum (x - y)^2 of ITS train row against each query in fp32.  EMIT: rows under the query's threshold join its candidate list;
-// otherwise the thread keeps the two smallest values it saw per query.
+// 32-float chunks through LDS with whole 128-byte global segments, the item's query rows beside them; thread t accumulates its train row against each query in fp32, two
+// elements per instruction (v_pk_fma_f32).  Two forms of the value:
+//   DIRECT (MODE 0)   v = sum (x - y)^2            relative error g: sharp for near neighbours; the form of the one-sweep path,
+//                                                  whose threshold comes from the coarse pass
+//   PRODUCT (MODE 1, 2)  v = |t|^2 - 2 sum x y     = d2 - |q|^2, absolute error E(q, t) ~ g |q| |t|: the form of the rows that come
+//                     without a threshold.  A query a thousand million times larger than the train rows (a BIG query row,
+//                     fix_scale) has d2 = |q|^2 (1 + O(1e-9)) for EVERY train row: the direct form cannot tell them apart
+//                     in fp32 (all of them would be candidates), the product form orders them by q.t as well as it orders unit rows.
+// MODE 0 / 2 emit the rows under the query's threshold into its candidate list (MODE 2: v - E(q, t) <= U, the row's own error
+// bound); MODE 1 keeps the two smallest UPPER bounds v + E(q, t) the thread saw per query, over the first `rows` train rows only.
 #define MID_LD 36
-template <bool EMIT>
-__device__ __forceinline__ void mid_sweep(const MidArgs &a, const ImgDev &ti, const float *const *qptr, int nq, int first, const float *thr,
-                                          float *tt, float *tq, float (&m1)[RCN_MIDQ], float (&m2)[RCN_MIDQ])
+// |v - (d2 - |q|^2)| <= E: the fp32 dot product ((D + 2) 2^-24 |q| |t|, doubled by the factor 2, with room), the rounding of |t|^2 to
+// fp32 and of the final fma, and the rounding of the oracle's own fp64 chain (the ORDER to reproduce is that of its rounded values)
+__device__ __forceinline__ float mid_err(int D, float qn, float tn)
+{
+    const float s = qn + tn;
+    return ((float)(D + 8) * 2.3841858e-7f * qn * tn + 4.7683716e-7f * tn * tn + (float)(D + 8) * 2.220446e-16f * s * s) * 1.0001f + 1.0e-30f;
+}
+template <int MODE>
+__device__ __forceinline__ void mid_sweep(const MidArgs &a, const ImgDev &ti, const float *const *qptr, int nq, int first, const float *thr, const float *qnorm,
+                                          int rows, float *tt, float *tq, float (&m1)[RCN_MIDQ], float (&m2)[RCN_MIDQ])
 {
     const int t = threadIdx.x, D = a.D, nchunk = (D + 31) / 32;
-    for (int base = 0; base < ti.K; base += 256) {
-        float acc[RCN_MIDQ];
+    const int ntile = (rows + 255) / 256, nit = ntile * nchunk;
+    float4 v[8], vq;
+    auto fetch = [&](int it) {
+        const int base = (it / nchunk) * 256, col = (it % nchunk) * 32 + (t & 7) * 4;
 #pragma unroll
-        for (int q = 0; q < RCN_MIDQ; ++q) acc[q] = 0.f;
-        for (int ch = 0; ch < nchunk; ++ch) {
-            const int col = ch * 32 + (t & 7) * 4;
-            float4 v[8];
+        for (int i = 0; i < 8; ++i) {
+            const int r = base + i * 32 + (t >> 3);
+            v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (col < D && r < rows) v[i] = *reinterpret_cast<const float4 *>(ti.f32 + (size_t)r * D + col);
+        }
+        vq = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (t < 8 * RCN_MIDQ && (t >> 3) < nq && col < D) vq = *reinterpret_cast<const float4 *>(qptr[t >> 3] + col);
+    };
+    float acc[RCN_MIDQ];
+    for (int it = 0; it < nit; ++it) {
+        const int ch = it % nchunk, base = (it / nchunk) * 256;
+        if (ch == 0) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int r = base + i * 32 + (t >> 3);
-                v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (col < D && r < ti.K) v[i] = *reinterpret_cast<const float4 *>(ti.f32 + (size_t)r * D + col);
-            }
-            float4 vq = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (t < 8 * RCN_MIDQ && (t >> 3) < nq && col < D) vq = *reinterpret_cast<const float4 *>(qptr[t >> 3] + col);
-            __syncthreads();                                    // the previous chunk's LDS reads are done
+            for (int q = 0; q < RCN_MIDQ; ++q) acc[q] = 0.f;
+        }
+        fetch(it);                                          // (a prefetch of chunk it + 1 behind the arithmetic costs 32 registers and, with them, three of
+                                                            //  the four workgroups a CU holds: 5.9 ms instead of 3.8 on the mixed-magnitudes grid; packed fp32
+                                                            //  -- v_pk_fma_f32 over pairs of elements -- doubles the accumulators and spills: no faster either)
+        __syncthreads();                                    // the previous chunk's LDS reads are done
 #pragma unroll
-            for (int i = 0; i < 8; ++i) *reinterpret_cast<float4 *>(tt + (i * 32 + (t >> 3)) * MID_LD + (t & 7) * 4) = v[i];
-            if (t < 8 * RCN_MIDQ) *reinterpret_cast<float4 *>(tq + (t >> 3) * MID_LD + (t & 7) * 4) = vq;
-            __syncthreads();
-            float y[32];
+        for (int i = 0; i < 8; ++i) *reinterpret_cast<float4 *>(tt + (i * 32 + (t >> 3)) * MID_LD + (t & 7) * 4) = v[i];
+        if (t < 8 * RCN_MIDQ) *reinterpret_cast<float4 *>(tq + (t >> 3) * MID_LD + (t & 7) * 4) = vq;
+        __syncthreads();
+        float y[32];
+#pragma unroll
+        for (int k4 = 0; k4 < 8; ++k4) {
+            const float4 w4 = *reinterpret_cast<const float4 *>(tt + t * MID_LD + 4 * k4);
+            y[4 * k4] = w4.x; y[4 * k4 + 1] = w4.y; y[4 * k4 + 2] = w4.z; y[4 * k4 + 3] = w4.w;
+        }
+#pragma unroll
+        for (int q = 0; q < RCN_MIDQ; ++q) {
+            if (q >= nq) break;                               // nq is uniform over the workgroup
+            float s = acc[q];
 #pragma unroll
             for (int k4 = 0; k4 < 8; ++k4) {
-                const float4 w4 = *reinterpret_cast<const float4 *>(tt + t * MID_LD + 4 * k4);
-                y[4 * k4] = w4.x; y[4 * k4 + 1] = w4.y; y[4 * k4 + 2] = w4.z; y[4 * k4 + 3] = w4.w;
-            }
-#pragma unroll
-            for (int q = 0; q < RCN_MIDQ; ++q) {
-                if (q >= nq) break;                               // nq is uniform over the workgroup
-                float s = acc[q];
-#pragma unroll
-                for (int k4 = 0; k4 < 8; ++k4) {
-                    const float4 x = *reinterpret_cast<const float4 *>(tq + q * MID_LD + 4 * k4);      // one address for the whole wave: a broadcast
+                const float4 x = *reinterpret_cast<const float4 *>(tq + q * MID_LD + 4 * k4);      // one address for the whole wave: a broadcast
+                if (MODE == 0) {
                     float d;
                     d = x.x - y[4 * k4]; s = fmaf(d, d, s);
                     d = x.y - y[4 * k4 + 1]; s = fmaf(d, d, s);
                     d = x.z - y[4 * k4 + 2]; s = fmaf(d, d, s);
                     d = x.w - y[4 * k4 + 3]; s = fmaf(d, d, s);
+                } else {
+                    s = fmaf(x.x, y[4 * k4], s); s = fmaf(x.y, y[4 * k4 + 1], s);
+                    s = fmaf(x.z, y[4 * k4 + 2], s); s = fmaf(x.w, y[4 * k4 + 3], s);
                 }
-                acc[q] = s;
             }
+            acc[q] = s;
         }
+        if (ch != nchunk - 1) continue;
         const int j = base + t;
-        if (j < ti.K) {
+        if (j < rows) {
+            const float nt = MODE == 0 ? 0.f : (float)ti.nrm2[j];
+            const float tn = MODE == 0 ? 0.f : sqrtf(nt) * 1.000001f;
 #pragma unroll
             for (int q = 0; q < RCN_MIDQ; ++q) {
                 if (q >= nq) break;
-                const float v = acc[q];
-                if (EMIT) {
-                    if (v <= thr[q]) {
+                const float dot = acc[q];
+                const float val = MODE == 0 ? dot : fmaf(-2.f, dot, nt);
+                if (MODE == 0) {
+                    if (val <= thr[q]) {
                         const unsigned pos = atomicAdd(a.ccount + first + q, 1u);
                         if (pos < (unsigned)RCN_MIDCAP) a.clist[(size_t)(first + q) * RCN_MIDCAP + pos] = j;
                     }
-                } else if (v < m1[q]) { m2[q] = m1[q]; m1[q] = v; }
-                else if (v < m2[q]) m2[q] = v;
+                } else {
+                    const float E = mid_err(D, qnorm[q], tn);
+                    if (MODE == 2) {
+                        // (a NaN value fails the test: such a row is never a neighbour, K2b would not select it either; an infinite
+                        //  bound lets everything through, the list overflows and K2b decides)
+                        if (val - E <= thr[q]) {
+                            const unsigned pos = atomicAdd(a.ccount + first + q, 1u);
+                            if (pos < (unsigned)RCN_MIDCAP) a.clist[(size_t)(first + q) * RCN_MIDCAP + pos] = j;
+                        }
+                    } else {
+                        const float ub = val + E;            // the row's exact value is at most this
+                        if (ub < m1[q]) { m2[q] = m1[q]; m1[q] = ub; }
+                        else if (ub < m2[q]) m2[q] = ub;
+                    }
+                }
             }
         }
     }
 }
-__global__ __launch_bounds__(256) void k_mid_eval(MidArgs a)
+__global__ __launch_bounds__(256, 4) void k_mid_eval(MidArgs a)
 {
     __shared__ __attribute__((aligned(16))) float tt[256 * MID_LD];
     __shared__ __attribute__((aligned(16))) float tq[RCN_MIDQ * MID_LD];
     __shared__ const float *qptr[RCN_MIDQ];
-    __shared__ float thr[RCN_MIDQ];
+    __shared__ float thr[RCN_MIDQ], qnorm[RCN_MIDQ];
     __shared__ float red[4][RCN_MIDQ][2];
-    __shared__ int s_need2;
+    __shared__ int s_need2, s_bin;
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const unsigned n_items = *a.n_items;
     for (unsigned it = blockIdx.x; it < n_items; it += gridDim.x) {
-        const int4 item = a.items[it];
-        const int first = item.y, nq = item.z;
-        const ImgDev ti = a.imgs[item.x];
         __syncthreads();                                        // the previous item's readers of qptr / thr are done
-        if (t == 0) s_need2 = 0;
+        if (t == 0) {
+            int lo = 0, hi = a.n_slots;                         // the last bin b with ibase[b] <= it (bins without rows share their successor's base)
+            while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (a.ibase[mid] <= it) lo = mid; else hi = mid; }
+            s_bin = lo;
+            s_need2 = 0;
+        }
         __syncthreads();
+        const int bin = s_bin;
+        const unsigned k = it - a.ibase[bin], h = a.offs[bin + 1] - a.offs[bin];
+        const int first = (int)(a.offs[bin] + RCN_MIDQ * k), nq = (int)min((unsigned)RCN_MIDQ, h - RCN_MIDQ * k);
+        const ImgDev ti = a.imgs[bin];
         if (t < nq) {
             const unsigned long long e = a.sorted[first + t];
             const int pair = (int)(e >> 32), q = (int)(e & 0xFFFFFFFFu);
-            qptr[t] = a.imgs[a.pairs[2 * pair]].f32 + (size_t)q * a.D;
+            const ImgDev qi = a.imgs[a.pairs[2 * pair]];
+            qptr[t] = qi.f32 + (size_t)q * a.D;
+            qnorm[t] = (float)(sqrt(qi.nrm2[q]) * (1.0 + 1e-6));
             const float th = a.thr[first + t];
             thr[t] = th;
             if (!(th < INFINITY)) s_need2 = 1;
         }
         __syncthreads();
         float m1[RCN_MIDQ], m2[RCN_MIDQ];
-        if (s_need2) {
-            // no bound on the second neighbour before the sweep: the second smallest fp32 value is one after it
-#pragma unroll
-            for (int q = 0; q < RCN_MIDQ; ++q) { m1[q] = INFINITY; m2[q] = INFINITY; }
-            mid_sweep<false>(a, ti, qptr, nq, first, thr, tt, tq, m1, m2);
-#pragma unroll
-            for (int q = 0; q < RCN_MIDQ; ++q) {
-                float b1 = m1[q], b2 = m2[q];
-                for (int o = 32; o; o >>= 1) {
-                    const float c1 = __shfl_xor(b1, o), c2 = __shfl_xor(b2, o);
-                    const float lo = fminf(b1, c1), hi = fmaxf(b1, c1);
-                    b2 = fminf(hi, fminf(b2, c2)); b1 = lo;
-                }
-                if (lane == 0) { red[w][q][0] = b1; red[w][q][1] = b2; }
-            }
-            __syncthreads();
-            if (t < nq) {
-                float b1 = red[0][t][0], b2 = red[0][t][1];
-                for (int k = 1; k < 4; ++k) {
-                    const float c1 = red[k][t][0], c2 = red[k][t][1];
-                    const float lo = fminf(b1, c1), hi = fmaxf(b1, c1);
-                    b2 = fminf(hi, fminf(b2, c2)); b1 = lo;
-                }
-                // exact second neighbour <= (b2 + tiny) / (1 - g); rows within that have fp32 value <= b2 (1 + 3 g) + tiny
-                const double g = (double)(a.D + 8) * 1.1920928955078125e-7;
-                const double tv = ((double)b2 * (1.0 + 3.0 * g) + 3.0e-30) * (1.0 + 1.0e-6);
-                const float mine = tv < 3.0e38 ? (float)tv : INFINITY;
-                thr[t] = fminf(thr[t], mine);                   // a bound known before the sweep stays if it is the tighter one
-            }
-            __syncthreads();
+        if (!s_need2) {
+            mid_sweep<0>(a, ti, qptr, nq, first, thr, qnorm, ti.K, tt, tq, m1, m2);
+            continue;
         }
-        mid_sweep<true>(a, ti, qptr, nq, first, thr, tt, tq, m1, m2);
+        // No bound on the second neighbour before the sweep.  ANY two rows give one: the second smallest upper bound over a
+        // prefix of the train image (a quarter of it, at least 512 rows: the expected number of rows of the whole image under
+        // that bound is about eight), then one sweep over the whole image against it.
+        const int prefix = min(ti.K, max(512, ti.K / 4));
+#pragma unroll
+        for (int q = 0; q < RCN_MIDQ; ++q) { m1[q] = INFINITY; m2[q] = INFINITY; }
+        mid_sweep<1>(a, ti, qptr, nq, first, thr, qnorm, prefix, tt, tq, m1, m2);
+#pragma unroll
+        for (int q = 0; q < RCN_MIDQ; ++q) {
+            float b1 = m1[q], b2 = m2[q];
+            for (int o = 32; o; o >>= 1) {
+                const float c1 = __shfl_xor(b1, o), c2 = __shfl_xor(b2, o);
+                const float lo = fminf(b1, c1), hi = fmaxf(b1, c1);
+                b2 = fminf(hi, fminf(b2, c2)); b1 = lo;
+            }
+            if (lane == 0) { red[w][q][0] = b1; red[w][q][1] = b2; }
+        }
+        __syncthreads();
+        if (t < nq) {
+            float b1 = red[0][t][0], b2 = red[0][t][1];
+            for (int kk = 1; kk < 4; ++kk) {
+                const float c1 = red[kk][t][0], c2 = red[kk][t][1];
+                const float lo = fminf(b1, c1), hi = fmaxf(b1, c1);
+                b2 = fminf(hi, fminf(b2, c2)); b1 = lo;
+            }
+            // two rows have exact values <= b2: so has the second neighbour.  A row within that has v - E(q, t) <= b2.
+            thr[t] = b2 < INFINITY ? b2 + fabsf(b2) * 1.0e-6f : INFINITY;      // (a NaN bound compares false: INFINITY, K2b decides)
+        }
+        __syncthreads();
+        mid_sweep<2>(a, ti, qptr, nq, first, thr, qnorm, ti.K, tt, tq, m1, m2);
     }
 }
 // one wave per row of the tier: the canonical fp64 chain of its candidates, (value, index)-ordered top-2, ratio test
@@ -2026,9 +2105,8 @@ int rcn_int_match_grid(rcn_ctx *ctx, const int32_t *pairs_host, int32_t n_pairs,
     const size_t mid_rows_cap = (size_t)std::min<int64_t>(std::max<int64_t>(1, cap_rows), ctx->mid_rows);
     auto al = [](size_t b) { return (b + 255) / 256 * 256; };
     // (the bins come FIRST: their place must not move with the row count of the grid, they carry state -- zeros -- from call to call)
-    const size_t mo_bins = 0, mo_sorted = mo_bins + al(4 * 3 * ((size_t)n_slots + 1)), mo_thr = mo_sorted + al(8 * mid_rows_cap), mo_cc = mo_thr + al(4 * mid_rows_cap),
-                 mo_cl = mo_cc + al(4 * mid_rows_cap), mo_items = mo_cl + al(4 * mid_rows_cap * RCN_MIDCAP),
-                 mo_fb2 = mo_items + al(16 * (mid_rows_cap + (size_t)n_slots + 1)), mo_end = mo_fb2 + al(8 * mid_rows_cap);
+    const size_t mo_bins = 0, mo_sorted = mo_bins + al(4 * 4 * ((size_t)n_slots + 1)), mo_thr = mo_sorted + al(8 * mid_rows_cap), mo_cc = mo_thr + al(4 * mid_rows_cap),
+                 mo_cl = mo_cc + al(4 * mid_rows_cap), mo_fb2 = mo_cl + al(4 * mid_rows_cap * RCN_MIDCAP), mo_end = mo_fb2 + al(8 * mid_rows_cap);
     if (mid) {
         const bool fresh = mo_end > ctx->mid_ws.cap;
         RCN_HIP(ctx->mid_ws.reserve(mo_end));
@@ -2191,8 +2269,8 @@ int rcn_int_match_grid(rcn_ctx *ctx, const int32_t *pairs_host, int32_t n_pairs,
                 memset(&ma, 0, sizeof(ma));
                 ma.imgs = imgs; ma.pairs = pairs; ma.cand = cand_c; ma.fb_list = ra.fb_list; ma.fb_count = ccnt;
                 ma.sorted = (unsigned long long *)(mw + mo_sorted); ma.thr = (float *)(mw + mo_thr); ma.ccount = (unsigned *)(mw + mo_cc);
-                ma.clist = (int32_t *)(mw + mo_cl); ma.items = (int4 *)(mw + mo_items); ma.fb2_list = (unsigned long long *)(mw + mo_fb2);
-                ma.hist = (unsigned *)(mw + mo_bins); ma.offs = ma.hist + (n_slots + 1); ma.cursor = ma.offs + (n_slots + 1);
+                ma.clist = (int32_t *)(mw + mo_cl); ma.fb2_list = (unsigned long long *)(mw + mo_fb2);
+                ma.hist = (unsigned *)(mw + mo_bins); ma.offs = ma.hist + (n_slots + 1); ma.cursor = ma.offs + (n_slots + 1); ma.ibase = ma.cursor + (n_slots + 1);
                 ma.n_items = ccnt + 3; ma.fb2_count = ccnt + 2;
                 ma.out = out_dev; ma.out_stride = out_stride; ma.sc = ra.sc; ma.n_slots = n_slots; ma.kq_stride = kq_stride; ma.D = ctx->D;
                 ma.all_to_fallback = ra.all_to_fallback; ma.idx_mask = idx_mask; ma.ratio = ratio; ma.midrows = (uint32_t)ctx->mid_rows;

@@ -140,9 +140,10 @@ int rcn_int_compact_begin(rcn_ctx *ctx, const int32_t *table_dev, int64_t stride
         return RCN_ERR_ARG;
     }
     if (total == 0) return RCN_OK;
-    const int b = ctx->cmp_next;
-    ctx->cmp_next ^= 1;
-    // staging buffer b was last read by the copy of two calls ago
+    // ONE staging buffer in HBM (round 3 alternated two: 2 x 4.1 GB at cfg 3).  The compaction of step k+1 waits for the copy
+    // of step k on the device (an event, not the host) -- a copy that is issued a whole grid call earlier and has long finished.
+    const int b = 0;
+    // the staging buffer was last read by the copy of the previous call
     if (ctx->cmp_busy[b]) RCN_HIP(hipStreamWaitEvent(st, ctx->cmp_ev[b], 0));
     if ((size_t)total * sizeof(int2) > ctx->cmp_qt[b].cap) {
         if (ctx->cmp_busy[b]) RCN_HIP(hipEventSynchronize(ctx->cmp_ev[b]));

@@ -70,3 +70,66 @@ def test_cfg3_full_grid(gpu_ctx):
         assert st["used_mfma_path"] == 1 and st["rows_total"] == P * K and st["rows_reranked"] > 0
     finally:
         sh.close()
+
+
+def test_a_2000_image_grid_fits_the_device(gpu_ctx):
+    """Twice the images of cfg 3: 2000 x 4096 x 256, 1 999 000 pairs, 8.2e9 query rows.  Round 3 sized the candidate table
+    and the two row lists for the whole grid (3 x 65 GB here, beside 33 GB of results: more than the device has); the
+    pipeline chunks bound them at 0.5 GB each.  Checked through properties of the whole table, through the match the scene
+    plants (row r of image i is a noisy copy of world point (37 i + r) mod 8192), and against the oracle for a few pairs."""
+    import torch
+    from oracle import orc
+    from reconstructor_amd.matcher import HipL2Matcher
+    n, K, D, W = 2000, 4096, 256, 8192
+    gen = torch.Generator(device="cuda").manual_seed(77)
+    world = torch.randn((W, D), generator=gen, device="cuda", dtype=torch.float32)
+    world /= world.norm(dim=1, keepdim=True)
+    block = torch.empty((n, K, D), dtype=torch.float32, device="cuda")
+    ar = torch.arange(K, device="cuda")
+    for i in range(n):
+        rows = world[(37 * i + ar) % W] + 0.02 * torch.randn((K, D), generator=gen, device="cuda")
+        block[i] = rows / rows.norm(dim=1, keepdim=True)
+    P = n * (n - 1) // 2
+    out = torch.empty((P, K), dtype=torch.int32, device="cuda")
+    cnt = torch.empty((P,), dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    m = HipL2Matcher(ctx=gpu_ctx)
+    m.clear()
+    free0, _ = torch.cuda.mem_get_info()
+    m.upload_batch_device(0, n, block.data_ptr(), K, D)
+    gpu_ctx.check(gpu_ctx.lib.rcn_match_grid_device(gpu_ctx.h, None, P, 0.7, out.data_ptr(), K, cnt.data_ptr()))
+    gpu_ctx.check(gpu_ctx.lib.rcn_synchronize(gpu_ctx.h))
+    free1, _ = torch.cuda.mem_get_info()
+    st = m.stats()
+    try:
+        assert st["used_mfma_path"] == 1 and st["rows_total"] == P * K and st["chunks"] > 50
+        # what the library itself holds for this grid: fp16 copies + norms of the images (4.4 GB) and the chunked workspace
+        assert (free0 - free1) / 1e9 < 8.0, (free0 - free1) / 1e9
+        total = 0
+        for a in range(0, P, 16384):
+            t = out[a:a + 16384]
+            assert int(t.min().item()) >= -1 and int(t.max().item()) < K
+            valid = t >= 0
+            assert torch.equal(valid.sum(1).to(torch.int32), cnt[a:a + 16384])
+            total += int(valid.sum().item())
+        assert total > P
+        # the planted correspondence on sampled pairs: query row r of image i and train row r' of image j show the same world
+        # point when 37 i + r = 37 j + r' (mod 8192); nearly all of those rows must be matched, and to exactly that row
+        rng = np.random.default_rng(5)
+        for _ in range(12):
+            i, j = sorted(rng.choice(n, 2, replace=False).tolist())
+            p = i * (2 * n - i - 1) // 2 + (j - i - 1)
+            row = out[p].cpu().numpy()
+            r = np.arange(K)
+            rp = (37 * i + r - 37 * j) % W
+            shared = rp < K
+            hit = row[shared] == rp[shared]
+            assert hit.mean() > 0.97, (i, j, hit.mean())
+            assert (row[~shared] < 0).mean() > 0.97
+        # and the oracle outright on three pairs (first, one in the middle, last pair of the list)
+        for (i, j) in ((0, 1), (731, 1408), (n - 2, n - 1)):
+            p = i * (2 * n - i - 1) // 2 + (j - i - 1)
+            exp, ec = orc.match_grid([block[i].cpu().numpy(), block[j].cpu().numpy()], np.array([[0, 1]], np.int32), threads=8)
+            assert np.array_equal(out[p].cpu().numpy(), exp[0]) and int(cnt[p].item()) == int(ec[0])
+    finally:
+        m.clear()
