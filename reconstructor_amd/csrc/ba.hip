@@ -371,13 +371,25 @@ __global__ __launch_bounds__(256) void k_ba_absmax(const double *a, size_t na, c
 }
 
 // out[slot] = scale * sum(partial[0..n)) in a fixed order (deterministic)
-__global__ __launch_bounds__(256) void k_finish_sum(const double *partial, int n, double *out, double scale)
+// (flag -> flag_out: the factorisation's flag word rides home with the scalars of the step instead of in a copy of its own)
+__global__ __launch_bounds__(256) void k_finish_sum(const double *partial, int n, double *out, double scale, const int *flag = nullptr, double *flag_out = nullptr)
 {
     __shared__ double sh[4];
     double v = 0.0;
     for (int i = threadIdx.x; i < n; i += 256) v += partial[i];
     const double s = block_sum(v, sh);
-    if (threadIdx.x == 0) *out = scale * s;
+    if (threadIdx.x == 0) { *out = scale * s; if (flag) *flag_out = (double)*flag; }
+}
+// the four sums behind k_ba_plus in one launch (block q: partial + q * stride -> out[q]); sums 2 and 3 (gradient . delta, the
+// non-finite count) also go to their second home out2[0 .. 1]: four launches and a device-to-device copy less per LM iteration
+__global__ __launch_bounds__(256) void k_finish_sum4(const double *partial, int n, int stride, double *out, double *out2)
+{
+    __shared__ double sh[4];
+    const int q = blockIdx.x;
+    double v = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) v += partial[(size_t)q * stride + i];
+    const double s = block_sum(v, sh);
+    if (threadIdx.x == 0) { out[q] = s; if (q >= 2) out2[q - 2] = s; }
 }
 
 // K5: per point  Vraw = sum Jp'Jp (3x3), gpraw = sum Jp'r
@@ -874,6 +886,20 @@ __global__ __launch_bounds__(256) void k_ba_schur_diag_fin(BaDev d, double inv_r
     schur_diag_finish(d, c, threadIdx.x, v, inv_radius);
 }
 
+#define RCN_RHS_BETA 1.0e200
+// Everything between the Schur build and the factorisation in ONE launch (round 4; three clears and two small kernels before):
+// the padded rows of the dense system -- zero, identity on the diagonal, the right-hand side in row n under its huge diagonal
+// entry (k_ba_S_rhs_row) -- and the factorisation's flag word and stream counters.
+__global__ __launch_bounds__(256) void k_ba_S_finish(BaDev d)
+{
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x, cnt = (size_t)(d.npad - d.n) * d.npad;
+    if (idx < 8) d.flag[idx] = 0;
+    if (idx >= cnt) return;
+    const int i = d.n + (int)(idx / d.npad), j = (int)(idx % d.npad);
+    double v = i == j ? 1.0 : 0.0;
+    if (i == d.n) v = j < d.n ? d.rhs[j] : (j == d.n ? RCN_RHS_BETA : 0.0);
+    d.S[(size_t)i * d.npad + j] = v;
+}
 // padded rows of the dense system: identity (the gather form writes every other lower block itself)
 __global__ void k_ba_S_pad(BaDev d)
 {
@@ -884,7 +910,6 @@ __global__ void k_ba_S_pad(BaDev d)
 // Forward substitution for free: the reduced right-hand side rides through the factorisation as
 // row n of the padded system (a padding row: zero elsewhere) under a huge diagonal entry, so the
 // panel kernels leave  y = L^-1 b  in that row of the factor:  [S b; b' beta] = [L 0; y' .][L 0; y' .]'.
-#define RCN_RHS_BETA 1.0e200
 __global__ void k_ba_S_rhs_row(BaDev d)
 {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
@@ -892,12 +917,13 @@ __global__ void k_ba_S_rhs_row(BaDev d)
     d.S[(size_t)d.n * d.npad + j] = j < d.n ? d.rhs[j] : RCN_RHS_BETA;
 }
 // y out of row n of the factor: sub-diagonal tiles live in L, the last diagonal tile in S
-__global__ void k_ba_y_from_row(BaDev d)
+__global__ void k_ba_y_from_row(BaDev d, int sentinel)
 {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= d.npad) return;
     const int last0 = (d.npad / NB - 1) * NB;
     d.yc[j] = j < d.n ? (j < last0 ? d.L : d.S)[(size_t)d.n * d.npad + j] : 0.0;
+    if (sentinel) reinterpret_cast<unsigned long long *>(d.rhs)[j] = 0xFFFFFFFFFFFFFFFFull;      // k_trsv_bwd_chain's "not there yet" (the right-hand side itself went into the system's last row)
 }
 
 // dense padded reduced system from the block buffer: lower blocks (c2 <= c) of
@@ -2097,12 +2123,14 @@ int rcn_int_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_option
         RCN_HIP(H2D(p_ocam, pb->obs_cam, sizeof(int) * no));
         RCN_HIP(H2D(p_opt, pb->obs_pt, sizeof(int) * no));
     }
-    RCN_HIP(H2D(p_camobs, cam_obs.data(), sizeof(int) * no));
-    RCN_HIP(H2D(p_ptoff, pt_off.data(), sizeof(int) * (np + 1)));
-    RCN_HIP(H2D(p_camobsoff, cam_obs_off.data(), sizeof(int) * (nc + 1)));
-    RCN_HIP(H2D(p_camoff, cam_off.data(), sizeof(int) * (nc + 1)));
-    RCN_HIP(H2D(p_camdim, cam_dim.data(), sizeof(int) * nc));
-    RCN_HIP(H2D(p_cols, cols.data(), sizeof(int) * 10 * nc));
+    {   // the six structure arrays lie back to back on the device (p_camobs .. p_cols): one copy instead of six
+        std::vector<int> stage((size_t)(p_flag - p_camobs));
+        int *o = stage.data();
+        auto put = [&](const std::vector<int> &v, size_t cnt) { if (cnt) memcpy(o, v.data(), cnt * sizeof(int)); o += cnt; };
+        put(cam_obs, (size_t)no); put(pt_off, (size_t)np + 1); put(cam_obs_off, (size_t)nc + 1); put(cam_off, (size_t)nc + 1); put(cam_dim, (size_t)nc); put(cols, 10 * (size_t)nc);
+        RCN_HIP(H2D(p_camobs, stage.data(), stage.size() * sizeof(int)));
+        RCN_HIP(hipStreamSynchronize(st));      // `stage` leaves scope
+    }
     RCN_HIP(hipMemsetAsync(vecs, 0, sizeof(double) * 12 * nvec, st));
     RCN_HIP(hipMemsetAsync(d.S, 0, sizeof(double) * (size_t)npad * npad, st));   // upper part / padding never rewritten
     RCN_HIP(hipMemsetAsync(d.Linv, 0, sizeof(double) * (size_t)nblk * NB * NB, st));   // upper triangles of the tile inverses stay zero
@@ -2130,6 +2158,9 @@ int rcn_int_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_option
     ctx->ba_pair_token = (gather && np > 0 && res) ? res->pair_token : 0;
     sum->pair_lists_reused = pairs_cached ? 1 : 0;
 
+    // phase times (summary.schur_seconds ...: HIP events on the stream) only where a phase outlasts the six event records of an
+    // iteration: a 25-camera solve is ~35 launches of a few microseconds each, and every record is one more
+    const bool phase_times = no >= 50000;
     double hs[32];
     auto read_scal = [&](int cnt) -> hipError_t {
         hipError_t e = hipMemcpyAsync(hs, d.scal, sizeof(double) * cnt, hipMemcpyDeviceToHost, st);
@@ -2138,23 +2169,23 @@ int rcn_int_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_option
     };
     // cost at (poses,intr,pts) -> scal[slot]; JAC also refreshes the observation rows and the raw blocks
     bool jac_pending = false;
-    auto eval = [&](bool jac, const double *ps, const double *in, const double *x, int slot) -> hipError_t {
+    auto eval = [&](bool jac, const double *ps, const double *in, const double *x, int slot, bool with_flag = false) -> hipError_t {
         if (no > 0) {
             if (jac) {
                 // the streaming kernel of the solve, timed on its own (summary.jacobian_seconds): 224 B written per observation
-                if (jac_pending) {       // the previous pair of events has long completed (a read of the scalars came after it)
+                if (jac_pending && phase_times) {       // the previous pair of events has long completed (a read of the scalars came after it)
                     float ms = 0.f;
                     if (hipEventElapsedTime(&ms, ctx->ba_tev[4], ctx->ba_tev[5]) == hipSuccess) { sum->jacobian_seconds += 1e-3 * ms; sum->jacobian_evals++; }
                     else (void)hipGetLastError();
                 }
                 k_ba_cam_rot<<<(nc + 127) / 128, 128, 0, st>>>(ps, nc, d.crot);
-                (void)hipEventRecord(ctx->ba_tev[4], st);
+                if (phase_times) (void)hipEventRecord(ctx->ba_tev[4], st);
                 k_ba_eval<true><<<ebj, 128, 0, st>>>(d, ps, in, x, d.partial);
-                (void)hipEventRecord(ctx->ba_tev[5], st);
+                if (phase_times) (void)hipEventRecord(ctx->ba_tev[5], st);
                 jac_pending = true;
             } else k_ba_eval<false><<<eb, 256, 0, st>>>(d, ps, in, x, d.partial);
         }
-        k_finish_sum<<<1, 256, 0, st>>>(d.partial, no > 0 ? (jac ? ebj : eb) : 0, d.scal + slot, 0.5);
+        k_finish_sum<<<1, 256, 0, st>>>(d.partial, no > 0 ? (jac ? ebj : eb) : 0, d.scal + slot, 0.5, with_flag ? d.flag : nullptr, d.scal + 13);
         if (jac) {
             if (np > 0) k_ba_point_raw<<<(np + 127) / 128, 128, 0, st>>>(d);
             k_ba_cam_raw<<<nc * csplit, 128 * CR_GROUPS, 0, st>>>(d, csplit);
@@ -2206,11 +2237,18 @@ int rcn_int_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_option
             RCN_HIP(hipGetLastError());
         }
         const double ir = 1.0 / radius;
-        RCN_HIP(hipEventRecord(ctx->ba_tev[0], st));
-        RCN_HIP(hipMemsetAsync(d.flag, 0, 8 * sizeof(int), st));      // [0] breakdown / gate flag, [2..7] progress counters of the factorisation's streams
-        if (!gather) RCN_HIP(hipMemsetAsync(Sb, 0, sizeof(double) * 100 * (size_t)nc * nc, st));
-        if (npad > n) RCN_HIP(hipMemsetAsync(d.S + (size_t)n * npad, 0, sizeof(double) * (size_t)(npad - n) * npad, st));
-        RCN_HIP(hipMemsetAsync(d.rhs, 0, sizeof(double) * npad, st));
+        if (phase_times) RCN_HIP(hipEventRecord(ctx->ba_tev[0], st));
+        // [0] breakdown / gate flag, [2..7] progress counters of the factorisation's streams.  In the default form (gather Schur build, the
+        // right-hand side as row n of the padded system) the flag words, the padded rows and the right-hand-side row are all written by
+        // k_ba_S_finish behind the Schur kernels, and nothing has to be cleared up front: the Schur kernels write every entry of rhs below n.
+        const bool rhs_row = npad > n && !ctx->ba_trsv_fwd;
+        const bool fused_finish = gather && rhs_row;
+        if (!fused_finish) {
+            RCN_HIP(hipMemsetAsync(d.flag, 0, 8 * sizeof(int), st));
+            if (!gather) RCN_HIP(hipMemsetAsync(Sb, 0, sizeof(double) * 100 * (size_t)nc * nc, st));
+            if (npad > n) RCN_HIP(hipMemsetAsync(d.S + (size_t)n * npad, 0, sizeof(double) * (size_t)(npad - n) * npad, st));
+            RCN_HIP(hipMemsetAsync(d.rhs, 0, sizeof(double) * npad, st));
+        }
         if (np > 0) k_ba_point_solve<<<(np + 127) / 128, 128, 0, st>>>(d, ir);
         if (no > 0) k_ba_wy<<<(unsigned)((10 * (size_t)no + 255) / 256), 256, 0, st>>>(d);
         if (gather) {
@@ -2222,16 +2260,16 @@ int rcn_int_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_option
             if (csplit > 1) k_ba_schur_diag_mfma<12><<<nc * csplit, 1024, 0, st>>>(d, pk_off, pk_list, ir, csplit);
             else k_ba_schur_diag_mfma<4><<<nc, 1024, 0, st>>>(d, pk_off, pk_list, ir, 1);
             if (csplit > 1) k_ba_schur_diag_fin<<<nc, 256, 0, st>>>(d, ir, csplit);
-            if (npad > n) k_ba_S_pad<<<(npad - n + 127) / 128, 128, 0, st>>>(d);
+            if (fused_finish) k_ba_S_finish<<<(unsigned)(((size_t)(npad - n) * npad + 255) / 256), 256, 0, st>>>(d);
+            else if (npad > n) k_ba_S_pad<<<(npad - n + 127) / 128, 128, 0, st>>>(d);
         } else {
             if (np > 0) k_ba_schur<<<np, std::min(256, std::max(64, 64 * ((kmax * kmax + 7) / 8))), 0, st>>>(d, Sb);
             k_ba_S_assemble<<<nc + 1, 256, 0, st>>>(d, Sb, ir);
             k_ba_cam_rhs<<<nc, 64, 0, st>>>(d);
         }
-        const bool rhs_row = npad > n && !ctx->ba_trsv_fwd;
-        if (rhs_row) k_ba_S_rhs_row<<<(n + 1 + 255) / 256, 256, 0, st>>>(d);
+        if (rhs_row && !fused_finish) k_ba_S_rhs_row<<<(n + 1 + 255) / 256, 256, 0, st>>>(d);
         RCN_HIP(hipGetLastError());
-        RCN_HIP(hipEventRecord(ctx->ba_tev[1], st));
+        if (phase_times) RCN_HIP(hipEventRecord(ctx->ba_tev[1], st));
         // Dense Cholesky, right-looking, 128-wide panels, on three streams with critical-tile-first ordering.  Step k:
         //   D(k)  diagonal block (k, k) -> its factor's inverse                                   k_chol_diag      chain A
         //   T(k)  the critical tile: L(k+1, k) = S(k+1, k) Linv_k', then S(k+1, k+1) -= L(k+1, k) L(k+1, k)'
@@ -2351,31 +2389,33 @@ int rcn_int_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_option
         };
         // (up to two blocks there is no panel rest, no column rest and no bulk update: nothing for the other two streams to do)
         RCN_HIP(factorise(ctx->chol_safe || nblk <= 2));
-        RCN_HIP(hipEventRecord(ctx->ba_tev[2], st));
-        if (rhs_row) k_ba_y_from_row<<<(npad + 255) / 256, 256, 0, st>>>(d);
+        if (phase_times) RCN_HIP(hipEventRecord(ctx->ba_tev[2], st));
+        const bool chain = ctx->trsv_chain && 2 * nblk <= ctx->prop.multiProcessorCount;
+        if (rhs_row) k_ba_y_from_row<<<(npad + 255) / 256, 256, 0, st>>>(d, chain ? 1 : 0);
         else for (int kb = 0; kb < nblk; ++kb) k_trsv_fwd<<<nblk - kb, 128, 0, st>>>(d.L, npad, kb, d.Linv, d.rhs, d.yc);
-        if (ctx->trsv_chain && 2 * nblk <= ctx->prop.multiProcessorCount) {
-            RCN_HIP(hipMemsetAsync(d.rhs, 0xFF, sizeof(double) * npad, st));      // the sentinel (the right-hand side itself went into the system's last row)
+        if (chain) {
+            if (!rhs_row) RCN_HIP(hipMemsetAsync(d.rhs, 0xFF, sizeof(double) * npad, st));      // the sentinel
             k_trsv_bwd_chain<<<nblk, 512, 0, st>>>(d.L, npad, nblk, d.Linv, d.yc, d.rhs, d.flag);
         }
         else for (int kb = nblk - 1; kb >= 0; --kb) k_trsv_bwd<<<kb + 1, 512, 0, st>>>(d.L, npad, kb, d.Linv, d.yc, d.rhs);
         RCN_HIP(hipGetLastError());
-        RCN_HIP(hipMemcpyAsync(d.yc, d.rhs, sizeof(double) * npad, hipMemcpyDeviceToDevice, st));
-        if (no > 0) k_ba_backsub_obs<<<ebj, 128, 0, st>>>(d);
-        k_ba_backsub<<<std::max((std::max(n, np) + 127) / 128, 1), 128, 0, st>>>(d);
+        {   // the solution sits in d.rhs: the two kernels that read it take it from there (round 3 copied it to d.yc first)
+            BaDev dx = d;
+            dx.yc = d.rhs;
+            if (no > 0) k_ba_backsub_obs<<<ebj, 128, 0, st>>>(dx);
+            k_ba_backsub<<<std::max((std::max(n, np) + 127) / 128, 1), 128, 0, st>>>(dx);
+        }
         if (no > 0) k_ba_model<<<ebj, 128, 0, st>>>(d, d.partial);
         k_finish_sum<<<1, 256, 0, st>>>(d.partial, no > 0 ? ebj : 0, d.scal + 2, -1.0);
         // candidate at alpha = 1 (+ norms, gradient.delta, finite check) and its cost
         k_ba_plus<<<pbk, 256, 0, st>>>(d, 1.0, d.partial, pbk);
-        for (int q = 0; q < 4; ++q) k_finish_sum<<<1, 256, 0, st>>>(d.partial + (size_t)q * pbk, pbk, d.scal + 3 + q, 1.0);
-        // scal: [3] |dx|^2  [4] |x|^2  [5] g.delta -> moved to [8]  [6] non-finite count -> [9]
+        // scal: [3] |dx|^2  [4] |x|^2  [5] g.delta, also in [8]  [6] non-finite count, also in [9]
+        k_finish_sum4<<<4, 256, 0, st>>>(d.partial, pbk, pbk, d.scal + 3, d.scal + 8);
         RCN_HIP(hipGetLastError());
-        RCN_HIP(hipMemcpyAsync(d.scal + 8, d.scal + 5, 2 * sizeof(double), hipMemcpyDeviceToDevice, st));
-        RCN_HIP(eval(false, d.poses2, d.intr2, d.pts2, 1));
-        int hflag = 0;
-        RCN_HIP(hipMemcpyAsync(&hflag, d.flag, sizeof(int), hipMemcpyDeviceToHost, st));
-        RCN_HIP(hipEventRecord(ctx->ba_tev[3], st));
-        RCN_HIP(read_scal(13));
+        RCN_HIP(eval(false, d.poses2, d.intr2, d.pts2, 1, true));       // + the factorisation's flag word into scal[13]
+        if (phase_times) RCN_HIP(hipEventRecord(ctx->ba_tev[3], st));
+        RCN_HIP(read_scal(14));
+        const int hflag = (int)hs[13];
         if (grad_pending) {
             grad_pending = false;
             if (hs[12] <= opt->gradient_tolerance) {      // converged before this step: it does not count and is not looked at
@@ -2384,7 +2424,7 @@ int rcn_int_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_option
                 break;
             }
         }
-        {
+        if (phase_times) {
             float ms = 0.f;
             RCN_HIP(hipEventElapsedTime(&ms, ctx->ba_tev[0], ctx->ba_tev[1])); sum->schur_seconds += 1e-3 * ms;
             RCN_HIP(hipEventElapsedTime(&ms, ctx->ba_tev[1], ctx->ba_tev[2])); sum->cholesky_seconds += 1e-3 * ms;
@@ -2496,7 +2536,7 @@ int rcn_int_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_option
     }
     RCN_HIP(hipStreamSynchronize(st));
     sum->solve_seconds = now_s() - t_start;
-    if (jac_pending) {
+    if (jac_pending && phase_times) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, ctx->ba_tev[4], ctx->ba_tev[5]) == hipSuccess) { sum->jacobian_seconds += 1e-3 * ms; sum->jacobian_evals++; }
         else (void)hipGetLastError();

@@ -325,7 +325,8 @@ struct CoarseArgs {
 //   ring of RCN_NBUF buffers by LDS-DMA, RCN_PD tiles ahead, across pair boundaries; one raw
 //   s_barrier per tile behind a counted s_waitcnt vmcnt (never 0 in steady state).
 // ABL (ablation bits, diagnostics only -- results are wrong unless ABL == 0):
-//   1 skip the top-2 epilogue, 8 stage only the first tiles.
+//   1 skip the top-2 epilogue, 2 fold the VALUES only (two vector operations per element instead of three: what an exact top-2
+//   without the index in the key would cost), 8 stage only the first tiles.
 // SH: MFMA shape.  0: v_mfma_f32_32x32x16_f16 (two 32-column blocks per wave, 16 accumulators per lane and tile);
 //   1: v_mfma_f32_16x16x32_f16 -- the same 64 query columns per wave as four 16-column blocks, a 32-row train block as
 //   two 16-row halves, 4 accumulators per lane and tile; same operand bytes per MAC from LDS, same registers, same
@@ -502,13 +503,13 @@ __global__ __launch_bounds__(512, 2) void k_coarse_top2(CoarseArgs a)
             if (!(ABL & 1)) {
 #pragma unroll
                 for (int reg = ks * 16 / KS; reg < (ks + 1) * 16 / KS; ++reg)
-                    top2(0, (__float_as_uint(p0v[reg]) & hmask) | (prev_rowbase + (reg & 3) + 8 * (reg >> 2)));
+                    top2(0, (ABL & 2) ? __float_as_uint(p0v[reg]) : ((__float_as_uint(p0v[reg]) & hmask) | (prev_rowbase + (reg & 3) + 8 * (reg >> 2))));
             }
             c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bq[1][ks], ks == 0 ? hnv : c1, 0, 0, 0);
             if (!(ABL & 1)) {
 #pragma unroll
                 for (int reg = ks * 16 / KS; reg < (ks + 1) * 16 / KS; ++reg)
-                    top2(1, (__float_as_uint(p1v[reg]) & hmask) | (prev_rowbase + (reg & 3) + 8 * (reg >> 2)));
+                    top2(1, (ABL & 2) ? __float_as_uint(p1v[reg]) : ((__float_as_uint(p1v[reg]) & hmask) | (prev_rowbase + (reg & 3) + 8 * (reg >> 2))));
             }
         };
 #pragma unroll
@@ -2226,11 +2227,17 @@ int rcn_int_match_grid(rcn_ctx *ctx, const int32_t *pairs_host, int32_t n_pairs,
                     }
                 } else {
                     switch (ctx->DP) {
-                    case 32: e = launch_coarse<32>(ctx, ca, blocks); break;
+                    case 32:
+#ifdef RCN_DIAG
+                        if (ctx->ablate == 1) { e = launch_coarse<32, 1, 0>(ctx, ca, blocks); break; }
+                        if (ctx->ablate == 2) { e = launch_coarse<32, 2, 0>(ctx, ca, blocks); break; }
+#endif
+                        e = launch_coarse<32>(ctx, ca, blocks); break;
                     case 64: e = launch_coarse<64>(ctx, ca, blocks); break;
                     case 128:
 #ifdef RCN_DIAG
                         if (ctx->ablate == 1) { e = launch_coarse<128, 1, 0>(ctx, ca, blocks); break; }   // timing only: no top-2 fold
+                        if (ctx->ablate == 2) { e = launch_coarse<128, 2, 0>(ctx, ca, blocks); break; }   // timing only: values-only fold
 #endif
                         e = launch_coarse<128>(ctx, ca, blocks); break;
                     default: e = launch_coarse<256>(ctx, ca, blocks); break;
