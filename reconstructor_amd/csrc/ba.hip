@@ -20,6 +20,7 @@
 // The LM control flow on the host follows Ceres' TrustRegionMinimizer / LevenbergMarquardt
 // strategy step by step (same order of tests as the CPU restatement used for parity).
 #include "rcn_internal.h"
+#include <utility>
 #include "ba_linesearch.h"
 
 #include <cfloat>
@@ -1434,6 +1435,12 @@ void k_gemm_q(double *S, double *L, int ld, int kb, int first, int m, const doub
 // stride 128; no C tile, the product itself is stored): the rows of a panel below the critical tile, a tile per workgroup.
 // S is the matrix the result is written to (MODE 0: S, updated in place; MODE 1: L), Lm the matrix A is read from.
 #define PIPE_PRIO 0x200      // flag in toff: raise the wave priority (launches on the panel stream: they share SIMDs with the bulk update)
+#define PIPE_HEAD(h) ((h) << 12)   // field in toff: the launch's first h tile columns lead its map and signal tile by tile
+// f(integral_constant<int, BASE + I>) for I = 0 .. : the stage loop with the stage number as a compile-time constant
+template <int BASE, int... I, class F> __device__ __forceinline__ void pipe_for_seq(std::integer_sequence<int, I...>, F &&f)
+{
+    (f(std::integral_constant<int, BASE + I>{}), ...);
+}
 template <int DBG, int NST, int MODE = 0>
 __global__ __launch_bounds__(256, 2) void k_gemm_nt_pipe(double *S, const double *Lm, int ld, int kb, const unsigned *__restrict__ map, int toff, int *sig,
                                                           const double *Linv = nullptr)
@@ -1443,6 +1450,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt_pipe(double *S, const double
     const unsigned e = map[blockIdx.x];
     if (e == ~0u) return;
     if (toff & PIPE_PRIO) __builtin_amdgcn_s_setprio(2);
+    const unsigned head = (unsigned)(toff >> 12) & 15u;      // leading tile columns whose finished tiles are counted in *sig
     toff &= 0xff;
     [[maybe_unused]] const int tl_id = 8 * kb + (MODE == 1 ? 3 : toff == 1 ? 4 : 6);
     TL_MARK(tl_id, 0);
@@ -1466,11 +1474,12 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt_pipe(double *S, const double
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f64x4){0.0, 0.0, 0.0, 0.0};
-    const double *srcA = A + (size_t)(32 * w + fr) * ld + 2 * fk;
+    const double *srcA = A + (size_t)(32 * w + fr) * ld + 2 * fk;      // (advanced by the rolled middle of a long pass)
     const double *srcB = B + (size_t)(32 * w + fr) * ldb + 2 * fk;
-    auto issue = [&](int s) {
-        char *buf = gsm + (s % GST) * GSTAGE_BYTES + 2048 * w;
-        const int k0 = 8 * s;
+    // slot: ring slot of the stage (stage number mod GST); k0: its first column relative to where srcA / srcB point (the rolled
+    // middle of a long pass advances the two pointers, so that the offset stays an immediate)
+    auto issue = [&](int slot, int k0) {
+        char *buf = gsm + slot * GSTAGE_BYTES + 2048 * w;
         if (DBG & 4) return;
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
@@ -1498,14 +1507,14 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt_pipe(double *S, const double
         }
     };
     // "=&v": an LDS read writes its destination when the data returns -- it must not share a register with an address
-    auto read_stage = [&](int P, int s) {
-        const unsigned so = (unsigned)((s % GST) * GSTAGE_BYTES);
+    auto read_stage = [&](int P, int slot) {      // slot: ring slot of the stage that is read (stage number mod GST)
+        const unsigned so = (unsigned)(slot * GSTAGE_BYTES);
         asm volatile("ds_read_b128 %0, %8\n\tds_read_b128 %1, %8 offset:1024\n\tds_read_b128 %2, %8 offset:2048\n\tds_read_b128 %3, %8 offset:3072\n\t"
                      "ds_read_b128 %4, %9\n\tds_read_b128 %5, %9 offset:1024\n\tds_read_b128 %6, %9 offset:2048\n\tds_read_b128 %7, %9 offset:3072"
                      : "=&v"(ra[P][0]), "=&v"(ra[P][1]), "=&v"(ra[P][2]), "=&v"(ra[P][3]), "=&v"(rb[P][0]), "=&v"(rb[P][1]), "=&v"(rb[P][2]), "=&v"(rb[P][3])
                      : "v"(offA + so), "v"(offB + so) : "memory");
     };
-    for (int s = 0; s < GST; ++s) issue(s);
+    for (int s = 0; s < GST; ++s) issue(s, 8 * s);
     // Stage s sits in register buffer s & 1.  Per stage: make stage s + 1 visible (its DMA pieces have landed for every
     // wave) and refill the ring slot stage s has just left; fold C tile s in; request C tile s + 2; request the operands of
     // stage s + 1; the 32 MFMAs.  The sixteen 16x16 tiles of C are requested ONE at a time, tiles 0 and 1 behind the ring's
@@ -1518,7 +1527,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt_pipe(double *S, const double
     typedef int v2i __attribute__((ext_vector_type(2)));
     v2i craw[2][4];
     constexpr int NCT = MODE == 0 ? 16 : 0;            // C tiles
-    const bool with_c = NCT > 0 && !(DBG & 1);
+    constexpr bool with_c = NCT > 0 && !(DBG & 1);
     auto c_req = [&](int tile) {
         // inline asm: a load the compiler issues itself it also waits for itself, with vmcnt(0) -- the counter is in-order and
         // it cannot tell the DMA pieces behind the load from the load -- which would drain the ring at every stage
@@ -1543,30 +1552,38 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt_pipe(double *S, const double
     wait_vm(12 + 4 * n_c(0, 1));
     __builtin_amdgcn_s_barrier();
     read_stage(0, 0);
-#pragma unroll
-    for (int s = 0; s < NST; ++s) {
-        const int P = s & 1;
+    // One stage.  SC >= 0: the stage number is a compile-time constant (the first sixteen stages, which carry the C tiles, and the
+    // last four, whose waits shrink with the ring); SC < 0: a stage of the rolled middle of a long pass (K = 384, 512: round 4),
+    // stage number s_rt at run time, parity PAR of its register buffer at compile time, every wait the steady-state literal.
+    auto stage = [&](auto sc, auto pos, int s_rt) {
+        constexpr int SC = decltype(sc)::value, POS = decltype(pos)::value, P = POS & 1;      // POS: stage number mod GST
+        constexpr bool mid = SC < 0;
+        const int s = mid ? s_rt : SC;
         // my reads of stage s (requested one stage ago) have returned: the fragments are in their registers and the ring
         // slot is free on my side.  The ONLY LDS wait of the step -- the reads of stage s + 1 requested below stay in flight
         // behind this step's MFMAs (a wait in front of the MFMAs would wait for them too: the counter is in-order)
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ra[P][0]), "+v"(ra[P][1]), "+v"(ra[P][2]), "+v"(ra[P][3]), "+v"(rb[P][0]), "+v"(rb[P][1]), "+v"(rb[P][2]), "+v"(rb[P][3]) :: "memory");
-        if (s + 1 < NST) {
+        if (mid || SC + 1 < NST) {
             // needs D(s+1).  Younger: D(s+2), D(s+3); the C loads issued behind D(s+1): C0, C1 behind the prologue (all of
             // D0 .. D3 precede them), C(t+2) behind D(t+4) at stage t, i.e. C(s-1) .. C(s+1) for s >= 3
-            const int c_younger = s + 1 <= 3 ? n_c(0, s + 1) : n_c(s - 1, s + 1);
-            wait_vm(4 * ((s + 2 < NST) + (s + 3 < NST)) + 4 * c_younger);
+            if constexpr (mid) wait_vm(8);
+            else {
+                constexpr int c_younger = SC + 1 <= 3 ? (with_c ? (SC + 2 < NCT ? SC + 2 : NCT) : 0) : (with_c ? ((SC - 1 < NCT) + (SC < NCT) + (SC + 1 < NCT)) : 0);
+                wait_vm(4 * ((SC + 2 < NST) + (SC + 3 < NST)) + 4 * c_younger);
+            }
             __builtin_amdgcn_s_barrier();
-            if (s + GST < NST) issue(s + GST);                      // into the slot of stage s
+            if constexpr (mid) issue(POS, 8 * POS);                 // into the slot of stage s (the pointers stand at the loop trip's first stage + GST)
+            else if constexpr (SC + GST < NST) issue(POS, 8 * (SC + GST));
         }
-        if (with_c && s < NCT) {
+        if constexpr (!mid && with_c && SC < NCT) {
             // needs C(s), requested two stages ago (tiles 0, 1: behind the prologue).  Younger: C(s+1), and every D issued
             // behind C(s): D(s+3) and D(s+4) for s >= 2, D4 and D5 for s = 1, D4 for s = 0 -- those that exist
-            const int d_younger = s >= 2 ? (s + 3 < NST) + (s + GST < NST) : (s == 1 ? (4 < NST) + (5 < NST) : (4 < NST));
-            wait_vm(4 * d_younger + 4 * n_c(s + 1, s + 1));
-            fold(s);
-            if (s + 2 < NCT) c_req(s + 2);
+            constexpr int d_younger = SC >= 2 ? (SC + 3 < NST) + (SC + GST < NST) : (SC == 1 ? (4 < NST) + (5 < NST) : (4 < NST));
+            wait_vm(4 * d_younger + 4 * (SC + 1 < NCT ? 1 : 0));
+            fold(SC);
+            if (SC + 2 < NCT) c_req(SC + 2);
         }
-        if (s + 1 < NST) read_stage(1 - P, s + 1);
+        if (mid || SC + 1 < NST) read_stage(1 - P, (POS + 1) % GST);
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -1574,6 +1591,21 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt_pipe(double *S, const double
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(ra[P][i][h], rb[P][j][h], acc[i][j], 0, 0, 0);
+    };
+    using ic_m1 = std::integral_constant<int, -1>;
+    static_assert(GST == 4, "the rolled middle advances one ring turn per trip");
+    if constexpr (NST <= 32) {
+        // every stage at compile time (K = 128, 256)
+        pipe_for_seq<0>(std::make_integer_sequence<int, NST>{}, [&](auto sc) { stage(sc, std::integral_constant<int, decltype(sc)::value % GST>{}, 0); });
+    } else {
+        pipe_for_seq<0>(std::make_integer_sequence<int, 16>{}, [&](auto sc) { stage(sc, std::integral_constant<int, decltype(sc)::value % GST>{}, 0); });
+        srcA += 8 * (16 + GST); srcB += 8 * (16 + GST);                 // stage 16 issues stage 20
+        for (int s4 = 16; s4 < NST - 4; s4 += 4) {
+            stage(ic_m1{}, std::integral_constant<int, 0>{}, s4); stage(ic_m1{}, std::integral_constant<int, 1>{}, s4 + 1);
+            stage(ic_m1{}, std::integral_constant<int, 2>{}, s4 + 2); stage(ic_m1{}, std::integral_constant<int, 3>{}, s4 + 3);
+            srcA += 8 * GST; srcB += 8 * GST;
+        }
+        pipe_for_seq<NST - 4>(std::make_integer_sequence<int, 4>{}, [&](auto sc) { stage(sc, std::integral_constant<int, decltype(sc)::value % GST>{}, 0); });
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -1588,7 +1620,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt_pipe(double *S, const double
                 }
     // A two-panel update tells the other streams when its first two tile columns are done, tile by tile: they are all
     // the next two diagonal blocks and panels need of it, and they come first in its map (build_bulk_maps).
-    if (sig && (e & 0xffffu) < 2u) {
+    if (sig && (e & 0xffffu) < head) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (t == 0) __hip_atomic_fetch_add(sig, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
@@ -1906,10 +1938,10 @@ static int build_bulk_maps(rcn_ctx *ctx, int nblk)
     ctx->pair_map_grid.assign(nm, 0);
     // head2: the tiles of the first two columns lead the map, rows dealt to the XCDs eight apart (the two tiles of a row
     // share its panel rows in that XCD's L2); the rest of the triangle follows in supertiles as before
-    auto make = [&](int mt, bool head2, std::vector<int> &off, std::vector<int> &grid) {
+    auto make = [&](int mt, int head, std::vector<int> &off, std::vector<int> &grid) {
         std::vector<unsigned> per[8];
-        const int c_first = head2 ? std::min(2, mt) : 0;
-        if (head2)
+        const int c_first = std::min(head, mt);
+        if (head > 0)
             for (int r = 0; r < mt; ++r)
                 for (int c = 0; c < c_first && c <= r; ++c) per[r & 7].push_back(((unsigned)r << 16) | (unsigned)c);
         const int SS = mt >= 24 ? 4 : 2, R = (mt + SS - 1) / SS;
@@ -1936,16 +1968,22 @@ static int build_bulk_maps(rcn_ctx *ctx, int nblk)
         for (size_t sl = 0; sl < slots; ++sl)
             for (int x = 0; x < 8; ++x) all.push_back(sl < per[x].size() ? per[x][sl] : ~0u);
     };
+    ctx->quad_map_off.assign(nm, 0);
+    ctx->quad_map_grid.assign(nm, 0);
     for (int mt = 1; mt <= nblk - 2; ++mt) {
-        make(mt, false, ctx->bulk_map_off, ctx->bulk_map_grid);
-        make(mt, true, ctx->pair_map_off, ctx->pair_map_grid);
+        make(mt, 0, ctx->bulk_map_off, ctx->bulk_map_grid);
+        make(mt, 2, ctx->pair_map_off, ctx->pair_map_grid);
+        make(mt, 4, ctx->quad_map_off, ctx->quad_map_grid);
     }
-    // tile columns for the pipelined kernel on the panel stream: rows 1, 2, .. of column 0 (a panel below its critical tile,
-    // the rest of the first trailing column) and the same rows of columns 0 and 1 side by side (first of a pair)
-    ctx->col_map_off1 = (int)all.size();
-    for (int r = 1; r <= nblk; ++r) all.push_back((unsigned)r << 16);
-    ctx->col_map_off2 = (int)all.size();
-    for (int r = 1; r <= nblk; ++r) { all.push_back((unsigned)r << 16); all.push_back(((unsigned)r << 16) | 1u); }
+    // tile columns for the pipelined kernel on the panel stream, row-major: column 0 from row 1 (a panel below its critical tile, the
+    // rest of the first trailing column), columns 1 .. nc - 1 from their diagonal tile -- the trailing columns the first steps of a
+    // group of panels update themselves.  A launch for m tile rows takes the leading col_map_count(m, nc) entries.
+    for (int ncol = 1; ncol <= 4; ++ncol) {
+        ctx->col_map_offn[ncol] = (int)all.size();
+        for (int r = 1; r <= nblk; ++r)
+            for (int c = 0; c < ncol && c <= r; ++c) all.push_back(((unsigned)r << 16) | (unsigned)c);
+    }
+    ctx->col_map_off1 = ctx->col_map_offn[1];
     RCN_HIP(hipStreamSynchronize(ctx->stream));          // nobody may still read the old maps
     RCN_HIP(ctx->bulk_map.reserve(all.size() * sizeof(unsigned)));
     RCN_HIP(hipMemcpy(ctx->bulk_map.p, all.data(), all.size() * sizeof(unsigned), hipMemcpyHostToDevice));
@@ -2137,6 +2175,7 @@ int rcn_int_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_option
     RCN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_chol_diag), hipFuncAttributeMaxDynamicSharedMemorySize, NB * DL * 8));
     RCN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_nt_pipe<0, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, GST * GSTAGE_BYTES));
     RCN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_nt_pipe<0, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, GST * GSTAGE_BYTES));
+    RCN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_nt_pipe<0, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, GST * GSTAGE_BYTES));
     RCN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_nt_pipe<0, 16, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, GST * GSTAGE_BYTES));
     { int rcm = build_bulk_maps(ctx, nblk); if (rcm) return rcm; }
     RCN_HIP(hipStreamSynchronize(st));   // host vectors go out of use; timing starts with inputs resident
@@ -2315,12 +2354,20 @@ int rcn_int_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_option
                 if (e != hipSuccess) return e;
             }
             const unsigned *maps = ctx->bulk_map.as<unsigned>();
-            bool pair_open = false;                   // the step before this one was the first of a pair
+            // GROUPS of panels (round 4 generalises round 3's pairs).  While many tile rows remain, g = 4 (then 2) consecutive steps
+            // form a group: step number i of it (i = 0 .. g-1) updates the g - i tile columns behind its own panel itself (C),
+            // so that the whole group can be factored without a bulk update, and the last step's bulk kernel applies all g
+            // panels at once, K = 128 g, to the columns behind the group: the C tile of the bulk kernel travels once per 512 k
+            // instead of once per 256 (tools/gemm_nt_bench: 60.6 TFLOP/s against 55.6), and half as many launches fill and drain
+            // the chip.  The price is column work on the panel stream: (g + 1) / 2 columns per step instead of 1.5.
+            int g_size = 1, g_pos = 0;                // size of the current group, position of this step in it
+            auto col_map_count = [](int mrows, int ncol) { int k = 0; for (int r = 1; r <= mrows - 1; ++r) k += std::min(ncol, r + 1); return k; };
             for (int kb = 0; kb < nblk; ++kb) {
                 const int m = nblk - kb - 1;          // tiles below the diagonal block
-                const bool second = pair_open;
-                const bool first_of_pair = !second && m - 2 >= ctx->chol_pair_min && m >= 4;
-                const bool two_cols = first_of_pair;
+                if (g_pos == 0)                       // a new group: its bulk update covers m - g tile rows
+                    g_size = (ctx->chol_group >= 4 && m - 4 >= ctx->chol_pair_min && m >= 6) ? 4 : (ctx->chol_group >= 2 && m - 2 >= ctx->chol_pair_min && m >= 4) ? 2 : 1;
+                const int ncols = g_size - g_pos;     // trailing columns C(kb) updates: kb + 1 .. kb + ncols (a step on its own: the first one)
+                const bool last_of_group = g_pos == g_size - 1;
                 // D(kb): publishes "T(kb-1) done"
                 k_chol_diag<<<1, 64 * CDW, NB * DL * 8, sA>>>(d.S, npad, kb, d.Linv, d.flag, kb == nblk - 1, gate(nullptr, 0, Wr{nullptr, 0}, cT, kb));
                 if (m <= 0) break;
@@ -2345,25 +2392,30 @@ int rcn_int_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_option
                     if (piped) k_gemm_nt_pipe<0, 16, 1><<<m - 1, 256, GST * GSTAGE_BYTES, sB>>>(d.L, d.S, npad, kb, maps + ctx->col_map_off1, 1 | PIPE_PRIO, nullptr, d.Linv);
                     else k_gemm_q<0><<<gq, 256, 0, sB>>>(d.S, d.L, npad, kb, 1, m - 1, d.Linv, none);
                     // C(kb): its gate publishes "P(kb) done" and waits for T(kb) and the bulk updates of the column(s) it writes
-                    if (!safe) k_ring_gate<<<1, 64, 0, sB>>>(gate(cT, kb + 1, two_cols ? later(lastw[kb + 1], lastw[kb + 2]) : lastw[kb + 1], cP, kb + 1));
-                    if (piped) {
-                        if (two_cols) k_gemm_nt_pipe<0, 16><<<2 * (m - 1), 256, GST * GSTAGE_BYTES, sB>>>(d.S, d.L, npad, kb, maps + ctx->col_map_off2, 1 | PIPE_PRIO, nullptr);
-                        else k_gemm_nt_pipe<0, 16><<<m - 1, 256, GST * GSTAGE_BYTES, sB>>>(d.S, d.L, npad, kb, maps + ctx->col_map_off1, 1 | PIPE_PRIO, nullptr);
-                    } else {
-                        k_gemm_q<1><<<gq, 256, 0, sB>>>(d.S, d.L, npad, kb, 1, m - 1, d.Linv, none);
-                        if (two_cols) k_gemm_q<1><<<gq, 256, 0, sB>>>(d.S, d.L, npad, kb, 1, m - 1, d.Linv, none, 2);
+                    {
+                        Wr wcols = lastw[kb + 1];
+                        for (int c = 2; c <= ncols; ++c) wcols = later(wcols, lastw[kb + c]);
+                        if (!safe) k_ring_gate<<<1, 64, 0, sB>>>(gate(cT, kb + 1, wcols, cP, kb + 1));
                     }
-                    if (first_of_pair) {
-                        pair_open = true;             // no bulk kernel at this step
-                    } else if (second) {
-                        // B(kb), two panels: columns >= kb + 2, counted from kb - 1; waits for P(kb)
-                        pair_open = false;
-                        const int mt = m - 1;
+                    if (piped) {
+                        k_gemm_nt_pipe<0, 16><<<col_map_count(m, ncols), 256, GST * GSTAGE_BYTES, sB>>>(d.S, d.L, npad, kb, maps + ctx->col_map_offn[ncols], 1 | PIPE_PRIO, nullptr);
+                    } else {
+                        for (int c = 1; c <= ncols; ++c) k_gemm_q<1><<<gq, 256, 0, sB>>>(d.S, d.L, npad, kb, 1, m - 1, d.Linv, none, c);
+                    }
+                    if (!last_of_group) {
+                        ++g_pos;                      // no bulk kernel at this step
+                    } else if (g_size > 1) {
+                        // B(kb), g panels: columns >= kb + 2, panels counted from kb - (g - 1); waits for P(kb)
+                        const int mt = m - 1, head = g_size == 4 ? 4 : 2;
+                        g_pos = 0;
                         ++bulk_ord;
                         if (!safe) k_ring_gate<<<1, 64, 0, sC>>>(gate(cP, kb + 1, Wr{nullptr, 0}, cB, bulk_ord - 1));
-                        k_gemm_nt_pipe<0, 32><<<ctx->pair_map_grid[mt], 256, GST * GSTAGE_BYTES, sC>>>(d.S, d.L, npad, kb - 1, maps + ctx->pair_map_off[mt], 3, safe ? nullptr : sig);
-                        sig_cum += mt >= 2 ? 2 * mt - 1 : 1;
-                        for (int j = kb + 2; j < nblk; ++j) lastw[j] = j < kb + 4 ? Wr{sig, sig_cum} : Wr{cB, bulk_ord};
+                        if (g_size == 4)
+                            k_gemm_nt_pipe<0, 64><<<ctx->quad_map_grid[mt], 256, GST * GSTAGE_BYTES, sC>>>(d.S, d.L, npad, kb - 3, maps + ctx->quad_map_off[mt], 5 | PIPE_HEAD(4), safe ? nullptr : sig);
+                        else
+                            k_gemm_nt_pipe<0, 32><<<ctx->pair_map_grid[mt], 256, GST * GSTAGE_BYTES, sC>>>(d.S, d.L, npad, kb - 1, maps + ctx->pair_map_off[mt], 3 | PIPE_HEAD(2), safe ? nullptr : sig);
+                        for (int c = 0; c < head && c < mt; ++c) sig_cum += mt - c;          // tiles of the leading columns
+                        for (int j = kb + 2; j < nblk; ++j) lastw[j] = j < kb + 2 + head ? Wr{sig, sig_cum} : Wr{cB, bulk_ord};
                     } else {
                         // B(kb), one panel, columns >= kb + 2: its gate publishes "the bulk kernel before it is done" and waits for P(kb)
                         ++bulk_ord;

@@ -99,6 +99,8 @@ int rcn_create(int device_id, rcn_ctx **out)
     ctx->chol_break = cbk ? std::atoi(cbk) : 0;
     const char *cpm = std::getenv("RCN_CHOL_PAIR_MIN");
     if (cpm) ctx->chol_pair_min = std::atoi(cpm);
+    const char *cgr = std::getenv("RCN_CHOL_GROUP");
+    if (cgr) ctx->chol_group = std::atoi(cgr);
     const char *cpi = std::getenv("RCN_CHOL_PIPE_MIN");
     if (cpi) ctx->chol_pipe_min = std::atoi(cpi);
     const char *ch = std::getenv("RCN_CHUNK_ROWS");

@@ -186,7 +186,11 @@ struct rcn_ctx {
     DevBuf bulk_map;
     std::vector<int> bulk_map_off, bulk_map_grid;
     std::vector<int> pair_map_off, pair_map_grid;   // the same triangles with their first two tile columns leading (two-panel updates)
-    int col_map_off1 = 0, col_map_off2 = 0;          // tile columns for the pipelined kernel on the panel stream
+    std::vector<int> quad_map_off, quad_map_grid;   // ... and with their first four leading (four-panel updates)
+    int col_map_off1 = 0, col_map_offn[5] = {0};     // tile columns for the pipelined kernel on the panel stream: one, and the first 1 .. 4 side by side
+    int chol_group = 2;                              // panels per bulk update while many tile rows remain: 2 (K = 256).  4 (K = 512; diagnostic build: RCN_CHOL_GROUP=4) is built and
+                                                     // correct, and measured: the bulk kernel alone gains 8 % (tools/gemm_nt_bench: 60.6 against 55.6 TFLOP/s), the cfg-5 factorisation
+                                                     // 1.4 % (8.97 against 9.09 ms) -- the column work of a group, (g + 1) / 2 single-panel passes per step, grows as fast as the bulk shrinks
     int chol_pipe_min = 32;                          // panel / column kernels go through the pipelined kernel from this many tiles on
     bool trsv_chain = true;                          // backward substitution as one launch (k_trsv_bwd_chain); off after a flag timeout
     int chol_break = 0;                              // diagnostic build: 1 = break one cross-stream hand-off (forces the one-stream fallback); 2 = and put a NaN pivot behind it
