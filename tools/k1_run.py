@@ -24,6 +24,7 @@ for _ in range(reps):
     m.match_grid_device(pairs, out.data_ptr(), K, cnt.data_ptr())
 m.ctx.check(m.ctx.lib.rcn_synchronize(m.ctx.h))
 st = m.stats()
-pd = float(st["pair_distances"])
-ms = st["coarse_ms"] / max(1, st["profiled_calls"])
-print("K1 %.3f ms per launch, %.1f TFLOP/s, frac %.4f; matches %d" % (ms, 2.0 * D * pd / ms * 1e-9, 2.0 * D * pd / ms * 1e-9 / 2500.0, int(cnt.sum().item())))
+calls, launches = max(1, st["profiled_calls"]), max(1, st["coarse_launches"])
+pd = float(st["pair_distances"]) * calls / launches          # pair-distances of one launch (a large grid runs in pipeline chunks: several launches per call)
+ms = st["coarse_ms"] / launches
+print("K1 %.3f ms per launch, %.1f TFLOP/s, frac %.4f; matches %d; %d launches per call" % (ms, 2.0 * D * pd / ms * 1e-9, 2.0 * D * pd / ms * 1e-9 / 2500.0, int(cnt.sum().item()), launches // calls))

@@ -1,5 +1,5 @@
 """tools/pmc_report.py <prof dir> <out dir> [tag] -- condense the raw output of tools/profile_round.sh into the files under profiles/
-(named <tag>_*, tag = r03 by default):
+(named <tag>_*, tag = r04 by default):
 per-kernel counter means, the derived figures (effective clock, MFMA-pipe busy share, VALU per MFMA, fabric bytes per
 launch corrected as MI355X_MICROARCH.md prescribes) and the traffic JSON bench.py quotes.  Everything is stamped with
 the hash of the sources the profiled binary was built from (bench.source_hash) and the git HEAD of the build tree."""
@@ -33,7 +33,7 @@ def kernel_stats(d):
 
 def main():
     prof, outd = sys.argv[1], sys.argv[2]
-    tag = sys.argv[3] if len(sys.argv) > 3 else "r03"
+    tag = sys.argv[3] if len(sys.argv) > 3 else "r04"
     import bench
     stamp = {"source_hash": bench.source_hash()}
     try:
@@ -84,6 +84,23 @@ def main():
         for tab in (sq, lds, fe, wr):
             for (kn2, c), (v, n) in sorted(tab.items()):
                 lines.append("%-44s %-28s n=%d mean=%.5g" % (kn2[:44], c, n, v))
+    # the fold ablation at the SIFT shape (diagnostic build, RCN_COARSE_ABL): what a cheaper top-2 fold could buy at most
+    abl_names = {0: "shipping fold: and_or + med3 + min per element", 2: "values-only fold: med3 + min (results wrong by construction)", 1: "no fold at all"}
+    if any(os.path.isdir(os.path.join(prof, "fold_abl%d" % a)) for a in abl_names):
+        lines.append("")
+        lines.append("## top-2 fold ablation, k_coarse_top2<128> at 100 x 1500 x 128 (tools/profile_round.sh, diagnostic build)")
+        for a, nm in abl_names.items():
+            sqa = counters(os.path.join(prof, "fold_abl%d" % a))
+            ks = [k for (k, c) in sqa if "coarse" in k]
+            if not ks:
+                continue
+            ga = lambda c: sqa.get((ks[0], c), (float("nan"), 0))[0]
+            cyc = ga("GRBM_GUI_ACTIVE") / 8.0
+            k1 = [ln.strip() for ln in open(os.path.join(prof, "fold_abl%d.log" % a)) if ln.startswith("K1 ")] if os.path.exists(os.path.join(prof, "fold_abl%d.log" % a)) else []
+            lines.append("RCN_COARSE_ABL=%d  %-62s cycles %.4g  mfma_busy %.3f  valu_per_mfma %.2f  | %s" %
+                         (a, nm, cyc, ga("SQ_VALU_MFMA_BUSY_CYCLES") / (1024.0 * cyc), ga("SQ_INSTS_VALU") / ga("SQ_INSTS_MFMA"), k1[-1] if k1 else ""))
+            traffic["fold_ablation_%d" % a] = {"what": nm, "cycles_per_launch": cyc, "mfma_busy_share": ga("SQ_VALU_MFMA_BUSY_CYCLES") / (1024.0 * cyc),
+                                               "valu_per_mfma": ga("SQ_INSTS_VALU") / ga("SQ_INSTS_MFMA"), "k1_run_line": k1[-1] if k1 else None}
     json.dump(traffic, open(os.path.join(outd, tag + "_match_traffic.json"), "w"), indent=1)
     open(os.path.join(outd, tag + "_match_pmc_summary.txt"), "w").write("\n".join(lines) + "\n")
     # kernel-trace summaries
