@@ -111,7 +111,15 @@ def cpu_baseline(images, n_threads):
     orc.match_grid(images, allp[:n_threads], threads=n_threads)  # warm (page-in, transposes)
     v, n, dt = timed(max(n_threads, int(100 * n_threads * scale)), n_threads)
     v4, n4, dt4 = timed(max(4, int(96 * scale)), 4)
-    return {"value": v, "unit": "pair-distances/s", "cores": n_threads, "kind": "port",
+    # every core the affinity mask lists (OpenMP threads of this one process).  The box gives a one-GPU job a CPU
+    # share of 16 cores, so the figure shows what that share yields with every core asked for, not 256 free cores; stated as measured
+    n_all = max(1, min(256, len(os.sched_getaffinity(0))))
+    all_cores = None
+    if n_all > n_threads:
+        va, na, dta = timed(max(n_all, int(8 * n_all * scale)), n_all)
+        all_cores = {"value": va, "cores": n_all, "sample": "%d pairs, %.1f s" % (na, dta),
+                     "note": "threads = cores in the affinity mask; the pool's CPU share for a one-GPU box is 16 cores"}
+    return {"value": v, "unit": "pair-distances/s", "cores": n_threads, "kind": "port", "at_all_affinity_cores": all_cores,
             "sample": "%d image pairs (%dx%dx256 each) among the first %d images of the workload, oracle/match_oracle.c (-O3 -march=native), OpenMP over pairs, %.1f s"
                       % (n, K, K, len(images), dt),
             "host": host_info(),

@@ -204,6 +204,50 @@ __device__ __forceinline__ double block_sum(double v, double *sh)
     return s;  // valid on thread 0
 }
 
+// The sums of a launch, finished BY the launch (round 4; a one-block k_finish_sum launch behind every reduction before: four launches
+// of the ~35 of an LM iteration).  Every workgroup delivers its partial sums and takes a ticket; the one that draws the last
+// ticket adds the partials up -- in index order, so the result does not depend on who that is -- and writes the scalars.
+// The hand-off needs no L2-wide fence: a partial is an agent-coherent (sc1) store, drained (vmcnt(0)) before the ticket is
+// taken, and the summing workgroup reads with agent-coherent loads (MI355X_MICROARCH.md, inter-workgroup visibility,
+// valid forms).  The ticket word is left at zero for the next launch.
+struct Fin {
+    double *out;            // NS results (scaled), consecutive
+    double *out2;           // optional second home of results 2 and 3 (k_ba_plus: gradient . delta, non-finite count)
+    unsigned *ticket;
+    const int *flag;        // optional: the factorisation's flag word rides home with the scalars of the step
+    double *flag_out;
+    double *zero;           // optional: a cell to clear (where the next gradient maximum is collected)
+    double scale;
+};
+template <int NS>
+__device__ __forceinline__ void finish_sums(const double (&mine)[NS], double *partial, int stride, const Fin &f, double *sh)
+{
+    __shared__ int s_last;
+    const int t = threadIdx.x, nb = (int)gridDim.x;
+    if (t == 0) {
+#pragma unroll
+        for (int q = 0; q < NS; ++q)
+            __hip_atomic_store(partial + (size_t)q * stride + blockIdx.x, mine[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned k = __hip_atomic_fetch_add(f.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = k == (unsigned)nb - 1u;
+    }
+    __syncthreads();
+    if (!s_last) return;
+#pragma unroll
+    for (int q = 0; q < NS; ++q) {
+        double v = 0.0;
+        for (int i = t; i < nb; i += (int)blockDim.x) v += __hip_atomic_load(partial + (size_t)q * stride + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const double s = block_sum(v, sh);
+        if (t == 0) { f.out[q] = f.scale * s; if (f.out2 && q >= 2) f.out2[q - 2] = f.scale * s; }
+    }
+    if (t == 0) {
+        __hip_atomic_store(f.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (f.flag) *f.flag_out = (double)__hip_atomic_load(f.flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (f.zero) *f.zero = 0.0;
+    }
+}
+
 // residual of one observation and (JAC) its 2 x 15 Jacobian over [pose 6 | intrinsics 6 | point 3]
 template <bool JAC>
 __device__ __forceinline__ void obs_residual(const double *ps, const double *in, const double *X, const double *uv,
@@ -273,7 +317,7 @@ __device__ __forceinline__ void lds_to_rows(double *__restrict__ dst, size_t row
 // LDS, the wave stores its 64 rows as one contiguous block (HBM-bound: 224 B written per observation).
 template <bool JAC>
 __global__ __launch_bounds__(JAC ? 128 : 256) void k_ba_eval(BaDev d, const double *poses, const double *intr,
-                                                              const double *pts, double *partial)
+                                                              const double *pts, double *partial, Fin fin)
 {
     constexpr int NW = JAC ? 2 : 4;          // JAC: 30 KB of LDS per workgroup, five workgroups per CU
     __shared__ double sh[4];
@@ -320,8 +364,8 @@ __global__ __launch_bounds__(JAC ? 128 : 256) void k_ba_eval(BaDev d, const doub
         const int nrows = (int)min((long long)64, (long long)d.no - (long long)row0);
         if (nrows > 0) lds_to_rows<JCH>(d.J, row0, nrows, stage + w * 64 * JLD, lane);
     }
-    const double s = block_sum(c2, sh);
-    if (threadIdx.x == 0) partial[blockIdx.x] = s;
+    const double mine[1] = {block_sum(c2, sh)};
+    finish_sums<1>(mine, partial, 0, fin, sh);
 }
 
 // Line search (bounds present): directional derivative of the cost at a trial point along the step held in
@@ -381,18 +425,6 @@ __global__ __launch_bounds__(256) void k_finish_sum(const double *partial, int n
     const double s = block_sum(v, sh);
     if (threadIdx.x == 0) { *out = scale * s; if (flag) *flag_out = (double)*flag; }
 }
-// the four sums behind k_ba_plus in one launch (block q: partial + q * stride -> out[q]); sums 2 and 3 (gradient . delta, the
-// non-finite count) also go to their second home out2[0 .. 1]: four launches and a device-to-device copy less per LM iteration
-__global__ __launch_bounds__(256) void k_finish_sum4(const double *partial, int n, int stride, double *out, double *out2)
-{
-    __shared__ double sh[4];
-    const int q = blockIdx.x;
-    double v = 0.0;
-    for (int i = threadIdx.x; i < n; i += 256) v += partial[(size_t)q * stride + i];
-    const double s = block_sum(v, sh);
-    if (threadIdx.x == 0) { out[q] = s; if (q >= 2) out2[q - 2] = s; }
-}
-
 // K5: per point  Vraw = sum Jp'Jp (3x3), gpraw = sum Jp'r
 __global__ void k_ba_point_raw(BaDev d)
 {
@@ -1790,7 +1822,7 @@ __global__ void k_ba_backsub(BaDev d)
 }
 
 // model: sum_o m (r + m/2), m = Js step  (partial per block); observation rows staged through LDS like k_ba_eval writes them
-__global__ __launch_bounds__(128) void k_ba_model(BaDev d, double *partial)
+__global__ __launch_bounds__(128) void k_ba_model(BaDev d, double *partial, Fin fin)
 {
     __shared__ double sh[4];
     __shared__ __attribute__((aligned(16))) double stage[2 * 64 * JLD];
@@ -1823,13 +1855,13 @@ __global__ __launch_bounds__(128) void k_ba_model(BaDev d, double *partial)
             acc += m * (row[26 + i] + 0.5 * m);
         }
     }
-    const double s = block_sum(acc, sh);
-    if (threadIdx.x == 0) partial[blockIdx.x] = s;
+    const double tot[1] = {block_sum(acc, sh)};
+    finish_sums<1>(tot, partial, 0, fin, sh);
 }
 
 // delta = alpha * step .* scale ; candidate = clamp(x + delta) ; partials of |dx|^2, |x|^2,
 // gradient.delta and the finite check.  which: 0 -> also writes dlc/dlp (alpha = 1 first time)
-__global__ __launch_bounds__(256) void k_ba_plus(BaDev d, double alpha, double *partial, int nblocks)
+__global__ __launch_bounds__(256) void k_ba_plus(BaDev d, double alpha, double *partial, int nblocks, Fin fin)
 {
     __shared__ double sh[4];
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1881,11 +1913,9 @@ __global__ __launch_bounds__(256) void k_ba_plus(BaDev d, double alpha, double *
             if (used) xn += x * x;
         }
     }
-    double s;
-    s = block_sum(dn, sh); if (threadIdx.x == 0) partial[blockIdx.x] = s;
-    s = block_sum(xn, sh); if (threadIdx.x == 0) partial[nblocks + blockIdx.x] = s;
-    s = block_sum(g0, sh); if (threadIdx.x == 0) partial[2 * nblocks + blockIdx.x] = s;
-    s = block_sum(bad, sh); if (threadIdx.x == 0) partial[3 * nblocks + blockIdx.x] = s;
+    double mine[4];
+    mine[0] = block_sum(dn, sh); mine[1] = block_sum(xn, sh); mine[2] = block_sum(g0, sh); mine[3] = block_sum(bad, sh);
+    finish_sums<4>(mine, partial, nblocks, fin, sh);
 }
 
 // projected gradient max-norm of the unscaled gradient (gcraw / gpraw); *out zeroed by the caller.
@@ -2104,7 +2134,7 @@ int rcn_int_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_option
     d.poses = ws.get<double>(6 * (size_t)nc); d.intr = ws.get<double>(6 * (size_t)nc); d.pts = ws.get<double>(3 * (size_t)np);
     d.poses2 = ws.get<double>(6 * (size_t)nc); d.intr2 = ws.get<double>(6 * (size_t)nc); d.pts2 = ws.get<double>(3 * (size_t)np);
     double *uv = ws.get<double>(2 * (size_t)no);
-    int *ints = ws.get<int>((size_t)no * 3 + np + 1 + 2 * (nc + 1) + nc + 10 * (size_t)nc + 8);
+    int *ints = ws.get<int>((size_t)no * 3 + np + 1 + 2 * (nc + 1) + nc + 10 * (size_t)nc + 24);      // + flag words [0..7] and reduction tickets [8..11]
     int *p_ocam = ints, *p_opt = p_ocam + no, *p_camobs = p_opt + no, *p_ptoff = p_camobs + no,
         *p_camobsoff = p_ptoff + np + 1, *p_camoff = p_camobsoff + nc + 1, *p_camdim = p_camoff + nc + 1,
         *p_cols = p_camdim + nc, *p_flag = p_cols + 10 * (size_t)nc;
@@ -2169,6 +2199,7 @@ int rcn_int_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_option
         RCN_HIP(H2D(p_camobs, stage.data(), stage.size() * sizeof(int)));
         RCN_HIP(hipStreamSynchronize(st));      // `stage` leaves scope
     }
+    RCN_HIP(hipMemsetAsync(p_flag, 0, 24 * sizeof(int), st));
     RCN_HIP(hipMemsetAsync(vecs, 0, sizeof(double) * 12 * nvec, st));
     RCN_HIP(hipMemsetAsync(d.S, 0, sizeof(double) * (size_t)npad * npad, st));   // upper part / padding never rewritten
     RCN_HIP(hipMemsetAsync(d.Linv, 0, sizeof(double) * (size_t)nblk * NB * NB, st));   // upper triangles of the tile inverses stay zero
@@ -2208,6 +2239,10 @@ int rcn_int_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_option
     };
     // cost at (poses,intr,pts) -> scal[slot]; JAC also refreshes the observation rows and the raw blocks
     bool jac_pending = false;
+    // tickets of the in-kernel reductions (finish_sums): d.flag + 8 .. 11, zero at rest
+    auto fin = [&](double *out, double scale, int which, bool with_flag, double *zero, double *out2 = nullptr) {
+        return Fin{out, out2, reinterpret_cast<unsigned *>(d.flag + 8 + which), with_flag ? d.flag : nullptr, d.scal + 13, zero, scale};
+    };
     auto eval = [&](bool jac, const double *ps, const double *in, const double *x, int slot, bool with_flag = false) -> hipError_t {
         if (no > 0) {
             if (jac) {
@@ -2219,12 +2254,14 @@ int rcn_int_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_option
                 }
                 k_ba_cam_rot<<<(nc + 127) / 128, 128, 0, st>>>(ps, nc, d.crot);
                 if (phase_times) (void)hipEventRecord(ctx->ba_tev[4], st);
-                k_ba_eval<true><<<ebj, 128, 0, st>>>(d, ps, in, x, d.partial);
+                k_ba_eval<true><<<ebj, 128, 0, st>>>(d, ps, in, x, d.partial, fin(d.scal + slot, 0.5, 0, false, d.scal + 12));
                 if (phase_times) (void)hipEventRecord(ctx->ba_tev[5], st);
                 jac_pending = true;
-            } else k_ba_eval<false><<<eb, 256, 0, st>>>(d, ps, in, x, d.partial);
+            } else k_ba_eval<false><<<eb, 256, 0, st>>>(d, ps, in, x, d.partial, fin(d.scal + slot, 0.5, 0, with_flag, nullptr));
+        } else {
+            k_finish_sum<<<1, 256, 0, st>>>(d.partial, 0, d.scal + slot, 0.5, with_flag ? d.flag : nullptr, d.scal + 13);      // no observations: the sums are zero
+            if (jac) (void)hipMemsetAsync(d.scal + 12, 0, sizeof(double), st);
         }
-        k_finish_sum<<<1, 256, 0, st>>>(d.partial, no > 0 ? (jac ? ebj : eb) : 0, d.scal + slot, 0.5, with_flag ? d.flag : nullptr, d.scal + 13);
         if (jac) {
             if (np > 0) k_ba_point_raw<<<(np + 127) / 128, 128, 0, st>>>(d);
             k_ba_cam_raw<<<nc * csplit, 128 * CR_GROUPS, 0, st>>>(d, csplit);
@@ -2252,7 +2289,7 @@ int rcn_int_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_option
             // and the value rides home with the scalars of the step that follows (one host synchronisation per iteration
             // instead of two: a quarter of a small problem's iteration).  If it was below the tolerance after all, that step
             // is dropped unseen -- it has only written candidate buffers -- and the loop ends where Ceres' would have.
-            RCN_HIP(hipMemsetAsync(d.scal + 12, 0, sizeof(double), st));
+            // (its cell, scal[12], was cleared by the evaluation at this point: k_ba_eval<true>, finish_sums)
             k_ba_gradmax<<<std::max(1, std::min(1024, (std::max(nc, 3 * np) + 255) / 256)), 256, 0, st>>>(d, d.scal + 12);
             RCN_HIP(hipGetLastError());
             need_gradient = false;
@@ -2457,12 +2494,11 @@ int rcn_int_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_option
             if (no > 0) k_ba_backsub_obs<<<ebj, 128, 0, st>>>(dx);
             k_ba_backsub<<<std::max((std::max(n, np) + 127) / 128, 1), 128, 0, st>>>(dx);
         }
-        if (no > 0) k_ba_model<<<ebj, 128, 0, st>>>(d, d.partial);
-        k_finish_sum<<<1, 256, 0, st>>>(d.partial, no > 0 ? ebj : 0, d.scal + 2, -1.0);
+        if (no > 0) k_ba_model<<<ebj, 128, 0, st>>>(d, d.partial, fin(d.scal + 2, -1.0, 1, false, nullptr));
+        else k_finish_sum<<<1, 256, 0, st>>>(d.partial, 0, d.scal + 2, -1.0);
         // candidate at alpha = 1 (+ norms, gradient.delta, finite check) and its cost
-        k_ba_plus<<<pbk, 256, 0, st>>>(d, 1.0, d.partial, pbk);
         // scal: [3] |dx|^2  [4] |x|^2  [5] g.delta, also in [8]  [6] non-finite count, also in [9]
-        k_finish_sum4<<<4, 256, 0, st>>>(d.partial, pbk, pbk, d.scal + 3, d.scal + 8);
+        k_ba_plus<<<pbk, 256, 0, st>>>(d, 1.0, d.partial, pbk, fin(d.scal + 3, 1.0, 2, false, nullptr, d.scal + 8));
         RCN_HIP(hipGetLastError());
         RCN_HIP(eval(false, d.poses2, d.intr2, d.pts2, 1, true));       // + the factorisation's flag word into scal[13]
         if (phase_times) RCN_HIP(hipEventRecord(ctx->ba_tev[3], st));
@@ -2520,8 +2556,7 @@ int rcn_int_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_option
             int bt = 0;
             bool found = false;
             auto trial = [&](double alpha) -> hipError_t {   // candidate, its cost and the step norms at alpha
-                k_ba_plus<<<pbk, 256, 0, st>>>(d, alpha, d.partial, pbk);
-                for (int q = 0; q < 2; ++q) k_finish_sum<<<1, 256, 0, st>>>(d.partial + (size_t)q * pbk, pbk, d.scal + 3 + q, 1.0);
+                k_ba_plus<<<pbk, 256, 0, st>>>(d, alpha, d.partial, pbk, fin(d.scal + 3, 1.0, 2, false, nullptr, d.scal + 14));      // ([14], [15]: nobody reads them here)
                 hipError_t e = eval(false, d.poses2, d.intr2, d.pts2, 1);
                 if (e != hipSuccess) return e;
                 e = read_scal(5);
