@@ -1,6 +1,9 @@
 """tools/chol_sweep.py ENV v1 v2 ... [-- n_cams n_points reps] -- A/B of one diagnostic-build switch on the cfg-5 factorisation: one process, one
 scene, a fresh ctx per value (rcn_create reads the environment in the diagnostic build), values interleaved over two passes.
-Prints the factorisation's time per LM iteration (HIP events inside the solve) per value."""
+Prints the factorisation's time per LM iteration (HIP events inside the solve) per value.
+CAUTION (round 4): valid for switches that do not change the number of streams.  The contexts of one process share the runtime's hardware queues;
+a switch that adds a stream (a second bulk stream, a stream with another CU mask) measured 13-14 ms per factorisation here and 9.1-10.5 ms in a
+process of its own (tools/chol_ab.sh: one process per value) -- use that for such switches."""
 import os
 import sys
 
