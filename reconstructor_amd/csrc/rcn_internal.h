@@ -179,6 +179,9 @@ struct rcn_ctx {
     std::vector<PairXY> fm_pairs_host;   // staging of fm_pairs (uploaded asynchronously)
     DevBuf fm_csr, fm_pairs;   // fused table filter: CSR of the matched points, per-pair coordinate pointers
     std::map<int32_t, std::pair<DevBuf, int32_t>> coords;   // image id -> (K x 2 int32 pixel coordinates in HBM, K)
+    std::vector<int> ba_graph_cam, ba_graph_pt;     // observation graph of the last plain rcn_ba_solve (host copy): an identical graph reuses the pair lists
+    int ba_graph_nc = 0, ba_graph_np = 0;
+    uint64_t ba_graph_serial = 0;
     uint64_t ba_pair_token = 0;         // whose pair lists the Schur-build workspace holds (0 = nobody's)
     hipStream_t aux_stream = nullptr;   // lookahead stream of the Cholesky: bulk trailing updates (CU mask leaves one CU per XCD to the diagonal kernel)
     hipStream_t panel_stream = nullptr; // second chain stream of the Cholesky: panels and first trailing columns behind the critical tile (same CU mask)

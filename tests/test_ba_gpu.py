@@ -209,6 +209,40 @@ def test_solve_is_bit_reproducible(gpu_ctx):
     assert np.array_equal(s1["cost_trace"], s2["cost_trace"])
 
 
+def test_pair_lists_are_kept_for_the_same_graph_only(gpu_ctx):
+    """rcn_ba_solve keeps the observation-pair lists of the Schur build for the next solve of the SAME graph (arrays compared
+    element by element): the same bits either way, and any change of the graph -- one observation moved to another camera,
+    another scene, a session solve in between -- rebuilds them."""
+    from reconstructor_amd import ba
+    sc = synth_ba.make_scene(30, 2500, obs_per_point=7, seed=33)
+    other = synth_ba.make_scene(5, 80, obs_per_point=4, seed=34)
+    ba.solve_scene(gpu_ctx, other)
+    P1, I1, X1, s1 = ba.solve_scene(gpu_ctx, sc)
+    P2, I2, X2, s2 = ba.solve_scene(gpu_ctx, sc)
+    assert (s1["pair_lists_reused"], s2["pair_lists_reused"]) == (0, 1)
+    assert P1.tobytes() == P2.tobytes() and I1.tobytes() == I2.tobytes() and X1.tobytes() == X2.tobytes()
+    assert np.array_equal(s1["cost_trace"], s2["cost_trace"])
+    # another start on the same graph: still reused, and equal to a solve that builds the lists
+    sc_b = dict(sc)
+    sc_b["points"] = sc["points"] + 1e-3
+    Pb, Ib, Xb, sb = ba.solve_scene(gpu_ctx, sc_b)
+    assert sb["pair_lists_reused"] == 1
+    ba.solve_scene(gpu_ctx, other)
+    Pc, Ic, Xc, s_c = ba.solve_scene(gpu_ctx, sc_b)
+    assert s_c["pair_lists_reused"] == 0 and Pb.tobytes() == Pc.tobytes() and Xb.tobytes() == Xc.tobytes()
+    # one observation seen by another camera (the arrays stay landmark-major): not the same graph
+    sc_m = dict(sc)
+    cam = sc["obs_cam"].copy()
+    j = sc["obs_pt"][0]
+    used = set(cam[sc["obs_pt"] == j].tolist())
+    cam[0] = next(c for c in range(30) if c not in used)
+    sc_m["obs_cam"] = cam
+    Pm, Im, Xm, sm = ba.solve_scene(gpu_ctx, sc_m)
+    assert sm["pair_lists_reused"] == 0
+    P0, I0, X0, s0 = orc_ba.solve(sc_m, threads=4)
+    assert sm["iterations"] == s0["iterations"] and abs(sm["final_rms_px"] - s0["final_rms_px"]) <= 1e-5
+
+
 _ALT = r"""
 import sys, numpy as np
 sys.path.insert(0, %r)
