@@ -128,10 +128,13 @@ void rcn_destroy(rcn_ctx *ctx)
     ctx->fm_state.release();
     ctx->fm_csr.release(); ctx->fm_pairs.release();
     for (auto &kv : ctx->coords) kv.second.first.release();
-    if (ctx->ev_made)
+    if (ctx->ev_made) {
         for (auto &call : ctx->ev_c)
             for (auto &row : call)
                 for (auto &e : row) (void)hipEventDestroy(e);
+        for (auto &row : ctx->ev_tail)
+            for (auto &e : row) (void)hipEventDestroy(e);
+    }
     ctx->mid_ws.release();
     if (ctx->ba_ev_made)
         { for (auto &e : ctx->ba_ev) (void)hipEventDestroy(e); for (auto &e : ctx->ba_tev) (void)hipEventDestroy(e); }

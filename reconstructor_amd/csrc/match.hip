@@ -767,61 +767,85 @@ __device__ __forceinline__ void list_append(unsigned long long *list, unsigned *
 // ratio test fails for every distance pair compatible with the error bound (the common case:
 // queries without a true counterpart have dist0 ~ dist1) or passes for every such pair (clear
 // matches: dist0 << dist1); only the undecided rows go to the survivor list.
-#define RCN_FB 1024   // rows per k_filter workgroup: one atomic per list per workgroup
-__global__ __launch_bounds__(RCN_FB) void k_filter(RerankArgs a)
+#define RCN_FT 1024   // threads of a k_filter workgroup
+#define RCN_FR 4      // rows per thread, RCN_FT apart (round 4, second session: a workgroup of one row per thread lived ~4 us -- one load, the
+                      // arithmetic, two barriers, one atomic -- and a CU holds two of them: the kernel was bound by that latency, 982 us per cfg-3
+                      // chunk at 1.6 TB/s of HBM traffic; four independent rows per thread overlap their loads)
+#define RCN_FB (RCN_FT * RCN_FR)   // rows per k_filter workgroup: one atomic per list per workgroup
+__global__ __launch_bounds__(RCN_FT) void k_filter(RerankArgs a)
 {
-    __shared__ unsigned wcnt[2][RCN_FB / 64];
-    __shared__ unsigned wbase[2][RCN_FB / 64];
+    __shared__ unsigned wcnt[2][RCN_FT / 64];
+    __shared__ unsigned wbase[2][RCN_FT / 64];
     const int pl = blockIdx.x / a.qblocks, pair = a.pair_base + pl;
-    const int q = (blockIdx.x - pl * a.qblocks) * blockDim.x + threadIdx.x;
+    const int q0 = (blockIdx.x - pl * a.qblocks) * RCN_FB + threadIdx.x;
     const ScaleDev S = *a.sc;
     const ImgDev qi = a.imgs[a.pairs[2 * pair]];
     const ImgDev ti = a.imgs[a.pairs[2 * pair + 1]];
-    bool surv = false, fb = false;
-    if (q < qi.K) {
-        int32_t *o = a.out + (size_t)pair * a.out_stride + q;
-        *o = -1;
-        if (ti.K >= 2) {
-            const double nq2 = qi.nrm2[q];
-            const uint2 c = a.all_to_fallback ? make_uint2(0u, 0u) : a.cand[(size_t)pair * a.kq_stride + q];
-            // exact kernel at once: no coarse pass at all; a BIG query row (no fp16 copy: fix_scale); fewer than two ordinary train
-            // rows (the second candidate is a padding / BIG row, whose accumulator says nothing about its distance)
-            if (a.all_to_fallback || !(nq2 < S.thr2) /* also a NaN norm: the exact kernel restates the oracle's arithmetic for it */ || !(__uint_as_float(c.y & ~a.idx_mask) < 1.0e29f)) fb = true;
-            else {
-                const double eps = coarse_eps(S, nq2);
-                // the train image's BIG rows never were candidates; every one of them is at least this far from the query
-                const double lb_big = big_lower_bound(ti.bigmin, nq2);
-                const double slack = S.rel_slack * (nq2 + S.n_max * S.n_max);
-                // every row has acc >= trunc(best); both candidates have acc < trunc(second)+quantum
-                const double lo = (double)__uint_as_float(c.x & ~a.idx_mask);
-                const double hi = (double)__uint_as_float((c.y & ~a.idx_mask) + a.idx_mask + 1u);
-                double lb0 = fmin(acc_to_d2(S, nq2, lo - eps) - slack, lb_big);
-                const double ub1 = acc_to_d2(S, nq2, hi + eps) + slack;
-                if (lb0 < 0.0) lb0 = 0.0;
-                surv = ratio_pass(lb0, ub1, a.ratio);
-                // certified PASS from the coarse values alone: the best candidate's exact
-                // distance is <= ub0, every other row's is >= lbnc (acc >= trunc(second)).
-                // sqrtf, the fp32 conversion and the product with a positive ratio are monotone,
-                // so the test holding at (ub0, lbnc) holds for the exact pair; ub0 < lbnc makes
-                // the candidate the unique nearest neighbour.  No distance needs recomputing.
-                if (surv && ti.K > 2) {
-                    const double hi0 = (double)__uint_as_float((c.x & ~a.idx_mask) + a.idx_mask + 1u);
-                    const double lo1 = (double)__uint_as_float(c.y & ~a.idx_mask);
-                    const double ub0 = acc_to_d2(S, nq2, hi0 + eps) + slack;
-                    double lbnc = fmin(acc_to_d2(S, nq2, lo1 - eps) - slack, lb_big);
-                    if (lbnc < 0.0) lbnc = 0.0;
-                    if (ub0 >= 0.0 && ub0 < lbnc && ratio_pass(ub0, lbnc, a.ratio)) {
-                        *o = (int32_t)(c.x & a.idx_mask);
-                        surv = false;
+    unsigned survm = 0u, fbm = 0u;      // bit r: row q0 + r * RCN_FT
+    double nq2v[RCN_FR];
+    uint2 cv[RCN_FR];
+#pragma unroll
+    for (int r = 0; r < RCN_FR; ++r) {
+        const int q = q0 + r * RCN_FT;
+        nq2v[r] = 0.0; cv[r] = make_uint2(0u, 0u);
+        if (q < qi.K && ti.K >= 2) {
+            nq2v[r] = qi.nrm2[q];
+            if (!a.all_to_fallback) cv[r] = a.cand[(size_t)pair * a.kq_stride + q];
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < RCN_FR; ++r) {
+        const int q = q0 + r * RCN_FT;
+        bool surv = false, fb = false;
+        if (q < qi.K) {
+            int32_t res = -1;
+            if (ti.K >= 2) {
+                const double nq2 = nq2v[r];
+                const uint2 c = cv[r];
+                // exact kernel at once: no coarse pass at all; a BIG query row (no fp16 copy: fix_scale); fewer than two ordinary train
+                // rows (the second candidate is a padding / BIG row, whose accumulator says nothing about its distance)
+                if (a.all_to_fallback || !(nq2 < S.thr2) /* also a NaN norm: the exact kernel restates the oracle's arithmetic for it */ || !(__uint_as_float(c.y & ~a.idx_mask) < 1.0e29f)) fb = true;
+                else {
+                    const double eps = coarse_eps(S, nq2);
+                    // the train image's BIG rows never were candidates; every one of them is at least this far from the query
+                    const double lb_big = big_lower_bound(ti.bigmin, nq2);
+                    const double slack = S.rel_slack * (nq2 + S.n_max * S.n_max);
+                    // every row has acc >= trunc(best); both candidates have acc < trunc(second)+quantum
+                    const double lo = (double)__uint_as_float(c.x & ~a.idx_mask);
+                    const double hi = (double)__uint_as_float((c.y & ~a.idx_mask) + a.idx_mask + 1u);
+                    double lb0 = fmin(acc_to_d2(S, nq2, lo - eps) - slack, lb_big);
+                    const double ub1 = acc_to_d2(S, nq2, hi + eps) + slack;
+                    if (lb0 < 0.0) lb0 = 0.0;
+                    surv = ratio_pass(lb0, ub1, a.ratio);
+                    // certified PASS from the coarse values alone: the best candidate's exact
+                    // distance is <= ub0, every other row's is >= lbnc (acc >= trunc(second)).
+                    // sqrtf, the fp32 conversion and the product with a positive ratio are monotone,
+                    // so the test holding at (ub0, lbnc) holds for the exact pair; ub0 < lbnc makes
+                    // the candidate the unique nearest neighbour.  No distance needs recomputing.
+                    if (surv && ti.K > 2) {
+                        const double hi0 = (double)__uint_as_float((c.x & ~a.idx_mask) + a.idx_mask + 1u);
+                        const double lo1 = (double)__uint_as_float(c.y & ~a.idx_mask);
+                        const double ub0 = acc_to_d2(S, nq2, hi0 + eps) + slack;
+                        double lbnc = fmin(acc_to_d2(S, nq2, lo1 - eps) - slack, lb_big);
+                        if (lbnc < 0.0) lbnc = 0.0;
+                        if (ub0 >= 0.0 && ub0 < lbnc && ratio_pass(ub0, lbnc, a.ratio)) {
+                            res = (int32_t)(c.x & a.idx_mask);
+                            surv = false;
+                        }
                     }
                 }
             }
+            a.out[(size_t)pair * a.out_stride + q] = res;
         }
+        survm |= surv ? 1u << r : 0u;
+        fbm |= fb ? 1u << r : 0u;
     }
     // workgroup-aggregated append (a single counter word takes only ~88 atomics per microsecond)
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    const unsigned long long ms = __ballot(surv), mf = __ballot(fb);
-    if (lane == 0) { wcnt[0][w] = (unsigned)__popcll(ms); wcnt[1][w] = (unsigned)__popcll(mf); }
+    unsigned ns = 0, nf = 0;
+#pragma unroll
+    for (int r = 0; r < RCN_FR; ++r) { ns += (unsigned)__popcll(__ballot(survm >> r & 1u)); nf += (unsigned)__popcll(__ballot(fbm >> r & 1u)); }
+    if (lane == 0) { wcnt[0][w] = ns; wcnt[1][w] = nf; }
     __syncthreads();
     if (threadIdx.x < 2) {
         unsigned tot = 0;
@@ -830,10 +854,16 @@ __global__ __launch_bounds__(RCN_FB) void k_filter(RerankArgs a)
         for (int i = 0; i < nw; ++i) wbase[threadIdx.x][i] += base;
     }
     __syncthreads();
-    const unsigned long long entry = ((unsigned long long)pair << 32) | (unsigned)q;
     const unsigned long long lt = (1ull << lane) - 1ull;
-    if (surv) a.sv_list[wbase[0][w] + __popcll(ms & lt)] = entry;
-    if (fb) a.fb_list[wbase[1][w] + __popcll(mf & lt)] = entry;
+    unsigned bs = wbase[0][w], bf = wbase[1][w];
+#pragma unroll
+    for (int r = 0; r < RCN_FR; ++r) {
+        const unsigned long long entry = ((unsigned long long)pair << 32) | (unsigned)(q0 + r * RCN_FT);
+        const unsigned long long ms = __ballot(survm >> r & 1u), mf = __ballot(fbm >> r & 1u);
+        if (survm >> r & 1u) a.sv_list[bs + __popcll(ms & lt)] = entry;
+        if (fbm >> r & 1u) a.fb_list[bf + __popcll(mf & lt)] = entry;
+        bs += (unsigned)__popcll(ms); bf += (unsigned)__popcll(mf);
+    }
 }
 
 // K2: exact fp64 re-rank of the survivors.  Only the BEST coarse candidate is re-computed:
@@ -844,7 +874,10 @@ __global__ __launch_bounds__(RCN_FB) void k_filter(RerankArgs a)
 // One wave = 64 survivors.  Rows are staged through LDS in 32-float chunks so that global reads
 // are whole 128-B segments (8 lanes per row) instead of 64 lanes striding 1-KiB rows; each
 // lane then walks its (query, candidate) chain in ascending k out of LDS.
-#define RR_ROWS 128
+// (round 4, second session) BOTH coarse candidates go through the chain: with the second exact distance in hand `certify` can also
+// say "no match" -- every row but the two candidates is at least lbnc away, so the exact second neighbour lies in [min(eb, lbnc), eb],
+// and a ratio test that fails against eb fails for whatever it is -- where round 3 sent every row it could not PASS to the next tier.
+#define RR_ROWS 192
 #define RR_LD 36  // floats per LDS row: 32 + 4 pad (conflict-free ds_read_b128 by row)
 __global__ __launch_bounds__(64) void k_rerank_lds(RerankArgs a)
 {
@@ -863,14 +896,17 @@ __global__ __launch_bounds__(64) void k_rerank_lds(RerankArgs a)
         const ImgDev qi = a.imgs[a.pairs[2 * pair]];
         const ImgDev ti = a.imgs[a.pairs[2 * pair + 1]];
         const uint2 c = a.cand[(size_t)pair * a.kq_stride + q];
-        const int ia = (int)(c.x & a.idx_mask);
+        int ia = (int)(c.x & a.idx_mask), ib = (int)(c.y & a.idx_mask);
+        if (ib >= ti.K) ib = ia;      // (a padding row as second candidate: k_filter keeps such rows off this list; never an address)
         __syncthreads();  // previous group's reads of rowptr/tile are done
         rowptr[lane] = qi.f32 + (size_t)q * D;
         rowptr[64 + lane] = ti.f32 + (size_t)ia * D;
+        rowptr[128 + lane] = ti.f32 + (size_t)ib * D;
         __syncthreads();
-        double acc = 0.0;
+        double acc = 0.0, acc2 = 0.0;
         const float *qrow = tile + lane * RR_LD;
         const float *trow = tile + (64 + lane) * RR_LD;
+        const float *trow2 = tile + (128 + lane) * RR_LD;
         for (int ch = 0; ch < nchunk; ++ch) {
             const int col = ch * 32 + (lane & 7) * 4;
 #pragma unroll
@@ -885,26 +921,33 @@ __global__ __launch_bounds__(64) void k_rerank_lds(RerankArgs a)
             for (int k4 = 0; k4 < kmax; k4 += 4) {
                 const float4 x = *reinterpret_cast<const float4 *>(qrow + k4);
                 const float4 y = *reinterpret_cast<const float4 *>(trow + k4);
+                const float4 z = *reinterpret_cast<const float4 *>(trow2 + k4);
                 double d;
                 d = (double)x.x - (double)y.x; acc = fma(d, d, acc);
                 d = (double)x.y - (double)y.y; acc = fma(d, d, acc);
                 d = (double)x.z - (double)y.z; acc = fma(d, d, acc);
                 d = (double)x.w - (double)y.w; acc = fma(d, d, acc);
+                d = (double)x.x - (double)z.x; acc2 = fma(d, d, acc2);
+                d = (double)x.y - (double)z.y; acc2 = fma(d, d, acc2);
+                d = (double)x.z - (double)z.z; acc2 = fma(d, d, acc2);
+                d = (double)x.w - (double)z.w; acc2 = fma(d, d, acc2);
             }
             __syncthreads();
         }
         bool fb = false;
         if (live) {
-            bool ok = false;
-            if (ti.K > 2) {
+            // the two candidates ordered by (exact value, index), as the oracle's scan would meet them
+            double ea = acc, eb = acc2;
+            if (ib != ia && (eb < ea || (eb == ea && ib < ia))) { ea = acc2; eb = acc; const int t = ia; ia = ib; ib = t; }
+            int res = -2;
+            if (ti.K > 2 && ib != ia) {
                 const double nq2 = qi.nrm2[q];
                 const double lbacc = (double)__uint_as_float(c.y & ~a.idx_mask);
-                double lbnc = fmin(acc_to_d2(S, nq2, lbacc - coarse_eps(S, nq2)) - S.rel_slack * (nq2 + S.n_max * S.n_max), big_lower_bound(ti.bigmin, nq2));
-                if (lbnc < 0.0) lbnc = 0.0;
-                ok = acc < lbnc && ratio_pass(acc, lbnc, a.ratio);
+                const double lbnc = fmin(acc_to_d2(S, nq2, lbacc - coarse_eps(S, nq2)) - S.rel_slack * (nq2 + S.n_max * S.n_max), big_lower_bound(ti.bigmin, nq2));
+                res = certify(ea, ia, eb, lbnc, a.ratio);
             }
-            if (ok) a.out[(size_t)pair * a.out_stride + q] = ia;
-            else fb = true;   // out stays -1 until the exact kernel decides
+            if (res >= 0) a.out[(size_t)pair * a.out_stride + q] = res;
+            else if (res == -2) fb = true;   // out stays -1 (which is also the certified "no match") until the next tier decides
         }
         list_append(a.fb_list, a.fb_count, fb, e);
     }
@@ -1109,6 +1152,7 @@ struct MidArgs {
     int32_t *clist;                        // [rows][RCN_MIDCAP] train rows
     unsigned *hist, *offs, *cursor, *ibase; // per image slot (+ 1): rows, first sorted row, fill cursor, first work item
     unsigned *n_items;
+    const float *thr_in;                   // deferred rows (k_mid_defer): their thresholds, computed while their chunk's candidate table was there
     unsigned long long *fb2_list;          // overflowed rows -> K2b
     unsigned *fb2_count;
     int32_t *out;
@@ -1174,11 +1218,31 @@ __global__ __launch_bounds__(1024) void k_mid_bins(MidArgs a)
     }
     if (t == 1023) { *a.n_items = s2[1023]; a.offs[a.n_slots] = s1[1023]; a.ibase[a.n_slots] = s2[1023]; }
 }
+// fp32 threshold of the one-sweep path for row (pair, q), from the chunk's candidate table; +infinity: none (two sweeps)
+__device__ __forceinline__ float mid_threshold(const MidArgs &a, const ScaleDev &S, int pair, int q)
+{
+    float thr = INFINITY;
+    if (!a.all_to_fallback) {
+        const double g = (double)(a.D + 8) * 1.1920928955078125e-7;
+        const ImgDev qi = a.imgs[a.pairs[2 * pair]];
+        const double nq2 = qi.nrm2[q];
+        const uint2 c = a.cand[(size_t)pair * a.kq_stride + q];
+        if (nq2 < S.thr2 && __uint_as_float(c.y & ~a.idx_mask) < 1.0e29f) {
+            // two ordinary rows (the coarse candidates) are within ub1 of the query: so is the exact second neighbour
+            const double hi = (double)__uint_as_float((c.y & ~a.idx_mask) + a.idx_mask + 1u);
+            const double ub1 = acc_to_d2(S, nq2, hi + coarse_eps(S, nq2)) + S.rel_slack * (nq2 + S.n_max * S.n_max);
+            if (ub1 >= 0.0) {
+                const double tv = (ub1 * (1.0 + g) + 1.0e-30) * (1.0 + 1.0e-6);
+                thr = tv < 3.0e38 ? (float)tv : INFINITY;      // a threshold that does not fit fp32 decides nothing: two sweeps
+            }
+        }
+    }
+    return thr;
+}
 __global__ __launch_bounds__(256) void k_mid_scatter(MidArgs a)
 {
     const unsigned n = mid_rows(a);
     const ScaleDev S = *a.sc;
-    const double g = (double)(a.D + 8) * 1.1920928955078125e-7;
     for (unsigned i0 = blockIdx.x * blockDim.x; i0 < n; i0 += gridDim.x * blockDim.x) {
         const unsigned i = i0 + threadIdx.x;
         const bool live = i < n;
@@ -1188,25 +1252,41 @@ __global__ __launch_bounds__(256) void k_mid_scatter(MidArgs a)
         const unsigned rank = wave_count(a.cursor, ts, live);
         if (!live) continue;
         const unsigned pos = a.offs[ts] + rank;
-        float thr = INFINITY;
-        if (!a.all_to_fallback) {
-            const ImgDev qi = a.imgs[a.pairs[2 * pair]];
-            const double nq2 = qi.nrm2[q];
-            const uint2 c = a.cand[(size_t)pair * a.kq_stride + q];
-            if (nq2 < S.thr2 && __uint_as_float(c.y & ~a.idx_mask) < 1.0e29f) {
-                // two ordinary rows (the coarse candidates) are within ub1 of the query: so is the exact second neighbour
-                const double hi = (double)__uint_as_float((c.y & ~a.idx_mask) + a.idx_mask + 1u);
-                const double ub1 = acc_to_d2(S, nq2, hi + coarse_eps(S, nq2)) + S.rel_slack * (nq2 + S.n_max * S.n_max);
-                if (ub1 >= 0.0) {
-                    const double tv = (ub1 * (1.0 + g) + 1.0e-30) * (1.0 + 1.0e-6);
-                    thr = tv < 3.0e38 ? (float)tv : INFINITY;      // a threshold that does not fit fp32 decides nothing: two sweeps
-                }
-            }
-        }
         a.sorted[pos] = e;
-        a.thr[pos] = thr;
+        a.thr[pos] = a.thr_in ? a.thr_in[i] : mid_threshold(a, S, pair, q);
         a.ccount[pos] = 0u;
     }
+}
+// Deferral (round 4): on a grid of several pipeline chunks the rows a chunk leaves for this tier are few per TRAIN image (cfg 3,
+// sixteen chunks: two per image and chunk), and a sweep over a train image costs the same for one row as for sixteen.  So the
+// chunk's rows -- with the one thing the tier needs of the chunk's candidate table, the threshold -- join ONE list of the call, as
+// long as it has room (cap rows; a chunk that does not fit goes through the tier at once, as before), and the tier runs once, behind
+// the last chunk, where an image's rows of all chunks share its sweeps.  c = the chunk counters (c[0] rows, c[7] rows deferred so far).
+__global__ __launch_bounds__(256) void k_mid_defer(MidArgs a, unsigned long long *def_e, float *def_thr, const unsigned *c, unsigned cap)
+{
+    const unsigned n = c[0], base = c[7];
+    if (n == 0 || base + n > cap || base + n < base) return;
+    const ScaleDev S = *a.sc;
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const unsigned long long e = a.fb_list[i];
+        def_e[base + i] = e;
+        def_thr[base + i] = mid_threshold(a, S, (int)(e >> 32), (int)(e & 0xFFFFFFFFu));
+    }
+}
+// (one thread, behind k_mid_defer: the same test; the rows count as fallback rows of the call and leave the chunk's list)
+__global__ void k_mid_defer_commit(unsigned *c, unsigned cap)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const unsigned n = c[0], base = c[7];
+    if (n == 0 || base + n > cap || base + n < base) return;
+    c[7] = base + n;
+    c[4] += n;
+    c[0] = 0u;
+}
+// (one thread, behind the deferred pass: what it passed on to K2b)
+__global__ void k_stats_acc_deferred(unsigned *c)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) c[6] += c[2];
 }
 // One workgroup (256 threads) per work item.  A sweep: the train image in tiles of 256 rows (one per thread), every tile in
 // 32-float chunks through LDS with whole 128-byte global segments, the item's query rows beside them; thread t accumulates its train row against each query in fp32, two
@@ -2107,7 +2187,10 @@ int rcn_int_match_grid(rcn_ctx *ctx, const int32_t *pairs_host, int32_t n_pairs,
     auto al = [](size_t b) { return (b + 255) / 256 * 256; };
     // (the bins come FIRST: their place must not move with the row count of the grid, they carry state -- zeros -- from call to call)
     const size_t mo_bins = 0, mo_sorted = mo_bins + al(4 * 4 * ((size_t)n_slots + 1)), mo_thr = mo_sorted + al(8 * mid_rows_cap), mo_cc = mo_thr + al(4 * mid_rows_cap),
-                 mo_cl = mo_cc + al(4 * mid_rows_cap), mo_fb2 = mo_cl + al(4 * mid_rows_cap * RCN_MIDCAP), mo_end = mo_fb2 + al(8 * mid_rows_cap);
+                 mo_cl = mo_cc + al(4 * mid_rows_cap), mo_fb2 = mo_cl + al(4 * mid_rows_cap * RCN_MIDCAP), mo_def = mo_fb2 + al(8 * mid_rows_cap),
+                 mo_defthr = mo_def + (n_chunks > 1 ? al(8 * mid_rows_cap) : 0), mo_end = mo_defthr + (n_chunks > 1 ? al(4 * mid_rows_cap) : 0);
+    // the call's list of deferred rows (k_mid_defer): as many rows as one pass of the tier takes
+    const bool defer = mid && n_chunks > 1 && uniq_lds && kq_max > 0;
     if (mid) {
         const bool fresh = mo_end > ctx->mid_ws.cap;
         RCN_HIP(ctx->mid_ws.reserve(mo_end));
@@ -2256,7 +2339,7 @@ int rcn_int_match_grid(rcn_ctx *ctx, const int32_t *pairs_host, int32_t n_pairs,
             const int qblocks = (kq_max + 255) / 256;
             dim3 g((unsigned)qblocks * (unsigned)np_c);
             ra.qblocks = (kq_max + RCN_FB - 1) / RCN_FB;
-            k_filter<<<(unsigned)ra.qblocks * (unsigned)np_c, RCN_FB, 0, st>>>(ra);
+            k_filter<<<(unsigned)ra.qblocks * (unsigned)np_c, RCN_FT, 0, st>>>(ra);
             RCN_HIP(hipGetLastError());
             // sharded grid: the fp32 rows of the other ranks' images travel on a side stream while the
             // coarse pass runs on the fp16 payload; the exact stages are the first to read them
@@ -2275,6 +2358,13 @@ int rcn_int_match_grid(rcn_ctx *ctx, const int32_t *pairs_host, int32_t n_pairs,
                 MidArgs ma;
                 memset(&ma, 0, sizeof(ma));
                 ma.imgs = imgs; ma.pairs = pairs; ma.cand = cand_c; ma.fb_list = ra.fb_list; ma.fb_count = ccnt;
+                if (defer) {
+                    // the chunk's rows join the call's list if they fit (then ccnt[0] is 0 and the kernels below find nothing to do)
+                    MidArgs md = ma;
+                    md.sc = ra.sc; md.kq_stride = kq_stride; md.D = ctx->D; md.all_to_fallback = ra.all_to_fallback; md.idx_mask = idx_mask;
+                    k_mid_defer<<<ctx->prop.multiProcessorCount * 2, 256, 0, st>>>(md, (unsigned long long *)(mw + mo_def), (float *)(mw + mo_defthr), ccnt, (unsigned)mid_rows_cap);
+                    k_mid_defer_commit<<<1, 64, 0, st>>>(ccnt, (unsigned)mid_rows_cap);
+                }
                 ma.sorted = (unsigned long long *)(mw + mo_sorted); ma.thr = (float *)(mw + mo_thr); ma.ccount = (unsigned *)(mw + mo_cc);
                 ma.clist = (int32_t *)(mw + mo_cl); ma.fb2_list = (unsigned long long *)(mw + mo_fb2);
                 ma.hist = (unsigned *)(mw + mo_bins); ma.offs = ma.hist + (n_slots + 1); ma.cursor = ma.offs + (n_slots + 1); ma.ibase = ma.cursor + (n_slots + 1);
@@ -2300,7 +2390,8 @@ int rcn_int_match_grid(rcn_ctx *ctx, const int32_t *pairs_host, int32_t n_pairs,
             if (!uniq_lds) k_unique_claim<<<g, 256, 0, st>>>(imgs, pairs, out_dev, out_stride, ctx->owner.as<int32_t>(), owner_stride, qblocks, p0);
             RCN_HIP(hipGetLastError());
         }
-        if (uniq_lds) k_unique_pair<<<np_c, 256, 0, st>>>(imgs, pairs, out_dev, out_stride, counts_dev, p0);
+        if (defer) { /* uniqueness follows the deferred pass, for every pair at once */ }
+        else if (uniq_lds) k_unique_pair<<<np_c, 256, 0, st>>>(imgs, pairs, out_dev, out_stride, counts_dev, p0);
         else {
             const int eblocks = (int)((out_stride + 255) / 256);
             dim3 g((unsigned)eblocks * (unsigned)np_c);
@@ -2309,6 +2400,37 @@ int rcn_int_match_grid(rcn_ctx *ctx, const int32_t *pairs_host, int32_t n_pairs,
         RCN_HIP(hipGetLastError());
         if (tm) RCN_HIP(hipEventRecord(ctx->ev_c[evi][c][kq_max > 0 ? 3 : 2], st));
         if (tm && kq_max <= 0) RCN_HIP(hipEventRecord(ctx->ev_c[evi][c][3], st));
+    }
+    ctx->ev_tail_on[evi] = false;
+    if (defer) {
+        // the deferred rows of every chunk in one pass of the tier (their thresholds came with them), K2b for what overflows its
+        // candidate lists, then uniqueness for all pairs
+        if (prof) { RCN_HIP(hipEventRecord(ctx->ev_tail[evi][0], st)); ctx->ev_tail_on[evi] = true; }
+        char *mw = ctx->mid_ws.as<char>();
+        RCN_HIP(hipMemsetAsync(ccnt + 2, 0, 2 * sizeof(unsigned), st));      // fb2 count, work items
+        MidArgs ma;
+        memset(&ma, 0, sizeof(ma));
+        ma.imgs = imgs; ma.pairs = pairs; ma.cand = nullptr; ma.fb_list = (const unsigned long long *)(mw + mo_def); ma.fb_count = ccnt + 7;
+        ma.thr_in = (const float *)(mw + mo_defthr);
+        ma.sorted = (unsigned long long *)(mw + mo_sorted); ma.thr = (float *)(mw + mo_thr); ma.ccount = (unsigned *)(mw + mo_cc);
+        ma.clist = (int32_t *)(mw + mo_cl); ma.fb2_list = (unsigned long long *)(mw + mo_fb2);
+        ma.hist = (unsigned *)(mw + mo_bins); ma.offs = ma.hist + (n_slots + 1); ma.cursor = ma.offs + (n_slots + 1); ma.ibase = ma.cursor + (n_slots + 1);
+        ma.n_items = ccnt + 3; ma.fb2_count = ccnt + 2;
+        ma.out = out_dev; ma.out_stride = out_stride; ma.sc = ra.sc; ma.n_slots = n_slots; ma.kq_stride = kq_stride; ma.D = ctx->D;
+        ma.all_to_fallback = ra.all_to_fallback; ma.idx_mask = idx_mask; ma.ratio = ratio; ma.midrows = (uint32_t)mid_rows_cap;
+        const int mb = ctx->prop.multiProcessorCount * 4;
+        k_mid_hist<<<mb, 256, 0, st>>>(ma);
+        k_mid_bins<<<1, 1024, 0, st>>>(ma);
+        k_mid_scatter<<<mb, 256, 0, st>>>(ma);
+        k_mid_eval<<<ctx->prop.multiProcessorCount * 4, 256, 0, st>>>(ma);
+        k_mid_exact<<<mb, 256, 0, st>>>(ma);
+        k_exact_rows_lds<<<ctx->prop.multiProcessorCount * 8, 64 * EX_WAVES, 0, st>>>(imgs, pairs, ma.fb2_list, ma.fb2_count, ctx->D, ratio, out_dev, out_stride);
+        k_stats_acc_deferred<<<1, 64, 0, st>>>(ccnt);
+        RCN_HIP(hipGetLastError());
+        if (prof) RCN_HIP(hipEventRecord(ctx->ev_tail[evi][1], st));
+        k_unique_pair<<<n_pairs, 256, 0, st>>>(imgs, pairs, out_dev, out_stride, counts_dev, 0);
+        RCN_HIP(hipGetLastError());
+        if (prof) RCN_HIP(hipEventRecord(ctx->ev_tail[evi][2], st));
     }
     if (prof) ctx->ev_n++;
     ctx->last_chunks = n_chunks;
@@ -2534,6 +2656,12 @@ int rcn_match_last_stats(const rcn_ctx *cctx, rcn_match_stats *out)
                 RCN_HIP(hipEventElapsedTime(&ms, ctx->ev_c[i][k][2], ctx->ev_c[i][k][3])); u += ms;
                 ++launches;
             }
+        for (int i = 0; i < n; ++i)
+            if (ctx->ev_tail_on[i]) {      // the deferred pass of the middle tier and the uniqueness of all pairs behind the last chunk
+                float ms = 0.f;
+                RCN_HIP(hipEventElapsedTime(&ms, ctx->ev_tail[i][0], ctx->ev_tail[i][1])); r += ms;
+                RCN_HIP(hipEventElapsedTime(&ms, ctx->ev_tail[i][1], ctx->ev_tail[i][2])); u += ms;
+            }
         ctx->last_stats.profiled_calls = n;
         ctx->last_stats.coarse_launches = launches;
         ctx->last_stats.coarse_ms = c; ctx->last_stats.rerank_ms = r; ctx->last_stats.unique_ms = u;
@@ -2577,6 +2705,8 @@ int rcn_match_profile(rcn_ctx *ctx, int enable)
         for (auto &call : ctx->ev_c)
             for (auto &row : call)
                 for (auto &e : row) RCN_HIP(hipEventCreate(&e));
+        for (auto &row : ctx->ev_tail)
+            for (auto &e : row) RCN_HIP(hipEventCreate(&e));
         ctx->ev_made = true;
     }
     ctx->profile = enable != 0;

@@ -146,6 +146,8 @@ struct rcn_ctx {
     bool profile = false;
 #define RCN_EV_CHUNKS 64
     hipEvent_t ev_c[64][RCN_EV_CHUNKS][4];   // per kept call and pipeline chunk: before coarse / after coarse / after the exact stages / after uniqueness
+    hipEvent_t ev_tail[64][3];               // per kept call: before the deferred pass of the middle tier / behind it / behind the uniqueness of all pairs
+    bool ev_tail_on[64] = {false};
     int ev_chunks[64] = {0};                 // chunks of that call that carry events (further chunks are not timed)
     int last_chunks = 1;                     // pipeline chunks of the last grid call
     int64_t chunk_rows = 1ll << 27;          // query-row slots of the candidate table per pipeline chunk (diagnostic build: RCN_CHUNK_ROWS)
