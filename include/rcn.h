@@ -324,7 +324,8 @@ typedef struct {
     int32_t line_search_backtracks; /* backtracks of the projected Armijo search (bounds present: >= 10 cameras) */
     int32_t bound_projections;  /* focal lengths clamped to their upper bound by a Plus */
     int32_t reduced_dim;        /* rows of the reduced camera system */
-    int32_t pair_lists_reused;  /* 1: the Schur build's observation-pair lists were still valid (rcn_ba_session_solve on an unchanged graph) */
+    int32_t pair_lists_reused;  /* 1: the Schur build's observation-pair lists were still valid (rcn_ba_session_solve on an unchanged graph;
+                                   rcn_ba_solve called again with the observation arrays of its last call, compared element by element) */
     int32_t reserved;
     double  solve_seconds;      /* wall time of the solve, inputs resident: pair lists of the Schur build + the LM loop */
     double  schur_seconds;      /* HIP-event time, summed over iterations: point blocks + Schur build */
