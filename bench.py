@@ -679,7 +679,9 @@ def grid_line(K, n_img, n_pairs_total, dt, steps, st, world, my_pairs):
     roof = {"bound": "mfma", "kernel": "k_coarse_top2<256, 0, 1> (v_mfma_f32_16x16x32_f16)", "achieved": achieved, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": achieved / MFMA_F16_PEAK_TFLOPS, "traffic": traffic,
             "traffic_note": "HBM bytes per launch from rocprofv3 --pmc passes on this exact source (profiles/r04_match_traffic.json); " + str(tnote),
-            "algorithmic_hbm_bytes_per_launch": float(n_img) * K * D * 2 + 8.0 * float(st["rows_total"]),
+            # per LAUNCH like `traffic`: every resident fp16 image once (a pipeline chunk's pairs meet nearly all of them as train images)
+            # + 8 B of candidate pair per query row of the launch's pairs
+            "algorithmic_hbm_bytes_per_launch": float(n_img) * K * D * 2 + 8.0 * float(st["rows_total"]) * calls / launches,
             "launch_ms": coarse_ms, "launches_per_step": launches / calls, "k1_ms_per_step": st["coarse_ms"] / calls,
             "algorithmic_flop_per_launch": flops_per_launch,
             "rerank_ms": st["rerank_ms"] / calls, "unique_ms": st["unique_ms"] / calls,

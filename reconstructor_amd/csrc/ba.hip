@@ -2251,10 +2251,23 @@ int rcn_int_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_option
     // iteration: a 25-camera solve is ~35 launches of a few microseconds each, and every record is one more
     const bool phase_times = no >= 50000;
     double hs[32];
+    // The cost at an ACCEPTED point (scal[0], written by the evaluation that also refreshes the Jacobian there) is not waited for: the
+    // host needs it only when the next step's scalars come home, and every read below starts at scal[0] -- so it rides with whichever
+    // read comes next (round 4, second session: one host round trip per iteration instead of two; the round trip and the idle stream
+    // behind it are ~35 us, an eighth of an iteration of the reference's own problem sizes).
+    double cost = 0.0;
+    bool cost_pending = false;
+    int cost_iter = 0;
     auto read_scal = [&](int cnt) -> hipError_t {
         hipError_t e = hipMemcpyAsync(hs, d.scal, sizeof(double) * cnt, hipMemcpyDeviceToHost, st);
         if (e != hipSuccess) return e;
-        return hipStreamSynchronize(st);
+        e = hipStreamSynchronize(st);
+        if (e == hipSuccess && cost_pending) {
+            cost = hs[0];
+            if (cost_iter < 160) sum->cost_trace[cost_iter] = cost;
+            cost_pending = false;
+        }
+        return e;
     };
     // cost at (poses,intr,pts) -> scal[slot]; JAC also refreshes the observation rows and the raw blocks
     bool jac_pending = false;
@@ -2294,7 +2307,7 @@ int rcn_int_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_option
     k_ba_diag<<<std::max(dgrid, 1), 256, 0, st>>>(d, 0, 0.0, 0.0, opt->jacobi_scaling);
     RCN_HIP(hipGetLastError());
     RCN_HIP(read_scal(1));
-    double cost = hs[0];
+    cost = hs[0];
     sum->initial_cost = cost;
     sum->initial_rms_px = std::sqrt(2.0 * cost / std::max(no, 1));
     sum->cost_trace[0] = cost;
@@ -2626,8 +2639,8 @@ int rcn_int_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_option
         if (rho > opt->min_relative_decrease) {
             std::swap(d.poses, d.poses2); std::swap(d.intr, d.intr2); std::swap(d.pts, d.pts2);
             RCN_HIP(eval(true, d.poses, d.intr, d.pts, 0));
-            RCN_HIP(read_scal(1));
-            cost = hs[0];
+            cost_pending = true;          // cost = scal[0] at the next read (read_scal, above)
+            cost_iter = iter;
             need_gradient = true;
             sum->successful_steps++;
             const double t = 2.0 * rho - 1.0;
@@ -2638,8 +2651,9 @@ int rcn_int_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_option
             sum->unsuccessful_steps++;
             radius /= decrease; decrease *= 2.0; reuse_diag = true;
         }
-        if (iter < 160) sum->cost_trace[iter] = cost;
+        if (iter < 160 && !cost_pending) sum->cost_trace[iter] = cost;
     }
+    if (cost_pending) RCN_HIP(read_scal(1));       // (every exit of the loop has read the scalars since the last accepted step: not reached)
     RCN_HIP(hipStreamSynchronize(st));
     sum->solve_seconds = now_s() - t_start;
     if (jac_pending && phase_times) {
