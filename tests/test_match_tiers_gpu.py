@@ -75,6 +75,25 @@ def test_exact_tiers_and_chunks_equal_the_oracle(env):
             assert d["chunks"] == 1
 
 
+def test_chunks_and_the_deferred_pass_do_not_change_what_reaches_the_tier():
+    """Pipeline chunks hand their rows to ONE deferred pass of the middle tier (k_mid_defer); a deferred list that is too small
+    sends a chunk's rows through the tier at once.  Either way the same rows leave the re-rank and the same rows reach K2b as in
+    one chunk (the tables are compared with the oracle inside the script)."""
+    import json
+    diag = os.path.join(ROOT, "tools", "librcn_diag.so")
+    assert os.path.exists(diag), "run __graft_entry__.build() first"
+    got = {}
+    for name, env in (("one", {}), ("chunks", {"RCN_CHUNK_ROWS": "4096"}), ("tiny-list", {"RCN_CHUNK_ROWS": "4096", "RCN_MID_ROWS": "40"})):
+        r = subprocess.run([sys.executable, "-c", SCRIPT % ROOT], env=dict(os.environ, RCN_LIB=diag, **env), capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout + r.stderr
+        got[name] = json.loads(r.stdout.strip().splitlines()[-1])
+    for a, b, c in zip(got["one"], got["chunks"], got["tiny-list"]):
+        assert a["chunks"] == 1 and b["chunks"] > 3 and c["chunks"] > 3
+        assert a["rows_total"] == b["rows_total"] == c["rows_total"]
+        assert a["rows_exact_fallback"] == b["rows_exact_fallback"] == c["rows_exact_fallback"]
+        assert a["rows_brute_force"] == b["rows_brute_force"]          # (a list of 40 rows leaves more to K2b: only the tables must agree there)
+
+
 def test_mid_tier_on_a_generic_descriptor_length(gpu_ctx):
     """D = 320 (> 256: no MFMA path, D % 4 == 0): every row goes through the middle tier of the SHIPPING library."""
     from reconstructor_amd.matcher import HipL2Matcher, all_pairs
