@@ -923,14 +923,19 @@ __global__ __launch_bounds__(256) void k_ba_schur_diag_fin(BaDev d, double inv_r
 // Everything between the Schur build and the factorisation in ONE launch (round 4; three clears and two small kernels before):
 // the padded rows of the dense system -- zero, identity on the diagonal, the right-hand side in row n under its huge diagonal
 // entry (k_ba_S_rhs_row) -- and the factorisation's flag word and stream counters.
-__global__ __launch_bounds__(256) void k_ba_S_finish(BaDev d)
+// (sentinel: the one-launch backward substitution follows -- the thread that has just moved rhs[j] into the system's last row leaves
+//  k_trsv_bwd_chain's "not there yet" pattern in its place: the solution will appear there)
+__global__ __launch_bounds__(256) void k_ba_S_finish(BaDev d, int sentinel)
 {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x, cnt = (size_t)(d.npad - d.n) * d.npad;
     if (idx < 8) d.flag[idx] = 0;
     if (idx >= cnt) return;
     const int i = d.n + (int)(idx / d.npad), j = (int)(idx % d.npad);
     double v = i == j ? 1.0 : 0.0;
-    if (i == d.n) v = j < d.n ? d.rhs[j] : (j == d.n ? RCN_RHS_BETA : 0.0);
+    if (i == d.n) {
+        v = j < d.n ? d.rhs[j] : (j == d.n ? RCN_RHS_BETA : 0.0);
+        if (sentinel) reinterpret_cast<unsigned long long *>(d.rhs)[j] = 0xFFFFFFFFFFFFFFFFull;
+    }
     d.S[(size_t)i * d.npad + j] = v;
 }
 // padded rows of the dense system: identity (the gather form writes every other lower block itself)
@@ -1724,7 +1729,10 @@ __global__ __launch_bounds__(512) void k_trsv_bwd(const double *S /* = L: sub-di
 // launch cannot deadlock whatever share of it is resident; the host still keeps it to nblk <= half the CUs.  An element that
 // does not come within 2 s raises *flag = 4 and the host repeats the substitution with the per-step kernels.
 #define TRSV_SENTINEL 0xFFFFFFFFFFFFFFFFull
-__global__ __launch_bounds__(512) void k_trsv_bwd_chain(const double *Lm, int ld, int nblk, const double *Linv, const double *y, double *x, int *flag)
+// (y == nullptr: y is row `yrow` of the factor -- the right-hand side went through the factorisation as the system's last row; its
+//  sub-diagonal tiles live in Lm, the last diagonal tile in Sm, entries from yrow on are zero: what k_ba_y_from_row extracts)
+__global__ __launch_bounds__(512) void k_trsv_bwd_chain(const double *Lm, int ld, int nblk, const double *Linv, const double *y, double *x, int *flag,
+                                                        const double *Sm = nullptr, int yrow = 0)
 {
     __shared__ double xk[NB], part[4][NB];
     const int t = threadIdx.x & 127, g = threadIdx.x >> 7;
@@ -1735,7 +1743,11 @@ __global__ __launch_bounds__(512) void k_trsv_bwd_chain(const double *Lm, int ld
 #pragma unroll
         for (int m = 0; m < 32; ++m) li[m] = Lk[(size_t)(32 * g + m) * NB + t];
     }
-    double yj = g == 0 ? y[(size_t)j * NB + t] : 0.0;
+    double yj = 0.0;
+    if (g == 0) {
+        const int idx = j * NB + t;
+        yj = y ? y[idx] : (idx < yrow ? (j < nblk - 1 ? Lm : Sm)[(size_t)yrow * ld + idx] : 0.0);
+    }
     auto fetch = [&](int i, double (&dst)[32]) {
         const double *blk = Lm + ((size_t)i * NB) * ld + (size_t)j * NB;      // L[i, j] tile: rows m, column t
 #pragma unroll
@@ -1921,10 +1933,29 @@ __global__ __launch_bounds__(256) void k_ba_plus(BaDev d, double alpha, double *
 // projected gradient max-norm of the unscaled gradient (gcraw / gpraw); *out zeroed by the caller.
 // max is order-independent and non-negative doubles order like their bit patterns, so one
 // integer atomicMax per workgroup keeps the result deterministic.
-__global__ __launch_bounds__(256) void k_ba_gradmax(BaDev d, double *out)
+// (with_diag: the clamped LM diagonal of k_ba_diag(what = 1) in the same launch -- after an accepted step both are due, from the same raw
+//  blocks: one launch less per iteration, the same arithmetic)
+__device__ __forceinline__ void ba_lm_diag_entry(const BaDev &d, int i, double lo, double hi)
+{
+    if (i < d.n) {
+        int a = 0, b = d.nc - 1;
+        while (a < b) { int m = (a + b + 1) >> 1; if (d.cam_off[m] <= i) a = m; else b = m - 1; }
+        while (d.cam_dim[a] == 0 || d.cam_off[a] + d.cam_dim[a] <= i) ++a;
+        const int k = i - d.cam_off[a];
+        const double u = d.Uraw[100 * (size_t)a + 11 * k];
+        d.dgc[i] = fmin(fmax(u * d.sc[i] * d.sc[i], lo), hi);
+    }
+    if (i < 3 * d.np) {
+        const double v = d.Vraw[9 * (size_t)(i / 3) + 4 * (i % 3)];
+        d.dgp[i] = fmin(fmax(v * d.sp[i] * d.sp[i], lo), hi);
+    }
+}
+__global__ __launch_bounds__(256) void k_ba_gradmax(BaDev d, double *out, int with_diag = 0, double lo = 0.0, double hi = 0.0)
 {
     __shared__ double sh[4];
     const int t0 = blockIdx.x * 256 + threadIdx.x, stride = gridDim.x * 256;
+    if (with_diag)
+        for (int i = t0; i < d.n || i < 3 * d.np; i += stride) ba_lm_diag_entry(d, i, lo, hi);
     double m = 0.0;
     for (int i = t0; i < d.nc; i += stride)
         for (int k = 0; k < d.cam_dim[i]; ++k) {
@@ -2313,7 +2344,7 @@ int rcn_int_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_option
     sum->cost_trace[0] = cost;
 
     double radius = opt->initial_trust_region_radius, decrease = 2.0;
-    bool reuse_diag = false, need_gradient = true, grad_pending = false;
+    bool reuse_diag = false, need_gradient = true, grad_pending = false, diag_fresh = false;
     int invalid_run = 0, termination = 0, iter = 0;
     for (;;) {
         if (need_gradient) {
@@ -2322,8 +2353,12 @@ int rcn_int_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_option
             // instead of two: a quarter of a small problem's iteration).  If it was below the tolerance after all, that step
             // is dropped unseen -- it has only written candidate buffers -- and the loop ends where Ceres' would have.
             // (its cell, scal[12], was cleared by the evaluation at this point: k_ba_eval<true>, finish_sums)
-            k_ba_gradmax<<<std::max(1, std::min(1024, (std::max(nc, 3 * np) + 255) / 256)), 256, 0, st>>>(d, d.scal + 12);
+            // (whenever the gradient is due, so is the LM diagonal -- an accepted step, or the start -- and both come from the raw blocks
+            //  of the evaluation just queued: one launch; a loop that ends below has written a diagonal nobody reads)
+            k_ba_gradmax<<<std::max(1, std::min(1024, (std::max(std::max(nc, n), 3 * np) + 255) / 256)), 256, 0, st>>>(d, d.scal + 12, reuse_diag ? 0 : 1,
+                                                                                                                     opt->min_lm_diagonal, opt->max_lm_diagonal);
             RCN_HIP(hipGetLastError());
+            diag_fresh = !reuse_diag;
             need_gradient = false;
             grad_pending = true;
         }
@@ -2340,10 +2375,11 @@ int rcn_int_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_option
         ++iter;
 
         // ---- LM step
-        if (!reuse_diag) {
+        if (!reuse_diag && !diag_fresh) {
             k_ba_diag<<<std::max(dgrid, 1), 256, 0, st>>>(d, 1, opt->min_lm_diagonal, opt->max_lm_diagonal, opt->jacobi_scaling);
             RCN_HIP(hipGetLastError());
         }
+        diag_fresh = false;
         const double ir = 1.0 / radius;
         if (phase_times) RCN_HIP(hipEventRecord(ctx->ba_tev[0], st));
         // [0] breakdown / gate flag, [2..7] progress counters of the factorisation's streams.  In the default form (gather Schur build, the
@@ -2351,6 +2387,7 @@ int rcn_int_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_option
         // k_ba_S_finish behind the Schur kernels, and nothing has to be cleared up front: the Schur kernels write every entry of rhs below n.
         const bool rhs_row = npad > n && !ctx->ba_trsv_fwd;
         const bool fused_finish = gather && rhs_row;
+        const bool chain = ctx->trsv_chain && 2 * nblk <= ctx->prop.multiProcessorCount;      // backward substitution as one launch
         if (!fused_finish) {
             RCN_HIP(hipMemsetAsync(d.flag, 0, 8 * sizeof(int), st));
             if (!gather) RCN_HIP(hipMemsetAsync(Sb, 0, sizeof(double) * 100 * (size_t)nc * nc, st));
@@ -2368,7 +2405,7 @@ int rcn_int_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_option
             if (csplit > 1) k_ba_schur_diag_mfma<12><<<nc * csplit, 1024, 0, st>>>(d, pk_off, pk_list, ir, csplit);
             else k_ba_schur_diag_mfma<4><<<nc, 1024, 0, st>>>(d, pk_off, pk_list, ir, 1);
             if (csplit > 1) k_ba_schur_diag_fin<<<nc, 256, 0, st>>>(d, ir, csplit);
-            if (fused_finish) k_ba_S_finish<<<(unsigned)(((size_t)(npad - n) * npad + 255) / 256), 256, 0, st>>>(d);
+            if (fused_finish) k_ba_S_finish<<<(unsigned)(((size_t)(npad - n) * npad + 255) / 256), 256, 0, st>>>(d, chain ? 1 : 0);
             else if (npad > n) k_ba_S_pad<<<(npad - n + 127) / 128, 128, 0, st>>>(d);
         } else {
             if (np > 0) k_ba_schur<<<np, std::min(256, std::max(64, 64 * ((kmax * kmax + 7) / 8))), 0, st>>>(d, Sb);
@@ -2511,12 +2548,15 @@ int rcn_int_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_option
         // (up to two blocks there is no panel rest, no column rest and no bulk update: nothing for the other two streams to do)
         RCN_HIP(factorise(ctx->chol_safe || nblk <= 2));
         if (phase_times) RCN_HIP(hipEventRecord(ctx->ba_tev[2], st));
-        const bool chain = ctx->trsv_chain && 2 * nblk <= ctx->prop.multiProcessorCount;
-        if (rhs_row) k_ba_y_from_row<<<(npad + 255) / 256, 256, 0, st>>>(d, chain ? 1 : 0);
-        else for (int kb = 0; kb < nblk; ++kb) k_trsv_fwd<<<nblk - kb, 128, 0, st>>>(d.L, npad, kb, d.Linv, d.rhs, d.yc);
+        // (rhs_row + chain, the default: the sentinel was left by k_ba_S_finish and the chain kernel reads y out of the factor's last row
+        //  itself -- no launch in between; k_ba_y_from_row remains for the per-step kernels and the other ways to build the system)
+        const bool y_in_row = chain && fused_finish;
+        if (rhs_row && !y_in_row) k_ba_y_from_row<<<(npad + 255) / 256, 256, 0, st>>>(d, chain ? 1 : 0);
+        else if (!rhs_row) for (int kb = 0; kb < nblk; ++kb) k_trsv_fwd<<<nblk - kb, 128, 0, st>>>(d.L, npad, kb, d.Linv, d.rhs, d.yc);
         if (chain) {
             if (!rhs_row) RCN_HIP(hipMemsetAsync(d.rhs, 0xFF, sizeof(double) * npad, st));      // the sentinel
-            k_trsv_bwd_chain<<<nblk, 512, 0, st>>>(d.L, npad, nblk, d.Linv, d.yc, d.rhs, d.flag);
+            if (y_in_row) k_trsv_bwd_chain<<<nblk, 512, 0, st>>>(d.L, npad, nblk, d.Linv, nullptr, d.rhs, d.flag, d.S, n);
+            else k_trsv_bwd_chain<<<nblk, 512, 0, st>>>(d.L, npad, nblk, d.Linv, d.yc, d.rhs, d.flag);
         }
         else for (int kb = nblk - 1; kb >= 0; --kb) k_trsv_bwd<<<kb + 1, 512, 0, st>>>(d.L, npad, kb, d.Linv, d.yc, d.rhs);
         RCN_HIP(hipGetLastError());
