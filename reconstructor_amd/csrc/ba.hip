@@ -59,6 +59,7 @@ struct BaDev {
     double *WY;                        // two planes of [n_obs][3][10], camera index fastest: scaled W_o = Jc'Jp at WY, Y_o = W_o Vinv at WY + 30 n_obs
     double *tobs;                      // per observation W_o' y_c (3): the back-substitution's per-observation term
     double *crot;                      // per camera CROT doubles: the camera part of the rotation and its derivative (k_ba_cam_rot)
+    double *crot2;                     // the same for the candidate poses (poses2), written by k_ba_plus; swapped with crot when the step is accepted
     int *flag;
 };
 
@@ -117,12 +118,19 @@ __device__ __forceinline__ void rotate(const double *w, const double *X, double 
 // with products: CROT doubles per camera, [0..8] R, [9..17] Jr, [18] cos, [19] sin, [20..22] axis, [23] 1 = small angle
 // (first-order branch of ceres::AngleAxisRotatePoint), [24..26] w.
 #define CROT 28
+__device__ __noinline__ void cam_rot_entry(const double *w, double *o);
 __global__ void k_ba_cam_rot(const double *__restrict__ poses, int nc, double *__restrict__ tab)
 {
     const int cidx = blockIdx.x * blockDim.x + threadIdx.x;
     if (cidx >= nc) return;
-    const double *w = poses + 6 * (size_t)cidx;
-    double *o = tab + CROT * (size_t)cidx;
+    cam_rot_entry(poses + 6 * (size_t)cidx, tab + CROT * (size_t)cidx);
+}
+// (one camera's entry: also called by k_ba_plus for the pose it has just written -- the table of a candidate that is accepted is then
+//  already there when the evaluation with the Jacobian is queued: one launch less per iteration.  NOT inlined: both callers run the
+//  same instructions, so a table does not depend on who wrote it -- inlined into k_ba_plus the compiler contracted other products
+//  into FMAs than in k_ba_cam_rot, and long far-off solves took other paths than before)
+__device__ __noinline__ void cam_rot_entry(const double *w, double *o)
+{
     const double th2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
     double R[9], Jr[9], c = 1.0, s = 0.0, n[3] = {0.0, 0.0, 0.0};
     const bool big = th2 > DBL_EPSILON;
@@ -426,9 +434,8 @@ __global__ __launch_bounds__(256) void k_finish_sum(const double *partial, int n
     if (threadIdx.x == 0) { *out = scale * s; if (flag) *flag_out = (double)*flag; }
 }
 // K5: per point  Vraw = sum Jp'Jp (3x3), gpraw = sum Jp'r
-__global__ void k_ba_point_raw(BaDev d)
+__device__ __forceinline__ void point_raw_body(const BaDev &d, int j)
 {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= d.np) return;
     double V[9] = {0}, g[3] = {0};
     for (int o = d.pt_off[j]; o < d.pt_off[j + 1]; ++o)
@@ -443,6 +450,10 @@ __global__ void k_ba_point_raw(BaDev d)
     for (int a = 0; a < 9; ++a) d.Vraw[9 * (size_t)j + a] = V[a];
     for (int a = 0; a < 3; ++a) d.gpraw[3 * (size_t)j + a] = g[a];
 }
+__global__ void k_ba_point_raw(BaDev d)
+{
+    point_raw_body(d, blockIdx.x * blockDim.x + threadIdx.x);
+}
 
 // K5: per camera  Uraw = sum Jc'Jc (10x10), gcraw = sum Jc'r ; one workgroup per camera, eight groups of
 // 128 threads: group g stages and sums the 32-observation chunks g, g+8, ... (a camera of the reference's own
@@ -450,10 +461,16 @@ __global__ void k_ba_point_raw(BaDev d)
 // With few cameras (the reference's regime) a camera is further split over `split` workgroups so that
 // the launch fills the chip; their partial sums go to d.csplit and are added in order by k_ba_cam_fin.
 #define CR_GROUPS 8
-__global__ __launch_bounds__(128 * CR_GROUPS) void k_ba_cam_raw(BaDev d, int split)
+// (point_blocks > 0: the launch also carries K5's per-point part -- the two read the same rows and depend on nothing of each other --
+//  in that many workgroups BEHIND the cameras': one launch less per evaluation with a Jacobian)
+__global__ __launch_bounds__(128 * CR_GROUPS) void k_ba_cam_raw(BaDev d, int split, int cam_blocks)
 {
     __shared__ __attribute__((aligned(16))) double sh[CR_GROUPS][32 * 22];
     __shared__ double part[CR_GROUPS][110];
+    if ((int)blockIdx.x >= cam_blocks) {       // (uniform over the workgroup: no barrier is skipped by part of it)
+        point_raw_body(d, ((int)blockIdx.x - cam_blocks) * (128 * CR_GROUPS) + (int)threadIdx.x);
+        return;
+    }
     const int c = blockIdx.x / split, sidx = blockIdx.x - c * split, g = threadIdx.x >> 7, t = threadIdx.x & 127;
     // thread t < 110 of a group owns one entry: 0..99 of U (a = t/10, b = t%10), 100..109 of g
     double acc = 0.0;
@@ -1910,6 +1927,7 @@ __global__ __launch_bounds__(256) void k_ba_plus(BaDev d, double alpha, double *
             d.poses2[6 * c + k] = ps2[k]; d.intr2[6 * c + k] = in2[k];
             dn += (ps2[k] - ps[k]) * (ps2[k] - ps[k]) + (in2[k] - in[k]) * (in2[k] - in[k]);
         }
+        cam_rot_entry(ps2, d.crot2 + CROT * (size_t)c);
     }
     if (i < d.np) {
         const bool used = d.pt_off[i + 1] > d.pt_off[i];
@@ -2171,6 +2189,7 @@ int rcn_int_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_option
         *p_cols = p_camdim + nc, *p_flag = p_cols + 10 * (size_t)nc;
     d.J = ws.get<double>(JROW * (size_t)no + 2); d.tobs = ws.get<double>(3 * (size_t)no);
     d.crot = ws.get<double>(CROT * (size_t)nc);
+    d.crot2 = ws.get<double>(CROT * (size_t)nc);
     d.Uraw = ws.get<double>(100 * (size_t)nc); d.gcraw = ws.get<double>(10 * (size_t)nc);
     d.Vraw = ws.get<double>(9 * (size_t)np); d.gpraw = ws.get<double>(3 * (size_t)np);
     const size_t nvec = (size_t)npad + 3 * (size_t)np + 16;
@@ -2306,7 +2325,7 @@ int rcn_int_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_option
     auto fin = [&](double *out, double scale, int which, bool with_flag, double *zero, double *out2 = nullptr) {
         return Fin{out, out2, reinterpret_cast<unsigned *>(d.flag + 8 + which), with_flag ? d.flag : nullptr, d.scal + 13, zero, scale};
     };
-    auto eval = [&](bool jac, const double *ps, const double *in, const double *x, int slot, bool with_flag = false) -> hipError_t {
+    auto eval = [&](bool jac, const double *ps, const double *in, const double *x, int slot, bool with_flag = false, bool rot_ready = false) -> hipError_t {
         if (no > 0) {
             if (jac) {
                 // the streaming kernel of the solve, timed on its own (summary.jacobian_seconds): 224 B written per observation
@@ -2315,7 +2334,7 @@ int rcn_int_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_option
                     if (hipEventElapsedTime(&ms, ctx->ba_tev[4], ctx->ba_tev[5]) == hipSuccess) { sum->jacobian_seconds += 1e-3 * ms; sum->jacobian_evals++; }
                     else (void)hipGetLastError();
                 }
-                k_ba_cam_rot<<<(nc + 127) / 128, 128, 0, st>>>(ps, nc, d.crot);
+                if (!rot_ready) k_ba_cam_rot<<<(nc + 127) / 128, 128, 0, st>>>(ps, nc, d.crot);      // (an accepted candidate brings its table: k_ba_plus)
                 if (phase_times) (void)hipEventRecord(ctx->ba_tev[4], st);
                 k_ba_eval<true><<<ebj, 128, 0, st>>>(d, ps, in, x, d.partial, fin(d.scal + slot, 0.5, 0, false, d.scal + 12));
                 if (phase_times) (void)hipEventRecord(ctx->ba_tev[5], st);
@@ -2326,8 +2345,8 @@ int rcn_int_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_option
             if (jac) (void)hipMemsetAsync(d.scal + 12, 0, sizeof(double), st);
         }
         if (jac) {
-            if (np > 0) k_ba_point_raw<<<(np + 127) / 128, 128, 0, st>>>(d);
-            k_ba_cam_raw<<<nc * csplit, 128 * CR_GROUPS, 0, st>>>(d, csplit);
+            const int pblocks = (np + 128 * CR_GROUPS - 1) / (128 * CR_GROUPS);
+            k_ba_cam_raw<<<nc * csplit + pblocks, 128 * CR_GROUPS, 0, st>>>(d, csplit, nc * csplit);
             if (csplit > 1) k_ba_cam_fin<<<nc, 128, 0, st>>>(d, csplit);
         }
         return hipGetLastError();
@@ -2677,8 +2696,8 @@ int rcn_int_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_option
         }
         const double rho = cost_change / model_change;
         if (rho > opt->min_relative_decrease) {
-            std::swap(d.poses, d.poses2); std::swap(d.intr, d.intr2); std::swap(d.pts, d.pts2);
-            RCN_HIP(eval(true, d.poses, d.intr, d.pts, 0));
+            std::swap(d.poses, d.poses2); std::swap(d.intr, d.intr2); std::swap(d.pts, d.pts2); std::swap(d.crot, d.crot2);
+            RCN_HIP(eval(true, d.poses, d.intr, d.pts, 0, false, true));
             cost_pending = true;          // cost = scal[0] at the next read (read_scal, above)
             cost_iter = iter;
             need_gradient = true;
