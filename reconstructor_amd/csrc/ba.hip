@@ -59,6 +59,7 @@ struct BaDev {
     double *WY;                        // two planes of [n_obs][3][10], camera index fastest: scaled W_o = Jc'Jp at WY, Y_o = W_o Vinv at WY + 30 n_obs
     double *tobs;                      // per observation W_o' y_c (3): the back-substitution's per-observation term
     double *crot;                      // per camera CROT doubles: the camera part of the rotation and its derivative (k_ba_cam_rot)
+    unsigned *tickets;                 // 2 nc words, zero at rest: the workgroups a camera is split over finish their sums themselves (cam / Schur-diagonal kernels)
     double *crot2;                     // the same for the candidate poses (poses2), written by k_ba_plus; swapped with crot when the step is accepted
     int *flag;
 };
@@ -459,7 +460,7 @@ __global__ void k_ba_point_raw(BaDev d)
 // 128 threads: group g stages and sums the 32-observation chunks g, g+8, ... (a camera of the reference's own
 // regime sees thousands of observations), the eight partial sums are added in group order.
 // With few cameras (the reference's regime) a camera is further split over `split` workgroups so that
-// the launch fills the chip; their partial sums go to d.csplit and are added in order by k_ba_cam_fin.
+// the launch fills the chip; their partial sums go to d.csplit and are added in order by the workgroup that finishes last.
 #define CR_GROUPS 8
 // (point_blocks > 0: the launch also carries K5's per-point part -- the two read the same rows and depend on nothing of each other --
 //  in that many workgroups BEHIND the cameras': one launch less per evaluation with a Jacobian)
@@ -512,21 +513,28 @@ __global__ __launch_bounds__(128 * CR_GROUPS) void k_ba_cam_raw(BaDev d, int spl
     if (g == 0 && t < 110) {
         double s = 0.0;
         for (int k = 0; k < CR_GROUPS; ++k) s += part[k][t];
-        if (split > 1) d.csplit[((size_t)c * split + sidx) * 256 + t] = s;
+        if (split > 1) __hip_atomic_store(d.csplit + ((size_t)c * split + sidx) * 256 + t, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         else if (t < 100) d.Uraw[100 * (size_t)c + t] = s;
         else d.gcraw[10 * (size_t)c + (t - 100)] = s;
     }
+    if (split > 1) {
+        // the camera's workgroups finish the sum themselves (k_ba_cam_fin, a launch of its own, before): partials delivered as
+        // agent-coherent stores and drained, one ticket per workgroup, the one that draws the last adds them in index order --
+        // the hand-off of finish_sums, per camera
+        __shared__ int s_last;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) s_last = __hip_atomic_fetch_add(d.tickets + c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)split - 1u;
+        __syncthreads();
+        if (s_last && g == 0 && t < 110) {
+            double s = 0.0;
+            for (int k = 0; k < split; ++k) s += __hip_atomic_load(d.csplit + ((size_t)c * split + k) * 256 + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (t < 100) d.Uraw[100 * (size_t)c + t] = s;
+            else d.gcraw[10 * (size_t)c + (t - 100)] = s;
+            if (t == 0) __hip_atomic_store(d.tickets + c, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
 }
-__global__ __launch_bounds__(128) void k_ba_cam_fin(BaDev d, int split)
-{
-    const int c = blockIdx.x, t = threadIdx.x;
-    if (t >= 110) return;
-    double s = 0.0;
-    for (int k = 0; k < split; ++k) s += d.csplit[((size_t)c * split + k) * 256 + t];
-    if (t < 100) d.Uraw[100 * (size_t)c + t] = s;
-    else d.gcraw[10 * (size_t)c + (t - 100)] = s;
-}
-
 // Jacobi scaling (initial point) or clamped LM diagonal (scaled Jacobian) from the raw diagonals
 __global__ void k_ba_diag(BaDev d, int what, double lo, double hi, int jacobi)
 {
@@ -923,19 +931,23 @@ __global__ __launch_bounds__(1024) void k_ba_schur_diag_mfma(BaDev d, const int 
     if (threadIdx.x < 256) {
         double v = 0.0;
         for (int k = 0; k < 16; ++k) v += part[k][threadIdx.x];
-        if (split > 1) d.csplit[((size_t)c * split + sidx) * 256 + threadIdx.x] = v;
+        if (split > 1) __hip_atomic_store(d.csplit + ((size_t)c * split + sidx) * 256 + threadIdx.x, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         else schur_diag_finish(d, c, threadIdx.x, v, inv_radius);
     }
+    if (split > 1) {      // as in k_ba_cam_raw: the last of the camera's workgroups adds the partial blocks, in index order (k_ba_schur_diag_fin before)
+        __shared__ int s_last;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) s_last = __hip_atomic_fetch_add(d.tickets + d.nc + c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)split - 1u;
+        __syncthreads();
+        if (s_last && threadIdx.x < 256) {
+            double v = 0.0;
+            for (int k = 0; k < split; ++k) v += __hip_atomic_load(d.csplit + ((size_t)c * split + k) * 256 + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            schur_diag_finish(d, c, threadIdx.x, v, inv_radius);
+            if (threadIdx.x == 0) __hip_atomic_store(d.tickets + d.nc + c, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
 }
-__global__ __launch_bounds__(256) void k_ba_schur_diag_fin(BaDev d, double inv_radius, int split)
-{
-    const int c = blockIdx.x;
-    if (d.cam_dim[c] == 0) return;
-    double v = 0.0;
-    for (int k = 0; k < split; ++k) v += d.csplit[((size_t)c * split + k) * 256 + threadIdx.x];
-    schur_diag_finish(d, c, threadIdx.x, v, inv_radius);
-}
-
 #define RCN_RHS_BETA 1.0e200
 // Everything between the Schur build and the factorisation in ONE launch (round 4; three clears and two small kernels before):
 // the padded rows of the dense system -- zero, identity on the diagonal, the right-hand side in row n under its huge diagonal
@@ -2190,6 +2202,7 @@ int rcn_int_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_option
     d.J = ws.get<double>(JROW * (size_t)no + 2); d.tobs = ws.get<double>(3 * (size_t)no);
     d.crot = ws.get<double>(CROT * (size_t)nc);
     d.crot2 = ws.get<double>(CROT * (size_t)nc);
+    d.tickets = ws.get<unsigned>(2 * (size_t)std::max(nc, 1));
     d.Uraw = ws.get<double>(100 * (size_t)nc); d.gcraw = ws.get<double>(10 * (size_t)nc);
     d.Vraw = ws.get<double>(9 * (size_t)np); d.gpraw = ws.get<double>(3 * (size_t)np);
     const size_t nvec = (size_t)npad + 3 * (size_t)np + 16;
@@ -2250,6 +2263,7 @@ int rcn_int_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_option
         RCN_HIP(hipStreamSynchronize(st));      // `stage` leaves scope
     }
     RCN_HIP(hipMemsetAsync(p_flag, 0, 24 * sizeof(int), st));
+    RCN_HIP(hipMemsetAsync(d.tickets, 0, 2 * (size_t)std::max(nc, 1) * sizeof(unsigned), st));
     RCN_HIP(hipMemsetAsync(vecs, 0, sizeof(double) * 12 * nvec, st));
     RCN_HIP(hipMemsetAsync(d.S, 0, sizeof(double) * (size_t)npad * npad, st));   // upper part / padding never rewritten
     RCN_HIP(hipMemsetAsync(d.Linv, 0, sizeof(double) * (size_t)nblk * NB * NB, st));   // upper triangles of the tile inverses stay zero
@@ -2347,7 +2361,6 @@ int rcn_int_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_option
         if (jac) {
             const int pblocks = (np + 128 * CR_GROUPS - 1) / (128 * CR_GROUPS);
             k_ba_cam_raw<<<nc * csplit + pblocks, 128 * CR_GROUPS, 0, st>>>(d, csplit, nc * csplit);
-            if (csplit > 1) k_ba_cam_fin<<<nc, 128, 0, st>>>(d, csplit);
         }
         return hipGetLastError();
     };
@@ -2423,7 +2436,6 @@ int rcn_int_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_option
             }
             if (csplit > 1) k_ba_schur_diag_mfma<12><<<nc * csplit, 1024, 0, st>>>(d, pk_off, pk_list, ir, csplit);
             else k_ba_schur_diag_mfma<4><<<nc, 1024, 0, st>>>(d, pk_off, pk_list, ir, 1);
-            if (csplit > 1) k_ba_schur_diag_fin<<<nc, 256, 0, st>>>(d, ir, csplit);
             if (fused_finish) k_ba_S_finish<<<(unsigned)(((size_t)(npad - n) * npad + 255) / 256), 256, 0, st>>>(d, chain ? 1 : 0);
             else if (npad > n) k_ba_S_pad<<<(npad - n + 127) / 128, 128, 0, st>>>(d);
         } else {
