@@ -2295,18 +2295,23 @@ int rcn_int_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_option
     // estimates (another start, other options) skips the 0.75 ms the lists cost at 1M observations.
     const uint64_t pair_token = res ? res->pair_token : plain_token;
     const bool pairs_cached = pair_token != 0 && ctx->ba_pair_token == pair_token;
-    if (gather && np > 0 && !pairs_cached) {
-        RCN_HIP(hipMemsetAsync(pk, 0, sizeof(int) * (3 * (size_t)nkeys + 4 + (nkeys + 1023) / 1024), st));
+    // The lists are built on the panel stream, BESIDE the first evaluation (which needs nothing of them; both are eight launches or so, and
+    // on the reference's problem sizes a solve is a few hundred launch-bound microseconds): the ctx stream waits for them in front of the loop.
+    const bool pairs_build = gather && np > 0 && !pairs_cached;
+    if (pairs_build) {
+        hipStream_t sp = ctx->panel_stream;          // idle: the stream was synchronised above and every factorisation joins its streams
+        RCN_HIP(hipMemsetAsync(pk, 0, sizeof(int) * (3 * (size_t)nkeys + 4 + (nkeys + 1023) / 1024), sp));
         const int thr = std::min(256, std::max(64, (kmax * kmax + 63) / 64 * 64));
-        k_pair_count<<<np, thr, 0, st>>>(d, pk_cnt);
+        k_pair_count<<<np, thr, 0, sp>>>(d, pk_cnt);
         const int nchunks = (nkeys + 1023) / 1024;
-        k_scan_sums<<<nchunks, 1024, 0, st>>>(pk_cnt, pk_sums, nkeys);
-        k_scan_top<<<1, 1024, 0, st>>>(pk_sums, nchunks, pk_off + nkeys);
-        k_scan_apply<<<nchunks, 1024, 0, st>>>(pk_cnt, pk_sums, pk_off, nkeys);
-        k_pair_fill<<<np, thr, 0, st>>>(d, pk_off, pk_fill, pk_list);
-        k_pair_sort<<<(nkeys + 127) / 128, 128, 0, st>>>(pk_off, pk_list, nkeys);
-        k_pair_sort_long<<<nkeys, 256, 0, st>>>(pk_off, pk_list);
+        k_scan_sums<<<nchunks, 1024, 0, sp>>>(pk_cnt, pk_sums, nkeys);
+        k_scan_top<<<1, 1024, 0, sp>>>(pk_sums, nchunks, pk_off + nkeys);
+        k_scan_apply<<<nchunks, 1024, 0, sp>>>(pk_cnt, pk_sums, pk_off, nkeys);
+        k_pair_fill<<<np, thr, 0, sp>>>(d, pk_off, pk_fill, pk_list);
+        k_pair_sort<<<(nkeys + 127) / 128, 128, 0, sp>>>(pk_off, pk_list, nkeys);
+        k_pair_sort_long<<<nkeys, 256, 0, sp>>>(pk_off, pk_list);
         RCN_HIP(hipGetLastError());
+        RCN_HIP(hipEventRecord(ctx->ba_ev[7], sp));
     }
     ctx->ba_pair_token = (gather && np > 0) ? pair_token : 0;
     sum->pair_lists_reused = pairs_cached ? 1 : 0;
@@ -2375,6 +2380,7 @@ int rcn_int_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_option
     sum->initial_rms_px = std::sqrt(2.0 * cost / std::max(no, 1));
     sum->cost_trace[0] = cost;
 
+    if (pairs_build) RCN_HIP(hipStreamWaitEvent(st, ctx->ba_ev[7], 0));      // the Schur build of the first iteration reads the lists
     double radius = opt->initial_trust_region_radius, decrease = 2.0;
     bool reuse_diag = false, need_gradient = true, grad_pending = false, diag_fresh = false;
     int invalid_run = 0, termination = 0, iter = 0;
