@@ -1135,7 +1135,10 @@ __device__ unsigned long long g_stamps[64];
 #define CDW 8          // waves of the diagonal kernel: wave 0 owns the leaves, the others the matrix work between them.  Eight since the
                        // leaf moved to the matrix pipe (136 registers; the vector-ALU leaf of round 2 wanted ~340 and spilled at
                        // eight waves); the doubling steps (2c) deal their tiles to exactly eight waves
-__global__ __launch_bounds__(64 * CDW) void k_chol_diag(double *S, int ld, int kb, double *Linv, int *flag, int store_L, Gate g)
+// nact: the block's ACTIVE rows -- below them it is the identity padding of the system (the last block of every factorisation; the only
+// block of the reference's own problem sizes: 3 cameras are 13 rows of 128).  Only the leaves that hold active rows are factored; the
+// rest of the block is its own factor and inverse, and is written as such.
+__global__ __launch_bounds__(64 * CDW) void k_chol_diag(double *S, int ld, int kb, double *Linv, int *flag, int store_L, Gate g, int nact = NB)
 {
     __builtin_amdgcn_s_setprio(3);
     TL_MARK(8 * kb, 0);
@@ -1262,21 +1265,25 @@ __global__ __launch_bounds__(64 * CDW) void k_chol_diag(double *S, int ld, int k
                 if (m == c) rd[c0 + c] = Lc[p];
             }
             };
+    const int NA = LB * ((min(max(nact, 1), NB) + LB - 1) / LB);      // rows of the leaves that hold active rows (a multiple of 16, at least one leaf)
     if (w == 0) leaf_factor(0);
+    // the padding: unit diagonal of the factor (rd: what store_L reads) and of the inverse; everything else there is zero already --
+    // the block was loaded with zeros above the diagonal, the padding rows are zero left of it, and the inverse's buffer starts as zeros
+    for (int i = NA + t; i < NB; i += 64 * CDW) { rd[i] = 1.0; out[(size_t)i * NB + i] = 1.0; }
     __syncthreads();
     STAMP(1);
     f64x4 tcur = {0.0, 0.0, 0.0, 0.0};       // waves 1..7: T_j of the inverse's next block row (2., below)
-    for (int c0 = 0; c0 < NB; c0 += LB) {
+    for (int c0 = 0; c0 < NA; c0 += LB) {
         if (misc[0] != 0.0) {
             if (t == 0) flag_raise(flag, 1);
             return;
         }
         const int r0 = c0 + LB, kk = c0 / LB;
-        if (r0 >= NB) break;
+        if (r0 >= NA) break;
         // 1b. rows below: X = A * D^-T as 16x16 MFMA tiles (one wave per tile), in place:
         //     X[r][c] = sum_{k<=c} A[r][k] * Dinv[c][k]
         {
-            const int leaf = c0 / LB, ntile = (NB - r0) / 16;
+            const int leaf = c0 / LB, ntile = (NA - r0) / 16;
             for (int tile = w; tile < ntile; tile += CDW) {
                 double *At = L + (r0 + 16 * tile) * DL + c0;
                 f64x4 acc = {0.0, 0.0, 0.0, 0.0};
@@ -1298,7 +1305,7 @@ __global__ __launch_bounds__(64 * CDW) void k_chol_diag(double *S, int ld, int k
         //     leaf's diagonal block -- and goes straight on to factor and invert that leaf while waves
         //     1..3 update the rest of the square, so the serial leaf work hides behind the MFMA work.
         {
-            const int nt = (NB - r0) / 16, ntile = nt * (nt + 1) / 2;
+            const int nt = (NA - r0) / 16, ntile = nt * (nt + 1) / 2;
             for (int tile = w == 0 ? 0 : w; tile < ntile; tile += (w == 0 ? ntile : CDW - 1)) {
                 int tr = (int)((sqrtf(8.f * tile + 1.f) - 1.f) * 0.5f);
                 while ((tr + 1) * (tr + 2) / 2 <= tile) ++tr;
@@ -1386,9 +1393,10 @@ __global__ __launch_bounds__(64 * CDW) void k_chol_diag(double *S, int ld, int k
             if (c <= r) A[(size_t)r * ld + c] = r / LB != c / LB ? L[r * DL + c] : r == c ? rd[r] : L[c * DL + r];
         }
     STAMP(14);
-    // the last block row of the inverse: its leaf was the last thing the loop did
+    // the last ACTIVE block row of the inverse: its leaf was the last thing the loop did (tile columns left of it only: with one
+    // active leaf there are none)
     if (w >= 1) {
-        const int j = w - 1, c0 = NB - LB, ci = lane & 15, kq = lane >> 4;
+        const int j = w - 1, c0 = NA - LB, ci = lane & 15, kq = lane >> 4;
         f64x4 R = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int sx = 0; sx < 4; ++sx) {
@@ -1396,8 +1404,9 @@ __global__ __launch_bounds__(64 * CDW) void k_chol_diag(double *S, int ld, int k
             const double a = k <= ci ? -L[(c0 + ci) * DL + c0 + k] : 0.0;
             R = __builtin_amdgcn_mfma_f64_16x16x4f64(a, tcur[sx], R, 0, 0, 0);
         }
+        if (LB * j < c0)
 #pragma unroll
-        for (int reg = 0; reg < 4; ++reg) out[(size_t)(c0 + kq + 4 * reg) * NB + LB * j + ci] = R[reg];
+            for (int reg = 0; reg < 4; ++reg) out[(size_t)(c0 + kq + 4 * reg) * NB + LB * j + ci] = R[reg];
         if (w == 1) {
 #pragma unroll
             for (int sx = 0; sx < 4; ++sx) {
@@ -2512,7 +2521,9 @@ int rcn_int_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_option
                 const int ncols = g_size - g_pos;     // trailing columns C(kb) updates: kb + 1 .. kb + ncols (a step on its own: the first one)
                 const bool last_of_group = g_pos == g_size - 1;
                 // D(kb): publishes "T(kb-1) done"
-                k_chol_diag<<<1, 64 * CDW, NB * DL * 8, sA>>>(d.S, npad, kb, d.Linv, d.flag, kb == nblk - 1, gate(nullptr, 0, Wr{nullptr, 0}, cT, kb));
+                // (active rows of the block: the system's n rows, and the right-hand-side row behind them when it rides along)
+                const int nact = std::min(NB, (rhs_row ? n + 1 : n) - kb * NB);
+                k_chol_diag<<<1, 64 * CDW, NB * DL * 8, sA>>>(d.S, npad, kb, d.Linv, d.flag, kb == nblk - 1, gate(nullptr, 0, Wr{nullptr, 0}, cT, kb), nact);
                 if (m <= 0) break;
                 const int gq1 = 32;                   // grid of k_gemm_q for one tile: strips 0..3 on 4 of the 8 XCD slots
                 // T(kb), first half: publishes "D(kb) done"; waits for C(kb-1) and the bulk updates of column kb + 1
