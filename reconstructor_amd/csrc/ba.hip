@@ -572,7 +572,8 @@ __global__ void k_ba_point_solve(BaDev d, double inv_radius)
     const double det = a * A + b * B + c * C;
     double Vi[9];
     if (!(det > 0.0) || !isfinite(det)) {
-        *d.flag = 1;
+        d.flag[0] = 1;
+        d.flag[1] = 1;      // (k_ba_S_finish clears the flag words BEHIND this kernel: it restores [0] from this word)
         for (int i = 0; i < 9; ++i) Vi[i] = 0.0;
     } else {
         const double id = 1.0 / det;
@@ -957,7 +958,10 @@ __global__ __launch_bounds__(1024) void k_ba_schur_diag_mfma(BaDev d, const int 
 __global__ __launch_bounds__(256) void k_ba_S_finish(BaDev d, int sentinel)
 {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x, cnt = (size_t)(d.npad - d.n) * d.npad;
-    if (idx < 8) d.flag[idx] = 0;
+    // ([1]: k_ba_point_solve met a block that is singular in floating point in THIS iteration -- the step is invalid, as in the oracle;
+    //  the other words belong to the factorisation that follows)
+    if (idx == 0) { const int ps = d.flag[1]; d.flag[1] = 0; d.flag[0] = ps ? 1 : 0; }
+    else if (idx >= 2 && idx < 8) d.flag[idx] = 0;
     if (idx >= cnt) return;
     const int i = d.n + (int)(idx / d.npad), j = (int)(idx % d.npad);
     double v = i == j ? 1.0 : 0.0;
