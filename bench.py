@@ -683,6 +683,9 @@ def grid_line(K, n_img, n_pairs_total, dt, steps, st, world, my_pairs):
             # + 8 B of candidate pair per query row of the launch's pairs
             "algorithmic_hbm_bytes_per_launch": float(n_img) * K * D * 2 + 8.0 * float(st["rows_total"]) * calls / launches,
             "launch_ms": coarse_ms, "launches_per_step": launches / calls, "k1_ms_per_step": st["coarse_ms"] / calls,
+            # K1's time per image pair of THIS rank: the same at every N unless something competes with the kernel (at N > 1 the fp32 rows
+            # arrive on a side stream beside it: any interference of that gather shows here against the N = 1 line's figure)
+            "k1_us_per_pair_rank0": 1e3 * st["coarse_ms"] / calls / max(1, my_pairs),
             "algorithmic_flop_per_launch": flops_per_launch,
             "rerank_ms": st["rerank_ms"] / calls, "unique_ms": st["unique_ms"] / calls,
             "rows_brute_force": int(st.get("rows_brute_force", 0)),
@@ -946,11 +949,6 @@ def main():
                 line["orb32"] = small_d_leg(torch, ctx, dev, "orb", 32)
                 line["mixed_magnitudes"] = mixed_magnitude_leg(torch, ctx, dev)
                 shard.reserve(n_img, K, D)         # the clear above dropped the shard's images: nothing is matched through it again
-            if not args.no_cpu_baseline:
-                images = [local[i] for i in range(min(local.shape[0], 64))]
-                line["cpu_baseline"] = cpu_baseline(images, host_threads())
-            else:
-                line["cpu_baseline"] = None
             if not args.no_ba:
                 shard.close()
                 shard = None
@@ -958,6 +956,17 @@ def main():
                 line["ba_lm_iterations_per_s"] = line["ba"]["cfg5"]["lm_iterations_per_s"]   # 1k cams / 100k pts / 1M obs
                 line["epipolar_filter"] = fmat_leg(ctx, not args.no_cpu_baseline)
                 line["cfg1"] = cfg1_leg(ctx, not args.no_cpu_baseline)
+        # the CPU baseline rides in EVERY line: rank 0 times the oracle on the same bounded sample of its own images behind
+        # the timed region while the other ranks wait at the closing barrier (at N > 1 they are idle: the host cores are rank 0's)
+        if not args.no_cpu_baseline:
+            images = [local[i] for i in range(min(local.shape[0], 64))]
+            line["cpu_baseline"] = cpu_baseline(images, host_threads())
+        else:
+            line["cpu_baseline"] = None
+        if info["comm_ranks"] != world:
+            sys.stderr.write("bench.py: the communicator has %d ranks, the job %d\n" % (info["comm_ranks"], world))
+            raise SystemExit(3)
+        line["config"]["rccl_ranks"] = int(info["comm_ranks"])
         print(json.dumps(line), flush=True)
     if shard is not None:
         shard.close()

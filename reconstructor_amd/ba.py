@@ -30,8 +30,9 @@ def summary_dict(s):
     return d
 
 
-def solve_flat(ctx, poses, intrinsics, points, obs_uv, obs_cam, obs_pt, options=None):
-    """Returns (poses, intrinsics, points, summary); inputs are copied, not modified."""
+def solve_flat(ctx, poses, intrinsics, points, obs_uv, obs_cam, obs_pt, options=None, allow_failure=False):
+    """Returns (poses, intrinsics, points, summary); inputs are copied, not modified.
+    allow_failure: a solve that ends in RCN_BA_FAILURE (RCN_ERR_NUMERIC; the summary is filled) returns instead of raising."""
     poses = np.array(poses, np.float64, order="C")
     intr = np.array(intrinsics, np.float64, order="C")
     pts = np.array(points, np.float64, order="C").reshape(-1, 3)
@@ -44,13 +45,15 @@ def solve_flat(ctx, poses, intrinsics, points, obs_uv, obs_cam, obs_pt, options=
                         pt.ctypes.data if pt.size else None)
     o = options if options is not None else default_options(ctx, poses.shape[0])
     s = _lib.BaSummary()
-    ctx.check(ctx.lib.rcn_ba_solve(ctx.h, C.byref(pb), C.byref(o), C.byref(s)))
+    rc = ctx.lib.rcn_ba_solve(ctx.h, C.byref(pb), C.byref(o), C.byref(s))
+    if not (allow_failure and rc == -6 and s.termination == 6):
+        ctx.check(rc)
     return poses, intr, pts, summary_dict(s)
 
 
-def solve_scene(ctx, scene, options=None):
+def solve_scene(ctx, scene, options=None, allow_failure=False):
     return solve_flat(ctx, scene["poses"], scene["intrinsics"], scene["points"], scene["obs_uv"],
-                      scene["obs_cam"], scene["obs_pt"], options)
+                      scene["obs_cam"], scene["obs_pt"], options, allow_failure)
 
 
 def _rot_to_angle_axis(R):

@@ -1085,19 +1085,27 @@ __device__ __forceinline__ void ring_wait(const int *counter, int need, int *fla
 //            the publishing stream nothing (a trailing signal kernel would cost ~5 us of the chain per step);
 //   wait     thread 0 of every workgroup polls (relaxed), then ONE agent-scope acquire, then the workgroup barrier:
 //            the consumer recipe of MI355X_MICROARCH.md (inter-workgroup visibility), after which plain loads are safe.
-struct Gate { const int *c0; int n0; const int *c1; int n1; int *pub; int pubval; int *flag; };
+struct Gate { const int *c[5]; int n[5]; int nw; int *pub; int pubval; int *flag; };
+__host__ __device__ inline Gate gate_none(int *flag)
+{
+    Gate g = {{nullptr, nullptr, nullptr, nullptr, nullptr}, {0, 0, 0, 0, 0}, 0, nullptr, 0, flag};
+    return g;
+}
 __device__ __forceinline__ void gate_enter(const Gate &g)
 {
     if (threadIdx.x == 0) {
         if (g.pub && blockIdx.x == 0) __hip_atomic_store(g.pub, g.pubval, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (g.c0) ring_wait(g.c0, g.n0, g.flag);
-        if (g.c1) ring_wait(g.c1, g.n1, g.flag);
-        if (g.c0 || g.c1) {
+        if (g.nw > 0) ring_wait(g.c[0], g.n[0], g.flag);
+        if (g.nw > 1) ring_wait(g.c[1], g.n[1], g.flag);
+        if (g.nw > 2) ring_wait(g.c[2], g.n[2], g.flag);
+        if (g.nw > 3) ring_wait(g.c[3], g.n[3], g.flag);
+        if (g.nw > 4) ring_wait(g.c[4], g.n[4], g.flag);
+        if (g.nw > 0) {
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
     }
-    if (g.c0 || g.c1) __syncthreads();
+    if (g.nw > 0) __syncthreads();
 }
 
 __global__ __launch_bounds__(64) void k_ring_gate(Gate g)
@@ -1142,12 +1150,12 @@ __device__ unsigned long long g_stamps[64];
 // nact: the block's ACTIVE rows -- below them it is the identity padding of the system (the last block of every factorisation; the only
 // block of the reference's own problem sizes: 3 cameras are 13 rows of 128).  Only the leaves that hold active rows are factored; the
 // rest of the block is its own factor and inverse, and is written as such.
-__global__ __launch_bounds__(64 * CDW) void k_chol_diag(double *S, int ld, int kb, double *Linv, int *flag, int store_L, Gate g, int nact = NB)
+__global__ __launch_bounds__(64 * CDW) void k_chol_diag(double *S, int ld, int kb, double *Linv, int *flag, int store_L, Gate g, int nact = NB, int tl = 0)
 {
     __builtin_amdgcn_s_setprio(3);
-    TL_MARK(8 * kb, 0);
+    TL_MARK(tl, 0);
     gate_enter(g);
-    TL_MARK(8 * kb, 1);
+    TL_MARK(tl, 1);
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     double *L = reinterpret_cast<double *>(smem_raw);  // [128][DL]
     if (threadIdx.x >= 64) __builtin_amdgcn_s_setprio(2);   // wave 0 carries the serial chain: its few MFMAs go before its SIMD neighbour's
@@ -1421,7 +1429,7 @@ __global__ __launch_bounds__(64 * CDW) void k_chol_diag(double *S, int ld, int k
     }
     STAMP(16);
     STAMP(17);
-    TL_MARK(8 * kb, 2);
+    TL_MARK(tl, 2);
 }
 
 // Dense blocked Cholesky, GEMM side.  S holds the reduced system and its trailing updates; the
@@ -1442,10 +1450,10 @@ __global__ __launch_bounds__(64 * CDW) void k_chol_diag(double *S, int ld, int k
 // first / m: the tiles kb + 1 + first .. kb + 1 + first + m - 1 of the tile column (the critical tile is first = 0, m = 1)
 template <int MODE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(96)))
-void k_gemm_q(double *S, double *L, int ld, int kb, int first, int m, const double *Linv, Gate g, int dj = 1)
+void k_gemm_q(double *S, double *L, int ld, int kb, int first, int m, const double *Linv, Gate g, int dj = 1, int tl = 0)
 {
     __builtin_amdgcn_s_setprio(3);      // these waves share SIMDs with the bulk update's: their few MFMAs and loads go first
-    [[maybe_unused]] const int tl_id = 8 * kb + (MODE == 0 ? (first == 0 ? 1 : 3) : (first == 0 ? 2 : (dj == 2 ? 5 : 4)));
+    [[maybe_unused]] const int tl_id = tl;
     TL_MARK(tl_id, 0);
     gate_enter(g);
     TL_MARK(tl_id, 1);
@@ -1485,6 +1493,71 @@ void k_gemm_q(double *S, double *L, int ld, int kb, int first, int m, const doub
     TL_MARK(tl_id, 2);
 }
 
+// Two-level regime (round 5): block row `pos` of W = L_JJ^-1, the inverse of the factor of the super-diagonal block [p, p + g) --
+// g x g tiles, lower block-triangular, row-major in SI (row stride ldsi = 128 g):
+//     W[pos][pos] = Linv_c,     W[pos][m] = -Linv_c  sum_{r = m .. pos-1} L(c, p + r) W[r][m]     (c = p + pos, m < pos)
+// from L W = I.  With it every row below the super-block is ONE product, L(i, J) = S(i, J) W' (k_gemm_nt_pipe, MODE 2), instead
+// of g panel products with g (g - 1) / 2 column updates between them.  Workgroup b < 8 pos: tile m = b / 8, its 16-column strip
+// b % 8 -- eight waves, wave w the strip's rows 16 w .. 16 w + 15: first the sum (operands straight from L2 into MFMA layout,
+// both fed with the same k permutation), through LDS, then the product with Linv_c, whose rows 16 w .. end at column 16 w + 15.
+// The last workgroup copies the diagonal tile.  A few microseconds behind the chain's next diagonal block; only the last row
+// of a super-block is waited for.
+__global__ __launch_bounds__(512) void k_sinv(const double *L, int ld, const double *Linv, double *SI, int ldsi, int p, int pos, Gate g, int tl)
+{
+    __builtin_amdgcn_s_setprio(3);
+    TL_MARK(tl, 0);
+    gate_enter(g);
+    TL_MARK(tl, 1);
+    const int c = p + pos, t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const double *Lc = Linv + (size_t)c * NB * NB;
+    if ((int)blockIdx.x == 8 * pos) {
+        for (int i = t; i < NB * NB / 2; i += 512) {
+            const int r = i / (NB / 2), c2 = i % (NB / 2);
+            *reinterpret_cast<f64x2 *>(SI + ((size_t)pos * NB + r) * ldsi + (size_t)pos * NB + 2 * c2) = *reinterpret_cast<const f64x2 *>(Lc + (size_t)r * NB + 2 * c2);
+        }
+        TL_MARK(tl, 2);
+        return;
+    }
+    const int m = blockIdx.x >> 3, strip = blockIdx.x & 7;
+    __shared__ double Y[NB][17];
+    const int fr = lane & 15, fk = lane >> 4;
+    f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+    for (int r = m; r < pos; ++r) {
+        const double *A = L + ((size_t)c * NB + 16 * w + fr) * ld + (size_t)(p + r) * NB + 2 * fk;
+        const double *B = SI + ((size_t)r * NB + 2 * fk) * ldsi + (size_t)m * NB + 16 * strip + fr;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            f64x2 a[8];
+            double b0[8], b1[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int k0 = 64 * half + 8 * q;
+                a[q] = *reinterpret_cast<const f64x2 *>(A + k0);
+                b0[q] = B[(size_t)k0 * ldsi];
+                b1[q] = B[(size_t)(k0 + 1) * ldsi];
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q][0], b0[q], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q][1], b1[q], acc, 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) Y[16 * w + fk + 4 * reg][fr] = acc[reg];
+    __syncthreads();
+    f64x4 o = {0.0, 0.0, 0.0, 0.0};
+    const double *Ar = Lc + (size_t)(16 * w + fr) * NB + 2 * fk;
+    for (int k0 = 0; k0 < 16 * (w + 1); k0 += 8) {
+        const f64x2 a = *reinterpret_cast<const f64x2 *>(Ar + k0);
+        o = __builtin_amdgcn_mfma_f64_16x16x4f64(-a[0], Y[k0 + 2 * fk][fr], o, 0, 0, 0);
+        o = __builtin_amdgcn_mfma_f64_16x16x4f64(-a[1], Y[k0 + 2 * fk + 1][fr], o, 0, 0, 0);
+    }
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) SI[((size_t)pos * NB + 16 * w + fk + 4 * reg) * ldsi + (size_t)m * NB + 16 * strip + fr] = o[reg];
+    TL_MARK(tl, 2);
+}
+
 // Bulk trailing update, LDS-DMA ring:  S[i,j] -= L[i, kb..] L[j, kb..]^T  over 8-wide k-stages.  Operands reach LDS by LDS-DMA only -- no staging registers --
 // through a 4-stage ring, three stages (24 k) ahead of the MFMAs, behind counted vmcnt waits and one
 // raw s_barrier per stage.  A stage holds, per operand, 128 rows x 8 doubles as eight 1-KiB
@@ -1506,37 +1579,44 @@ void k_gemm_q(double *S, double *L, int ld, int kb, int first, int m, const doub
 //     later -- no load of C is waited for, and what is left at the end is the store.  C moves through buffer
 //     instructions (one descriptor in SGPRs, one per-lane offset, wave-uniform row / tile offsets as scalar offsets): with
 //     128 accumulator and 64 operand registers per lane there is no room for per-tile 64-bit addresses.
-// NST = stages of 8 k per pass, a compile-time 16 or 32 (K = 128 or 256: one or two panels per pass): with the stage
-// index known at compile time every wait count below is a literal and the loop has no branch.
-// map: the launch's tiles, one word (row << 16 | column, relative to tile kb + 2; ~0 = none) per workgroup, dealt so that
-// the eight XCDs -- workgroup b runs on XCD b % 8 -- carry equal shares of whole supertiles (build_bulk_maps).
-// MODE 1 is the PANEL product on the same pipeline, L(i, kb) = S(i, kb) Linv_kb' (B = the inverse of the diagonal block, row
-// stride 128; no C tile, the product itself is stored): the rows of a panel below the critical tile, a tile per workgroup.
-// S is the matrix the result is written to (MODE 0: S, updated in place; MODE 1: L), Lm the matrix A is read from.
-#define PIPE_PRIO 0x200      // flag in toff: raise the wave priority (launches on the panel stream: they share SIMDs with the bulk update)
-#define PIPE_HEAD(h) ((h) << 12)   // field in toff: the launch's first h tile columns lead its map and signal tile by tile
+// With the stage index known at compile time every wait count below is a literal and the loop has no branch.
+#define PIPE_PRIO 0x200      // flag: raise the wave priority (launches on the panel stream: they share SIMDs with the bulk update)
 // f(integral_constant<int, BASE + I>) for I = 0 .. : the stage loop with the stage number as a compile-time constant
 template <int BASE, int... I, class F> __device__ __forceinline__ void pipe_for_seq(std::integer_sequence<int, I...>, F &&f)
 {
     (f(std::integral_constant<int, BASE + I>{}), ...);
 }
+// Round 5.  Map entries name ABSOLUTE tiles: row << 16 | class << 14 | column (chol_plan.h); a tile of class 1 / 2 is counted out in
+// sig[0] / sig[1] when it is finished (the tiles the next steps read first lead the launch).
+// NST = 16 / 32: every stage at compile time (K = 128 / 256).  NST = 0: the ROLLED form for any longer pass -- sixteen compile-time
+// stages that carry the C tiles, four-stage trips with running operand pointers, four compile-time stages at the end; the stage
+// count is a run-time value, nst_rt (a multiple of 4, at least 24): one instance serves K = 512 and K = 1024 and the ragged
+// passes of MODE 2.
+// MODE 0  S(i, j) -= L(i, kb ..) L(j, kb ..)'          Out = S, Ain = L
+// MODE 1  L(i, kb) = S(i, kb) Linv_kb'                 Out = L, Ain = S, Bm = Linv (row stride 128); no C tile
+// MODE 2  L(i, kb + c) = S(i, kb .. kb + c) W[c][.]'    Out = L, Ain = S, Bm = the super-block's inverse W (row stride ldb_arg),
+//         c = the entry's column: a pass of 16 (c + 1) stages; no C tile (the two-level regime's panel product)
 template <int DBG, int NST, int MODE = 0>
-__global__ __launch_bounds__(256, 2) void k_gemm_nt_pipe(double *S, const double *Lm, int ld, int kb, const unsigned *__restrict__ map, int toff, int *sig,
-                                                          const double *Linv = nullptr)
+__global__ __launch_bounds__(256, 2) void k_gemm_nt_pipe(double *Out, const double *Ain, int ld, int kb, const unsigned *__restrict__ map, int flags, int *sig,
+                                                          const double *Bm = nullptr, int ldb_arg = 0, int nst_rt = 0, int tl = 0)
 {
-    static_assert(NST % 4 == 0 && NST >= 16, "C tiles are folded in during stages 0 .. 15");
+    constexpr bool rolled = NST == 0;
+    constexpr int NSTC = rolled ? 64 : NST;      // what the compile-time stages see: in the rolled form the first sixteen are far from the end and the last four know their distance to it
+    static_assert(rolled || (NST % 4 == 0 && NST >= 16 && NST <= 32), "C tiles are folded in during stages 0 .. 15");
+    static_assert(MODE != 2 || rolled, "the panel product of the two-level regime has ragged pass lengths");
     extern __shared__ __attribute__((aligned(16))) char gsm[];
     const unsigned e = map[blockIdx.x];
     if (e == ~0u) return;
-    if (toff & PIPE_PRIO) __builtin_amdgcn_s_setprio(2);
-    const unsigned head = (unsigned)(toff >> 12) & 15u;      // leading tile columns whose finished tiles are counted in *sig
-    toff &= 0xff;
-    [[maybe_unused]] const int tl_id = 8 * kb + (MODE == 1 ? 3 : toff == 1 ? 4 : 6);
+    if (flags & PIPE_PRIO) __builtin_amdgcn_s_setprio(2);
+    [[maybe_unused]] const int tl_id = tl;
     TL_MARK(tl_id, 0);
-    const int ti = kb + toff + (int)(e >> 16), tj = MODE == 1 ? kb : kb + toff + (int)(e & 0xffffu);
-    const double *A = Lm + ((size_t)ti * NB) * ld + (size_t)kb * NB;
-    const double *B = MODE == 1 ? Linv + (size_t)kb * NB * NB : Lm + ((size_t)tj * NB) * ld + (size_t)kb * NB;
-    const int ldb = MODE == 1 ? NB : ld;
+    const int ti = (int)(e >> 16), ecol = (int)(e & 0x3fffu), cls = (int)((e >> 14) & 3u);
+    const int tj = MODE == 0 ? ecol : MODE == 1 ? kb : kb + ecol;
+    const int nst = __builtin_amdgcn_readfirstlane(rolled ? (MODE == 2 ? 16 * (ecol + 1) : nst_rt) : NST);
+    const double *A = Ain + ((size_t)ti * NB) * ld + (size_t)kb * NB;
+    const double *B = MODE == 0 ? Ain + ((size_t)tj * NB) * ld + (size_t)kb * NB : MODE == 1 ? Bm + (size_t)kb * NB * NB : Bm + ((size_t)ecol * NB) * ldb_arg;
+    const int ldb = MODE == 0 ? ld : MODE == 1 ? NB : ldb_arg;
+    double *S = Out;
     const int t = threadIdx.x, lane = t & 63;
     const int w = __builtin_amdgcn_readfirstlane(t >> 6);      // wave-uniform, and the compiler should know: everything derived
                                                                // from it (ring slots, C descriptor, tile offsets) lives in SGPRs
@@ -1642,27 +1722,27 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt_pipe(double *S, const double
         // slot is free on my side.  The ONLY LDS wait of the step -- the reads of stage s + 1 requested below stay in flight
         // behind this step's MFMAs (a wait in front of the MFMAs would wait for them too: the counter is in-order)
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ra[P][0]), "+v"(ra[P][1]), "+v"(ra[P][2]), "+v"(ra[P][3]), "+v"(rb[P][0]), "+v"(rb[P][1]), "+v"(rb[P][2]), "+v"(rb[P][3]) :: "memory");
-        if (mid || SC + 1 < NST) {
+        if (mid || SC + 1 < NSTC) {
             // needs D(s+1).  Younger: D(s+2), D(s+3); the C loads issued behind D(s+1): C0, C1 behind the prologue (all of
             // D0 .. D3 precede them), C(t+2) behind D(t+4) at stage t, i.e. C(s-1) .. C(s+1) for s >= 3
             if constexpr (mid) wait_vm(8);
             else {
                 constexpr int c_younger = SC + 1 <= 3 ? (with_c ? (SC + 2 < NCT ? SC + 2 : NCT) : 0) : (with_c ? ((SC - 1 < NCT) + (SC < NCT) + (SC + 1 < NCT)) : 0);
-                wait_vm(4 * ((SC + 2 < NST) + (SC + 3 < NST)) + 4 * c_younger);
+                wait_vm(4 * ((SC + 2 < NSTC) + (SC + 3 < NSTC)) + 4 * c_younger);
             }
             __builtin_amdgcn_s_barrier();
             if constexpr (mid) issue(POS, 8 * POS);                 // into the slot of stage s (the pointers stand at the loop trip's first stage + GST)
-            else if constexpr (SC + GST < NST) issue(POS, 8 * (SC + GST));
+            else if constexpr (SC + GST < NSTC) issue(POS, 8 * (SC + GST));
         }
         if constexpr (!mid && with_c && SC < NCT) {
             // needs C(s), requested two stages ago (tiles 0, 1: behind the prologue).  Younger: C(s+1), and every D issued
             // behind C(s): D(s+3) and D(s+4) for s >= 2, D4 and D5 for s = 1, D4 for s = 0 -- those that exist
-            constexpr int d_younger = SC >= 2 ? (SC + 3 < NST) + (SC + GST < NST) : (SC == 1 ? (4 < NST) + (5 < NST) : (4 < NST));
+            constexpr int d_younger = SC >= 2 ? (SC + 3 < NSTC) + (SC + GST < NSTC) : (SC == 1 ? (4 < NSTC) + (5 < NSTC) : (4 < NSTC));
             wait_vm(4 * d_younger + 4 * (SC + 1 < NCT ? 1 : 0));
             fold(SC);
             if (SC + 2 < NCT) c_req(SC + 2);
         }
-        if (mid || SC + 1 < NST) read_stage(1 - P, (POS + 1) % GST);
+        if (mid || SC + 1 < NSTC) read_stage(1 - P, (POS + 1) % GST);
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -1673,18 +1753,18 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt_pipe(double *S, const double
     };
     using ic_m1 = std::integral_constant<int, -1>;
     static_assert(GST == 4, "the rolled middle advances one ring turn per trip");
-    if constexpr (NST <= 32) {
+    if constexpr (!rolled) {
         // every stage at compile time (K = 128, 256)
         pipe_for_seq<0>(std::make_integer_sequence<int, NST>{}, [&](auto sc) { stage(sc, std::integral_constant<int, decltype(sc)::value % GST>{}, 0); });
     } else {
         pipe_for_seq<0>(std::make_integer_sequence<int, 16>{}, [&](auto sc) { stage(sc, std::integral_constant<int, decltype(sc)::value % GST>{}, 0); });
         srcA += 8 * (16 + GST); srcB += 8 * (16 + GST);                 // stage 16 issues stage 20
-        for (int s4 = 16; s4 < NST - 4; s4 += 4) {
+        for (int s4 = 16; s4 < nst - 4; s4 += 4) {
             stage(ic_m1{}, std::integral_constant<int, 0>{}, s4); stage(ic_m1{}, std::integral_constant<int, 1>{}, s4 + 1);
             stage(ic_m1{}, std::integral_constant<int, 2>{}, s4 + 2); stage(ic_m1{}, std::integral_constant<int, 3>{}, s4 + 3);
             srcA += 8 * GST; srcB += 8 * GST;
         }
-        pipe_for_seq<NST - 4>(std::make_integer_sequence<int, 4>{}, [&](auto sc) { stage(sc, std::integral_constant<int, decltype(sc)::value % GST>{}, 0); });
+        pipe_for_seq<NSTC - 4>(std::make_integer_sequence<int, 4>{}, [&](auto sc) { stage(sc, std::integral_constant<int, decltype(sc)::value % GST>{}, 0); });
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -1694,15 +1774,15 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt_pipe(double *S, const double
             for (int reg = 0; reg < 4; ++reg)
                 if (!(DBG & 2) || acc[i][j][reg] == 1.2345e300) {
                     union { v2i r; double d; } u;
-                    u.d = MODE == 1 ? acc[i][j][reg] : -acc[i][j][reg];                  // C - A B'  (MODE 1: A B')
+                    u.d = MODE != 0 ? acc[i][j][reg] : -acc[i][j][reg];                  // C - A B'  (MODE 1, 2: A B')
                     __builtin_amdgcn_raw_buffer_store_b64(u.r, crs, cvo + 128 * j, (16 * i + 4 * reg) * ld8, 0);
                 }
-    // A two-panel update tells the other streams when its first two tile columns are done, tile by tile: they are all
-    // the next two diagonal blocks and panels need of it, and they come first in its map (build_bulk_maps).
-    if (sig && (e & 0xffffu) < head) {
+    // The tiles the next steps read first lead the launch and are counted out one by one (class 1 / 2 of the map entry): nobody
+    // waits for a whole bulk update except through stream order.
+    if (sig && cls) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (t == 0) __hip_atomic_fetch_add(sig, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        if (t == 0) __hip_atomic_fetch_add(sig + (cls - 1), 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 #ifdef RCN_DIAG
         if (g_tl && t == 0) atomicMax(&g_tl[3 * tl_id + 1], (unsigned long long)wall_clock64());      // a head tile finished
 #endif
@@ -2025,73 +2105,22 @@ __global__ __launch_bounds__(256) void k_ba_gradmax(BaDev d, double *out, int wi
 // =========================================================================================
 // host side
 // =========================================================================================
-// Tile maps of the bulk trailing update for a factorisation of nblk blocks: for every trailing size mt (tiles per side of
-// the lower triangle the update covers) the list of its mt (mt + 1) / 2 tiles in launch order.  Workgroups go round-robin
-// to the 8 XCDs (block b -> XCD b % 8, observed, speed only), and a supertile's workgroups should share an XCD -- its
-// panel tiles then stay in that XCD's L2 -- so WHOLE supertiles (4 x 4 tiles, 2 x 2 below 24) are dealt to the XCDs,
-// heaviest first to the least loaded (round 2 dealt 8 x 8 supertiles in index order: the busiest XCD carried 1.3x the
-// mean at mt = 45 and 2.4x at mt = 20).  Entry b of a map = tile of workgroup b (row << 16 | col), ~0 = none.
-static int build_bulk_maps(rcn_ctx *ctx, int nblk)
+// The factorisation's schedule for nblk blocks (chol_plan.h): built once per shape and parameter set, its tile maps uploaded once.
+static int ensure_chol_plan(rcn_ctx *ctx, int nblk)
 {
-    if (ctx->bulk_map_nblk == nblk && ctx->bulk_map.p) return RCN_OK;
-    std::vector<unsigned> all;
-    const size_t nm = (size_t)std::max(nblk, 1);
-    ctx->bulk_map_off.assign(nm, 0);
-    ctx->bulk_map_grid.assign(nm, 0);
-    ctx->pair_map_off.assign(nm, 0);
-    ctx->pair_map_grid.assign(nm, 0);
-    // head2: the tiles of the first two columns lead the map, rows dealt to the XCDs eight apart (the two tiles of a row
-    // share its panel rows in that XCD's L2); the rest of the triangle follows in supertiles as before
-    auto make = [&](int mt, int head, std::vector<int> &off, std::vector<int> &grid) {
-        std::vector<unsigned> per[8];
-        const int c_first = std::min(head, mt);
-        if (head > 0)
-            for (int r = 0; r < mt; ++r)
-                for (int c = 0; c < c_first && c <= r; ++c) per[r & 7].push_back(((unsigned)r << 16) | (unsigned)c);
-        const int SS = mt >= 24 ? 4 : 2, R = (mt + SS - 1) / SS;
-        std::vector<std::vector<unsigned>> st;
-        for (int sr = 0; sr < R; ++sr)
-            for (int sc = 0; sc <= sr; ++sc) {
-                std::vector<unsigned> tl;
-                for (int r = sr * SS; r < std::min(mt, sr * SS + SS); ++r)
-                    for (int c = sc * SS; c < sc * SS + SS; ++c)
-                        if (c <= r && c >= c_first) tl.push_back(((unsigned)r << 16) | (unsigned)c);
-                if (!tl.empty()) st.push_back(std::move(tl));
-            }
-        std::stable_sort(st.begin(), st.end(), [](const std::vector<unsigned> &a, const std::vector<unsigned> &b) { return a.size() > b.size(); });
-        for (auto &tl : st) {
-            int x = 0;
-            for (int i = 1; i < 8; ++i)
-                if (per[i].size() < per[x].size()) x = i;
-            per[x].insert(per[x].end(), tl.begin(), tl.end());
-        }
-        size_t slots = 0;
-        for (auto &v : per) slots = std::max(slots, v.size());
-        off[mt] = (int)all.size();
-        grid[mt] = (int)(8 * slots);
-        for (size_t sl = 0; sl < slots; ++sl)
-            for (int x = 0; x < 8; ++x) all.push_back(sl < per[x].size() ? per[x][sl] : ~0u);
-    };
-    ctx->quad_map_off.assign(nm, 0);
-    ctx->quad_map_grid.assign(nm, 0);
-    for (int mt = 1; mt <= nblk - 2; ++mt) {
-        make(mt, 0, ctx->bulk_map_off, ctx->bulk_map_grid);
-        make(mt, 2, ctx->pair_map_off, ctx->pair_map_grid);
-        make(mt, 4, ctx->quad_map_off, ctx->quad_map_grid);
-    }
-    // tile columns for the pipelined kernel on the panel stream, row-major: column 0 from row 1 (a panel below its critical tile, the
-    // rest of the first trailing column), columns 1 .. nc - 1 from their diagonal tile -- the trailing columns the first steps of a
-    // group of panels update themselves.  A launch for m tile rows takes the leading col_map_count(m, nc) entries.
-    for (int ncol = 1; ncol <= 4; ++ncol) {
-        ctx->col_map_offn[ncol] = (int)all.size();
-        for (int r = 1; r <= nblk; ++r)
-            for (int c = 0; c < ncol && c <= r; ++c) all.push_back(((unsigned)r << 16) | (unsigned)c);
-    }
-    ctx->col_map_off1 = ctx->col_map_offn[1];
+    chol::Params prm;
+    prm.nblk = nblk; prm.tl_g = ctx->chol_tl_g; prm.tl_min = ctx->chol_tl_min; prm.pair = ctx->chol_group >= 2 ? 1 : 0;
+    prm.pair_min = ctx->chol_pair_min; prm.pipe_min = ctx->chol_pipe_min; prm.pg_stream = ctx->chol_pg_stream;
+    const chol::Params &o = ctx->chol_plan.prm;
+    if (ctx->chol_plan_valid && o.nblk == prm.nblk && o.tl_g == prm.tl_g && o.tl_min == prm.tl_min && o.pair == prm.pair && o.pair_min == prm.pair_min &&
+        o.pipe_min == prm.pipe_min && o.pg_stream == prm.pg_stream) return RCN_OK;
+    ctx->chol_plan_valid = false;
+    ctx->chol_plan = chol::make_plan(prm);
     RCN_HIP(hipStreamSynchronize(ctx->stream));          // nobody may still read the old maps
-    RCN_HIP(ctx->bulk_map.reserve(all.size() * sizeof(unsigned)));
-    RCN_HIP(hipMemcpy(ctx->bulk_map.p, all.data(), all.size() * sizeof(unsigned), hipMemcpyHostToDevice));
-    ctx->bulk_map_nblk = nblk;
+    const size_t nm = std::max<size_t>(ctx->chol_plan.maps.size(), 1);
+    RCN_HIP(ctx->bulk_map.reserve(nm * sizeof(unsigned)));
+    if (!ctx->chol_plan.maps.empty()) RCN_HIP(hipMemcpy(ctx->bulk_map.p, ctx->chol_plan.maps.data(), ctx->chol_plan.maps.size() * sizeof(unsigned), hipMemcpyHostToDevice));
+    ctx->chol_plan_valid = true;
     return RCN_OK;
 }
 
@@ -2139,6 +2168,33 @@ void rcn_ba_default_options(int32_t n_cams, rcn_ba_options *o)
     o->parameter_tolerance = 1e-8;
     o->max_consecutive_invalid_steps = 5;
     o->jacobi_scaling = 1;
+}
+
+int rcn_ba_factor_plan(int32_t n_blocks, const int32_t *params, int32_t *ops, int64_t ops_cap, uint32_t *maps, int64_t maps_cap, int64_t *n_ops, int64_t *n_maps)
+{
+    if (n_blocks < 1 || n_blocks > 16383 || !n_ops || !n_maps) return RCN_ERR_ARG;
+    chol::Params prm;
+    {
+        rcn_ctx defaults;      // (never created on a device: only the schedule's parameters are read)
+        prm.tl_g = defaults.chol_tl_g; prm.tl_min = defaults.chol_tl_min; prm.pair = defaults.chol_group >= 2; prm.pair_min = defaults.chol_pair_min; prm.pipe_min = defaults.chol_pipe_min;
+        prm.pg_stream = defaults.chol_pg_stream;
+    }
+    prm.nblk = n_blocks;
+    if (params) { prm.tl_g = params[0]; prm.tl_min = params[1]; prm.pair = params[2]; prm.pair_min = params[3]; prm.pipe_min = params[4]; prm.pg_stream = params[5]; }
+    if (prm.tl_g < 0 || prm.tl_g == 1 || prm.tl_g > 16 || prm.pipe_min < 1) return RCN_ERR_ARG;
+    const chol::Plan pl = chol::make_plan(prm);
+    *n_ops = (int64_t)pl.ops.size();
+    *n_maps = (int64_t)pl.maps.size();
+    if ((int64_t)pl.ops.size() > ops_cap || (int64_t)pl.maps.size() > maps_cap || (!ops && !pl.ops.empty()) || (!maps && !pl.maps.empty())) return RCN_ERR_ARG;
+    for (size_t i = 0; i < pl.ops.size(); ++i) {
+        const chol::Op &o = pl.ops[i];
+        int32_t *w = ops + RCN_PLAN_OP_WORDS * i;
+        const int32_t v[RCN_PLAN_OP_WORDS] = {o.kind, o.stream, o.ticket, o.kb, o.first, o.m, o.dj, o.nst, o.map_off, o.map_n, o.g, o.pos, o.nw,
+                                              o.w[0].ctr, o.w[0].val, o.w[1].ctr, o.w[1].val, o.w[2].ctr, o.w[2].val, o.w[3].ctr, o.w[3].val, o.w[4].ctr, o.w[4].val, o.tl, o.awaited};
+        memcpy(w, v, sizeof(v));
+    }
+    if (!pl.maps.empty()) memcpy(maps, pl.maps.data(), pl.maps.size() * sizeof(uint32_t));
+    return RCN_OK;
 }
 
 int rcn_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_options *opt, rcn_ba_summary *sum)
@@ -2227,6 +2283,7 @@ int rcn_int_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_option
     d.S = ws.get<double>((size_t)npad * npad);
     d.L = ws.get<double>((size_t)npad * npad);
     d.Linv = ws.get<double>((size_t)nblk * NB * NB);
+    double *SI = ws.get<double>((size_t)(NB * std::max(ctx->chol_tl_g, 1)) * (NB * std::max(ctx->chol_tl_g, 1)));      // a super-block's inverse (two-level regime of the factorisation)
     double *Sb = ws.get<double>(100 * (size_t)nc * nc);
     // gather lists of the Schur build (RCN_BA_SCHUR_ATOMICS=1 falls back to the atomic form)
     const bool gather = !ctx->ba_atomics;
@@ -2283,9 +2340,10 @@ int rcn_int_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_option
     RCN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_chol_diag), hipFuncAttributeMaxDynamicSharedMemorySize, NB * DL * 8));
     RCN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_nt_pipe<0, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, GST * GSTAGE_BYTES));
     RCN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_nt_pipe<0, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, GST * GSTAGE_BYTES));
-    RCN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_nt_pipe<0, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, GST * GSTAGE_BYTES));
+    RCN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_nt_pipe<0, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, GST * GSTAGE_BYTES));
     RCN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_nt_pipe<0, 16, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, GST * GSTAGE_BYTES));
-    { int rcm = build_bulk_maps(ctx, nblk); if (rcm) return rcm; }
+    RCN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_nt_pipe<0, 0, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, GST * GSTAGE_BYTES));
+    { int rcm = ensure_chol_plan(ctx, nblk); if (rcm) return rcm; }
     uint64_t plain_token = 0;
     if (!res && no > 0) {
         const bool same = ctx->ba_graph_nc == nc && ctx->ba_graph_np == np && ctx->ba_graph_cam.size() == (size_t)no &&
@@ -2307,7 +2365,9 @@ int rcn_int_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_option
     // (SequentialReconstructor.cpp:1040-1094 adds a view before every adjust); a caller that re-solves after changing only the
     // estimates (another start, other options) skips the 0.75 ms the lists cost at 1M observations.
     const uint64_t pair_token = res ? res->pair_token : plain_token;
-    const bool pairs_cached = pair_token != 0 && ctx->ba_pair_token == pair_token;
+    // (the lists also depend on WHICH cameras have no free parameter -- pair_key drops their pairs -- i.e. on the options: ADVICE r4.  The
+    //  per-camera dimensions the lists were built for are kept beside the token and compared; a session's token does not cover options either)
+    const bool pairs_cached = pair_token != 0 && ctx->ba_pair_token == pair_token && ctx->ba_pair_camdim == cam_dim;
     // The lists are built on the panel stream, BESIDE the first evaluation (which needs nothing of them; both are eight launches or so, and
     // on the reference's problem sizes a solve is a few hundred launch-bound microseconds): the ctx stream waits for them in front of the loop.
     const bool pairs_build = gather && np > 0 && !pairs_cached;
@@ -2327,6 +2387,7 @@ int rcn_int_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_option
         RCN_HIP(hipEventRecord(ctx->ba_ev[7], sp));
     }
     ctx->ba_pair_token = (gather && np > 0) ? pair_token : 0;
+    if (!pairs_cached) ctx->ba_pair_camdim = cam_dim;
     sum->pair_lists_reused = pairs_cached ? 1 : 0;
 
     // phase times (summary.schur_seconds ...: HIP events on the stream) only where a phase outlasts the six event records of an
@@ -2465,136 +2526,105 @@ int rcn_int_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_option
         if (rhs_row && !fused_finish) k_ba_S_rhs_row<<<(n + 1 + 255) / 256, 256, 0, st>>>(d);
         RCN_HIP(hipGetLastError());
         if (phase_times) RCN_HIP(hipEventRecord(ctx->ba_tev[1], st));
-        // Dense Cholesky, right-looking, 128-wide panels, on three streams with critical-tile-first ordering.  Step k:
-        //   D(k)  diagonal block (k, k) -> its factor's inverse                                   k_chol_diag      chain A
-        //   T(k)  the critical tile: L(k+1, k) = S(k+1, k) Linv_k', then S(k+1, k+1) -= L(k+1, k) L(k+1, k)'
-        //         -- all D(k+1) needs of panel k                                                 k_gemm_q<0/1>    chain A
-        //   P(k)  the rest of the panel, rows >= k + 2                                           k_gemm_q<0>      panels B
-        //   C(k)  the rest of the first trailing column, S(i, k+1) -= L(i, k) L(k+1, k)'         k_gemm_q<1>      panels B
-        //   B(k)  the bulk update of columns >= k + 2                                            k_gemm_nt_pipe   bulk C
-        // The serial chain is D(k) T(k) D(k+1) T(k+1) ...: two small launches between two diagonal blocks where round 2 had the
-        // whole panel, a gate and the whole first column (131 us per step, of which 83 the diagonal block).  Cross-stream
-        // dependencies travel through five device counters (Gate, above):
-        //   T(k)  waits for C(k-1) [S(k+1, k) complete] and B(k-1) [tile (k+1, k+1) updated by every earlier panel]
-        //   P(k)  waits for D(k) and B(k-2);   C(k) for T(k) and B(k-1);   B(k) for P(k)
-        // and every counter is published by the FIRST thread of the kernel that follows the work on its own stream.
-        // A wait that times out (2 s: a runtime that does not let the three streams progress side by side) raises flag 3;
-        // the factorisation is then repeated on one stream in plain order, and every later one runs that way (ctx->chol_safe).
-        // TWO-PANEL bulk updates (round 3).  While many tile rows remain (ctx->chol_pair_min), steps go in pairs (p, q = p + 1):
-        //   C(p) also takes the SECOND trailing column, S(i, p+2) -= L(i, p) L(p+2, p)', so that everything steps p and q need
-        //   of panel p is in place without a bulk update; there is no B(p); and B(q) applies panels p and q together,
-        //   K = 256, to columns >= p + 3.  The C tile of the bulk kernel is loaded and stored once per 256 k instead of once
-        //   per 128 (286 us -> 241 us per panel at 77 tile rows).  What the next pair needs of B(q) early are its first two
-        //   tile columns (p+3: D/T/P of step p+2 and p+3; p+4: C(p+2), T(p+3)); they lead its map and every finished tile of
-        //   them bumps a device counter (sig), so the chain never waits for a whole two-panel update except through stream order.
-        // Who has to wait for which bulk kernel is looked up per tile column: lastw[j] names the last bulk-stream kernel that
-        // writes column j -- either "all of kernel #ord" (cB, published by the gate in front of the next bulk kernel) or
-        // "the leading columns of a two-panel kernel" (sig reaching a cumulative tile count).
+        // Dense Cholesky of the padded system: the schedule is DATA (chol_plan.h) -- a list of tile operations in an order that is a
+        // correct sequential algorithm, each with its stream (A: the chain of diagonal blocks and critical tiles, B: panels and
+        // columns, C: bulk trailing updates) and the device counters it waits for, derived from the tiles it reads and writes.
+        // Hand-offs (Gate, above): every stream owns a progress counter; an operation publishes "everything before me on my stream
+        // is done" with its FIRST thread (stream order has completed that work and the kernel boundary has released its writes) and
+        // waits for other streams' counters itself -- inside the kernel on the chain and for the small kernels, in a ONE-WAVE gate
+        // kernel in front of a pipelined launch (a grid of a thousand workgroups that spins while it holds its CU slots could keep
+        // the very kernel it waits for from becoming resident).  A bulk update counts the tiles the next steps read first out one
+        // by one (two classes, flag[5], flag[6]).  A wait that times out (2 s: a runtime that does not let the three streams
+        // progress side by side) raises flag 3; the factorisation is then repeated on ONE stream in list order, and every later
+        // one runs that way (ctx->chol_safe).  Same bits either way: no operation's arithmetic depends on where it runs.
         auto factorise = [&](bool safe) -> hipError_t {
-            hipStream_t sA = st, sB = safe ? st : ctx->panel_stream, sC = safe ? st : ctx->aux_stream;
-            int *cD = d.flag + 2, *cT = d.flag + 3, *cP = d.flag + 4, *cC = d.flag + 5, *cB = d.flag + 6, *sig = d.flag + 7;
-            const Gate none = {nullptr, 0, nullptr, 0, nullptr, 0, d.flag};
-            struct Wr { const int *c; int n; };
-            auto gate = [&](const int *c0, int n0, Wr w, int *pub, int pubval) {
-                Gate g = {safe ? nullptr : c0, n0, safe ? nullptr : w.c, w.n, safe ? nullptr : pub, pubval, d.flag};
-                return g;
-            };
-            std::vector<Wr> lastw((size_t)nblk + 4, Wr{nullptr, 0});
-            // the younger of two lookups: kernels counted by cB (one panel) only ever follow those that signal through sig (two panels)
-            auto later = [&](Wr a, Wr b) { return !a.c ? b : !b.c ? a : (a.c == b.c ? (a.n >= b.n ? a : b) : (a.c == cB ? a : b)); };
-            int bulk_ord = 0, sig_cum = 0;
+            hipStream_t str[chol::N_STREAMS] = {st, safe ? st : ctx->panel_stream, safe ? st : ctx->aux_stream, safe ? st : ctx->panel2_stream};
+            int *ctr[chol::N_CTR] = {d.flag + 2, d.flag + 3, d.flag + 4, d.flag + 5, d.flag + 6, d.flag + 7};
+            const chol::Plan &plan = ctx->chol_plan;
             if (!safe) {
-                hipError_t e = hipEventRecord(ctx->ba_ev[0], sA);
-                if (e == hipSuccess) e = hipStreamWaitEvent(sB, ctx->ba_ev[0], 0);     // B and C start behind everything queued so far
-                if (e == hipSuccess) e = hipStreamWaitEvent(sC, ctx->ba_ev[0], 0);
+                hipError_t e = hipEventRecord(ctx->ba_ev[0], str[0]);
+                for (int s2 = 1; s2 < chol::N_STREAMS && e == hipSuccess; ++s2)
+                    if (plan.n_ops[s2]) e = hipStreamWaitEvent(str[s2], ctx->ba_ev[0], 0);     // the other streams start behind everything queued so far
                 if (e != hipSuccess) return e;
             }
             const unsigned *maps = ctx->bulk_map.as<unsigned>();
-            // GROUPS of panels (round 4 generalises round 3's pairs).  While many tile rows remain, g = 4 (then 2) consecutive steps
-            // form a group: step number i of it (i = 0 .. g-1) updates the g - i tile columns behind its own panel itself (C),
-            // so that the whole group can be factored without a bulk update, and the last step's bulk kernel applies all g
-            // panels at once, K = 128 g, to the columns behind the group: the C tile of the bulk kernel travels once per 512 k
-            // instead of once per 256 (tools/gemm_nt_bench: 60.6 TFLOP/s against 55.6), and half as many launches fill and drain
-            // the chip.  The price is column work on the panel stream: (g + 1) / 2 columns per step instead of 1.5.
-            int g_size = 1, g_pos = 0;                // size of the current group, position of this step in it
-            auto col_map_count = [](int mrows, int ncol) { int k = 0; for (int r = 1; r <= mrows - 1; ++r) k += std::min(ncol, r + 1); return k; };
-            for (int kb = 0; kb < nblk; ++kb) {
-                const int m = nblk - kb - 1;          // tiles below the diagonal block
-                if (g_pos == 0)                       // a new group: its bulk update covers m - g tile rows
-                    g_size = (ctx->chol_group >= 4 && m - 4 >= ctx->chol_pair_min && m >= 6) ? 4 : (ctx->chol_group >= 2 && m - 2 >= ctx->chol_pair_min && m >= 4) ? 2 : 1;
-                const int ncols = g_size - g_pos;     // trailing columns C(kb) updates: kb + 1 .. kb + ncols (a step on its own: the first one)
-                const bool last_of_group = g_pos == g_size - 1;
-                // D(kb): publishes "T(kb-1) done"
-                // (active rows of the block: the system's n rows, and the right-hand-side row behind them when it rides along)
-                const int nact = std::min(NB, (rhs_row ? n + 1 : n) - kb * NB);
-                k_chol_diag<<<1, 64 * CDW, NB * DL * 8, sA>>>(d.S, npad, kb, d.Linv, d.flag, kb == nblk - 1, gate(nullptr, 0, Wr{nullptr, 0}, cT, kb), nact);
-                if (m <= 0) break;
-                const int gq1 = 32;                   // grid of k_gemm_q for one tile: strips 0..3 on 4 of the 8 XCD slots
-                // T(kb), first half: publishes "D(kb) done"; waits for C(kb-1) and the bulk updates of column kb + 1
-                // (diagnostic build, RCN_CHOL_BREAK=1: step 1 waits for a count that never comes -- the test of the fallback)
-                k_gemm_q<0><<<gq1, 256, 0, sA>>>(d.S, d.L, npad, kb, 0, 1, d.Linv, gate(cC, ctx->chol_break && kb == 1 ? 1 << 30 : kb, lastw[kb + 1], cD, kb + 1));
-                k_gemm_q<1><<<gq1, 256, 0, sA>>>(d.S, d.L, npad, kb, 0, 1, d.Linv, none);
+            const int ldsi = NB * std::max(plan.prm.tl_g, 1);
+            const size_t lds_pipe = GST * GSTAGE_BYTES;
 #ifdef RCN_DIAG
-                if (ctx->chol_break == 2 && kb == 1 && !safe) k_diag_poison<<<1, 1, 0, sA>>>(d.S, npad, kb + 1);      // the next diagonal kernel meets a NaN pivot AFTER the timeout
+            const double th0 = now_s();
 #endif
-                // On B and C the waits are ONE-WAVE gate kernels in front of the work, never inside it: a grid of a thousand
-                // workgroups that spins while it holds its CU slots could keep the very kernel it waits for from becoming resident.
-                if (m > 1) {
-                    const int gq = 32 * ((4 * (m - 1) + 7) / 8);
-                    // P(kb): its gate publishes "C(kb-1) done" and waits for D(kb) and the bulk updates of column kb.
-                    // Long tile columns go through the pipelined kernel, a 128x128 tile per workgroup (m - 1 workgroups that
-                    // stage their operands in LDS, where k_gemm_q needs 16 (m - 1) that stream theirs from L2 and crowd the
-                    // bulk update beside them); short ones stay with k_gemm_q, whose single tile finishes in 8 us, not 20.
-                    const bool piped = m - 1 >= ctx->chol_pipe_min;
-                    if (!safe) k_ring_gate<<<1, 64, 0, sB>>>(gate(cD, kb + 1, lastw[kb], cC, kb));
-                    if (piped) k_gemm_nt_pipe<0, 16, 1><<<m - 1, 256, GST * GSTAGE_BYTES, sB>>>(d.L, d.S, npad, kb, maps + ctx->col_map_off1, 1 | PIPE_PRIO, nullptr, d.Linv);
-                    else k_gemm_q<0><<<gq, 256, 0, sB>>>(d.S, d.L, npad, kb, 1, m - 1, d.Linv, none);
-                    // C(kb): its gate publishes "P(kb) done" and waits for T(kb) and the bulk updates of the column(s) it writes
-                    {
-                        Wr wcols = lastw[kb + 1];
-                        for (int c = 2; c <= ncols; ++c) wcols = later(wcols, lastw[kb + c]);
-                        if (!safe) k_ring_gate<<<1, 64, 0, sB>>>(gate(cT, kb + 1, wcols, cP, kb + 1));
-                    }
-                    if (piped) {
-                        k_gemm_nt_pipe<0, 16><<<col_map_count(m, ncols), 256, GST * GSTAGE_BYTES, sB>>>(d.S, d.L, npad, kb, maps + ctx->col_map_offn[ncols], 1 | PIPE_PRIO, nullptr);
-                    } else {
-                        for (int c = 1; c <= ncols; ++c) k_gemm_q<1><<<gq, 256, 0, sB>>>(d.S, d.L, npad, kb, 1, m - 1, d.Linv, none, c);
-                    }
-                    if (!last_of_group) {
-                        ++g_pos;                      // no bulk kernel at this step
-                    } else if (g_size > 1) {
-                        // B(kb), g panels: columns >= kb + 2, panels counted from kb - (g - 1); waits for P(kb)
-                        const int mt = m - 1, head = g_size == 4 ? 4 : 2;
-                        g_pos = 0;
-                        ++bulk_ord;
-                        if (!safe) k_ring_gate<<<1, 64, 0, sC>>>(gate(cP, kb + 1, Wr{nullptr, 0}, cB, bulk_ord - 1));
-                        if (g_size == 4)
-                            k_gemm_nt_pipe<0, 64><<<ctx->quad_map_grid[mt], 256, GST * GSTAGE_BYTES, sC>>>(d.S, d.L, npad, kb - 3, maps + ctx->quad_map_off[mt], 5 | PIPE_HEAD(4), safe ? nullptr : sig);
-                        else
-                            k_gemm_nt_pipe<0, 32><<<ctx->pair_map_grid[mt], 256, GST * GSTAGE_BYTES, sC>>>(d.S, d.L, npad, kb - 1, maps + ctx->pair_map_off[mt], 3 | PIPE_HEAD(2), safe ? nullptr : sig);
-                        for (int c = 0; c < head && c < mt; ++c) sig_cum += mt - c;          // tiles of the leading columns
-                        for (int j = kb + 2; j < nblk; ++j) lastw[j] = j < kb + 2 + head ? Wr{sig, sig_cum} : Wr{cB, bulk_ord};
-                    } else {
-                        // B(kb), one panel, columns >= kb + 2: its gate publishes "the bulk kernel before it is done" and waits for P(kb)
-                        ++bulk_ord;
-                        if (!safe) k_ring_gate<<<1, 64, 0, sC>>>(gate(cP, kb + 1, Wr{nullptr, 0}, cB, bulk_ord - 1));
-                        k_gemm_nt_pipe<0, 16><<<ctx->bulk_map_grid[m - 1], 256, GST * GSTAGE_BYTES, sC>>>(d.S, d.L, npad, kb, maps + ctx->bulk_map_off[m - 1], 2, nullptr);
-                        for (int j = kb + 2; j < nblk; ++j) lastw[j] = Wr{cB, bulk_ord};
-                    }
-                } else if (!safe) {
-                    // one tile left below the diagonal block: no panel rest and no bulk update, but T(kb) still waits to hear
-                    // that C(kb-1) and the last bulk kernel are done
-                    k_ring_gate<<<1, 64, 0, sB>>>(gate(nullptr, 0, Wr{nullptr, 0}, cC, kb));
-                    k_ring_gate<<<1, 64, 0, sC>>>(gate(nullptr, 0, Wr{nullptr, 0}, cB, bulk_ord));
+            for (const chol::Op &op : plan.ops) {
+                hipStream_t sq = str[op.stream];
+                Gate g = gate_none(d.flag);
+                if (!safe) {
+                    g.nw = op.nw;
+                    for (int i = 0; i < op.nw; ++i) { g.c[i] = ctr[op.w[i].ctr]; g.n[i] = op.w[i].val; }
+                    g.pub = ctr[op.stream]; g.pubval = op.ticket - 1;
+#ifdef RCN_DIAG
+                    // RCN_CHOL_BREAK=1: the critical tile of step 1 waits for a count that never comes -- the test of the fallback
+                    if (ctx->chol_break && op.kind == chol::TRSM_Q && op.stream == chol::ST_A && op.kb == 1 && g.nw > 0) g.n[0] = 1 << 30;
+#endif
+                }
+                // Where the wait stands.  On the chain (stream A) inside the kernel: its grids are small and nothing is saved by a launch in
+                // front.  On every other stream in a ONE-WAVE gate kernel in front of the work, never inside it: a grid of hundreds of
+                // workgroups that spins while it holds its CU slots -- and polls one counter from every workgroup -- could keep the very
+                // kernel it waits for from becoming resident, and slows the chain's kernels beside it (measured: the critical-tile
+                // kernels took 11 us instead of 4 with the panel kernels spinning next to them).
+                const bool in_kernel = op.stream == chol::ST_A || ctx->chol_gate_in_kernel;
+                const bool pipe_kind = op.kind == chol::TRSM_PIPE || op.kind == chol::UPD_PIPE || op.kind == chol::PGEMM || op.kind == chol::PUBLISH;
+                const Gate none = gate_none(d.flag);
+                const bool gate_kernel = !safe && (pipe_kind || !in_kernel) && (op.nw > 0 || op.awaited);
+                if (gate_kernel) k_ring_gate<<<1, 64, 0, sq>>>(g);
+                const Gate &gk = (pipe_kind || !in_kernel) ? none : g;
+                const int gq = 32 * ((4 * op.m + 7) / 8);                          // k_gemm_q: strips of 32 rows on the eight XCD slots
+                const int prio = op.stream == chol::ST_C ? 0 : PIPE_PRIO;
+                switch (op.kind) {
+                case chol::DIAG: {
+                    // (active rows of the block: the system's n rows, and the right-hand-side row behind them when it rides along)
+                    const int nact = std::min(NB, (rhs_row ? n + 1 : n) - op.kb * NB);
+                    k_chol_diag<<<1, 64 * CDW, NB * DL * 8, sq>>>(d.S, npad, op.kb, d.Linv, d.flag, op.kb == nblk - 1, gk, nact, op.tl);
+                    break;
+                }
+                case chol::TRSM_Q:
+                    k_gemm_q<0><<<gq, 256, 0, sq>>>(d.S, d.L, npad, op.kb, op.first, op.m, d.Linv, gk, 1, op.tl);
+                    break;
+                case chol::UPD_Q:
+                    k_gemm_q<1><<<gq, 256, 0, sq>>>(d.S, d.L, npad, op.kb, op.first, op.m, d.Linv, gk, op.dj, op.tl);
+#ifdef RCN_DIAG
+                    if (ctx->chol_break == 2 && op.stream == chol::ST_A && op.kb == 1 && !safe) k_diag_poison<<<1, 1, 0, sq>>>(d.S, npad, op.kb + 1);      // the next diagonal kernel meets a NaN pivot AFTER the timeout
+#endif
+                    break;
+                case chol::TRSM_PIPE:
+                    k_gemm_nt_pipe<0, 16, 1><<<op.map_n, 256, lds_pipe, sq>>>(d.L, d.S, npad, op.kb, maps + op.map_off, prio, nullptr, d.Linv, NB, 16, op.tl);
+                    break;
+                case chol::UPD_PIPE: {
+                    int *sg = (op.stream == chol::ST_C && !safe) ? ctr[chol::CTR_SIG1] : nullptr;
+                    if (op.nst == 16) k_gemm_nt_pipe<0, 16><<<op.map_n, 256, lds_pipe, sq>>>(d.S, d.L, npad, op.kb, maps + op.map_off, prio, sg, nullptr, 0, 16, op.tl);
+                    else if (op.nst == 32) k_gemm_nt_pipe<0, 32><<<op.map_n, 256, lds_pipe, sq>>>(d.S, d.L, npad, op.kb, maps + op.map_off, prio, sg, nullptr, 0, 32, op.tl);
+                    else k_gemm_nt_pipe<0, 0><<<op.map_n, 256, lds_pipe, sq>>>(d.S, d.L, npad, op.kb, maps + op.map_off, prio, sg, nullptr, 0, op.nst, op.tl);
+                    break;
+                }
+                case chol::SINV:
+                    k_sinv<<<8 * op.pos + 1, 512, 0, sq>>>(d.L, npad, d.Linv, SI, ldsi, op.kb, op.pos, gk, op.tl);
+                    break;
+                case chol::PGEMM:
+                    k_gemm_nt_pipe<0, 0, 2><<<op.map_n, 256, lds_pipe, sq>>>(d.L, d.S, npad, op.kb, maps + op.map_off, prio, nullptr, SI, ldsi, 0, op.tl);
+                    break;
+                case chol::PUBLISH:
+                    break;
                 }
             }
+#ifdef RCN_DIAG
+            if (ctx->chol_host_time) fprintf(stderr, "factorise: %zu operations enqueued in %.3f ms of host time\n", plan.ops.size(), 1e3 * (now_s() - th0));
+#endif
             hipError_t e = hipGetLastError();
             if (e != hipSuccess || safe) return e;
-            // the chain continues (triangular solves) behind the last kernels of the other two streams
-            e = hipEventRecord(ctx->ba_ev[1], sB);
-            if (e == hipSuccess) e = hipStreamWaitEvent(sA, ctx->ba_ev[1], 0);
-            if (e == hipSuccess) e = hipEventRecord(ctx->ba_ev[2], sC);
-            if (e == hipSuccess) e = hipStreamWaitEvent(sA, ctx->ba_ev[2], 0);
+            // the chain continues (triangular solves) behind the last kernels of the other streams
+            for (int s2 = 1; s2 < chol::N_STREAMS && e == hipSuccess; ++s2) {
+                if (!plan.n_ops[s2]) continue;
+                e = hipEventRecord(ctx->ba_ev[s2], str[s2]);
+                if (e == hipSuccess) e = hipStreamWaitEvent(str[0], ctx->ba_ev[s2], 0);
+            }
             return e;
         };
         // (up to two blocks there is no panel rest, no column rest and no bulk update: nothing for the other two streams to do)
@@ -2662,7 +2692,7 @@ int rcn_int_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_option
         const bool solve_ok = hflag == 0 && hs[9] == 0.0 && std::isfinite(model_change);
         if (!solve_ok || !(model_change > 0.0)) {
             sum->invalid_steps++;
-            if (++invalid_run > opt->max_consecutive_invalid_steps) { termination = RCN_BA_FAILURE; break; }
+            if (++invalid_run >= opt->max_consecutive_invalid_steps) { termination = RCN_BA_FAILURE; break; }      // Ceres' HandleInvalidStep: pre-increment, `>=` (see the oracle)
             radius /= decrease; decrease *= 2.0; reuse_diag = false;
             if (iter < 160) sum->cost_trace[iter] = cost;
             continue;

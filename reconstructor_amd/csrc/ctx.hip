@@ -60,8 +60,16 @@ int rcn_create(int device_id, rcn_ctx **out)
             (void)hipGetLastError();
             ctx->panel_stream = nullptr;
         }
+        if (hipExtStreamCreateWithCUMask(&ctx->panel2_stream, (uint32_t)mask.size(), mask.data()) != hipSuccess) {
+            (void)hipGetLastError();
+            ctx->panel2_stream = nullptr;
+        }
     }
     if (!ctx->panel_stream && hipStreamCreateWithFlags(&ctx->panel_stream, hipStreamNonBlocking) != hipSuccess) {
+        delete ctx;
+        return RCN_ERR_HIP;
+    }
+    if (!ctx->panel2_stream && hipStreamCreateWithFlags(&ctx->panel2_stream, hipStreamNonBlocking) != hipSuccess) {
         delete ctx;
         return RCN_ERR_HIP;
     }
@@ -101,6 +109,16 @@ int rcn_create(int device_id, rcn_ctx **out)
     if (cpm) ctx->chol_pair_min = std::atoi(cpm);
     const char *cgr = std::getenv("RCN_CHOL_GROUP");
     if (cgr) ctx->chol_group = std::atoi(cgr);
+    const char *ctl = std::getenv("RCN_CHOL_TL");
+    if (ctl) ctx->chol_tl_g = std::atoi(ctl);
+    const char *ctm = std::getenv("RCN_CHOL_TL_MIN");
+    if (ctm) ctx->chol_tl_min = std::atoi(ctm);
+    const char *cps = std::getenv("RCN_CHOL_PGSTREAM");
+    if (cps) ctx->chol_pg_stream = std::atoi(cps);
+    const char *cgk = std::getenv("RCN_CHOL_GATE_IN_KERNEL");
+    ctx->chol_gate_in_kernel = cgk && cgk[0] == '1';
+    const char *cht = std::getenv("RCN_CHOL_HOSTTIME");
+    ctx->chol_host_time = cht && cht[0] == '1';
     const char *cpi = std::getenv("RCN_CHOL_PIPE_MIN");
     if (cpi) ctx->chol_pipe_min = std::atoi(cpi);
     const char *ch = std::getenv("RCN_CHUNK_ROWS");
@@ -147,6 +165,7 @@ void rcn_destroy(rcn_ctx *ctx)
     ctx->cmp_off.release(); ctx->cmp_qt[0].release(); ctx->cmp_qt[1].release();
     if (ctx->aux_stream) (void)hipStreamDestroy(ctx->aux_stream);
     if (ctx->panel_stream) (void)hipStreamDestroy(ctx->panel_stream);
+    if (ctx->panel2_stream) (void)hipStreamDestroy(ctx->panel2_stream);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }

@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "../../include/rcn.h"
+#include "chol_plan.h"
 
 #define RCN_HIP(call)                                                                    \
     do {                                                                                 \
@@ -185,24 +186,26 @@ struct rcn_ctx {
     int ba_graph_nc = 0, ba_graph_np = 0;
     uint64_t ba_graph_serial = 0;
     uint64_t ba_pair_token = 0;         // whose pair lists the Schur-build workspace holds (0 = nobody's)
+    std::vector<int> ba_pair_camdim;    // ... and the per-camera tangent dimensions they were built for (a camera without free parameters has no pairs)
     hipStream_t aux_stream = nullptr;   // lookahead stream of the Cholesky: bulk trailing updates (CU mask leaves one CU per XCD to the diagonal kernel)
+    hipStream_t panel2_stream = nullptr; // two-level regime of the Cholesky: the panel product for the rows below the head (same CU mask)
     hipStream_t panel_stream = nullptr; // second chain stream of the Cholesky: panels and first trailing columns behind the critical tile (same CU mask)
-    // tile maps of the bulk trailing update (ba.hip, build_bulk_maps): one per trailing size, balanced over the XCDs
+    // the factorisation's schedule (chol_plan.h: operations, streams, waits, tile maps) for the last shape solved; its maps in HBM
     DevBuf bulk_map;
-    std::vector<int> bulk_map_off, bulk_map_grid;
-    std::vector<int> pair_map_off, pair_map_grid;   // the same triangles with their first two tile columns leading (two-panel updates)
-    std::vector<int> quad_map_off, quad_map_grid;   // ... and with their first four leading (four-panel updates)
-    int col_map_off1 = 0, col_map_offn[5] = {0};     // tile columns for the pipelined kernel on the panel stream: one, and the first 1 .. 4 side by side
-    int chol_group = 2;                              // panels per bulk update while many tile rows remain: 2 (K = 256).  4 (K = 512; diagnostic build: RCN_CHOL_GROUP=4) is built and
-                                                     // correct, and measured: the bulk kernel alone gains 8 % (tools/gemm_nt_bench: 60.6 against 55.6 TFLOP/s), the cfg-5 factorisation
-                                                     // 1.4 % (8.97 against 9.09 ms) -- the column work of a group, (g + 1) / 2 single-panel passes per step, grows as fast as the bulk shrinks
+    chol::Plan chol_plan;
+    bool chol_plan_valid = false;
+    int chol_tl_g = 4;                               // two-level regime: panels per super-step (K = 128 g per bulk update); 0 = right-looking steps only (diagnostic build: RCN_CHOL_TL)
+    int chol_pg_stream = 1;                          // two-level regime: the panel product below the head rows on a stream of its own (RCN_CHOL_PGSTREAM)
+    bool chol_gate_in_kernel = false;                // diagnostic build (RCN_CHOL_GATE_IN_KERNEL=1): waits of the small kernels off the chain inside them, not in a gate kernel in front
+    bool chol_host_time = false;                     // diagnostic build (RCN_CHOL_HOSTTIME=1): print the host time of every factorisation's enqueue
+    int chol_tl_min = 28;                            // ... while at least this many tile rows remain below the super-block (RCN_CHOL_TL_MIN)
+    int chol_group = 2;                              // right-looking regime: panels per bulk update while many tile rows remain, 2 (K = 256) or 1
     int chol_pipe_min = 32;                          // panel / column kernels go through the pipelined kernel from this many tiles on
     bool trsv_chain = true;                          // backward substitution as one launch (k_trsv_bwd_chain); off after a flag timeout
     int chol_break = 0;                              // diagnostic build: 1 = break one cross-stream hand-off (forces the one-stream fallback); 2 = and put a NaN pivot behind it
     int chol_pair_min = 24;                          // two-panel bulk updates while at least this many tile rows remain below the pair
-    int bulk_map_nblk = 0;
     bool chol_safe = false;             // a device-counter hand-off timed out once: factorise on one stream, in plain order, from then on
-    hipEvent_t ba_ev[9];
+    hipEvent_t ba_ev[9];             // [0]: fork of the factorisation's streams, [1..3]: their joins, [7]: pair lists
     hipEvent_t ba_tev[6];            // phase timing of rcn_ba_solve ([4], [5]: around k_ba_eval<true>)
     bool ba_ev_made = false;
 

@@ -22,6 +22,33 @@
 
 static_assert(sizeof(ncclUniqueId) == RCN_SHARD_ID_BYTES, "rcn.h: RCN_SHARD_ID_BYTES must be sizeof(ncclUniqueId)");
 
+// Host words a read-back in front of a BOUNDED wait lands in.  Pinned on purpose: a device-to-host copy into pageable
+// memory is staged by the runtime and may wait, inside hipMemcpyAsync, for everything queued before it -- the collective a dead
+// peer never joins included -- and the polling loop with its time limit would never be reached.
+template <class T> struct PinVec {
+    T *p = nullptr;
+    size_t n = 0, cap = 0;
+    hipError_t assign(size_t count, T v)
+    {
+        if (count > cap) {
+            if (p) (void)hipHostFree(p);
+            p = nullptr; cap = 0;
+            hipError_t e = hipHostMalloc(reinterpret_cast<void **>(&p), std::max<size_t>(count, 1) * sizeof(T), hipHostMallocDefault);
+            if (e != hipSuccess) { p = nullptr; n = 0; return e; }
+            cap = std::max<size_t>(count, 1);
+        }
+        n = count;
+        for (size_t i = 0; i < count; ++i) p[i] = v;
+        return hipSuccess;
+    }
+    T *data() { return p; }
+    const T *data() const { return p; }
+    T &operator[](size_t i) { return p[i]; }
+    const T &operator[](size_t i) const { return p[i]; }
+    size_t size() const { return n; }
+    void release() { if (p) (void)hipHostFree(p); p = nullptr; n = cap = 0; }
+};
+
 struct rcn_shard {
     rcn_ctx *ctx = nullptr;
     ncclComm_t comm = nullptr;         // ctx stream: scale statistics + fp16 payload (the critical path)
@@ -34,7 +61,7 @@ struct rcn_shard {
     DevBuf landing;                    // [world * per][K][D] fp32: one K-row slot per image
     DevBuf counts;                     // [world * per] int32: rows in use per slot (all-gathered every exchange)
     std::vector<int32_t> local_K;      // this rank's block of `counts` (rcn_shard_put_image / exchange argument)
-    std::vector<int32_t> all_K;        // host copy of `counts` after the gather
+    PinVec<int32_t> all_K;             // host copy of `counts` after the gather (pinned: read back in front of a bounded wait)
     int32_t n_images = 0, per = 0, K = 0, D = 0;
     int slab = -1;
     bool own_table = false;            // the last rcn_shard_match wrote into the shard's own tables (tab / cnt below)
@@ -49,7 +76,8 @@ struct rcn_shard {
     int fault = 0;                     // diagnostic build: rcn_diag_shard_fault
     // gather of the lists to one rank (rcn_shard_gather_lists)
     DevBuf g_tot, g_cnt, g_recv, g_loff, g_goff, g_out, g_ccnt;
-    std::vector<int64_t> g_tot_host;
+    PinVec<int64_t> g_tot_host;
+    PinVec<int64_t> words;             // [8] pinned staging words of rcn_shard_gather_lists (status marker, capacity verdict, buffer vote)
     bool f32_queued = false;           // ev_f32 has been recorded: a later writer of the landing buffer waits for it
     bool exchanged = false;            // the last rcn_shard_exchange went through on every rank
     // Status vote.  A rank-local failure (a reserve that could not allocate, a put_image that did not fit, whatever
@@ -59,7 +87,7 @@ struct rcn_shard {
     int32_t local_status = 0;
     DevBuf verdict;                    // rcn_shard_filter: the filter's verdict per pair of this rank
     DevBuf vote;                       // [world][VOTE_WORDS] int32, allocated with the communicators
-    std::vector<int32_t> vote_host;    // status, n_images, K, D, "my block is ragged", 3 spare
+    PinVec<int32_t> vote_host;         // status, n_images, K, D, "my block is ragged", 3 spare
     // optional per-phase timing (rcn_shard_profile): HIP events on the streams the work runs on
     bool profile = false, prof_made = false;
     hipEvent_t pev[64][6];             // [step % 64]: exchange begin / end (ctx stream), fp32 gather begin / end (side), match begin / end
@@ -235,9 +263,10 @@ int rcn_shard_create(rcn_ctx *ctx, int32_t rank, int32_t world, const uint8_t id
     }
     hipError_t e = hipStreamCreateWithFlags(&sh->side, hipStreamNonBlocking);
     if (e == hipSuccess) e = sh->vote.reserve((size_t)world * VOTE_WORDS * sizeof(int32_t));
-    sh->vote_host.assign((size_t)world * VOTE_WORDS, 0);
+    if (e == hipSuccess) e = sh->vote_host.assign((size_t)world * VOTE_WORDS, 0);
     if (e == hipSuccess) e = sh->g_tot.reserve((size_t)world * sizeof(int64_t));
-    sh->g_tot_host.assign((size_t)world, 0);
+    if (e == hipSuccess) e = sh->g_tot_host.assign((size_t)world, 0);
+    if (e == hipSuccess) e = sh->words.assign(8, 0);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&sh->ev_wait, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&sh->ev_local, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&sh->ev_f32, hipEventDisableTiming);
@@ -249,6 +278,7 @@ int rcn_shard_create(rcn_ctx *ctx, int32_t rank, int32_t world, const uint8_t id
         if (sh->ev_local) (void)hipEventDestroy(sh->ev_local);
         if (sh->ev_wait) (void)hipEventDestroy(sh->ev_wait);
         sh->vote.release(); sh->g_tot.release();
+        sh->vote_host.release(); sh->g_tot_host.release(); sh->words.release();
         delete sh;
         return RCN_ERR_HIP;
     }
@@ -287,6 +317,7 @@ void rcn_shard_destroy(rcn_shard *sh)
         sh->counts.release();
         sh->vote.release();
         sh->verdict.release();
+        sh->vote_host.release(); sh->g_tot_host.release(); sh->words.release(); sh->all_K.release();
     }
     delete sh;
 }
@@ -322,7 +353,8 @@ int rcn_shard_reserve(rcn_shard *sh, int32_t n_images, int32_t K, int32_t D, flo
         // the shape and the (tiny) count block first: with them even a rank whose landing buffer cannot be had joins the vote
         sh->n_images = n_images; sh->per = per; sh->K = K; sh->D = D;
         sh->local_K.assign((size_t)per, 0);
-        sh->all_K.assign((size_t)sh->world * per, 0);
+        e = sh->all_K.assign((size_t)sh->world * per, 0);
+        if (e != hipSuccess) return local_fail(e, "rcn_shard_reserve: host copy of the row counts");
         {
             int32_t lo = 0, cnt = 0;
             rcn_shard_owned_images(n_images, sh->world, sh->rank, &lo, &cnt);
@@ -736,10 +768,15 @@ int rcn_shard_gather_lists(rcn_shard *sh, int32_t root, const int32_t *table_dev
     RCN_SHARD_ALIVE(sh);
     const int world = sh->world, rank = sh->rank;
     const bool is_root = rank == root;
-    // argument errors that every rank can see alike return before anything collective
-    if (root < 0 || root >= world || sh->n_images < 1 || !sh->exchanged) { ctx->set_error("rcn_shard_gather_lists: bad root, or no exchange to gather from"); return RCN_ERR_ARG; }
+    // only what EVERY rank sees alike may return before the collectives: the root argument and the shape all ranks reserved
+    if (root < 0 || root >= world || sh->n_images < 1) { ctx->set_error("rcn_shard_gather_lists: bad root, or nothing reserved"); return RCN_ERR_ARG; }
     int32_t status = 0;
     std::string why;
+    // Rank-local: "my last exchange did not go through" -- after an error behind the vote only the failing rank knows, its
+    // peers hear of it in the NEXT vote -- and a failure that is still waiting for that vote.  Such a rank must not walk away: its peers
+    // are about to enter the totals all-gather.  It joins it with the failure marker, and every rank leaves with an error, together.
+    if (!sh->exchanged) { status = RCN_ERR_ARG; why = "rcn_shard_gather_lists: this rank's last exchange did not go through (no exchange to gather from)"; }
+    else if (sh->local_status) { status = sh->local_status; why = "rcn_shard_gather_lists: a local failure is waiting for the next exchange's vote"; }
     if (!table_dev && !counts_dev) {
         if (!sh->own_table) { status = RCN_ERR_ARG; why = "rcn_shard_gather_lists: call rcn_shard_match with NULL tables first (or pass the tables)"; }
         table_dev = sh->tab.as<int32_t>(); counts_dev = sh->cnt.as<int32_t>(); stride = sh->K;
@@ -772,9 +809,8 @@ int rcn_shard_gather_lists(rcn_shard *sh, int32_t root, const int32_t *table_dev
     }
     // ---- vote + totals: status rides in the high word of nothing -- a total of -1 - code marks a failed rank
     if (status) {
-        const int64_t bad = -1 - (int64_t)(-status);
-        (void)hipMemcpyAsync(gtot + rank, &bad, sizeof(int64_t), hipMemcpyHostToDevice, st);
-        (void)hipStreamSynchronize(st);      // `bad` is on this frame
+        sh->words[0] = -1 - (int64_t)(-status);
+        (void)hipMemcpyAsync(gtot + rank, sh->words.data(), sizeof(int64_t), hipMemcpyHostToDevice, st);
     }
     {
         ncclResult_t r = ncclGroupStart();
@@ -802,14 +838,15 @@ int rcn_shard_gather_lists(rcn_shard *sh, int32_t root, const int32_t *table_dev
     // the root's capacity is the root's business: it says so to everybody before any payload moves
     int64_t *fits = gtot;      // reuse word `root` of the totals block as the broadcast word
     {
-        const int64_t ok = !is_root || total <= capacity ? 1 : 0;
+        sh->words[1] = !is_root || total <= capacity ? 1 : 0;      // (pinned words: the copies below are asynchronous for real)
+        sh->words[2] = 0;
         hipError_t e = hipSuccess;
-        if (is_root) { e = hipMemcpyAsync(fits + root, &ok, sizeof(int64_t), hipMemcpyHostToDevice, st); if (e == hipSuccess) e = hipStreamSynchronize(st); }
+        if (is_root) e = hipMemcpyAsync(fits + root, sh->words.data() + 1, sizeof(int64_t), hipMemcpyHostToDevice, st);
         ncclResult_t r = ncclBroadcast(fits + root, fits + root, 1, ncclInt64, root, sh->comm, st);
-        int64_t got = 0;
-        if (e == hipSuccess && r == ncclSuccess) e = hipMemcpyAsync(&got, fits + root, sizeof(int64_t), hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess && r == ncclSuccess) e = hipMemcpyAsync(sh->words.data() + 2, fits + root, sizeof(int64_t), hipMemcpyDeviceToHost, st);
         if (e != hipSuccess || r != ncclSuccess) { ctx->set_error("rcn_shard_gather_lists: broadcast failed; communicators aborted"); shard_abort(sh); return RCN_ERR_COMM; }
         { int rcw = shard_wait(sh, st, "rcn_shard_gather_lists (capacity)"); if (rcw) return rcw; }
+        const int64_t got = sh->words[2];
         if (!got) {
             ctx->set_error(is_root ? "rcn_shard_gather_lists: qt_host holds fewer entries than the grid has matches (*total_out says how many)"
                                    : "rcn_shard_gather_lists: the root's buffer is too small; the gather was abandoned on every rank");
@@ -833,8 +870,9 @@ int rcn_shard_gather_lists(rcn_shard *sh, int32_t root, const int32_t *table_dev
     }
     {   // one word per rank: "I could not get my buffers" (always entered: whether anybody had to grow is not known to the others)
         int32_t *vote = sh->vote.as<int32_t>();
-        hipError_t e = hipMemcpyAsync(vote + (size_t)rank * VOTE_WORDS, &gstat, sizeof(int32_t), hipMemcpyHostToDevice, st);
-        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        sh->words[3] = 0;
+        *reinterpret_cast<int32_t *>(sh->words.data() + 3) = gstat;
+        hipError_t e = hipMemcpyAsync(vote + (size_t)rank * VOTE_WORDS, sh->words.data() + 3, sizeof(int32_t), hipMemcpyHostToDevice, st);
         ncclResult_t r = ncclAllGather(vote + (size_t)rank * VOTE_WORDS, vote, VOTE_WORDS, ncclInt32, sh->comm, st);
         if (e == hipSuccess && r == ncclSuccess) e = hipMemcpyAsync(sh->vote_host.data(), vote, (size_t)world * VOTE_WORDS * sizeof(int32_t), hipMemcpyDeviceToHost, st);
         if (e != hipSuccess || r != ncclSuccess) { ctx->set_error("rcn_shard_gather_lists: vote failed; communicators aborted"); shard_abort(sh); return RCN_ERR_COMM; }

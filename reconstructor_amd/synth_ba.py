@@ -138,3 +138,23 @@ def make_validity_case(n_cams, n_points, obs_per_point=10, seed=7, defect_rate=0
     return {"poses34": poses_to_34(poses), "intrinsics": intr, "points": pts, "pt_off": pt_off,
             "obs_cam": np.ascontiguousarray(cam.reshape(-1)[sel].astype(np.int32)),
             "obs_xy": np.ascontiguousarray(xy[sel])}
+
+
+def make_always_invalid_scene(seed=7):
+    """A scene whose EVERY LM step is invalid, exactly and in any floating-point arithmetic (tests of the invalid-step counter): the last
+    camera has fx = fy = 0 -- its projection is the constant (cx, cy), every Jacobian entry of its observations is exactly zero -- and one
+    extra landmark is seen by that camera only, so that landmark's 3 x 3 block is exactly zero; with min_lm_diagonal = 0 the damped
+    block stays zero whatever the radius, the block solve fails, and the step cannot be computed.  The other cameras and landmarks are
+    an ordinary scene (the gradient is far from zero, so the loop does not end on the gradient test)."""
+    sc = make_scene(6, 60, obs_per_point=3, seed=seed)
+    sc = dict(sc)
+    last = sc["poses"].shape[0] - 1
+    intr = sc["intrinsics"].copy()
+    intr[last, 0] = intr[last, 1] = 0.0
+    sc["intrinsics"] = intr
+    sc["points"] = np.concatenate([sc["points"], [[0.1, -0.2, 0.3]]])
+    j = sc["points"].shape[0] - 1
+    sc["obs_pt"] = np.concatenate([sc["obs_pt"], [j, j]]).astype(np.int32)
+    sc["obs_cam"] = np.concatenate([sc["obs_cam"], [last, last]]).astype(np.int32)
+    sc["obs_uv"] = np.concatenate([sc["obs_uv"], [[100.0, 90.0], [101.0, 91.0]]])
+    return sc

@@ -243,6 +243,60 @@ def test_pair_lists_are_kept_for_the_same_graph_only(gpu_ctx):
     assert sm["iterations"] == s0["iterations"] and abs(sm["final_rms_px"] - s0["final_rms_px"]) <= 1e-5
 
 
+def test_consecutive_invalid_steps_end_the_solve_where_the_oracle_ends_it(gpu_ctx):
+    """the boundary of max_consecutive_invalid_steps.  Every step of this scene is invalid (a landmark block that is exactly
+    zero, no floor under the LM diagonal): the solve ends in FAILURE after exactly `limit` steps -- Ceres' `>=` -- with the parameters
+    untouched, on the GPU as in the oracle; with the default floor both solve it."""
+    from reconstructor_amd import ba
+    sc = synth_ba.make_always_invalid_scene()
+    for limit in (1, 5, 6):
+        o = ba.default_options(gpu_ctx, 6)
+        o.min_lm_diagonal = 0.0
+        o.max_consecutive_invalid_steps = limit
+        P, I, X, s = ba.solve_scene(gpu_ctx, sc, o, allow_failure=True)
+        oo = orc_ba.default_options(6)
+        oo.min_lm_diagonal = 0.0
+        oo.max_consecutive_invalid_steps = limit
+        P0, I0, X0, s0 = orc_ba.solve(sc, options=oo, threads=2)
+        assert s["termination"] == 6 == s0["termination"]
+        assert s["invalid_steps"] == limit == s0["invalid_steps"] and s["iterations"] == limit == s0["iterations"]
+        assert s["final_cost"] == s["initial_cost"] and np.array_equal(P, sc["poses"]) and np.array_equal(X, sc["points"])
+    P, I, X, s = ba.solve_scene(gpu_ctx, sc)
+    P0, I0, X0, s0 = orc_ba.solve(sc, threads=2)
+    assert s["termination"] == s0["termination"] != 6 and s["iterations"] == s0["iterations"] and s["invalid_steps"] == 0
+    assert abs(s["final_rms_px"] - s0["final_rms_px"]) <= 1e-5
+
+
+def test_pair_lists_are_rebuilt_when_the_options_free_another_camera(gpu_ctx):
+    """the pair lists also depend on the options -- a camera without free parameters (camera 0 with its pose fixed and all
+    intrinsics constant) has no pairs in them.  The same graph solved again with the bounded-intrinsics branch, in which camera 0
+    has four free columns, must rebuild the lists: the result equals a solve that never saw the first one, and the oracle's."""
+    import ctypes as C
+    from reconstructor_amd import ba
+    sc = synth_ba.make_scene(8, 300, obs_per_point=4, seed=91)
+    o0 = ba.default_options(gpu_ctx, 8)
+    assert o0.intrinsics_mode == 0 and o0.fix_cam0_pose == 1          # fewer than ten cameras: camera 0 has no free parameter
+    P0, I0, X0, s0 = ba.solve_scene(gpu_ctx, sc, o0)
+    o1 = ba.default_options(gpu_ctx, 8)
+    o1.intrinsics_mode = 1                                            # same graph, camera 0 now carries fx, fy, k1, k2
+    P1, I1, X1, s1 = ba.solve_scene(gpu_ctx, sc, o1)
+    assert s1["pair_lists_reused"] == 0, "lists built without camera 0's pairs must not serve a solve in which it is free"
+    other = synth_ba.make_scene(5, 80, obs_per_point=4, seed=34)
+    ba.solve_scene(gpu_ctx, other)                                    # drops the lists: the next solve builds them from scratch
+    P2, I2, X2, s2 = ba.solve_scene(gpu_ctx, sc, o1)
+    assert s2["pair_lists_reused"] == 0
+    assert P1.tobytes() == P2.tobytes() and I1.tobytes() == I2.tobytes() and X1.tobytes() == X2.tobytes()
+    oo = orc_ba.default_options(8)
+    oo.intrinsics_mode = 1
+    Pr, Ir, Xr, sr = orc_ba.solve(sc, options=oo, threads=4)
+    assert s1["iterations"] == sr["iterations"] and abs(s1["final_rms_px"] - sr["final_rms_px"]) <= 1e-5
+    # and back: the first options again, lists rebuilt once more, same bits as the very first solve
+    P3, I3, X3, s3 = ba.solve_scene(gpu_ctx, sc, o0)
+    assert s3["pair_lists_reused"] == 0 and P3.tobytes() == P0.tobytes() and X3.tobytes() == X0.tobytes()
+    P4, I4, X4, s4 = ba.solve_scene(gpu_ctx, sc, o0)
+    assert s4["pair_lists_reused"] == 1 and P4.tobytes() == P0.tobytes()
+
+
 _ALT = r"""
 import sys, numpy as np
 sys.path.insert(0, %r)

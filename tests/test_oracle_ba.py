@@ -143,3 +143,22 @@ def test_bounds_line_search_backtracks_and_still_descends():
         tr = np.array(s["cost_trace"][: s["iterations"] + 1])
         assert (np.diff(tr) <= 0).all() and s["final_rms_px"] < 0.7
         assert (I[:, :2] <= 1000.0).all()
+
+
+def test_consecutive_invalid_steps_end_the_solve_at_the_limit_not_one_later():
+    """Ceres' HandleInvalidStep: `++num_consecutive_invalid_steps_ >= max_num_consecutive_invalid_steps` -> FAILURE (restated from
+    memory; DESIGN.md section 1 records the choice).  On a scene whose every step is invalid (one landmark block exactly zero, no LM
+    floor) the solve must take exactly `max` steps, all invalid, and leave the parameters alone."""
+    sc = synth_ba.make_always_invalid_scene()
+    for limit in (1, 5, 6):
+        o = orc_ba.default_options(6)
+        o.min_lm_diagonal = 0.0
+        o.max_consecutive_invalid_steps = limit
+        P, I, X, s = orc_ba.solve(sc, options=o, threads=2)
+        assert s["termination"] == 6 and s["invalid_steps"] == limit and s["iterations"] == limit, s
+        assert s["successful_steps"] == 0 and s["final_cost"] == s["initial_cost"]
+        assert np.array_equal(P, sc["poses"]) and np.array_equal(X, sc["points"])
+    # with the floor of the LM diagonal in place (Ceres' default 1e-6) the same scene is solvable: the zero block is damped
+    o = orc_ba.default_options(6)
+    P, I, X, s = orc_ba.solve(sc, options=o, threads=2)
+    assert s["termination"] != 6 and s["invalid_steps"] == 0 and s["final_cost"] < s["initial_cost"]

@@ -32,7 +32,10 @@ def main():
     torch.cuda.synchronize()
     assert fn(None) == 0
     t = buf.cpu().numpy().reshape(nblk + 2, 8, 3).astype("float64") / 100.0     # 100 MHz -> us
-    names = {0: "D", 1: "T1", 2: "T2", 3: "P", 4: "C", 5: "C2", 6: "B"}
+    # (at the LAST step of a two-level super-step, which has no critical tile of its own: P / C / C2 = the head rows' column 0, their
+    #  product with the super-block's inverse, the update of the next super-diagonal block; T1 / T2 = column 0 and the product for all rows
+    #  below; W = a block row of the super-block's inverse)
+    names = {0: "D", 1: "T1", 2: "T2", 3: "P", 4: "C", 5: "C2", 6: "B", 7: "W"}
     print("%d iterations, chol %.3f ms per iteration, %d block steps" % (s["iterations"], 1e3 * s["cholesky_seconds"] / s["iterations"], nblk))
     prev = None
     for k in range(nblk):
@@ -40,7 +43,7 @@ def main():
         if d0 == 0:
             continue
         parts = []
-        for kind in range(7):
+        for kind in range(8):
             a, g, e = t[k, kind]
             if a == 0 and e == 0:
                 continue

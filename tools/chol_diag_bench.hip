@@ -22,7 +22,7 @@ int main()
     for (int rep = 0; rep < 4; ++rep) {      // rep 0 also stores L (checked below); the others time the kernel as the chain runs it
         (void)hipMemcpy(dA, A.data(), n * n * 8, hipMemcpyHostToDevice);
         (void)hipEventRecord(e0);
-        k_chol_diag<<<1, 64 * CDW, NB * DL * 8>>>(dA, n, 0, dLinv, dflag, rep == 0, Gate{nullptr, 0, nullptr, 0, nullptr, 0, dflag});
+        k_chol_diag<<<1, 64 * CDW, NB * DL * 8>>>(dA, n, 0, dLinv, dflag, rep == 0, gate_none(dflag));
         (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
         float ms; (void)hipEventElapsedTime(&ms, e0, e1);
         unsigned long long st[64];
@@ -39,7 +39,7 @@ int main()
     }
     // check: L L^T == A and Linv L == I (one more run that stores L)
     (void)hipMemcpy(dA, A.data(), n * n * 8, hipMemcpyHostToDevice);
-    k_chol_diag<<<1, 64 * CDW, NB * DL * 8>>>(dA, n, 0, dLinv, dflag, 1, Gate{nullptr, 0, nullptr, 0, nullptr, 0, dflag});
+    k_chol_diag<<<1, 64 * CDW, NB * DL * 8>>>(dA, n, 0, dLinv, dflag, 1, gate_none(dflag));
     std::vector<double> L(n * n), Li(n * n);
     (void)hipMemcpy(L.data(), dA, n * n * 8, hipMemcpyDeviceToHost); (void)hipMemcpy(Li.data(), dLinv, n * n * 8, hipMemcpyDeviceToHost);
     double e1m = 0, e2m = 0;
