@@ -495,20 +495,24 @@ def parity_cfg2(out, counts):
 
 
 def parity_cfg3(world, rank):
-    """The sampled pairs of cfg3 this rank computed (pair number p -> rank p % world) against the CPU oracle: 512 pairs by
-    row hash + count, 64 from every residue of the pair number modulo 8 (tests/golden/match_cfg3_sample512.npz)."""
+    """The sampled pairs of cfg3 this rank computed (pair number p -> rank p % world) against the CPU oracle by row hash + count: 512
+    pairs, 64 from every residue of the pair number modulo 8 (tests/golden/match_cfg3_sample512.npz), and 5120 more, 40 for every
+    sixteenth of the pair list x residue (match_cfg3_sample5k.npz: the pipeline chunks of the one-GPU call, the ranks of an 8-GPU node)."""
     def check(out, counts):
         import torch
         from reconstructor_amd import tablehash
-        path = os.path.join(ROOT, "tests", "golden", "match_cfg3_sample512.npz")
-        if not os.path.exists(path):
-            return {"equal_to_cpu": None, "note": "fixture missing"}
-        g = np.load(path)
-        mine = np.nonzero(g["pair_numbers"] % world == rank)[0]
-        rows = torch.from_numpy(g["pair_numbers"][mine] // world).to(out.device)          # row of pair p in this rank's table
-        h, c = tablehash.row_hashes(out[rows].cpu().numpy(), int(g["K"]))
-        ok = bool(np.array_equal(h, g["hashes"][mine]) and np.array_equal(c, g["counts"][mine]) and np.array_equal(counts[rows].cpu().numpy(), g["counts"][mine]))
-        return {"equal_to_cpu": ok, "pairs_compared": int(len(mine))}
+        ok, n = True, 0
+        for name in ("match_cfg3_sample512.npz", "match_cfg3_sample5k.npz"):
+            path = os.path.join(ROOT, "tests", "golden", name)
+            if not os.path.exists(path):
+                return {"equal_to_cpu": None, "note": "fixture missing: " + name}
+            g = np.load(path)
+            mine = np.nonzero(g["pair_numbers"] % world == rank)[0]
+            rows = torch.from_numpy(g["pair_numbers"][mine] // world).to(out.device)          # row of pair p in this rank's table
+            h, c = tablehash.row_hashes(out[rows].cpu().numpy(), int(g["K"]))
+            ok = ok and bool(np.array_equal(h, g["hashes"][mine]) and np.array_equal(c, g["counts"][mine]) and np.array_equal(counts[rows].cpu().numpy(), g["counts"][mine]))
+            n += int(len(mine))
+        return {"equal_to_cpu": ok, "pairs_compared": n}
     return check
 
 
@@ -904,8 +908,8 @@ def main():
                        "exchange_bytes_f16_payload": int(info["exchange_bytes_f16"]), "exchange_bytes_f32_side_stream": int(info["exchange_bytes_f32"]),
                        "rows_reranked": rows[0], "rows_exact_fallback": rows[1], "rows_total": rows[2],
                        "hbm_used_gb_rank0": st.get("hbm_used_bytes", 0) / 1e9, "pipeline_chunks": int(st.get("chunks", 1)),
-                       # the table of the LAST timed step against the CPU oracle (outside the timed region): cfg3 = 512 sampled
-                       # pairs by row hash + count, 64 per residue of the pair number mod 8, over all ranks; cfg2 = all 4950 pairs
+                       # the table of the LAST timed step against the CPU oracle (outside the timed region): cfg3 = 5632 sampled
+                       # pairs by row hash + count (every residue of the pair number mod 8 x every sixteenth of the pair list), over all ranks; cfg2 = all 4950 pairs
                        "equal_to_cpu": par["equal_to_cpu"], "pairs_compared_with_cpu": par["pairs_compared"]},
             "roofline": roof,
             # the collective side of the step, per step, max over ranks (HIP events inside librcn.so): `ranks` is

@@ -347,11 +347,12 @@ int rcn_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *problem, const rcn_ba_optio
  * with its stream and the device counters it waits for, and the tile maps of the pipelined launches.  tests/test_chol_plan.py executes
  * it in numpy (list order; random orders that respect only the waits) and checks that the waits order every pair of operations that
  * touch a common tile.  params: {panels per super-step, min rows for a super-step, pairs (0/1), min rows for a pair, min tiles for the
- * pipelined panel kernels, own stream for the two-level panel product (0/1)}, NULL = what the library uses.  An operation is
+ * pipelined panel kernels, own stream for the two-level panel product (0/1), that product as the tail of the previous bulk launch (0/1)},
+ * NULL = what the library uses.  An operation is
  * RCN_PLAN_OP_WORDS int32: kind, stream, ticket, kb, first, m, dj, nst, map_off, map_n, g, pos, n_waits, 5 x (counter, value), timeline
- * slot, awaited.  Counters 0 .. 3 are the streams' progress counters, 4 and 5 count the two classes of leading tiles of the bulk updates.  Returns RCN_ERR_ARG when a buffer is too
+ * slot, awaited, index of the bulk update whose launch carries this operation's tiles as its tail (-1: none).  Counters 0 .. 3 are the streams' progress counters, 4 and 5 count the two classes of leading tiles of the bulk updates.  Returns RCN_ERR_ARG when a buffer is too
  * small (the needed sizes are still written). */
-#define RCN_PLAN_OP_WORDS 25
+#define RCN_PLAN_OP_WORDS 26
 int rcn_ba_factor_plan(int32_t n_blocks, const int32_t *params, int32_t *ops, int64_t ops_cap, uint32_t *maps, int64_t maps_cap,
                        int64_t *n_ops, int64_t *n_maps);
 

@@ -1596,23 +1596,21 @@ template <int BASE, int... I, class F> __device__ __forceinline__ void pipe_for_
 // MODE 1  L(i, kb) = S(i, kb) Linv_kb'                 Out = L, Ain = S, Bm = Linv (row stride 128); no C tile
 // MODE 2  L(i, kb + c) = S(i, kb .. kb + c) W[c][.]'    Out = L, Ain = S, Bm = the super-block's inverse W (row stride ldb_arg),
 //         c = the entry's column: a pass of 16 (c + 1) stages; no C tile (the two-level regime's panel product)
-template <int DBG, int NST, int MODE = 0>
-__global__ __launch_bounds__(256, 2) void k_gemm_nt_pipe(double *Out, const double *Ain, int ld, int kb, const unsigned *__restrict__ map, int flags, int *sig,
-                                                          const double *Bm = nullptr, int ldb_arg = 0, int nst_rt = 0, int tl = 0)
+//         (column 0 as 24 stages, K = 192: the rolled form's shortest pass -- the 64 extra columns meet the zero block W[0][1])
+template <int DBG, int NST, int MODE>
+__device__ __forceinline__ void pipe_body(double *Out, const double *Ain, int ld, int kb, const unsigned e, int flags, int *sig, const double *Bm, int ldb_arg, int nst_rt, int tl)
 {
     constexpr bool rolled = NST == 0;
     constexpr int NSTC = rolled ? 64 : NST;      // what the compile-time stages see: in the rolled form the first sixteen are far from the end and the last four know their distance to it
     static_assert(rolled || (NST % 4 == 0 && NST >= 16 && NST <= 32), "C tiles are folded in during stages 0 .. 15");
     static_assert(MODE != 2 || rolled, "the panel product of the two-level regime has ragged pass lengths");
     extern __shared__ __attribute__((aligned(16))) char gsm[];
-    const unsigned e = map[blockIdx.x];
-    if (e == ~0u) return;
     if (flags & PIPE_PRIO) __builtin_amdgcn_s_setprio(2);
     [[maybe_unused]] const int tl_id = tl;
     TL_MARK(tl_id, 0);
     const int ti = (int)(e >> 16), ecol = (int)(e & 0x3fffu), cls = (int)((e >> 14) & 3u);
     const int tj = MODE == 0 ? ecol : MODE == 1 ? kb : kb + ecol;
-    const int nst = __builtin_amdgcn_readfirstlane(rolled ? (MODE == 2 ? 16 * (ecol + 1) : nst_rt) : NST);
+    const int nst = __builtin_amdgcn_readfirstlane(rolled ? (MODE == 2 ? (ecol == 0 ? 24 : 16 * (ecol + 1)) : nst_rt) : NST);
     const double *A = Ain + ((size_t)ti * NB) * ld + (size_t)kb * NB;
     const double *B = MODE == 0 ? Ain + ((size_t)tj * NB) * ld + (size_t)kb * NB : MODE == 1 ? Bm + (size_t)kb * NB * NB : Bm + ((size_t)ecol * NB) * ldb_arg;
     const int ldb = MODE == 0 ? ld : MODE == 1 ? NB : ldb_arg;
@@ -1788,6 +1786,46 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt_pipe(double *Out, const doub
 #endif
     }
     TL_MARK(tl_id, 2);
+}
+template <int DBG, int NST, int MODE = 0>
+__global__ __launch_bounds__(256, 2) void k_gemm_nt_pipe(double *Out, const double *Ain, int ld, int kb, const unsigned *__restrict__ map, int flags, int *sig,
+                                                          const double *Bm = nullptr, int ldb_arg = 0, int nst_rt = 0, int tl = 0)
+{
+    const unsigned e = map[blockIdx.x];
+    if (e == ~0u) return;
+    pipe_body<DBG, NST, MODE>(Out, Ain, ld, kb, e, flags, sig, Bm, ldb_arg, nst_rt, tl);
+}
+// ONE launch, two kinds of tiles (round 5): the trailing update of super-step J (the first `split` workgroups: MODE 0, rolled) and,
+// behind them, the panel product of super-step J + 1 for the rows below its head (MODE 2).  Measured in the device timeline: as a
+// launch of its own on another stream that product ran 2-5 times longer beside the bulk update than alone, and the bulk update
+// 15 % longer beside it (47 against 53-59 TFLOP/s); here its tiles start where the bulk update's last round leaves slots free --
+// they fill the drain -- and the next bulk update follows in stream order, without a gate.
+// What a tail tile needs was produced elsewhere: the panel columns it reads by THIS launch's class-2 tiles (they lead the launch, so
+// they were dispatched long before a tail workgroup can become resident: the wait cannot hold up what it waits for), the
+// super-block's inverse by the chain and its followers on the panel stream, which run a super-step ahead of the bulk stream.
+// Thread 0 polls (relaxed, bounded: 2 s -> flag 3 -> the one-stream schedule), one agent-scope acquire, workgroup barrier.
+__global__ __launch_bounds__(256, 2) void k_gemm_nt_pipe_tail(double *S, double *L, int ld, int kb0, int nst0, const unsigned *__restrict__ map0, int split, int flags0, int *sig, int tl0,
+                                                               int kb2, const unsigned *__restrict__ map2, const double *SI, int ldsi, Gate g2, int tl2)
+{
+    if ((int)blockIdx.x < split) {
+        const unsigned e = map0[blockIdx.x];
+        if (e == ~0u) return;
+        pipe_body<0, 0, 0>(S, L, ld, kb0, e, flags0, sig, nullptr, 0, nst0, tl0);
+    } else {
+        const unsigned e = map2[blockIdx.x - split];
+        if (e == ~0u) return;
+        if (threadIdx.x == 0) {
+            for (int i = 0; i < 5; ++i)
+                if (i < g2.nw) ring_wait(g2.c[i], g2.n[i], g2.flag);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();
+#ifdef RCN_DIAG
+        if (g_tl && threadIdx.x == 0 && (int)blockIdx.x == split) atomicMax(&g_tl[3 * tl2 + 0], (unsigned long long)wall_clock64());
+#endif
+        pipe_body<0, 0, 2>(L, S, ld, kb2, e, 0, nullptr, SI, ldsi, 0, tl2);
+    }
 }
 
 // forward substitution step kb: y_kb = Linv_kb b_kb ; b_i -= L[i,kb] y_kb for i > kb.
@@ -2110,12 +2148,13 @@ static int ensure_chol_plan(rcn_ctx *ctx, int nblk)
 {
     chol::Params prm;
     prm.nblk = nblk; prm.tl_g = ctx->chol_tl_g; prm.tl_min = ctx->chol_tl_min; prm.pair = ctx->chol_group >= 2 ? 1 : 0;
-    prm.pair_min = ctx->chol_pair_min; prm.pipe_min = ctx->chol_pipe_min; prm.pg_stream = ctx->chol_pg_stream;
-    const chol::Params &o = ctx->chol_plan.prm;
+    prm.pair_min = ctx->chol_pair_min; prm.pipe_min = ctx->chol_pipe_min; prm.pg_stream = ctx->chol_pg_stream; prm.fuse_tail = ctx->chol_fuse_tail;
+    const chol::Params &o = ctx->chol_plan.prm_asked;
     if (ctx->chol_plan_valid && o.nblk == prm.nblk && o.tl_g == prm.tl_g && o.tl_min == prm.tl_min && o.pair == prm.pair && o.pair_min == prm.pair_min &&
-        o.pipe_min == prm.pipe_min && o.pg_stream == prm.pg_stream) return RCN_OK;
+        o.pipe_min == prm.pipe_min && o.pg_stream == prm.pg_stream && o.fuse_tail == prm.fuse_tail) return RCN_OK;
     ctx->chol_plan_valid = false;
     ctx->chol_plan = chol::make_plan(prm);
+    ctx->chol_plan.prm_asked = prm;
     RCN_HIP(hipStreamSynchronize(ctx->stream));          // nobody may still read the old maps
     const size_t nm = std::max<size_t>(ctx->chol_plan.maps.size(), 1);
     RCN_HIP(ctx->bulk_map.reserve(nm * sizeof(unsigned)));
@@ -2177,10 +2216,10 @@ int rcn_ba_factor_plan(int32_t n_blocks, const int32_t *params, int32_t *ops, in
     {
         rcn_ctx defaults;      // (never created on a device: only the schedule's parameters are read)
         prm.tl_g = defaults.chol_tl_g; prm.tl_min = defaults.chol_tl_min; prm.pair = defaults.chol_group >= 2; prm.pair_min = defaults.chol_pair_min; prm.pipe_min = defaults.chol_pipe_min;
-        prm.pg_stream = defaults.chol_pg_stream;
+        prm.pg_stream = defaults.chol_pg_stream; prm.fuse_tail = defaults.chol_fuse_tail;
     }
     prm.nblk = n_blocks;
-    if (params) { prm.tl_g = params[0]; prm.tl_min = params[1]; prm.pair = params[2]; prm.pair_min = params[3]; prm.pipe_min = params[4]; prm.pg_stream = params[5]; }
+    if (params) { prm.tl_g = params[0]; prm.tl_min = params[1]; prm.pair = params[2]; prm.pair_min = params[3]; prm.pipe_min = params[4]; prm.pg_stream = params[5]; prm.fuse_tail = params[6]; }
     if (prm.tl_g < 0 || prm.tl_g == 1 || prm.tl_g > 16 || prm.pipe_min < 1) return RCN_ERR_ARG;
     const chol::Plan pl = chol::make_plan(prm);
     *n_ops = (int64_t)pl.ops.size();
@@ -2190,7 +2229,7 @@ int rcn_ba_factor_plan(int32_t n_blocks, const int32_t *params, int32_t *ops, in
         const chol::Op &o = pl.ops[i];
         int32_t *w = ops + RCN_PLAN_OP_WORDS * i;
         const int32_t v[RCN_PLAN_OP_WORDS] = {o.kind, o.stream, o.ticket, o.kb, o.first, o.m, o.dj, o.nst, o.map_off, o.map_n, o.g, o.pos, o.nw,
-                                              o.w[0].ctr, o.w[0].val, o.w[1].ctr, o.w[1].val, o.w[2].ctr, o.w[2].val, o.w[3].ctr, o.w[3].val, o.w[4].ctr, o.w[4].val, o.tl, o.awaited};
+                                              o.w[0].ctr, o.w[0].val, o.w[1].ctr, o.w[1].val, o.w[2].ctr, o.w[2].val, o.w[3].ctr, o.w[3].val, o.w[4].ctr, o.w[4].val, o.tl, o.awaited, o.fuse_with};
         memcpy(w, v, sizeof(v));
     }
     if (!pl.maps.empty()) memcpy(maps, pl.maps.data(), pl.maps.size() * sizeof(uint32_t));
@@ -2337,12 +2376,14 @@ int rcn_int_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_option
     RCN_HIP(hipMemsetAsync(vecs, 0, sizeof(double) * 12 * nvec, st));
     RCN_HIP(hipMemsetAsync(d.S, 0, sizeof(double) * (size_t)npad * npad, st));   // upper part / padding never rewritten
     RCN_HIP(hipMemsetAsync(d.Linv, 0, sizeof(double) * (size_t)nblk * NB * NB, st));   // upper triangles of the tile inverses stay zero
+    if (nblk > 2) RCN_HIP(hipMemsetAsync(SI, 0, sizeof(double) * (size_t)(NB * std::max(ctx->chol_tl_g, 1)) * (NB * std::max(ctx->chol_tl_g, 1)), st));   // blocks above a super-block inverse's diagonal stay zero (a column-0 pass reads 64 columns of one)
     RCN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_chol_diag), hipFuncAttributeMaxDynamicSharedMemorySize, NB * DL * 8));
     RCN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_nt_pipe<0, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, GST * GSTAGE_BYTES));
     RCN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_nt_pipe<0, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, GST * GSTAGE_BYTES));
     RCN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_nt_pipe<0, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, GST * GSTAGE_BYTES));
     RCN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_nt_pipe<0, 16, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, GST * GSTAGE_BYTES));
     RCN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_nt_pipe<0, 0, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, GST * GSTAGE_BYTES));
+    RCN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_nt_pipe_tail), hipFuncAttributeMaxDynamicSharedMemorySize, GST * GSTAGE_BYTES));
     { int rcm = ensure_chol_plan(ctx, nblk); if (rcm) return rcm; }
     uint64_t plain_token = 0;
     if (!res && no > 0) {
@@ -2553,7 +2594,21 @@ int rcn_int_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_option
 #ifdef RCN_DIAG
             const double th0 = now_s();
 #endif
-            for (const chol::Op &op : plan.ops) {
+            // a bulk update whose launch carries the next super-step's panel product as its tail (chol_plan.h, fuse_with): found per host
+            std::vector<int> tail_of(plan.ops.size(), -1);
+            if (!safe)
+                for (size_t i = 0; i < plan.ops.size(); ++i)
+                    if (plan.ops[i].fuse_with >= 0) tail_of[(size_t)plan.ops[i].fuse_with] = (int)i;
+            auto gate_of = [&](const chol::Op &o2, bool with_pub) {
+                Gate g2 = gate_none(d.flag);
+                g2.nw = o2.nw;
+                for (int i = 0; i < o2.nw; ++i) { g2.c[i] = ctr[o2.w[i].ctr]; g2.n[i] = o2.w[i].val; }
+                if (with_pub) { g2.pub = ctr[o2.stream]; g2.pubval = o2.ticket - 1; }
+                return g2;
+            };
+            for (size_t oi = 0; oi < plan.ops.size(); ++oi) {
+                const chol::Op &op = plan.ops[oi];
+                if (!safe && op.fuse_with >= 0) continue;      // its tiles went out with the bulk update in front of it
                 hipStream_t sq = str[op.stream];
                 Gate g = gate_none(d.flag);
                 if (!safe) {
@@ -2577,7 +2632,7 @@ int rcn_int_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_option
                 if (gate_kernel) k_ring_gate<<<1, 64, 0, sq>>>(g);
                 const Gate &gk = (pipe_kind || !in_kernel) ? none : g;
                 const int gq = 32 * ((4 * op.m + 7) / 8);                          // k_gemm_q: strips of 32 rows on the eight XCD slots
-                const int prio = op.stream == chol::ST_C ? 0 : PIPE_PRIO;
+                const int prio = (op.stream == chol::ST_C || (op.stream == chol::ST_D && !ctx->chol_pg_prio)) ? 0 : PIPE_PRIO;
                 switch (op.kind) {
                 case chol::DIAG: {
                     // (active rows of the block: the system's n rows, and the right-hand-side row behind them when it rides along)
@@ -2601,6 +2656,11 @@ int rcn_int_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_option
                     int *sg = (op.stream == chol::ST_C && !safe) ? ctr[chol::CTR_SIG1] : nullptr;
                     if (op.nst == 16) k_gemm_nt_pipe<0, 16><<<op.map_n, 256, lds_pipe, sq>>>(d.S, d.L, npad, op.kb, maps + op.map_off, prio, sg, nullptr, 0, 16, op.tl);
                     else if (op.nst == 32) k_gemm_nt_pipe<0, 32><<<op.map_n, 256, lds_pipe, sq>>>(d.S, d.L, npad, op.kb, maps + op.map_off, prio, sg, nullptr, 0, 32, op.tl);
+                    else if (tail_of[oi] >= 0) {
+                        const chol::Op &tp = plan.ops[(size_t)tail_of[oi]];
+                        k_gemm_nt_pipe_tail<<<op.map_n + tp.map_n, 256, lds_pipe, sq>>>(d.S, d.L, npad, op.kb, op.nst, maps + op.map_off, op.map_n, prio, sg, op.tl,
+                                                                                          tp.kb, maps + tp.map_off, SI, ldsi, gate_of(tp, false), tp.tl);
+                    }
                     else k_gemm_nt_pipe<0, 0><<<op.map_n, 256, lds_pipe, sq>>>(d.S, d.L, npad, op.kb, maps + op.map_off, prio, sg, nullptr, 0, op.nst, op.tl);
                     break;
                 }

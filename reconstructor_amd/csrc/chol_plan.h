@@ -41,22 +41,26 @@ struct Op {
     int nw = 0;
     Wait w[5] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}};
     int tl = 0;              // slot of the diagnostic build's device timeline
+    int fuse_with = -1;      // PGEMM on the bulk stream: index of the bulk update whose launch carries this product's tiles as its tail (-1: a launch of its own)
     int awaited = 0;         // somebody waits for the operation BEFORE this one on its stream: a pipe operation then needs its gate kernel even without waits of its own
 };
 
 struct Params {
     int nblk = 1;
     int tl_g = 4;         // panels per super-step of the two-level regime (0: none)
-    int tl_min = 28;      // ... while at least this many tile rows remain below the super-block
+    int tl_min = 40;      // ... while at least this many tile rows remain below the super-block (below that the chain, not the bulk update, bounds a step)
     int pair = 1;         // right-looking regime: two panels per bulk update ...
     int pair_min = 24;    // ... while at least this many tile rows remain below the pair
     int pipe_min = 32;    // panel / column kernels go through the pipelined kernel from this many tiles on
-    int pg_stream = 1;    // two-level regime: the product for the rows below the head runs on a stream of its own (D) -- on B it would hold up the
+    int fuse_tail = 1;    // two-level regime: the panel product for the rows below the head rides as the TAIL of the previous bulk update's launch
+                          // (it fills that launch's drain; as a launch of its own beside the bulk update both ran 15 % and more slower)
+    int pg_stream = 1;    // two-level regime (first super-step, or fuse_tail = 0): the product for the rows below the head runs on a stream of its own (D) -- on B it would hold up the
                           // next super-step's in-block work, which the chain waits for
 };
 
 struct Plan {
     Params prm;
+    Params prm_asked;             // what the caller asked for (prm.fuse_tail is 0 when the fused form could not be used)
     std::vector<Op> ops;
     std::vector<uint32_t> maps;
     int n_ops[N_STREAMS] = {0, 0, 0, 0};
@@ -72,6 +76,7 @@ public:
         plan.prm = p;
         cells.resize(2 * N2 + (size_t)nblk + 64);
     }
+    bool fusion_failed() const { return fuse_bad; }
     Plan build()
     {
         int p = 0;
@@ -110,6 +115,8 @@ private:
     std::vector<int> cum1, cum2;      // per operation: head tiles of class 1 / 2 counted out by the bulk stream up to and including it
     int sig_total[2] = {0, 0};
     int have[N_STREAMS][N_CTR] = {};
+    bool fuse_bad = false;
+    int last_bulk = -1;               // the last bulk update of the two-level regime: the next super-step's panel product may ride in its launch
 
     int tS(int i, int j) const { return i * nblk + j; }
     int tL(int i, int j) const { return (int)N2 + i * nblk + j; }
@@ -125,7 +132,8 @@ private:
         auto dep = [&](int y, int cls) {
             if (y < 0) return;
             const Op &oy = plan.ops[(size_t)y];
-            if (oy.stream == o.stream) return;                       // stream order
+            if (oy.stream == o.stream && o.fuse_with == y && cls == 0) fuse_bad = true;      // a tail that needs an ordinary tile of its host cannot ride in its launch
+            if (oy.stream == o.stream && !(o.fuse_with == y && cls > 0)) return;      // stream order (a tail inside its host's launch still waits for the host's leading tiles it reads)
             if (cls > 0) { int &v = need[CTR_SIG1 + cls - 1]; v = std::max(v, cls == 1 ? cum1[(size_t)y] : cum2[(size_t)y]); }
             else { int &v = need[oy.stream]; v = std::max(v, oy.ticket); }
         };
@@ -205,11 +213,11 @@ private:
         add(o, rd, wr);
     }
     // S(i, j) -= L(i, kb ..) L(j, kb ..)' over npan panels for the listed tiles (class in the entry)
-    void upd_pipe(int stream, int kb, int npan, const std::vector<uint32_t> (&per)[8], int tl)
+    int upd_pipe(int stream, int kb, int npan, const std::vector<uint32_t> (&per)[8], int tl)
     {
         Op o; o.kind = UPD_PIPE; o.stream = stream; o.kb = kb; o.nst = 16 * npan; o.tl = tl;
         o.map_off = put_map(per, &o.map_n);
-        if (o.map_n == 0) return;
+        if (o.map_n == 0) return -1;
         std::vector<int> rd;
         std::vector<Wr> wr;
         std::vector<char> seen((size_t)nblk, 0);
@@ -220,7 +228,7 @@ private:
                 for (int r : {i, j})
                     if (!seen[(size_t)r]) { seen[(size_t)r] = 1; for (int q = 0; q < npan; ++q) rd.push_back(tL(r, kb + q)); }
             }
-        add(o, rd, wr);
+        return add(o, rd, wr);
     }
     void upd_pipe_list(int stream, int kb, int npan, const std::vector<uint32_t> &tiles, int tl)
     {
@@ -236,16 +244,17 @@ private:
         add(o, rd, {{tSI(pos), 0}});
     }
     // L(i, p + c) = sum_{m <= c} S(i, p + m) SI[c][m]'  for rows r0 .. r1 - 1, columns 1 .. g - 1 (column 0 is a plain panel product)
-    void pgemm(int stream, int p, int g, int r0, int r1, int tl)
+    // (c_lo = 0: column 0 too -- as a 24-stage pass whose last 64 columns meet the zero block W[0][1]; a tail has no other kernel to send it to)
+    void pgemm(int stream, int p, int g, int r0, int r1, int tl, int c_lo = 1, int fuse_with = -1)
     {
         if (r1 <= r0 || g < 2) return;
-        Op o; o.kind = PGEMM; o.stream = stream; o.kb = p; o.g = g; o.tl = tl;
+        Op o; o.kind = PGEMM; o.stream = stream; o.kb = p; o.g = g; o.tl = tl; o.fuse_with = fuse_with;
         std::vector<uint32_t> tiles;
         std::vector<int> rd;
         std::vector<Wr> wr;
-        for (int c = g - 1; c >= 1; --c)                 // longest passes first
+        for (int c = g - 1; c >= c_lo; --c)              // longest passes first
             for (int r = r0; r < r1; ++r) { tiles.push_back(map_entry(r, c)); wr.push_back({tL(r, p + c), 0}); }
-        for (int c = 1; c < g; ++c) rd.push_back(tSI(c));
+        for (int c = c_lo; c < g; ++c) rd.push_back(tSI(c));
         for (int r = r0; r < r1; ++r)
             for (int c = 0; c < g; ++c) rd.push_back(tS(r, p + c));
         o.map_off = put_list(tiles, &o.map_n);
@@ -319,10 +328,14 @@ private:
         }
         if (H1 >= nblk) return;
         // every row below
-        const int sp = prm.pg_stream ? ST_D : ST_B;
-        if (nblk - H1 >= 8) trsm_pipe(sp, p, H1, nblk, 8 * kl + 1);
-        else trsm_q(sp, p, H1 - p - 1, nblk - H1, 8 * kl + 1);
-        pgemm(sp, p, g, H1, nblk, 8 * kl + 2);
+        if (prm.fuse_tail && last_bulk >= 0) {
+            pgemm(ST_C, p, g, H1, nblk, 8 * kl + 2, 0, last_bulk);
+        } else {
+            const int sp = prm.pg_stream ? ST_D : ST_B;
+            if (nblk - H1 >= 8) trsm_pipe(sp, p, H1, nblk, 8 * kl + 1);
+            else trsm_q(sp, p, H1 - p - 1, nblk - H1, 8 * kl + 1);
+            pgemm(sp, p, g, H1, nblk, 8 * kl + 2);
+        }
         // the trailing update, K = 128 g: everything from column R0 on but the next super-diagonal block.  Class 1 (counted out
         // first): what the head of the NEXT super-step reads -- its head rows' tiles of its own panel columns and the super-diagonal
         // block behind them; class 2: the rest of those panel columns.
@@ -337,7 +350,7 @@ private:
                 for (int j = R0; j < H1; ++j) lead.push_back(map_entry(i, j, 2));
             std::vector<uint32_t> per[8];
             region_map(R0, lead, [&](int i, int j) { return (i < H1) || (j < H1) || (i < H2 && j < H2); }, per);
-            upd_pipe(ST_C, p, g, per, 8 * kl + 6);
+            last_bulk = upd_pipe(ST_C, p, g, per, 8 * kl + 6);
         }
     }
 
@@ -379,6 +392,14 @@ private:
     }
 };
 
-inline Plan make_plan(const Params &p) { return Builder(p).build(); }
+inline Plan make_plan(const Params &p)
+{
+    Builder b(p);
+    Plan pl = b.build();
+    if (!b.fusion_failed()) return pl;
+    Params q = p;
+    q.fuse_tail = 0;
+    return Builder(q).build();
+}
 
 }  // namespace chol

@@ -39,30 +39,52 @@ int rcn_create(int device_id, rcn_ctx **out)
         return RCN_ERR_HIP;
     }
     ctx->stream = ctx->own_stream;
-    // The auxiliary stream carries throughput work (bulk trailing updates of the Cholesky) beside
-    // the latency chain on the main stream.  Its CU mask leaves one CU per XCD free (mask bits
-    // interleave over the XCDs: bit i -> XCD i % 8), so the chain's single-workgroup diagonal
-    // kernel (132 KB of LDS) never queues behind the bulk kernel's resident workgroups.
+    // Streams of the dense factorisation (ba.hip, chol_plan.h).  Throughput work -- the bulk trailing updates (aux_stream) and the
+    // two-level regime's panel products below the head rows (panel2_stream) -- runs under a CU mask that leaves a few CUs free (mask
+    // bits interleave over the XCDs: bit i -> XCD i % 8, so whole rounds of eight keep the XCDs even): the chain's single-workgroup
+    // diagonal kernel (132 KB of LDS) never queues behind resident bulk workgroups.  Round 5: the panel stream, which carries the
+    // small kernels the chain WAITS for (in-block panels and columns, block rows of a super-block's inverse, the head rows'
+    // product and the update of the next super-diagonal block), is NOT masked any more and gets the highest stream priority: with
+    // two bulk workgroups per CU holding every vector register of the masked CUs, its kernels could only start where a bulk
+    // workgroup retired -- 40-100 us for a 5-us kernel once a bulk tile lives 165 us (K = 512), measured in the device timeline.
     {
         const int ncu = ctx->prop.multiProcessorCount;
         std::vector<uint32_t> mask((ncu + 31) / 32, 0xFFFFFFFFu);
         if (ncu % 32) mask.back() = (1u << (ncu % 32)) - 1u;
         bool carve = ncu >= 64;
+        int reserved = 8;
+        int panel_mode = 1;      // 0: the panel stream under the bulk streams' mask (rounds 2-4); 1: unmasked, highest priority; 2: masked off the chain's eight CUs only
 #ifdef RCN_DIAG
         if (getenv("RCN_NO_CU_MASK")) carve = false;
+        if (const char *rc = getenv("RCN_RESERVED_CUS")) reserved = std::max(8, std::min(64, std::atoi(rc) / 8 * 8));
+        if (const char *pm = getenv("RCN_PANEL_MODE")) panel_mode = std::atoi(pm);
 #endif
-        if (carve) mask[0] &= ~0xFFu;
+        std::vector<uint32_t> mask8 = mask;
+        if (carve) {
+            for (int i = 0; i < reserved; ++i) mask[(size_t)i / 32] &= ~(1u << (i % 32));
+            mask8[0] &= ~0xFFu;
+        }
         if (hipExtStreamCreateWithCUMask(&ctx->aux_stream, (uint32_t)mask.size(), mask.data()) != hipSuccess) {
             (void)hipGetLastError();
             ctx->aux_stream = nullptr;
         }
-        if (hipExtStreamCreateWithCUMask(&ctx->panel_stream, (uint32_t)mask.size(), mask.data()) != hipSuccess) {
-            (void)hipGetLastError();
-            ctx->panel_stream = nullptr;
-        }
         if (hipExtStreamCreateWithCUMask(&ctx->panel2_stream, (uint32_t)mask.size(), mask.data()) != hipSuccess) {
             (void)hipGetLastError();
             ctx->panel2_stream = nullptr;
+        }
+        if (panel_mode != 1) {
+            const std::vector<uint32_t> &pm = panel_mode == 2 ? mask8 : mask;
+            if (hipExtStreamCreateWithCUMask(&ctx->panel_stream, (uint32_t)pm.size(), pm.data()) != hipSuccess) {
+                (void)hipGetLastError();
+                ctx->panel_stream = nullptr;
+            }
+        } else {
+            int lo = 0, hi = 0;
+            if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { (void)hipGetLastError(); lo = hi = 0; }
+            if (hipStreamCreateWithPriority(&ctx->panel_stream, hipStreamNonBlocking, hi) != hipSuccess) {
+                (void)hipGetLastError();
+                ctx->panel_stream = nullptr;
+            }
         }
     }
     if (!ctx->panel_stream && hipStreamCreateWithFlags(&ctx->panel_stream, hipStreamNonBlocking) != hipSuccess) {
@@ -115,6 +137,10 @@ int rcn_create(int device_id, rcn_ctx **out)
     if (ctm) ctx->chol_tl_min = std::atoi(ctm);
     const char *cps = std::getenv("RCN_CHOL_PGSTREAM");
     if (cps) ctx->chol_pg_stream = std::atoi(cps);
+    const char *cft = std::getenv("RCN_CHOL_FUSE_TAIL");
+    if (cft) ctx->chol_fuse_tail = std::atoi(cft);
+    const char *cpp = std::getenv("RCN_CHOL_PG_PRIO");
+    if (cpp) ctx->chol_pg_prio = cpp[0] != '0';
     const char *cgk = std::getenv("RCN_CHOL_GATE_IN_KERNEL");
     ctx->chol_gate_in_kernel = cgk && cgk[0] == '1';
     const char *cht = std::getenv("RCN_CHOL_HOSTTIME");

@@ -326,7 +326,7 @@ struct CoarseArgs {
 //   s_barrier per tile behind a counted s_waitcnt vmcnt (never 0 in steady state).
 // ABL (ablation bits, diagnostics only -- results are wrong unless ABL == 0):
 //   1 skip the top-2 epilogue, 2 fold the VALUES only (two vector operations per element instead of three: what an exact top-2
-//   without the index in the key would cost), 8 stage only the first tiles.
+//   without the index in the key would cost), 4 (with 2) keep the running MINIMUM only -- one operation per element, 8 stage only the first tiles.
 // SH: MFMA shape.  0: v_mfma_f32_32x32x16_f16 (two 32-column blocks per wave, 16 accumulators per lane and tile);
 //   1: v_mfma_f32_16x16x32_f16 -- the same 64 query columns per wave as four 16-column blocks, a 32-row train block as
 //   two 16-row halves, 4 accumulators per lane and tile; same operand bytes per MAC from LDS, same registers, same
@@ -458,6 +458,7 @@ __global__ __launch_bounds__(512, 2) void k_coarse_top2(CoarseArgs a)
     f32x16 pX0, pX1, pY0, pY1;          // SH 0: current / previous row block, two column blocks
     f32x4 qX[2][4], qY[2][4];           // SH 1: [16-row half][column block]
     auto top2 = [&](int cb, unsigned u) {
+        if constexpr ((ABL & 4) != 0) { m1[cb] = min(m1[cb], u); return; }      // ONE operation per element: the running minimum alone (round 5: what a fold that leaves the second neighbour to a later sweep would cost)
         // med3(m1,m2,u) spelled so that isel forms v_med3_u32 (scheduler sees a plain VALU op)
         const unsigned lo = min(m1[cb], m2[cb]), hi = max(m1[cb], m2[cb]);
         m2[cb] = max(lo, min(hi, u));
@@ -2314,6 +2315,7 @@ int rcn_int_match_grid(rcn_ctx *ctx, const int32_t *pairs_host, int32_t n_pairs,
 #ifdef RCN_DIAG
                         if (ctx->ablate == 1) { e = launch_coarse<32, 1, 0>(ctx, ca, blocks); break; }
                         if (ctx->ablate == 2) { e = launch_coarse<32, 2, 0>(ctx, ca, blocks); break; }
+                        if (ctx->ablate == 6) { e = launch_coarse<32, 6, 0>(ctx, ca, blocks); break; }
 #endif
                         e = launch_coarse<32>(ctx, ca, blocks); break;
                     case 64: e = launch_coarse<64>(ctx, ca, blocks); break;
@@ -2321,6 +2323,7 @@ int rcn_int_match_grid(rcn_ctx *ctx, const int32_t *pairs_host, int32_t n_pairs,
 #ifdef RCN_DIAG
                         if (ctx->ablate == 1) { e = launch_coarse<128, 1, 0>(ctx, ca, blocks); break; }   // timing only: no top-2 fold
                         if (ctx->ablate == 2) { e = launch_coarse<128, 2, 0>(ctx, ca, blocks); break; }   // timing only: values-only fold
+                        if (ctx->ablate == 6) { e = launch_coarse<128, 6, 0>(ctx, ca, blocks); break; }   // timing only: minimum-only fold (one operation per element)
 #endif
                         e = launch_coarse<128>(ctx, ca, blocks); break;
                     default: e = launch_coarse<256>(ctx, ca, blocks); break;

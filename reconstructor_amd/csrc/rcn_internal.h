@@ -195,10 +195,12 @@ struct rcn_ctx {
     chol::Plan chol_plan;
     bool chol_plan_valid = false;
     int chol_tl_g = 4;                               // two-level regime: panels per super-step (K = 128 g per bulk update); 0 = right-looking steps only (diagnostic build: RCN_CHOL_TL)
+    int chol_fuse_tail = 1;                          // two-level regime: the panel product below the head rows as the tail of the previous bulk launch (RCN_CHOL_FUSE_TAIL)
     int chol_pg_stream = 1;                          // two-level regime: the panel product below the head rows on a stream of its own (RCN_CHOL_PGSTREAM)
+    bool chol_pg_prio = true;                        // diagnostic build (RCN_CHOL_PG_PRIO=0): no raised wave priority for the panel product below the head rows
     bool chol_gate_in_kernel = false;                // diagnostic build (RCN_CHOL_GATE_IN_KERNEL=1): waits of the small kernels off the chain inside them, not in a gate kernel in front
     bool chol_host_time = false;                     // diagnostic build (RCN_CHOL_HOSTTIME=1): print the host time of every factorisation's enqueue
-    int chol_tl_min = 28;                            // ... while at least this many tile rows remain below the super-block (RCN_CHOL_TL_MIN)
+    int chol_tl_min = 40;                            // ... while at least this many tile rows remain below the super-block (RCN_CHOL_TL_MIN)
     int chol_group = 2;                              // right-looking regime: panels per bulk update while many tile rows remain, 2 (K = 256) or 1
     int chol_pipe_min = 32;                          // panel / column kernels go through the pipelined kernel from this many tiles on
     bool trsv_chain = true;                          // backward substitution as one launch (k_trsv_bwd_chain); off after a flag timeout

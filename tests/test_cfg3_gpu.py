@@ -1,7 +1,8 @@
 """GPU suite: BASELINE.json configs[2] in full -- 1000 images x 4096 keypoints x 256-d, all 499 500 image pairs on
 one GPU through the sharded-grid path (world size 1: the code every rank runs) -- checked against oracle outputs
 for 64 sampled pairs outright (tests/golden/match_cfg3_sample.npz), for 512 more by row hash and count, 64 from every
-residue of the pair number modulo 8 (match_cfg3_sample512.npz; both written by tests/golden/make_cfg3_golden.py), and
+residue of the pair number modulo 8 (match_cfg3_sample512.npz), for 5120 more stratified by pipeline chunk and residue
+(match_cfg3_sample5k.npz; all written by tests/golden/make_cfg3_golden.py), and
 through properties of the whole 8 GB match table."""
 import os
 
@@ -13,6 +14,7 @@ from reconstructor_amd import synth
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "match_cfg3_sample.npz")
 GOLD512 = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "match_cfg3_sample512.npz")
+GOLD5K = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "match_cfg3_sample5k.npz")
 
 
 def test_cfg3_full_grid(gpu_ctx):
@@ -52,6 +54,14 @@ def test_cfg3_full_grid(gpu_ctx):
         h, c = tablehash.row_hashes(rows, K)
         assert np.array_equal(c, g5["counts"]) and np.array_equal(cnt[torch.from_numpy(g5["pair_numbers"]).cuda()].cpu().numpy(), g5["counts"])
         assert np.array_equal(h, g5["hashes"]), g5["pairs"][h != g5["hashes"]][:8]
+        # ---- round 5: 5120 more, 40 for every (sixteenth of the pair list = where the pipeline chunks fall) x (residue modulo 8)
+        g6 = np.load(GOLD5K)
+        nums = g6["pair_numbers"]
+        assert len(nums) == 5120 and (np.bincount((nums * 16 // P) * 8 + nums % 8, minlength=128) == 40).all()
+        rows = out[torch.from_numpy(nums).cuda()].cpu().numpy()
+        h, c = tablehash.row_hashes(rows, K)
+        assert np.array_equal(c, g6["counts"]) and np.array_equal(cnt[torch.from_numpy(nums).cuda()].cpu().numpy(), g6["counts"])
+        assert np.array_equal(h, g6["hashes"]), g6["pairs"][h != g6["hashes"]][:8]
         # ---- the whole table: counts, index range, no train row claimed twice within a pair
         total = 0
         for a in range(0, P, 16384):

@@ -18,7 +18,7 @@ import pytest
 from reconstructor_amd import _lib
 
 DIAG, TRSM_Q, UPD_Q, TRSM_PIPE, UPD_PIPE, SINV, PGEMM, PUBLISH = range(8)
-OPW = 25
+OPW = 26
 N_STREAMS = 4          # counters 0 .. 3: progress of the streams; 4, 5: the two classes of leading tiles of the bulk updates
 NONE = 0xFFFFFFFF
 
@@ -42,7 +42,7 @@ def get_plan(nblk, params=None):
     for r in ops[:n_ops.value]:
         o = dict(kind=int(r[0]), stream=int(r[1]), ticket=int(r[2]), kb=int(r[3]), first=int(r[4]), m=int(r[5]), dj=int(r[6]), nst=int(r[7]),
                  map_off=int(r[8]), map_n=int(r[9]), g=int(r[10]), pos=int(r[11]), waits=[(int(r[13 + 2 * i]), int(r[14 + 2 * i])) for i in range(int(r[12]))],
-                 awaited=int(r[24]))
+                 awaited=int(r[24]), fuse_with=int(r[25]))
         o["tiles"] = [((int(e) >> 16), int(e) & 0x3FFF, (int(e) >> 14) & 3) for e in maps[o["map_off"]:o["map_off"] + o["map_n"]] if int(e) != NONE]
         out.append(o)
     return out
@@ -79,7 +79,8 @@ def accesses(o):
     elif o["kind"] == PGEMM:
         for i, col, _ in o["tiles"]:
             wr.append((("L", i, k + col), 0))
-            rd += [("SI", col)] + [("S", i, k + q) for q in range(col + 1)]
+            # (a column-0 tile runs as a K = 192 pass: its last 64 columns are the next panel column's, met by a zero block of the inverse)
+            rd += [("SI", col)] + [("S", i, k + q) for q in range(max(col, 1) + 1 if col == 0 else col + 1)]
     return rd, wr
 
 
@@ -177,11 +178,25 @@ def graph(ops):
             cum[c].append(tot[c])
     preds = [set() for _ in nodes]
     last_on_stream = {}
+    prev_on_stream = {}
     for i, o in enumerate(ops):
         p = set()
-        if o["stream"] in last_on_stream:
+        h = o.get("fuse_with", -1)
+        if h >= 0:
+            # the tail of bulk update h's launch: its workgroups follow h's in dispatch order but do not wait for them -- what holds them
+            # is their own waits (h's leading tiles among them) and whatever preceded the launch on the stream
+            assert ops[h]["kind"] == UPD_PIPE and ops[h]["stream"] == o["stream"] == 2 and last_on_stream[2] == h
+            if h in prev_on_stream:
+                j = prev_on_stream[h]
+                p |= {node_id[(j, pt)] for pt in parts[j]}
+        elif o["stream"] in last_on_stream:
             j = last_on_stream[o["stream"]]
             p |= {node_id[(j, pt)] for pt in parts[j]}
+            hj = ops[j].get("fuse_with", -1)
+            if hj >= 0:                       # behind a launch with a tail: behind both of its parts
+                p |= {node_id[(hj, pt)] for pt in parts[hj]}
+        if o["stream"] in last_on_stream:
+            prev_on_stream[i] = last_on_stream[o["stream"]]
         for ctr, val in o["waits"]:
             if ctr < N_STREAMS:
                 if val == 0:
@@ -265,7 +280,7 @@ def run_random_order(ops, nblk, T, A, seed):
 CASES = [
     (1, None), (2, None), (3, None), (6, None), (16, None),            # the reference's own sizes, cfg 4
     (40, None), (79, None),                                             # cfg 5: two-level super-steps, pairs, single steps
-    (45, (8, 20, 1, 24, 32, 1)), (37, (4, 8, 0, 24, 6, 0)), (30, (2, 6, 1, 10, 4, 1)), (26, (0, 0, 1, 8, 4, 1)), (23, (0, 0, 0, 8, 64, 0)), (79, (4, 28, 1, 24, 32, 0)),
+    (45, (8, 20, 1, 24, 32, 1, 1)), (37, (4, 8, 0, 24, 6, 0, 1)), (30, (2, 6, 1, 10, 4, 1, 0)), (26, (0, 0, 1, 8, 4, 1, 1)), (23, (0, 0, 0, 8, 64, 0, 0)), (79, (4, 28, 1, 24, 32, 0, 0)), (79, (4, 28, 1, 24, 32, 1, 0)), (60, (4, 12, 1, 16, 8, 1, 1)),
 ]
 
 
@@ -302,7 +317,7 @@ def test_waits_order_every_conflicting_pair(nblk, params):
         assert v < len(per_stream[c]), "the last operation of a stream is waited for and nothing publishes it"
 
 
-@pytest.mark.parametrize("nblk,params", [(6, None), (16, None), (40, None), (79, None), (45, (8, 20, 1, 24, 32, 1)), (37, (4, 8, 0, 24, 6, 0)), (30, (2, 6, 1, 10, 4, 1))])
+@pytest.mark.parametrize("nblk,params", [(6, None), (16, None), (40, None), (79, None), (45, (8, 20, 1, 24, 32, 1, 1)), (37, (4, 8, 0, 24, 6, 0, 1)), (30, (2, 6, 1, 10, 4, 1, 0))])
 def test_any_order_the_waits_allow_gives_the_same_bits(nblk, params):
     ops = get_plan(nblk, params)
     T = 2 if nblk > 50 else 3
@@ -321,6 +336,10 @@ def test_the_shipping_schedule_at_cfg5_is_two_level():
     bulk = [o for o in ops if o["kind"] == UPD_PIPE and o["stream"] == 2]
     assert max(o["nst"] for o in bulk) == 64                  # K = 512 per C-tile round trip while many rows remain
     assert sum(1 for o in bulk if o["nst"] == 64) >= 9
+    # from the second super-step on, the panel product below the head rows rides in the previous bulk update's launch
+    tails = [o for o in ops if o["fuse_with"] >= 0]
+    assert len(tails) >= 8 and all(o["kind"] == PGEMM and ops[o["fuse_with"]]["nst"] == 64 for o in tails)
+    assert not any(o["stream"] == 3 and o["kind"] != PUBLISH for o in ops[ops.index(tails[0]):]), "nothing is left for the fourth stream once the tails carry the products"
     # every tile is updated by every earlier panel exactly once -- except the rows below a super-block in its own columns, which take
     # the panels of their own super-step through the product with its inverse (PGEMM) instead
     nblk = 79
