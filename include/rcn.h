@@ -43,6 +43,11 @@ int         rcn_device_count(void);                  /* HIP devices visible to t
 int         rcn_create(int device_id, rcn_ctx **out);
 void        rcn_destroy(rcn_ctx *ctx);
 const char *rcn_last_error(const rcn_ctx *ctx);      /* never NULL */
+/* ABI revision of this header.  Bumped whenever a struct the library writes through a caller's pointer grows or an entry point changes
+ * its arguments: a caller built against an older header must not be linked against a newer library (rcn_match_last_stats copies the whole
+ * rcn_match_stats; revision 2 -> 3 added rows_brute_force, chunks, coarse_launches to it and rcn_ba_factor_plan to the library).
+ * rcn_version() names the library build ("reconstructor_amd 0.<revision> (gfx950)"); compare the two at start-up. */
+#define RCN_ABI_REVISION 3
 const char *rcn_version(void);
 /* Run all work of this ctx on an existing HIP stream (e.g. torch's current stream, passed as
  * the raw hipStream_t).  NULL = the ctx's own stream.  */
@@ -347,12 +352,14 @@ int rcn_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *problem, const rcn_ba_optio
  * with its stream and the device counters it waits for, and the tile maps of the pipelined launches.  tests/test_chol_plan.py executes
  * it in numpy (list order; random orders that respect only the waits) and checks that the waits order every pair of operations that
  * touch a common tile.  params: {panels per super-step, min rows for a super-step, pairs (0/1), min rows for a pair, min tiles for the
- * pipelined panel kernels, own stream for the two-level panel product (0/1), that product as the tail of the previous bulk launch (0/1)},
+ * pipelined panel kernels, own stream for the two-level panel product (0/1), that product as the tail of the previous bulk launch (0/1), the head rows'
+ * product and the next super-diagonal block's update through the latency kernel (0/1), rows below which a super-block's small operations
+ * run on the chain's own stream},
  * NULL = what the library uses.  An operation is
  * RCN_PLAN_OP_WORDS int32: kind, stream, ticket, kb, first, m, dj, nst, map_off, map_n, g, pos, n_waits, 5 x (counter, value), timeline
- * slot, awaited, index of the bulk update whose launch carries this operation's tiles as its tail (-1: none).  Counters 0 .. 3 are the streams' progress counters, 4 and 5 count the two classes of leading tiles of the bulk updates.  Returns RCN_ERR_ARG when a buffer is too
+ * slot, awaited, index of the bulk update whose launch carries this operation's tiles as its tail (-1: none), 1 = latency-kernel form.  Counters 0 .. 3 are the streams' progress counters, 4 and 5 count the two classes of leading tiles of the bulk updates.  Returns RCN_ERR_ARG when a buffer is too
  * small (the needed sizes are still written). */
-#define RCN_PLAN_OP_WORDS 26
+#define RCN_PLAN_OP_WORDS 27
 int rcn_ba_factor_plan(int32_t n_blocks, const int32_t *params, int32_t *ops, int64_t ops_cap, uint32_t *maps, int64_t maps_cap,
                        int64_t *n_ops, int64_t *n_maps);
 

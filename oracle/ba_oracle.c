@@ -171,13 +171,27 @@ static double now_s(void)
     return ts.tv_sec + 1e-9 * ts.tv_nsec;
 }
 
+/* Sums over the observations are taken in FIXED chunks of 4096, the chunk sums added in index order (round 5): the result does not
+   depend on the thread count or on how OpenMP combines a reduction -- a long, badly conditioned solve amplifies a last bit to a
+   different iteration count, and the GPU tests compare counts with this oracle (an `omp reduction` made it differ from run to run). */
+#define ORC_CHUNK 4096
+static double ordered_sum(const double *part, int n)
+{
+    double s = 0.0;
+    for (int i = 0; i < n; ++i) s += part[i];
+    return s;
+}
+
 /* cost = 1/2 sum r^2; optionally r, tangent Jacobians Jc (2 x 10 per obs), Jp (2 x 3) */
 static double evaluate(const Prob *P, const double *poses, const double *intr, const double *pts,
                        double *r, double *Jc, double *Jp)
 {
+    const int nch = (P->no + ORC_CHUNK - 1) / ORC_CHUNK;
+    double *part = (double *)calloc((size_t)(nch > 0 ? nch : 1), sizeof(double));
+#pragma omp parallel for schedule(static)
+    for (int ch = 0; ch < nch; ++ch) {
     double cost = 0.0;
-#pragma omp parallel for reduction(+ : cost) schedule(static)
-    for (int o = 0; o < P->no; ++o) {
+    for (int o = ch * ORC_CHUNK; o < P->no && o < (ch + 1) * ORC_CHUNK; ++o) {
         const int c = P->ocam[o], j = P->opt[o];
         double res[2], J[30];
         orc_ba_residual_jacobian(poses + 6 * c, intr + 6 * c, pts + 3 * j, P->uv + 2 * o, res, Jc ? J : NULL);
@@ -192,6 +206,10 @@ static double evaluate(const Prob *P, const double *poses, const double *intr, c
             }
         }
     }
+    part[ch] = cost;
+    }
+    const double cost = ordered_sum(part, nch);
+    free(part);
     return 0.5 * cost;
 }
 
@@ -454,17 +472,24 @@ double orc_ls_next_step(const double *start, const double *prev, const double *c
 /* sum_o r_o' (Jc_o dc + Jp_o dp): the gradient J'r of the tangent space, against a direction */
 static double dir_derivative(const Prob *P, const double *r, const double *Jc, const double *Jp, const double *dc, const double *dp)
 {
-    double acc = 0.0;
-#pragma omp parallel for reduction(+ : acc) schedule(static)
-    for (int o = 0; o < P->no; ++o) {
-        const int c = P->ocam[o], j = P->opt[o];
-        for (int i = 0; i < 2; ++i) {
-            double m = 0.0;
-            for (int k = 0; k < P->cam_dim[c]; ++k) m += Jc[20 * (size_t)o + 10 * i + k] * dc[P->cam_off[c] + k];
-            for (int k = 0; k < 3; ++k) m += Jp[6 * (size_t)o + 3 * i + k] * dp[3 * j + k];
-            acc += r[2 * o + i] * m;
+    const int nch = (P->no + ORC_CHUNK - 1) / ORC_CHUNK;
+    double *part = (double *)calloc((size_t)(nch > 0 ? nch : 1), sizeof(double));
+#pragma omp parallel for schedule(static)
+    for (int ch = 0; ch < nch; ++ch) {
+        double acc = 0.0;
+        for (int o = ch * ORC_CHUNK; o < P->no && o < (ch + 1) * ORC_CHUNK; ++o) {
+            const int c = P->ocam[o], j = P->opt[o];
+            for (int i = 0; i < 2; ++i) {
+                double m = 0.0;
+                for (int k = 0; k < P->cam_dim[c]; ++k) m += Jc[20 * (size_t)o + 10 * i + k] * dc[P->cam_off[c] + k];
+                for (int k = 0; k < 3; ++k) m += Jp[6 * (size_t)o + 3 * i + k] * dp[3 * j + k];
+                acc += r[2 * o + i] * m;
+            }
         }
+        part[ch] = acc;
     }
+    const double acc = ordered_sum(part, nch);
+    free(part);
     return acc;
 }
 
@@ -706,18 +731,24 @@ int orc_ba_solve(int n_cams, int n_points, int n_obs, double *poses, double *int
         reuse_diag = 1; /* LevenbergMarquardtStrategy::ComputeStep */
         double model_change = 0.0;
         if (solve_ok) {
-            double acc = 0.0;
-#pragma omp parallel for reduction(+ : acc) schedule(static)
-            for (int o = 0; o < n_obs; ++o) {
-                const int c = obs_cam[o], j = obs_pt[o];
-                for (int i = 0; i < 2; ++i) {
-                    double m = 0.0;
-                    for (int k = 0; k < P.cam_dim[c]; ++k) m += Jc[20 * o + 10 * i + k] * sc[P.cam_off[c] + k] * stc[P.cam_off[c] + k];
-                    for (int k = 0; k < 3; ++k) m += Jp[6 * o + 3 * i + k] * sp[3 * j + k] * stp[3 * j + k];
-                    acc += m * (r[2 * o + i] + 0.5 * m);
+            const int nch = (n_obs + ORC_CHUNK - 1) / ORC_CHUNK;
+            double *part = (double *)calloc((size_t)(nch > 0 ? nch : 1), sizeof(double));
+#pragma omp parallel for schedule(static)
+            for (int ch = 0; ch < nch; ++ch) {
+                double acc = 0.0;
+                for (int o = ch * ORC_CHUNK; o < n_obs && o < (ch + 1) * ORC_CHUNK; ++o) {
+                    const int c = obs_cam[o], j = obs_pt[o];
+                    for (int i = 0; i < 2; ++i) {
+                        double m = 0.0;
+                        for (int k = 0; k < P.cam_dim[c]; ++k) m += Jc[20 * o + 10 * i + k] * sc[P.cam_off[c] + k] * stc[P.cam_off[c] + k];
+                        for (int k = 0; k < 3; ++k) m += Jp[6 * o + 3 * i + k] * sp[3 * j + k] * stp[3 * j + k];
+                        acc += m * (r[2 * o + i] + 0.5 * m);
+                    }
                 }
+                part[ch] = acc;
             }
-            model_change = -acc;
+            model_change = -ordered_sum(part, nch);
+            free(part);
         }
         if (!solve_ok || !(model_change > 0.0)) { /* HandleInvalidStep */
             sum->invalid_steps++;

@@ -1493,6 +1493,59 @@ void k_gemm_q(double *S, double *L, int ld, int kb, int first, int m, const doub
     TL_MARK(tl_id, 2);
 }
 
+// The same latency form for the two-level regime's head (round 5): a LIST of tiles (map entry: row << 16 | column), several panels
+// per tile, the accumulators kept in registers across them --
+//   MODE 1  S(i, j) -= sum_q L(i, kb + q) L(j, kb + q)'              q < npan: the next super-diagonal block, K = 128 g
+//   MODE 2  L(i, kb + c) = sum_{m <= c} S(i, kb + m) W[c][m]'         c = the entry's column: the head rows' panel product
+// As pipelined launches (one 128 x 128 tile per workgroup, K = 512: 64 stages) these two sat on the chain's critical path for
+// ~70 us each alone and ~100 us beside the bulk update; here a tile is 32 workgroups of four 16 x 16 waves, operands straight
+// from L2 into MFMA layout, no LDS, at most 96 registers -- they fit beside anything.  Workgroup b: tile b / 16, a 32 x 32 part of it.
+template <int MODE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(96)))
+void k_gemm_qm(double *S, double *L, int ld, int kb, const unsigned *__restrict__ map, int npan, const double *SI, int ldsi, Gate g, int tl)
+{
+    static_assert(MODE == 1 || MODE == 2, "update / panel product");
+    __builtin_amdgcn_s_setprio(3);
+    TL_MARK(tl, 0);
+    gate_enter(g);
+    TL_MARK(tl, 1);
+    const unsigned e = map[blockIdx.x >> 4];
+    if (e == ~0u) return;
+    const int ti = (int)(e >> 16), ecol = (int)(e & 0x3fffu);
+    const int sub = blockIdx.x & 15, strip = sub >> 2, qj = sub & 3;      // strip: 32 rows of the tile, qj: 32 output columns
+    const int tj = MODE == 1 ? ecol : kb + ecol;
+    const int np = MODE == 1 ? npan : ecol + 1;
+    const size_t row0 = (size_t)ti * NB + 32 * (size_t)strip;
+    const double *A = (MODE == 1 ? L : S) + row0 * ld + (size_t)kb * NB;
+    const double *B = MODE == 1 ? L + ((size_t)tj * NB + 32 * qj) * ld + (size_t)kb * NB : SI + ((size_t)ecol * NB + 32 * qj) * ldsi;
+    const int ldb = MODE == 1 ? ld : ldsi;
+    double *C = (MODE == 1 ? S : L) + row0 * ld + (size_t)tj * NB + 32 * qj;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int wr = (w >> 1) * 16, wc = (w & 1) * 16;
+    const int fr = lane & 15, fk = lane >> 4;
+    const f64x2 *ap = reinterpret_cast<const f64x2 *>(A + (size_t)(wr + fr) * ld + 2 * fk);
+    const f64x2 *bp = reinterpret_cast<const f64x2 *>(B + (size_t)(wc + fr) * ldb + 2 * fk);
+    f64x4 acc;
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) acc[reg] = MODE == 2 ? 0.0 : C[(size_t)(wr + fk + 4 * reg) * ld + wc + fr];
+    for (int q = 0; q < np; ++q) {
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            f64x2 a[8], b[8];
+#pragma unroll
+            for (int gq = 0; gq < 8; ++gq) { a[gq] = ap[64 * q + 4 * (8 * half + gq)]; b[gq] = bp[64 * q + 4 * (8 * half + gq)]; }
+#pragma unroll
+            for (int gq = 0; gq < 8; ++gq)
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(MODE == 2 ? a[gq][h] : -a[gq][h], b[gq][h], acc, 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) C[(size_t)(wr + fk + 4 * reg) * ld + wc + fr] = acc[reg];
+    TL_MARK(tl, 2);
+}
+
 // Two-level regime (round 5): block row `pos` of W = L_JJ^-1, the inverse of the factor of the super-diagonal block [p, p + g) --
 // g x g tiles, lower block-triangular, row-major in SI (row stride ldsi = 128 g):
 //     W[pos][pos] = Linv_c,     W[pos][m] = -Linv_c  sum_{r = m .. pos-1} L(c, p + r) W[r][m]     (c = p + pos, m < pos)
@@ -2148,10 +2201,10 @@ static int ensure_chol_plan(rcn_ctx *ctx, int nblk)
 {
     chol::Params prm;
     prm.nblk = nblk; prm.tl_g = ctx->chol_tl_g; prm.tl_min = ctx->chol_tl_min; prm.pair = ctx->chol_group >= 2 ? 1 : 0;
-    prm.pair_min = ctx->chol_pair_min; prm.pipe_min = ctx->chol_pipe_min; prm.pg_stream = ctx->chol_pg_stream; prm.fuse_tail = ctx->chol_fuse_tail;
+    prm.pair_min = ctx->chol_pair_min; prm.pipe_min = ctx->chol_pipe_min; prm.pg_stream = ctx->chol_pg_stream; prm.fuse_tail = ctx->chol_fuse_tail; prm.head_small = ctx->chol_head_small; prm.tl_serial = ctx->chol_tl_serial;
     const chol::Params &o = ctx->chol_plan.prm_asked;
     if (ctx->chol_plan_valid && o.nblk == prm.nblk && o.tl_g == prm.tl_g && o.tl_min == prm.tl_min && o.pair == prm.pair && o.pair_min == prm.pair_min &&
-        o.pipe_min == prm.pipe_min && o.pg_stream == prm.pg_stream && o.fuse_tail == prm.fuse_tail) return RCN_OK;
+        o.pipe_min == prm.pipe_min && o.pg_stream == prm.pg_stream && o.fuse_tail == prm.fuse_tail && o.head_small == prm.head_small && o.tl_serial == prm.tl_serial) return RCN_OK;
     ctx->chol_plan_valid = false;
     ctx->chol_plan = chol::make_plan(prm);
     ctx->chol_plan.prm_asked = prm;
@@ -2216,10 +2269,10 @@ int rcn_ba_factor_plan(int32_t n_blocks, const int32_t *params, int32_t *ops, in
     {
         rcn_ctx defaults;      // (never created on a device: only the schedule's parameters are read)
         prm.tl_g = defaults.chol_tl_g; prm.tl_min = defaults.chol_tl_min; prm.pair = defaults.chol_group >= 2; prm.pair_min = defaults.chol_pair_min; prm.pipe_min = defaults.chol_pipe_min;
-        prm.pg_stream = defaults.chol_pg_stream; prm.fuse_tail = defaults.chol_fuse_tail;
+        prm.pg_stream = defaults.chol_pg_stream; prm.fuse_tail = defaults.chol_fuse_tail; prm.head_small = defaults.chol_head_small; prm.tl_serial = defaults.chol_tl_serial;
     }
     prm.nblk = n_blocks;
-    if (params) { prm.tl_g = params[0]; prm.tl_min = params[1]; prm.pair = params[2]; prm.pair_min = params[3]; prm.pipe_min = params[4]; prm.pg_stream = params[5]; prm.fuse_tail = params[6]; }
+    if (params) { prm.tl_g = params[0]; prm.tl_min = params[1]; prm.pair = params[2]; prm.pair_min = params[3]; prm.pipe_min = params[4]; prm.pg_stream = params[5]; prm.fuse_tail = params[6]; prm.head_small = params[7]; prm.tl_serial = params[8]; }
     if (prm.tl_g < 0 || prm.tl_g == 1 || prm.tl_g > 16 || prm.pipe_min < 1) return RCN_ERR_ARG;
     const chol::Plan pl = chol::make_plan(prm);
     *n_ops = (int64_t)pl.ops.size();
@@ -2229,7 +2282,7 @@ int rcn_ba_factor_plan(int32_t n_blocks, const int32_t *params, int32_t *ops, in
         const chol::Op &o = pl.ops[i];
         int32_t *w = ops + RCN_PLAN_OP_WORDS * i;
         const int32_t v[RCN_PLAN_OP_WORDS] = {o.kind, o.stream, o.ticket, o.kb, o.first, o.m, o.dj, o.nst, o.map_off, o.map_n, o.g, o.pos, o.nw,
-                                              o.w[0].ctr, o.w[0].val, o.w[1].ctr, o.w[1].val, o.w[2].ctr, o.w[2].val, o.w[3].ctr, o.w[3].val, o.w[4].ctr, o.w[4].val, o.tl, o.awaited, o.fuse_with};
+                                              o.w[0].ctr, o.w[0].val, o.w[1].ctr, o.w[1].val, o.w[2].ctr, o.w[2].val, o.w[3].ctr, o.w[3].val, o.w[4].ctr, o.w[4].val, o.tl, o.awaited, o.fuse_with, o.small};
         memcpy(w, v, sizeof(v));
     }
     if (!pl.maps.empty()) memcpy(maps, pl.maps.data(), pl.maps.size() * sizeof(uint32_t));
@@ -2322,7 +2375,8 @@ int rcn_int_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_option
     d.S = ws.get<double>((size_t)npad * npad);
     d.L = ws.get<double>((size_t)npad * npad);
     d.Linv = ws.get<double>((size_t)nblk * NB * NB);
-    double *SI = ws.get<double>((size_t)(NB * std::max(ctx->chol_tl_g, 1)) * (NB * std::max(ctx->chol_tl_g, 1)));      // a super-block's inverse (two-level regime of the factorisation)
+    const size_t si_elems = (size_t)(NB * std::max(ctx->chol_tl_g, 1)) * (NB * std::max(ctx->chol_tl_g, 1));
+    double *SI = ws.get<double>(2 * si_elems);      // a super-block's inverse (two-level regime of the factorisation), two buffers alternating by super-step
     double *Sb = ws.get<double>(100 * (size_t)nc * nc);
     // gather lists of the Schur build (RCN_BA_SCHUR_ATOMICS=1 falls back to the atomic form)
     const bool gather = !ctx->ba_atomics;
@@ -2376,7 +2430,7 @@ int rcn_int_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_option
     RCN_HIP(hipMemsetAsync(vecs, 0, sizeof(double) * 12 * nvec, st));
     RCN_HIP(hipMemsetAsync(d.S, 0, sizeof(double) * (size_t)npad * npad, st));   // upper part / padding never rewritten
     RCN_HIP(hipMemsetAsync(d.Linv, 0, sizeof(double) * (size_t)nblk * NB * NB, st));   // upper triangles of the tile inverses stay zero
-    if (nblk > 2) RCN_HIP(hipMemsetAsync(SI, 0, sizeof(double) * (size_t)(NB * std::max(ctx->chol_tl_g, 1)) * (NB * std::max(ctx->chol_tl_g, 1)), st));   // blocks above a super-block inverse's diagonal stay zero (a column-0 pass reads 64 columns of one)
+    if (nblk > 2) RCN_HIP(hipMemsetAsync(SI, 0, sizeof(double) * 2 * si_elems, st));   // blocks above a super-block inverse's diagonal stay zero (a column-0 pass reads 64 columns of one)
     RCN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_chol_diag), hipFuncAttributeMaxDynamicSharedMemorySize, NB * DL * 8));
     RCN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_nt_pipe<0, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, GST * GSTAGE_BYTES));
     RCN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_nt_pipe<0, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, GST * GSTAGE_BYTES));
@@ -2626,11 +2680,17 @@ int rcn_int_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_option
                 // kernel it waits for from becoming resident, and slows the chain's kernels beside it (measured: the critical-tile
                 // kernels took 11 us instead of 4 with the panel kernels spinning next to them).
                 const bool in_kernel = op.stream == chol::ST_A || ctx->chol_gate_in_kernel;
-                const bool pipe_kind = op.kind == chol::TRSM_PIPE || op.kind == chol::UPD_PIPE || op.kind == chol::PGEMM || op.kind == chol::PUBLISH;
-                const Gate none = gate_none(d.flag);
-                const bool gate_kernel = !safe && (pipe_kind || !in_kernel) && (op.nw > 0 || op.awaited);
-                if (gate_kernel) k_ring_gate<<<1, 64, 0, sq>>>(g);
-                const Gate &gk = (pipe_kind || !in_kernel) ? none : g;
+                const bool pipe_kind = ((op.kind == chol::TRSM_PIPE || op.kind == chol::UPD_PIPE || op.kind == chol::PGEMM) && !op.small) || op.kind == chol::PUBLISH;
+                Gate gk = gate_none(d.flag);           // what the kernel itself gets
+                if (!safe) {
+                    if (pipe_kind) {
+                        if (op.nw > 0 || op.awaited) k_ring_gate<<<1, 64, 0, sq>>>(g);
+                    } else if (in_kernel) gk = g;
+                    else {
+                        if (op.nw > 0) k_ring_gate<<<1, 64, 0, sq>>>(g);
+                        gk.pub = g.pub; gk.pubval = g.pubval;      // publishing costs one store: no launch for that alone
+                    }
+                }
                 const int gq = 32 * ((4 * op.m + 7) / 8);                          // k_gemm_q: strips of 32 rows on the eight XCD slots
                 const int prio = (op.stream == chol::ST_C || (op.stream == chol::ST_D && !ctx->chol_pg_prio)) ? 0 : PIPE_PRIO;
                 switch (op.kind) {
@@ -2653,22 +2713,24 @@ int rcn_int_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_option
                     k_gemm_nt_pipe<0, 16, 1><<<op.map_n, 256, lds_pipe, sq>>>(d.L, d.S, npad, op.kb, maps + op.map_off, prio, nullptr, d.Linv, NB, 16, op.tl);
                     break;
                 case chol::UPD_PIPE: {
+                    if (op.small) { k_gemm_qm<1><<<16 * op.map_n, 256, 0, sq>>>(d.S, d.L, npad, op.kb, maps + op.map_off, op.nst / 16, nullptr, 0, gk, op.tl); break; }
                     int *sg = (op.stream == chol::ST_C && !safe) ? ctr[chol::CTR_SIG1] : nullptr;
                     if (op.nst == 16) k_gemm_nt_pipe<0, 16><<<op.map_n, 256, lds_pipe, sq>>>(d.S, d.L, npad, op.kb, maps + op.map_off, prio, sg, nullptr, 0, 16, op.tl);
                     else if (op.nst == 32) k_gemm_nt_pipe<0, 32><<<op.map_n, 256, lds_pipe, sq>>>(d.S, d.L, npad, op.kb, maps + op.map_off, prio, sg, nullptr, 0, 32, op.tl);
                     else if (tail_of[oi] >= 0) {
                         const chol::Op &tp = plan.ops[(size_t)tail_of[oi]];
                         k_gemm_nt_pipe_tail<<<op.map_n + tp.map_n, 256, lds_pipe, sq>>>(d.S, d.L, npad, op.kb, op.nst, maps + op.map_off, op.map_n, prio, sg, op.tl,
-                                                                                          tp.kb, maps + tp.map_off, SI, ldsi, gate_of(tp, false), tp.tl);
+                                                                                          tp.kb, maps + tp.map_off, SI + (size_t)tp.dj * si_elems, ldsi, gate_of(tp, false), tp.tl);
                     }
                     else k_gemm_nt_pipe<0, 0><<<op.map_n, 256, lds_pipe, sq>>>(d.S, d.L, npad, op.kb, maps + op.map_off, prio, sg, nullptr, 0, op.nst, op.tl);
                     break;
                 }
                 case chol::SINV:
-                    k_sinv<<<8 * op.pos + 1, 512, 0, sq>>>(d.L, npad, d.Linv, SI, ldsi, op.kb, op.pos, gk, op.tl);
+                    k_sinv<<<8 * op.pos + 1, 512, 0, sq>>>(d.L, npad, d.Linv, SI + (size_t)op.dj * si_elems, ldsi, op.kb, op.pos, gk, op.tl);
                     break;
                 case chol::PGEMM:
-                    k_gemm_nt_pipe<0, 0, 2><<<op.map_n, 256, lds_pipe, sq>>>(d.L, d.S, npad, op.kb, maps + op.map_off, prio, nullptr, SI, ldsi, 0, op.tl);
+                    if (op.small) { k_gemm_qm<2><<<16 * op.map_n, 256, 0, sq>>>(d.S, d.L, npad, op.kb, maps + op.map_off, 0, SI + (size_t)op.dj * si_elems, ldsi, gk, op.tl); break; }
+                    k_gemm_nt_pipe<0, 0, 2><<<op.map_n, 256, lds_pipe, sq>>>(d.L, d.S, npad, op.kb, maps + op.map_off, prio, nullptr, SI + (size_t)op.dj * si_elems, ldsi, 0, op.tl);
                     break;
                 case chol::PUBLISH:
                     break;

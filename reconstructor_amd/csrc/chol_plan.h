@@ -34,13 +34,14 @@ struct Op {
     int kind = 0, stream = 0, ticket = 0;   // ticket: 1-based position on its stream; the operation publishes ctr[stream] = ticket - 1 when it starts
     int kb = 0;              // DIAG: the block; TRSM / UPD: the (first) panel; SINV / PGEMM: first block of the super-block
     int first = 0, m = 0;    // TRSM_Q / UPD_Q: tile rows kb + 1 + first .. kb + first + m
-    int dj = 0;              // UPD_Q: the column that is updated is kb + dj
+    int dj = 0;              // UPD_Q: the column that is updated is kb + dj; SINV / PGEMM: which of the two inverse buffers
     int nst = 0;             // pipe kernels: stages of 8 k (K = 8 nst = 128 panels); PGEMM: per tile, 16 (column + 1)
     int map_off = 0, map_n = 0;   // pipe kernels: slice of Plan::maps (row << 16 | class << 14 | column; ~0 = no tile), a multiple of 8 long
     int g = 0, pos = 0;      // SINV: block row pos of the inverse of super-block [kb, kb + g); PGEMM: g
     int nw = 0;
     Wait w[5] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}};
     int tl = 0;              // slot of the diagnostic build's device timeline
+    int small = 0;           // UPD_PIPE / PGEMM: a handful of chain-critical tiles -- the latency form (k_gemm_qm: 16 small workgroups per tile, no LDS) instead of the pipelined one
     int fuse_with = -1;      // PGEMM on the bulk stream: index of the bulk update whose launch carries this product's tiles as its tail (-1: a launch of its own)
     int awaited = 0;         // somebody waits for the operation BEFORE this one on its stream: a pipe operation then needs its gate kernel even without waits of its own
 };
@@ -52,6 +53,9 @@ struct Params {
     int pair = 1;         // right-looking regime: two panels per bulk update ...
     int pair_min = 24;    // ... while at least this many tile rows remain below the pair
     int pipe_min = 32;    // panel / column kernels go through the pipelined kernel from this many tiles on
+    int tl_serial = 0;    // two-level regime: below this many tile rows under the super-block the chain bounds a step, not the bulk update -- the
+                          // super-block's small operations then run ON the chain's stream, in order: no gate kernels, no cross-stream waits
+    int head_small = 1;   // two-level regime: the head rows' panel product and the update of the next super-diagonal block through the latency kernel
     int fuse_tail = 1;    // two-level regime: the panel product for the rows below the head rides as the TAIL of the previous bulk update's launch
                           // (it fills that launch's drain; as a launch of its own beside the bulk update both ran 15 % and more slower)
     int pg_stream = 1;    // two-level regime (first super-step, or fuse_tail = 0): the product for the rows below the head runs on a stream of its own (D) -- on B it would hold up the
@@ -116,17 +120,16 @@ private:
     int sig_total[2] = {0, 0};
     int have[N_STREAMS][N_CTR] = {};
     bool fuse_bad = false;
+    int sib = 0;                      // which of the two super-block inverse buffers the current super-step uses
     int last_bulk = -1;               // the last bulk update of the two-level regime: the next super-step's panel product may ride in its launch
 
     int tS(int i, int j) const { return i * nblk + j; }
     int tL(int i, int j) const { return (int)N2 + i * nblk + j; }
     int tLinv(int k) const { return (int)(2 * N2) + k; }
-    int tSI(int pos) const { return (int)(2 * N2) + nblk + pos; }
+    int tSI(int pos) const { return (int)(2 * N2) + nblk + 32 * sib + pos; }      // (two buffers, alternating by super-step: the inverse of the next super-block is built while the last one's product may still run)
 
     int add(Op o, const std::vector<int> &reads, const std::vector<Wr> &writes)
     {
-        const int idx = (int)plan.ops.size();
-        o.ticket = ++plan.n_ops[o.stream];
         int need[N_CTR];
         for (int &v : need) v = -1;
         auto dep = [&](int y, int cls) {
@@ -143,6 +146,18 @@ private:
             dep(c.wop, c.wcls);
             for (int r : c.readers) dep(r, 0);
         }
+        // Whoever is waited for must be followed by something that publishes its ticket -- and SOON: the counter moves when the next
+        // operation of that stream starts.  If the awaited operation is the last one queued on its stream so far, a publisher goes
+        // into the list right here, in front of the waiter (the first version left it to the end of the list: the only two
+        // operations of the fourth stream were published when the host had enqueued the whole factorisation, 0.5 ms late).
+        if (o.kind != PUBLISH)
+            for (int c = 0; c < N_STREAMS; ++c)
+                if (c != o.stream && need[c] > have[o.stream][c] && need[c] == plan.n_ops[c]) {
+                    Op pb; pb.kind = PUBLISH; pb.stream = c;
+                    add(pb, {}, {});
+                }
+        const int idx = (int)plan.ops.size();
+        o.ticket = ++plan.n_ops[o.stream];
         // (what an earlier operation of this stream has waited for, this one has too: streams run in order, counters only grow)
         o.nw = 0;
         for (int c = 0; c < N_CTR; ++c)
@@ -213,9 +228,9 @@ private:
         add(o, rd, wr);
     }
     // S(i, j) -= L(i, kb ..) L(j, kb ..)' over npan panels for the listed tiles (class in the entry)
-    int upd_pipe(int stream, int kb, int npan, const std::vector<uint32_t> (&per)[8], int tl)
+    int upd_pipe(int stream, int kb, int npan, const std::vector<uint32_t> (&per)[8], int tl, int small = 0)
     {
-        Op o; o.kind = UPD_PIPE; o.stream = stream; o.kb = kb; o.nst = 16 * npan; o.tl = tl;
+        Op o; o.kind = UPD_PIPE; o.stream = stream; o.kb = kb; o.nst = 16 * npan; o.tl = tl; o.small = small;
         o.map_off = put_map(per, &o.map_n);
         if (o.map_n == 0) return -1;
         std::vector<int> rd;
@@ -230,25 +245,25 @@ private:
             }
         return add(o, rd, wr);
     }
-    void upd_pipe_list(int stream, int kb, int npan, const std::vector<uint32_t> &tiles, int tl)
+    void upd_pipe_list(int stream, int kb, int npan, const std::vector<uint32_t> &tiles, int tl, int small = 0)
     {
         std::vector<uint32_t> per[8];
         for (size_t i = 0; i < tiles.size(); ++i) per[i & 7].push_back(tiles[i]);
-        upd_pipe(stream, kb, npan, per, tl);
+        upd_pipe(stream, kb, npan, per, tl, small);
     }
-    void sinv(int p, int g, int pos, int tl)
+    void sinv(int stream, int p, int g, int pos, int tl)
     {
-        Op o; o.kind = SINV; o.stream = ST_B; o.kb = p; o.g = g; o.pos = pos; o.tl = tl;
+        Op o; o.kind = SINV; o.stream = stream; o.kb = p; o.g = g; o.pos = pos; o.tl = tl; o.dj = sib;
         std::vector<int> rd{tLinv(p + pos)};
         for (int r = 0; r < pos; ++r) { rd.push_back(tL(p + pos, p + r)); rd.push_back(tSI(r)); }
         add(o, rd, {{tSI(pos), 0}});
     }
     // L(i, p + c) = sum_{m <= c} S(i, p + m) SI[c][m]'  for rows r0 .. r1 - 1, columns 1 .. g - 1 (column 0 is a plain panel product)
     // (c_lo = 0: column 0 too -- as a 24-stage pass whose last 64 columns meet the zero block W[0][1]; a tail has no other kernel to send it to)
-    void pgemm(int stream, int p, int g, int r0, int r1, int tl, int c_lo = 1, int fuse_with = -1)
+    void pgemm(int stream, int p, int g, int r0, int r1, int tl, int c_lo = 1, int fuse_with = -1, int small = 0)
     {
         if (r1 <= r0 || g < 2) return;
-        Op o; o.kind = PGEMM; o.stream = stream; o.kb = p; o.g = g; o.tl = tl; o.fuse_with = fuse_with;
+        Op o; o.kind = PGEMM; o.stream = stream; o.kb = p; o.g = g; o.tl = tl; o.fuse_with = fuse_with; o.small = small; o.dj = sib;
         std::vector<uint32_t> tiles;
         std::vector<int> rd;
         std::vector<Wr> wr;
@@ -291,7 +306,9 @@ private:
     // ---- a two-level super-step: panels p .. p + g - 1
     void superstep(int p, int g)
     {
+        sib ^= 1;
         const int R0 = p + g, H1 = std::min(nblk, R0 + g);
+        const int sb = nblk - R0 < prm.tl_serial ? ST_A : ST_B;      // where the super-block's small operations run
         for (int pos = 0; pos < g; ++pos) {
             const int k = p + pos, nin = g - 1 - pos;      // rows of the super-block below block k
             diag(k);
@@ -300,31 +317,34 @@ private:
                 upd_q(ST_A, k, 0, 1, 1, 8 * k + 2);
             }
             if (nin >= 2) {
-                trsm_q(ST_B, k, 1, nin - 1, 8 * k + 3);
-                upd_q(ST_B, k, 1, nin - 1, 1, 8 * k + 4);
+                trsm_q(sb, k, 1, nin - 1, 8 * k + 3);
+                upd_q(sb, k, 1, nin - 1, 1, 8 * k + 4);
                 // the other columns of the super-block, k + 2 .. p + g - 1
                 int cnt = 0;
                 for (int j = k + 2; j < R0; ++j) cnt += R0 - j;
                 if (cnt <= 3) {
-                    for (int j = k + 2; j < R0; ++j) upd_q(ST_B, k, j - k - 1, R0 - j, j - k, 8 * k + 5);
+                    for (int j = k + 2; j < R0; ++j) upd_q(sb, k, j - k - 1, R0 - j, j - k, 8 * k + 5);
                 } else {
                     std::vector<uint32_t> tiles;
                     for (int j = k + 2; j < R0; ++j)
                         for (int i = j; i < R0; ++i) tiles.push_back(map_entry(i, j));
-                    upd_pipe_list(ST_B, k, 1, tiles, 8 * k + 5);
+                    upd_pipe_list(sb, k, 1, tiles, 8 * k + 5);
                 }
             }
-            sinv(p, g, pos, 8 * k + 7);
+            sinv(sb, p, g, pos, 8 * k + 7);
         }
         // head rows: the next super-diagonal block's rows of this super-panel, then that block itself
         const int kl = R0 - 1;            // the timeline files what follows under the super-step's last block step
-        trsm_q(ST_B, p, g - 1, H1 - R0, 8 * kl + 3);
-        pgemm(ST_B, p, g, R0, H1, 8 * kl + 4);
+        if (prm.head_small) pgemm(sb, p, g, R0, H1, 8 * kl + 4, 0, -1, 1);
+        else {
+            trsm_q(sb, p, g - 1, H1 - R0, 8 * kl + 3);
+            pgemm(sb, p, g, R0, H1, 8 * kl + 4);
+        }
         {
             std::vector<uint32_t> tiles;
             for (int i = R0; i < H1; ++i)
                 for (int j = R0; j <= i; ++j) tiles.push_back(map_entry(i, j));
-            upd_pipe_list(ST_B, p, g, tiles, 8 * kl + 5);
+            upd_pipe_list(sb, p, g, tiles, 8 * kl + 5, prm.head_small);
         }
         if (H1 >= nblk) return;
         // every row below

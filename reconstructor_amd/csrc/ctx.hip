@@ -9,9 +9,9 @@ extern "C" {
 const char *rcn_version(void)
 {
 #ifdef RCN_DIAG
-    return "reconstructor_amd 0.2 (gfx950) DIAGNOSTIC BUILD";
+    return "reconstructor_amd 0.3 (gfx950) DIAGNOSTIC BUILD";
 #else
-    return "reconstructor_amd 0.2 (gfx950)";
+    return "reconstructor_amd 0.3 (gfx950)";
 #endif
 }
 
@@ -137,6 +137,10 @@ int rcn_create(int device_id, rcn_ctx **out)
     if (ctm) ctx->chol_tl_min = std::atoi(ctm);
     const char *cps = std::getenv("RCN_CHOL_PGSTREAM");
     if (cps) ctx->chol_pg_stream = std::atoi(cps);
+    const char *cts = std::getenv("RCN_CHOL_TL_SERIAL");
+    if (cts) ctx->chol_tl_serial = std::atoi(cts);
+    const char *chs = std::getenv("RCN_CHOL_HEAD_SMALL");
+    if (chs) ctx->chol_head_small = std::atoi(chs);
     const char *cft = std::getenv("RCN_CHOL_FUSE_TAIL");
     if (cft) ctx->chol_fuse_tail = std::atoi(cft);
     const char *cpp = std::getenv("RCN_CHOL_PG_PRIO");

@@ -2683,8 +2683,8 @@ int rcn_match_last_stats(const rcn_ctx *cctx, rcn_match_stats *out)
 int rcn_diag_coarse_table(rcn_ctx *ctx, uint32_t *cand_host, int64_t capacity_words, double *model)
 {
     if (!ctx || !model) return RCN_ERR_ARG;
-    if (ctx->last_chunks != 1) { ctx->set_error("rcn_diag_coarse_table: the last grid ran in several pipeline chunks; the table holds only the last one"); return RCN_ERR_UNSUPPORTED; }
     std::lock_guard<std::mutex> lk(ctx->mu);
+    if (ctx->last_chunks != 1) { ctx->set_error("rcn_diag_coarse_table: the last grid ran in several pipeline chunks; the table holds only the last one"); return RCN_ERR_UNSUPPORTED; }
     const int64_t words = 2 * (int64_t)ctx->last_n_pairs * ctx->last_kq_stride;
     { int rcs = rcn_int_resolve_scale(ctx); if (rcs) return rcs; }
     model[0] = ctx->scale; model[1] = ctx->bias; model[2] = ctx->max_norm; model[3] = (double)ctx->last_idx_mask;

@@ -18,7 +18,7 @@ import pytest
 from reconstructor_amd import _lib
 
 DIAG, TRSM_Q, UPD_Q, TRSM_PIPE, UPD_PIPE, SINV, PGEMM, PUBLISH = range(8)
-OPW = 26
+OPW = 27
 N_STREAMS = 4          # counters 0 .. 3: progress of the streams; 4, 5: the two classes of leading tiles of the bulk updates
 NONE = 0xFFFFFFFF
 
@@ -42,7 +42,7 @@ def get_plan(nblk, params=None):
     for r in ops[:n_ops.value]:
         o = dict(kind=int(r[0]), stream=int(r[1]), ticket=int(r[2]), kb=int(r[3]), first=int(r[4]), m=int(r[5]), dj=int(r[6]), nst=int(r[7]),
                  map_off=int(r[8]), map_n=int(r[9]), g=int(r[10]), pos=int(r[11]), waits=[(int(r[13 + 2 * i]), int(r[14 + 2 * i])) for i in range(int(r[12]))],
-                 awaited=int(r[24]), fuse_with=int(r[25]))
+                 awaited=int(r[24]), fuse_with=int(r[25]), small=int(r[26]))
         o["tiles"] = [((int(e) >> 16), int(e) & 0x3FFF, (int(e) >> 14) & 3) for e in maps[o["map_off"]:o["map_off"] + o["map_n"]] if int(e) != NONE]
         out.append(o)
     return out
@@ -74,13 +74,13 @@ def accesses(o):
                 rd += [("L", i, k + q), ("L", j, k + q)]
     elif o["kind"] == SINV:
         c = k + o["pos"]
-        rd = [("Linv", c)] + [("L", c, k + r) for r in range(o["pos"])] + [("SI", r) for r in range(o["pos"])]
-        wr = [(("SI", o["pos"]), 0)]
+        rd = [("Linv", c)] + [("L", c, k + r) for r in range(o["pos"])] + [("SI", o["dj"], r) for r in range(o["pos"])]
+        wr = [(("SI", o["dj"], o["pos"]), 0)]
     elif o["kind"] == PGEMM:
         for i, col, _ in o["tiles"]:
             wr.append((("L", i, k + col), 0))
             # (a column-0 tile runs as a K = 192 pass: its last 64 columns are the next panel column's, met by a zero block of the inverse)
-            rd += [("SI", col)] + [("S", i, k + q) for q in range(max(col, 1) + 1 if col == 0 else col + 1)]
+            rd += [("SI", o["dj"], col)] + [("S", i, k + q) for q in range(2 if (col == 0 and not o["small"]) else col + 1)]
     return rd, wr
 
 
@@ -128,17 +128,18 @@ class Machine:
                 self.t(self.S, i, j)[:] -= acc
         elif o["kind"] == SINV:
             pos, c = o["pos"], k + o["pos"]
-            self.SI[(pos, pos)] = self.Linv[c].copy()
+            b = o["dj"]
+            self.SI[(b, pos, pos)] = self.Linv[c].copy()
             for m in range(pos):
                 Y = np.zeros((self.T, self.T))
                 for r in range(m, pos):
-                    Y += self.t(self.L, c, k + r) @ self.SI[(r, m)]
-                self.SI[(pos, m)] = -self.Linv[c] @ Y
+                    Y += self.t(self.L, c, k + r) @ self.SI[(b, r, m)]
+                self.SI[(b, pos, m)] = -self.Linv[c] @ Y
         elif o["kind"] == PGEMM:
             for i, col, _ in o["tiles"]:
                 acc = np.zeros((self.T, self.T))
                 for m in range(col + 1):
-                    acc += self.t(self.S, i, k + m) @ self.SI[(col, m)].T
+                    acc += self.t(self.S, i, k + m) @ self.SI[(o["dj"], col, m)].T
                 self.t(self.L, i, k + col)[:] = acc
 
     def factor(self):
@@ -280,7 +281,7 @@ def run_random_order(ops, nblk, T, A, seed):
 CASES = [
     (1, None), (2, None), (3, None), (6, None), (16, None),            # the reference's own sizes, cfg 4
     (40, None), (79, None),                                             # cfg 5: two-level super-steps, pairs, single steps
-    (45, (8, 20, 1, 24, 32, 1, 1)), (37, (4, 8, 0, 24, 6, 0, 1)), (30, (2, 6, 1, 10, 4, 1, 0)), (26, (0, 0, 1, 8, 4, 1, 1)), (23, (0, 0, 0, 8, 64, 0, 0)), (79, (4, 28, 1, 24, 32, 0, 0)), (79, (4, 28, 1, 24, 32, 1, 0)), (60, (4, 12, 1, 16, 8, 1, 1)),
+    (45, (8, 20, 1, 24, 32, 1, 1, 1, 30)), (37, (4, 8, 0, 24, 6, 0, 1, 0, 0)), (30, (2, 6, 1, 10, 4, 1, 0, 1, 99)), (26, (0, 0, 1, 8, 4, 1, 1, 1, 0)), (23, (0, 0, 0, 8, 64, 0, 0, 0, 0)), (79, (4, 28, 1, 24, 32, 0, 0, 0, 0)), (79, (4, 16, 1, 24, 32, 1, 1, 1, 44)), (60, (4, 12, 1, 16, 8, 1, 1, 0, 30)),
 ]
 
 
@@ -317,7 +318,7 @@ def test_waits_order_every_conflicting_pair(nblk, params):
         assert v < len(per_stream[c]), "the last operation of a stream is waited for and nothing publishes it"
 
 
-@pytest.mark.parametrize("nblk,params", [(6, None), (16, None), (40, None), (79, None), (45, (8, 20, 1, 24, 32, 1, 1)), (37, (4, 8, 0, 24, 6, 0, 1)), (30, (2, 6, 1, 10, 4, 1, 0))])
+@pytest.mark.parametrize("nblk,params", [(6, None), (16, None), (40, None), (79, None), (45, (8, 20, 1, 24, 32, 1, 1, 1, 30)), (37, (4, 8, 0, 24, 6, 0, 1, 0, 0)), (30, (2, 6, 1, 10, 4, 1, 0, 1, 99))])
 def test_any_order_the_waits_allow_gives_the_same_bits(nblk, params):
     ops = get_plan(nblk, params)
     T = 2 if nblk > 50 else 3

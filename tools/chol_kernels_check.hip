@@ -1,6 +1,7 @@
 // tools/chol_kernels_check.hip -- the factorisation's round-5 kernels one by one against host arithmetic (tests/test_ba_gpu.py runs it):
 //   * k_gemm_nt_pipe<0, 0>     the rolled trailing update at 24 .. 128 stages (K = 192 .. 1024), one tile checked in full
 //   * k_gemm_nt_pipe<0, 0, 2>  the panel product of the two-level regime, L(i, p + c) = S(i, p .. p + c) W[c][.]', columns 1 .. 7
+//   * k_gemm_qm<1>, <2>        the latency form of both for the handful of head tiles
 //   * k_sinv                   block rows of a super-block's inverse, g = 4 and g = 8:  W L_JJ = I
 // Prints one line per check and "ALL OK" at the end; exit code 1 on the first failure.
 #include "../reconstructor_amd/csrc/ba.hip"
@@ -83,6 +84,60 @@ int main()
         printf("panel product with the super-block's inverse, columns 0 .. %d: max error %.2e, elsewhere %.2e  %s\n", g - 1, md, mo, good ? "ok" : "FAILED");
         ok &= good;
         (void)hipFree(dW);
+    }
+    // ---- the latency form of both (k_gemm_qm): a list of tiles, several panels per tile
+    {
+        const int g = 4, ldsi = g * NB, p = 2;
+        int *dflag;
+        (void)hipMalloc(&dflag, 64); (void)hipMemset(dflag, 0, 64);
+        // update: tiles (9, 8), (10, 10), four panels from column block p
+        unsigned hm[8] = {chol::map_entry(9, 8), chol::map_entry(10, 10), ~0u, ~0u, ~0u, ~0u, ~0u, ~0u};
+        (void)hipMemcpy(dmap, hm, sizeof(hm), hipMemcpyHostToDevice);
+        (void)hipMemcpy(dS, hS.data(), N * 8, hipMemcpyHostToDevice);
+        k_gemm_qm<1><<<16 * 8, 256>>>(dS, dL, npad, p, dmap, g, nullptr, 0, gate_none(dflag), 0);
+        std::vector<double> out(N);
+        (void)hipMemcpy(out.data(), dS, N * 8, hipMemcpyDeviceToHost);
+        double md = 0, mo = 0;
+        for (int i = 0; i < npad; ++i)
+            for (int j = 0; j < npad; ++j) {
+                const int ti = i / NB, tj = j / NB;
+                const bool mine = (ti == 9 && tj == 8) || (ti == 10 && tj == 10);
+                double want = hS[(size_t)i * npad + j];
+                if (mine)
+                    for (int k = 0; k < NB * g; ++k) want -= hL[(size_t)i * npad + (size_t)p * NB + k] * hL[(size_t)j * npad + (size_t)p * NB + k];
+                const double dd = fabs(want - out[(size_t)i * npad + j]);
+                if (mine) md = fmax(md, dd); else mo = fmax(mo, dd);
+            }
+        bool good = md < 1e-11 && mo == 0.0 && hipGetLastError() == hipSuccess;
+        printf("latency-form update, K = %d: max error %.2e, elsewhere %.2e  %s\n", NB * g, md, mo, good ? "ok" : "FAILED");
+        ok &= good;
+        // panel product: tiles (7, c), (11, c), c = 0 .. 3, random W
+        std::vector<double> hW((size_t)ldsi * ldsi);
+        for (auto &v : hW) v = rnd(seed);
+        double *dW;
+        (void)hipMalloc(&dW, hW.size() * 8);
+        (void)hipMemcpy(dW, hW.data(), hW.size() * 8, hipMemcpyHostToDevice);
+        unsigned hm2[8] = {chol::map_entry(7, 3), chol::map_entry(11, 3), chol::map_entry(7, 2), chol::map_entry(11, 2), chol::map_entry(7, 1), chol::map_entry(11, 1), chol::map_entry(7, 0), chol::map_entry(11, 0)};
+        (void)hipMemcpy(dmap, hm2, sizeof(hm2), hipMemcpyHostToDevice);
+        (void)hipMemcpy(dS, hS.data(), N * 8, hipMemcpyHostToDevice);
+        (void)hipMemset(dOut, 0, N * 8);
+        k_gemm_qm<2><<<16 * 8, 256>>>(dS, dOut, npad, p, dmap, 0, dW, ldsi, gate_none(dflag), 0);
+        (void)hipMemcpy(out.data(), dOut, N * 8, hipMemcpyDeviceToHost);
+        md = mo = 0;
+        for (int i = 0; i < npad; ++i)
+            for (int j = 0; j < npad; ++j) {
+                const int ti = i / NB, tj = j / NB, c = tj - p;
+                const bool mine = (ti == 7 || ti == 11) && c >= 0 && c < g;
+                double want = 0.0;
+                if (mine)
+                    for (int k = 0; k < NB * (c + 1); ++k) want += hS[(size_t)i * npad + (size_t)p * NB + k] * hW[((size_t)c * NB + j % NB) * ldsi + k];
+                const double dd = fabs(want - out[(size_t)i * npad + j]);
+                if (mine) md = fmax(md, dd); else mo = fmax(mo, dd);
+            }
+        good = md < 1e-11 && mo == 0.0 && hipGetLastError() == hipSuccess;
+        printf("latency-form panel product, columns 0 .. %d: max error %.2e, elsewhere %.2e  %s\n", g - 1, md, mo, good ? "ok" : "FAILED");
+        ok &= good;
+        (void)hipFree(dW); (void)hipFree(dflag);
     }
     // ---- the super-block's inverse: a lower-triangular L_JJ (g x g tiles at block p of the big matrix), its tile inverses from the host
     for (int g : {4, 8}) {
