@@ -717,6 +717,39 @@ def self_launch(args):
     raise SystemExit(subprocess.call(cmd, env=env))
 
 
+def chunk_ab_leg(torch, ctx, dev, n_img, K, n_pairs=32768, reps=3):
+    """what the pipeline chunks cost, A/B on THIS box.  The first 32 768 pairs of the resident cfg-3 grid (1.34e8 query rows:
+    exactly the default workspace) as one launch of K1, as two and as four (rcn_match_set_workspace_rows); tables left in HBM."""
+    from reconstructor_amd.matcher import HipL2Matcher, all_pairs
+    m = HipL2Matcher(ctx=ctx)
+    pairs = all_pairs(n_img)[:n_pairs]
+    out = torch.empty((len(pairs), K), dtype=torch.int32, device=dev)
+    cnt = torch.empty((len(pairs),), dtype=torch.int32, device=dev)
+    res = []
+    try:
+        for rows in (1 << 27, 1 << 26, 1 << 25):
+            m.set_workspace_rows(rows)
+            m.match_grid_device(pairs, out.data_ptr(), K, cnt.data_ptr())
+            ctx.check(ctx.lib.rcn_synchronize(ctx.h))
+            m.stats()
+            m.profile(True)
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                m.match_grid_device(pairs, out.data_ptr(), K, cnt.data_ptr())
+            ctx.check(ctx.lib.rcn_synchronize(ctx.h))
+            dt = (time.perf_counter() - t0) / reps
+            st = m.stats()
+            m.profile(False)
+            res.append({"chunks": int(st["chunks"]), "k1_ms": st["coarse_ms"] / max(1, st["profiled_calls"]), "call_ms": 1e3 * dt})
+    finally:
+        m.set_workspace_rows(0)
+        m.profile(False)
+    one = res[0]["k1_ms"]
+    return {"pairs": int(len(pairs)), "runs": res, "k1_single_launch_ms": one,
+            "k1_cost_of_chunks": {str(r["chunks"]): r["k1_ms"] / one - 1.0 for r in res[1:]},
+            "note": "same box, same data: K1's time for the first %d pairs of the grid as 1 / 2 / 4 launches; the full grid's sixteen chunks are this size" % len(pairs)}
+
+
 def small_d_leg(torch, ctx, dev, kind, Dd, n3=100, K3=1500):
     """K1 on the descriptor lengths the reference's classic detectors produce: a cfg2-sized grid (100 images x 1500 keypoints,
     4950 pairs) of SIFT-like 128-d or ORB-as-float 32-d rows, tables left in HBM; roofline of the coarse kernel against the
@@ -927,6 +960,8 @@ def main():
             line["rccl"]["gather_note"] = ("all ranks' (query, train) lists in canonical pair order in rank 0's pinned host memory: compaction on every GPU, ncclSend / ncclRecv "
                                            "device to device, interleave on the root's GPU, one D2H copy; `value` is quoted without it (each rank's lists in its own host memory)")
         if world == 1:
+            if is_cfg and args.workload == "cfg3":
+                line["roofline"]["chunk_ab"] = chunk_ab_leg(torch, ctx, dev, n_img, K)
             if not args.no_cfg2 and args.workload != "cfg2":
                 # BASELINE configs[1] on the same GPU, same path (exchange + match + materialise)
                 n2, K2 = WORKLOADS["cfg2"]

@@ -165,6 +165,10 @@ int rcn_match_last_stats(const rcn_ctx *ctx, rcn_match_stats *out);
 /* enable != 0: bracket the kernels of every following grid call with HIP events on the ctx
  * stream (up to 64 calls are kept); rcn_match_last_stats sums and clears them. */
 int rcn_match_profile(rcn_ctx *ctx, int enable);
+/* Workspace budget of the grid calls: query-row slots of the candidate table per pipeline chunk (8 bytes per slot, plus two row lists of
+ * at most as many entries).  Default (rows = 0): 2^27 slots = 1 GiB of candidates -- cfg 3 (2.05e9 query rows) then runs in sixteen chunks
+ * that reuse the workspace, at +0.2 % of K1's time against one 16-GiB chunk (same-box A/B in the bench line, `roofline.chunk_ab`). */
+int rcn_match_set_workspace_rows(rcn_ctx *ctx, int64_t rows);
 
 /* ---- pair grid sharded over the GPUs of one node -----------------------------------------
  * The N x N loop of SequentialReconstructor::matchFeatures (SequentialReconstructor.cpp:202-279) runs

@@ -19,7 +19,7 @@ SYMBOLS = [
     "rcn_create", "rcn_destroy", "rcn_last_error", "rcn_version", "rcn_set_stream",
     "rcn_synchronize", "rcn_desc_upload", "rcn_desc_upload_device", "rcn_desc_upload_batch_device", "rcn_desc_upload_batch", "rcn_desc_remove", "rcn_desc_sample_device", "rcn_desc_sample_errors", "rcn_desc_clear",
     "rcn_desc_count", "rcn_match_pair", "rcn_match_grid", "rcn_match_grid_device",
-    "rcn_match_last_stats", "rcn_match_profile", "rcn_ba_default_options", "rcn_ba_solve", "rcn_ba_factor_plan",
+    "rcn_match_last_stats", "rcn_match_profile", "rcn_match_set_workspace_rows", "rcn_ba_default_options", "rcn_ba_solve", "rcn_ba_factor_plan",
     "rcn_landmark_validity", "rcn_landmark_validity_device",
     "rcn_fmat_filter", "rcn_fmat_filter_grid", "rcn_fmat_filter_grid_device",
     "rcn_coords_upload", "rcn_coords_upload_batch", "rcn_coords_clear", "rcn_match_table_filter_device",

@@ -2699,6 +2699,16 @@ int rcn_diag_coarse_table(rcn_ctx *ctx, uint32_t *cand_host, int64_t capacity_wo
 }
 #endif
 
+// The workspace budget of the grid calls: query-row slots of the candidate table per pipeline chunk (8 bytes each, the row lists at most
+// as long again).  A grid larger than that runs in consecutive chunks that reuse the workspace.
+int rcn_match_set_workspace_rows(rcn_ctx *ctx, int64_t rows)
+{
+    if (!ctx || rows < 0) return RCN_ERR_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    ctx->chunk_rows = rows == 0 ? RCN_CHUNK_ROWS : std::max<int64_t>(rows, 1);
+    return RCN_OK;
+}
+
 int rcn_match_profile(rcn_ctx *ctx, int enable)
 {
     if (!ctx) return RCN_ERR_ARG;

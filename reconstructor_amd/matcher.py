@@ -166,6 +166,11 @@ class HipL2Matcher(FeatureMatcher):
             self.ctx.h, pairs.ctypes.data, pairs.shape[0], C.c_void_p(table_dev_ptr), out_stride,
             C.c_void_p(counts_dev_ptr), C.c_void_p(status_dev_ptr) if status_dev_ptr else None))
 
+    def set_workspace_rows(self, rows=0):
+        """Query-row slots of the candidate table per pipeline chunk (0 = the library's default, 2^27)."""
+        self.ctx.lib.rcn_match_set_workspace_rows.argtypes = [C.c_void_p, C.c_int64]
+        self.ctx.check(self.ctx.lib.rcn_match_set_workspace_rows(self.ctx.h, int(rows)))
+
     def profile(self, enable=True):
         self.ctx.check(self.ctx.lib.rcn_match_profile(self.ctx.h, 1 if enable else 0))
 
