@@ -2201,10 +2201,10 @@ static int ensure_chol_plan(rcn_ctx *ctx, int nblk)
 {
     chol::Params prm;
     prm.nblk = nblk; prm.tl_g = ctx->chol_tl_g; prm.tl_min = ctx->chol_tl_min; prm.pair = ctx->chol_group >= 2 ? 1 : 0;
-    prm.pair_min = ctx->chol_pair_min; prm.pipe_min = ctx->chol_pipe_min; prm.pg_stream = ctx->chol_pg_stream; prm.fuse_tail = ctx->chol_fuse_tail; prm.head_small = ctx->chol_head_small; prm.tl_serial = ctx->chol_tl_serial;
+    prm.pair_min = ctx->chol_pair_min; prm.pipe_min = ctx->chol_pipe_min; prm.pg_stream = ctx->chol_pg_stream; prm.fuse_tail = ctx->chol_fuse_tail; prm.head_small = ctx->chol_head_small; prm.tl_serial = ctx->chol_tl_serial; prm.window = ctx->chol_window;
     const chol::Params &o = ctx->chol_plan.prm_asked;
     if (ctx->chol_plan_valid && o.nblk == prm.nblk && o.tl_g == prm.tl_g && o.tl_min == prm.tl_min && o.pair == prm.pair && o.pair_min == prm.pair_min &&
-        o.pipe_min == prm.pipe_min && o.pg_stream == prm.pg_stream && o.fuse_tail == prm.fuse_tail && o.head_small == prm.head_small && o.tl_serial == prm.tl_serial) return RCN_OK;
+        o.pipe_min == prm.pipe_min && o.pg_stream == prm.pg_stream && o.fuse_tail == prm.fuse_tail && o.head_small == prm.head_small && o.tl_serial == prm.tl_serial && o.window == prm.window) return RCN_OK;
     ctx->chol_plan_valid = false;
     ctx->chol_plan = chol::make_plan(prm);
     ctx->chol_plan.prm_asked = prm;
@@ -2269,10 +2269,10 @@ int rcn_ba_factor_plan(int32_t n_blocks, const int32_t *params, int32_t *ops, in
     {
         rcn_ctx defaults;      // (never created on a device: only the schedule's parameters are read)
         prm.tl_g = defaults.chol_tl_g; prm.tl_min = defaults.chol_tl_min; prm.pair = defaults.chol_group >= 2; prm.pair_min = defaults.chol_pair_min; prm.pipe_min = defaults.chol_pipe_min;
-        prm.pg_stream = defaults.chol_pg_stream; prm.fuse_tail = defaults.chol_fuse_tail; prm.head_small = defaults.chol_head_small; prm.tl_serial = defaults.chol_tl_serial;
+        prm.pg_stream = defaults.chol_pg_stream; prm.fuse_tail = defaults.chol_fuse_tail; prm.head_small = defaults.chol_head_small; prm.tl_serial = defaults.chol_tl_serial; prm.window = defaults.chol_window;
     }
     prm.nblk = n_blocks;
-    if (params) { prm.tl_g = params[0]; prm.tl_min = params[1]; prm.pair = params[2]; prm.pair_min = params[3]; prm.pipe_min = params[4]; prm.pg_stream = params[5]; prm.fuse_tail = params[6]; prm.head_small = params[7]; prm.tl_serial = params[8]; }
+    if (params) { prm.tl_g = params[0]; prm.tl_min = params[1]; prm.pair = params[2]; prm.pair_min = params[3]; prm.pipe_min = params[4]; prm.pg_stream = params[5]; prm.fuse_tail = params[6]; prm.head_small = params[7]; prm.tl_serial = params[8]; prm.window = params[9]; }
     if (prm.tl_g < 0 || prm.tl_g == 1 || prm.tl_g > 16 || prm.pipe_min < 1) return RCN_ERR_ARG;
     const chol::Plan pl = chol::make_plan(prm);
     *n_ops = (int64_t)pl.ops.size();

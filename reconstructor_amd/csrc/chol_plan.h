@@ -53,6 +53,8 @@ struct Params {
     int pair = 1;         // right-looking regime: two panels per bulk update ...
     int pair_min = 24;    // ... while at least this many tile rows remain below the pair
     int pipe_min = 32;    // panel / column kernels go through the pipelined kernel from this many tiles on
+    int window = 0;       // two-level regime, measured and NOT shipped: the head rows and the next super-diagonal block through the per-step latency kernels (a 2 g-row
+                          // window of the chain).  The chain then reads tiles of the bulk update ONE super-step back instead of two, and waits for it: 8.9 against 8.45 ms
     int tl_serial = 0;    // two-level regime: below this many tile rows under the super-block the chain bounds a step, not the bulk update -- the
                           // super-block's small operations then run ON the chain's stream, in order: no gate kernels, no cross-stream waits
     int head_small = 1;   // two-level regime: the head rows' panel product and the update of the next super-diagonal block through the latency kernel
@@ -309,6 +311,31 @@ private:
         sib ^= 1;
         const int R0 = p + g, H1 = std::min(nblk, R0 + g);
         const int sb = nblk - R0 < prm.tl_serial ? ST_A : ST_B;      // where the super-block's small operations run
+        const int kl = R0 - 1;            // the timeline files the super-step's own operations under its last block step
+        if (prm.window) {
+            // WINDOW form (round 5, second pass): the chain's window is the super-block AND the next super-diagonal block's rows, 2 g tile
+            // rows.  Every step's panel product and update cover the window's tiles, K = 128, latency kernels: when the super-block's
+            // last diagonal block is done, the head rows of the panel and the next super-diagonal block are one panel product and one
+            // update away -- no inverse, no K = 128 g launches on the chain's critical path (the inverse is still built, behind the
+            // chain, for the rows below the window).
+            for (int pos = 0; pos < g; ++pos) {
+                const int k = p + pos;
+                diag(k);
+                if (k + 1 < H1) {
+                    trsm_q(ST_A, k, 0, 1, 8 * k + 1);
+                    upd_q(ST_A, k, 0, 1, 1, 8 * k + 2);
+                }
+                if (k + 2 < H1) {
+                    trsm_q(sb, k, 1, H1 - k - 2, 8 * k + 3);
+                    upd_q(sb, k, 1, H1 - k - 2, 1, 8 * k + 4);            // column k + 1: the next critical tile waits for it
+                    std::vector<uint32_t> tiles;
+                    for (int j = k + 2; j < H1; ++j)
+                        for (int i = j; i < H1; ++i) tiles.push_back(map_entry(i, j));
+                    if (!tiles.empty()) upd_pipe_list(sb, k, 1, tiles, 8 * k + 5, 1);
+                }
+                sinv(sb, p, g, pos, 8 * k + 7);
+            }
+        } else {
         for (int pos = 0; pos < g; ++pos) {
             const int k = p + pos, nin = g - 1 - pos;      // rows of the super-block below block k
             diag(k);
@@ -334,7 +361,6 @@ private:
             sinv(sb, p, g, pos, 8 * k + 7);
         }
         // head rows: the next super-diagonal block's rows of this super-panel, then that block itself
-        const int kl = R0 - 1;            // the timeline files what follows under the super-step's last block step
         if (prm.head_small) pgemm(sb, p, g, R0, H1, 8 * kl + 4, 0, -1, 1);
         else {
             trsm_q(sb, p, g - 1, H1 - R0, 8 * kl + 3);
@@ -345,6 +371,7 @@ private:
             for (int i = R0; i < H1; ++i)
                 for (int j = R0; j <= i; ++j) tiles.push_back(map_entry(i, j));
             upd_pipe_list(sb, p, g, tiles, 8 * kl + 5, prm.head_small);
+        }
         }
         if (H1 >= nblk) return;
         // every row below

@@ -137,6 +137,8 @@ int rcn_create(int device_id, rcn_ctx **out)
     if (ctm) ctx->chol_tl_min = std::atoi(ctm);
     const char *cps = std::getenv("RCN_CHOL_PGSTREAM");
     if (cps) ctx->chol_pg_stream = std::atoi(cps);
+    const char *cwn = std::getenv("RCN_CHOL_WINDOW");
+    if (cwn) ctx->chol_window = std::atoi(cwn);
     const char *cts = std::getenv("RCN_CHOL_TL_SERIAL");
     if (cts) ctx->chol_tl_serial = std::atoi(cts);
     const char *chs = std::getenv("RCN_CHOL_HEAD_SMALL");

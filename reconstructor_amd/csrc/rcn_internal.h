@@ -195,6 +195,7 @@ struct rcn_ctx {
     chol::Plan chol_plan;
     bool chol_plan_valid = false;
     int chol_tl_g = 4;                               // two-level regime: panels per super-step (K = 128 g per bulk update); 0 = right-looking steps only (diagnostic build: RCN_CHOL_TL)
+    int chol_window = 0;                             // two-level regime: 2 g-row window of the chain's latency kernels (RCN_CHOL_WINDOW)
     int chol_tl_serial = 0;                          // two-level regime: super-blocks with fewer tile rows below them run their small operations on the chain's stream (RCN_CHOL_TL_SERIAL)
     int chol_head_small = 1;                         // two-level regime: head rows' product + next super-diagonal block's update through k_gemm_qm (RCN_CHOL_HEAD_SMALL)
     int chol_fuse_tail = 1;                          // two-level regime: the panel product below the head rows as the tail of the previous bulk launch (RCN_CHOL_FUSE_TAIL)

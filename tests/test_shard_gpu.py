@@ -350,3 +350,79 @@ def test_failure_behind_the_vote_reaches_every_entry_point(kind):
         assert d["faulty"] == -7 and "aborted" in d["faulty_text"]                          # RCN_ERR_COMM
         for k in ("match", "lists", "gather", "next", "after", "match2", "reserve"):
             assert d[k] == -7, (k, d)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Two ranks, two GPUs.  The driver's GPU box has ONE device, so these are skipped there; on a node with two they
+# run each rank in a child process of its own (never re-exec'd; a rank that fails exits non-zero).
+_TWO_RANKS = r"""
+import sys, os, json, time
+import numpy as np
+sys.path.insert(0, %r)
+rank, world, mode, uid_hex = int(sys.argv[1]), 2, sys.argv[2], sys.argv[3]
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+import torch
+from reconstructor_amd import _lib, pairgrid, synth
+from reconstructor_amd.matcher import all_pairs
+ctx = _lib.Context(rank)
+sh = pairgrid.Shard(ctx, rank, world, bytes.fromhex(uid_hex))
+n, K, D = 6, 256, 256
+ims = synth.descriptor_set("superpoint", n, K, n_world=600, seed=11)
+lo, hi = pairgrid.owned_images(n, world, rank)
+sh.set_timeout(5.0)
+sh.reserve(n, K, D)
+for i in range(lo, hi):
+    sh.put_image(i, ims[i])
+out = {"rank": rank}
+if mode == "dead_peer" and rank == 1:
+    time.sleep(20)                       # never enters the collective: the peer must give up on its own
+    print(json.dumps(out)); sys.exit(0)
+t0 = time.time()
+try:
+    sh.exchange()
+    sh.match(0.7)
+    offs, qt = sh.gather_lists(root=0)
+    if rank == 0:
+        from oracle import orc
+        exp, ec = orc.match_grid(ims, all_pairs(n), threads=2)
+        ok = np.array_equal(np.diff(offs), ec) and all(exp[p][q] == t for p in range(len(ec)) for q, t in qt[offs[p]:offs[p + 1]])
+        out["gather_equals_oracle"] = bool(ok)
+    out["ok"] = True
+except _lib.RcnError as e:
+    out.update(ok=False, code=e.code, seconds=time.time() - t0)
+print(json.dumps(out))
+"""
+
+
+def _two_rank_run(mode):
+    import json
+    import os
+    import subprocess
+    import sys
+    from reconstructor_amd import _lib, pairgrid
+    if _lib.load().rcn_device_count() < 2:
+        pytest.skip("needs two GPUs")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    uid = pairgrid.unique_id().hex()
+    procs = [subprocess.Popen([sys.executable, "-c", _TWO_RANKS % root, str(r), mode, uid], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+             for r in range(2)]
+    outs = []
+    for p in procs:
+        so, se = p.communicate(timeout=120)
+        assert p.returncode == 0, se[-2000:]
+        outs.append(json.loads(so.strip().splitlines()[-1]))
+    return outs
+
+
+def test_two_ranks_gather_lists_equals_the_oracle():
+    """world = 2: the device path of rcn_shard_gather_lists (ncclSend / ncclRecv, interleave on the root) against the oracle's grid."""
+    outs = _two_rank_run("gather")
+    assert all(o["ok"] for o in outs) and outs[0]["gather_equals_oracle"]
+
+
+def test_a_peer_that_never_joins_costs_a_timeout_not_a_hang():
+    """One rank never enters the exchange: the other gives up after rcn_shard_set_timeout seconds with RCN_ERR_COMM (the read-backs in
+    front of the bounded waits land in pinned memory, so the host reaches its polling loop)."""
+    outs = _two_rank_run("dead_peer")
+    r0 = [o for o in outs if o["rank"] == 0][0]
+    assert r0["ok"] is False and r0["code"] == -7 and 4.0 <= r0["seconds"] <= 30.0, r0

@@ -36,10 +36,14 @@ def main():
     tag = sys.argv[3] if len(sys.argv) > 3 else "r04"
     import bench
     stamp = {"source_hash": bench.source_hash()}
-    try:
+    if os.environ.get("RCN_GIT_HEAD"):          # .git does not travel to the GPU box: the caller hands the head over (gpurun -- 'RCN_GIT_HEAD=... bash tools/profile_round.sh r05')
+        stamp["git_head"] = os.environ["RCN_GIT_HEAD"]
+        stamp["git_dirty"] = os.environ.get("RCN_GIT_DIRTY", "") not in ("", "0")
+    else:
+      try:
         stamp["git_head"] = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "HEAD"]).decode().strip()
         stamp["git_dirty"] = bool(subprocess.check_output(["git", "-C", ROOT, "status", "--porcelain", "--", "reconstructor_amd", "include"]).decode().strip())
-    except Exception:
+      except Exception:
         pass
     traffic = dict(stamp)
     traffic["_comment"] = ("fabric-side bytes per launch of K1 from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/profile_round.sh): counters in KiB; "
@@ -85,7 +89,7 @@ def main():
             for (kn2, c), (v, n) in sorted(tab.items()):
                 lines.append("%-44s %-28s n=%d mean=%.5g" % (kn2[:44], c, n, v))
     # the fold ablation at the SIFT shape (diagnostic build, RCN_COARSE_ABL): what a cheaper top-2 fold could buy at most
-    abl_names = {0: "shipping fold: and_or + med3 + min per element", 2: "values-only fold: med3 + min (results wrong by construction)", 1: "no fold at all"}
+    abl_names = {0: "shipping fold: and_or + med3 + min per element", 2: "values-only fold: med3 + min (results wrong by construction)", 6: "running minimum only: one operation (results wrong by construction)", 1: "no fold at all"}
     if any(os.path.isdir(os.path.join(prof, "fold_abl%d" % a)) for a in abl_names):
         lines.append("")
         lines.append("## top-2 fold ablation, k_coarse_top2<128> at 100 x 1500 x 128 (tools/profile_round.sh, diagnostic build)")

@@ -1,10 +1,10 @@
 #!/bin/bash
-# tools/profile_round.sh [TAG] -- every rocprofv3 pass behind profiles/<TAG>_* (TAG = r04 by default; run on the MI355X box from
-# the repo root:  gpurun -- 'bash tools/profile_round.sh r04').  Counter passes are separate runs with --pmc only (no trace domains),
+# tools/profile_round.sh [TAG] -- every rocprofv3 pass behind profiles/<TAG>_* (TAG = r05 by default; run on the MI355X box from
+# the repo root:  gpurun -- 'RCN_GIT_HEAD=$(git rev-parse HEAD) bash tools/profile_round.sh r05' -- .git does not travel, the head is handed over).  Counter passes are separate runs with --pmc only (no trace domains),
 # the program directly after `--`.  Raw output goes to gpurun_out/prof_<TAG>/, tools/pmc_report.py condenses it.
 set -o pipefail
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
-R=${1:-r04}
+R=${1:-r05}
 O=gpurun_out/prof_$R
 rm -rf "$O"; mkdir -p "$O"
 run() { echo "== $*"; "$@" || echo "   (rc=$?)"; }
@@ -23,9 +23,10 @@ done
 # ---- K1 traffic at the headline workload (cfg3: 1000 x 4096 x 256, one launch of ~3.2 s)
 run rocprofv3 --pmc FETCH_SIZE -d $O/k1_fetch_1000_4096_256 -o p --output-format csv -- python3 tools/k1_run.py 1000 4096 256 1 > $O/k1_fetch_cfg3.log 2>&1
 run rocprofv3 --pmc WRITE_SIZE -d $O/k1_write_1000_4096_256 -o p --output-format csv -- python3 tools/k1_run.py 1000 4096 256 1 > $O/k1_write_cfg3.log 2>&1
-run rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_INSTS_MFMA SQ_WAVE_CYCLES -d $O/k1_sq_1000_4096_256 -o p --output-format csv -- python3 tools/k1_run.py 1000 4096 256 1 > $O/k1_sq_cfg3.log 2>&1
+run rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_INSTS_MFMA SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY -d $O/k1_sq_1000_4096_256 -o p --output-format csv -- python3 tools/k1_run.py 1000 4096 256 1 > $O/k1_sq_cfg3.log 2>&1
+run rocprofv3 --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_ANY SQ_INSTS_SALU SQ_INSTS_VMEM -d $O/k1_lds_1000_4096_256 -o p --output-format csv -- python3 tools/k1_run.py 1000 4096 256 1 > $O/k1_lds_cfg3.log 2>&1
 # ---- the top-2 fold as a ceiling at the SIFT shape (diagnostic build): shipping fold (3 vector operations per accumulator element), values only (2), none
-for abl in 0 2 1; do
+for abl in 0 2 6 1; do
   RCN_LIB=$PWD/tools/librcn_diag.so RCN_COARSE_ABL=$abl rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_INSTS_MFMA SQ_WAVE_CYCLES -d $O/fold_abl$abl -o p --output-format csv -- python3 tools/k1_run.py 100 1500 128 6 > $O/fold_abl$abl.log 2>&1 || echo "   (rc=$?)"
 done
 # ---- BA cfg 5: kernel time and the factorisation chain's counters
