@@ -2106,13 +2106,28 @@ __global__ __launch_bounds__(256) void k_ba_plus(BaDev d, double alpha, double *
         }
         double ps2[6], in2[6];
         for (int k = 0; k < 6; ++k) { ps2[k] = ps[k]; in2[k] = in[k]; }
-        for (int k = 0; k < dc; ++k) {
-            const double dl = alpha * d.stc[off + k] * d.sc[off + k];
+        // (every input of the loop below is loaded BEFORE its first store -- round 5: with the loads inside the loop the compiler had to
+        //  keep each behind the store to dlc of the step before (the arrays may alias for all it knows), ten dependent round trips to L2
+        //  in a kernel of a few hundred threads: 14 of its 16 us on the reference's problem sizes)
+        double stc_[10], sc_[10], gcr_[10];
+        int col_[10];
+#pragma unroll
+        for (int k = 0; k < 10; ++k) {
+            const bool on = k < dc;
+            stc_[k] = on ? d.stc[off + k] : 0.0;
+            sc_[k] = on ? d.sc[off + k] : 0.0;
+            gcr_[k] = on ? d.gcraw[10 * (size_t)c + k] : 0.0;
+            col_[k] = on ? d.cols[10 * c + k] : 0;
+        }
+#pragma unroll
+        for (int k = 0; k < 10; ++k) {
+            if (k >= dc) break;
+            const double dl = alpha * stc_[k] * sc_[k];
             d.dlc[off + k] = dl;
             if (!isfinite(dl)) bad = 1.0;
-            const int col = d.cols[10 * c + k];
+            const int col = col_[k];
             // unscaled gradient of this coordinate = gcraw
-            g0 += d.gcraw[10 * (size_t)c + k] * dl;
+            g0 += gcr_[k] * dl;
             if (col < 6) ps2[col] += dl;
             else {
                 in2[col - 6] += dl;
@@ -2127,13 +2142,17 @@ __global__ __launch_bounds__(256) void k_ba_plus(BaDev d, double alpha, double *
     }
     if (i < d.np) {
         const bool used = d.pt_off[i + 1] > d.pt_off[i];
+        double stp_[3], sp_[3], x_[3], gp_[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { const size_t e = 3 * (size_t)i + k; stp_[k] = d.stp[e]; sp_[k] = d.sp[e]; x_[k] = d.pts[e]; gp_[k] = d.gpraw[e]; }
+#pragma unroll
         for (int k = 0; k < 3; ++k) {
             const size_t e = 3 * (size_t)i + k;
-            const double dl = alpha * d.stp[e] * d.sp[e];
+            const double dl = alpha * stp_[k] * sp_[k];
             d.dlp[e] = dl;
             if (!isfinite(dl)) bad = 1.0;
-            const double x = d.pts[e];
-            g0 += d.gpraw[e] * dl;
+            const double x = x_[k];
+            g0 += gp_[k] * dl;
             d.pts2[e] = x + dl;
             dn += dl * dl;
             if (used) xn += x * x;
@@ -2389,7 +2408,12 @@ int rcn_int_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_option
     unsigned long long *pk_list = ws.get<unsigned long long>(gather ? std::max<size_t>(npairs_lower, 1) : 1);
     d.WY = ws.get<double>(2 * WROW * (size_t)std::max(no, 1));        // W and Y planes: the Schur gathers and the back-substitution read them
     // few cameras: split every camera over several workgroups so that the per-camera kernels fill the chip
-    const int csplit = nc >= 128 ? 1 : std::max(1, std::min(16, 512 / std::max(nc, 1)));
+    // (round 5: and only as far as a camera's observations call for it -- a workgroup of the camera kernels takes 256 observations per trip
+    //  (k_ba_cam_raw) / 1024 (k_ba_schur_diag_mfma); splitting the reference's own problem sizes, a few hundred observations per camera,
+    //  over 16 workgroups bought nothing and cost the ticket hand-off: 14 -> ~7 us per launch at 6 cameras)
+    int max_cam_obs = 0;
+    for (int c = 0; c < nc; ++c) max_cam_obs = std::max(max_cam_obs, cam_obs_off[c + 1] - cam_obs_off[c]);
+    const int csplit = nc >= 128 ? 1 : std::max(1, std::min(std::min(16, 512 / std::max(nc, 1)), (max_cam_obs + 767) / 768));
     d.csplit = ws.get<double>((size_t)std::max(nc, 1) * csplit * 256);
     const int eb = (no + 255) / 256, ebj = (no + 127) / 128, pbk = (std::max(nc, np) + 255) / 256;
     d.partial = ws.get<double>(4 * (size_t)std::max(std::max(ebj, pbk), 1) + 16);
@@ -2609,7 +2633,7 @@ int rcn_int_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_option
                 if (npairs_lower / (size_t)nlow > 128) k_ba_schur_mfma_wg<<<nlow, 512, 0, st>>>(d, pk_off, pk_list);   // long lists: a workgroup per block
                 else k_ba_schur_mfma<<<(nlow + 3) / 4, 256, 0, st>>>(d, pk_off, pk_list);
             }
-            if (csplit > 1) k_ba_schur_diag_mfma<12><<<nc * csplit, 1024, 0, st>>>(d, pk_off, pk_list, ir, csplit);
+            if (nc < 128) k_ba_schur_diag_mfma<12><<<nc * csplit, 1024, 0, st>>>(d, pk_off, pk_list, ir, csplit);      // (few cameras: latency-bound, deep gathers)
             else k_ba_schur_diag_mfma<4><<<nc, 1024, 0, st>>>(d, pk_off, pk_list, ir, 1);
             if (fused_finish) k_ba_S_finish<<<(unsigned)(((size_t)(npad - n) * npad + 255) / 256), 256, 0, st>>>(d, chain ? 1 : 0);
             else if (npad > n) k_ba_S_pad<<<(npad - n + 127) / 128, 128, 0, st>>>(d);
