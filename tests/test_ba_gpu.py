@@ -243,6 +243,19 @@ def test_pair_lists_are_kept_for_the_same_graph_only(gpu_ctx):
     assert sm["iterations"] == s0["iterations"] and abs(sm["final_rms_px"] - s0["final_rms_px"]) <= 1e-5
 
 
+def test_factorisation_kernels_one_by_one(gpu_ctx):
+    """The kernels round 5 added to the factorisation, each against host arithmetic (tools/chol_kernels_check, built by
+    __graft_entry__.build()): the rolled trailing update at K = 192 .. 1024, the panel product with a super-block's inverse (pipelined
+    and latency form), the latency-form multi-panel update, the block rows of a super-block's inverse for g = 4 and 8."""
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "chol_kernels_check")
+    assert os.path.exists(exe), "tools/chol_kernels_check missing: run __graft_entry__.build()"
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "ALL OK" in r.stdout, r.stdout[-2000:] + r.stderr[-500:]
+    assert r.stdout.count(" ok") >= 12 and "FAILED" not in r.stdout
+
+
 def test_consecutive_invalid_steps_end_the_solve_where_the_oracle_ends_it(gpu_ctx):
     """the boundary of max_consecutive_invalid_steps.  Every step of this scene is invalid (a landmark block that is exactly
     zero, no floor under the LM diagonal): the solve ends in FAILURE after exactly `limit` steps -- Ceres' `>=` -- with the parameters
