@@ -358,12 +358,14 @@ int rcn_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *problem, const rcn_ba_optio
  * touch a common tile.  params: {panels per super-step, min rows for a super-step, pairs (0/1), min rows for a pair, min tiles for the
  * pipelined panel kernels, own stream for the two-level panel product (0/1), that product as the tail of the previous bulk launch (0/1), the head rows'
  * product and the next super-diagonal block's update through the latency kernel (0/1), rows below which a super-block's small operations
- * run on the chain's own stream, 2 g-row window of the chain's latency kernels (0/1)},
+ * run on the chain's own stream, 2 g-row window of the chain's latency kernels (0/1), the diagonal
+ * blocks in one resident workgroup (0/1)},
  * NULL = what the library uses.  An operation is
- * RCN_PLAN_OP_WORDS int32: kind, stream, ticket, kb, first, m, dj, nst, map_off, map_n, g, pos, n_waits, 5 x (counter, value), timeline
- * slot, awaited, index of the bulk update whose launch carries this operation's tiles as its tail (-1: none), 1 = latency-kernel form.  Counters 0 .. 3 are the streams' progress counters, 4 and 5 count the two classes of leading tiles of the bulk updates.  Returns RCN_ERR_ARG when a buffer is too
+ * RCN_PLAN_OP_WORDS int32: kind, stream, ticket, kb, first, m, dj, nst, map_off, map_n, g, pos, n_waits, 6 x (counter, value), timeline
+ * slot, awaited, index of the bulk update whose launch carries this operation's tiles as its tail (-1: none), 1 = latency-kernel form.  Counters 0 .. 4 are the streams' progress counters (4: the resident workgroup that factors the diagonal blocks), 5 and 6 count the two
+ * classes of leading tiles of the bulk updates.  Returns RCN_ERR_ARG when a buffer is too
  * small (the needed sizes are still written). */
-#define RCN_PLAN_OP_WORDS 27
+#define RCN_PLAN_OP_WORDS 29
 int rcn_ba_factor_plan(int32_t n_blocks, const int32_t *params, int32_t *ops, int64_t ops_cap, uint32_t *maps, int64_t maps_cap,
                        int64_t *n_ops, int64_t *n_maps);
 

@@ -961,7 +961,7 @@ __global__ __launch_bounds__(256) void k_ba_S_finish(BaDev d, int sentinel)
     // ([1]: k_ba_point_solve met a block that is singular in floating point in THIS iteration -- the step is invalid, as in the oracle;
     //  the other words belong to the factorisation that follows)
     if (idx == 0) { const int ps = d.flag[1]; d.flag[1] = 0; d.flag[0] = ps ? 1 : 0; }
-    else if (idx >= 2 && idx < 8) d.flag[idx] = 0;
+    else if ((idx >= 2 && idx < 8) || (idx >= 12 && idx < 24)) d.flag[idx] = 0;      // ([12 ..): the factorisation's stream counters)
     if (idx >= cnt) return;
     const int i = d.n + (int)(idx / d.npad), j = (int)(idx % d.npad);
     double v = i == j ? 1.0 : 0.0;
@@ -1068,13 +1068,27 @@ __device__ __forceinline__ void flag_raise(int *flag, int code)
 {
     (void)atomicCAS(flag, 0, code);
 }
+#ifdef RCN_DIAG
+__device__ int g_poll[2] = {0, 1};      // {the time-out by the clock (0) or by a count of polls (1), s_sleep(8) per poll}: tools/ only
+extern "C" int rcn_diag_set_poll(int mode, int sleeps)
+{
+    const int h[2] = {mode, sleeps};
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_poll), h, sizeof(h)) == hipSuccess ? 0 : -1;
+}
+#endif
 __device__ __forceinline__ void ring_wait(const int *counter, int need, int *flag, int code = 3)
 {
-    const unsigned long long t0 = wall_clock64();
+#ifdef RCN_DIAG
+    const int mode = g_poll[0], sleeps = g_poll[1];
+#else
+    const int mode = 0, sleeps = 1;
+#endif
+    const unsigned long long t0 = mode == 0 ? wall_clock64() : 0ull;
+    unsigned spins = 0;
     while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
         if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
-        __builtin_amdgcn_s_sleep(8);
-        if (wall_clock64() - t0 > 200000000ull) { flag_raise(flag, code); break; }
+        for (int q = 0; q < sleeps; ++q) __builtin_amdgcn_s_sleep(8);
+        if (mode == 0 ? wall_clock64() - t0 > 200000000ull : ++spins > 2000000u) { flag_raise(flag, code); break; }
     }
 }
 
@@ -1085,10 +1099,10 @@ __device__ __forceinline__ void ring_wait(const int *counter, int need, int *fla
 //            the publishing stream nothing (a trailing signal kernel would cost ~5 us of the chain per step);
 //   wait     thread 0 of every workgroup polls (relaxed), then ONE agent-scope acquire, then the workgroup barrier:
 //            the consumer recipe of MI355X_MICROARCH.md (inter-workgroup visibility), after which plain loads are safe.
-struct Gate { const int *c[5]; int n[5]; int nw; int *pub; int pubval; int *flag; };
+struct Gate { const int *c[6]; int n[6]; int nw; int *pub; int pubval; int *flag; };
 __host__ __device__ inline Gate gate_none(int *flag)
 {
-    Gate g = {{nullptr, nullptr, nullptr, nullptr, nullptr}, {0, 0, 0, 0, 0}, 0, nullptr, 0, flag};
+    Gate g = {{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}, {0, 0, 0, 0, 0, 0}, 0, nullptr, 0, flag};
     return g;
 }
 __device__ __forceinline__ void gate_enter(const Gate &g)
@@ -1100,6 +1114,7 @@ __device__ __forceinline__ void gate_enter(const Gate &g)
         if (g.nw > 2) ring_wait(g.c[2], g.n[2], g.flag);
         if (g.nw > 3) ring_wait(g.c[3], g.n[3], g.flag);
         if (g.nw > 4) ring_wait(g.c[4], g.n[4], g.flag);
+        if (g.nw > 5) ring_wait(g.c[5], g.n[5], g.flag);
         if (g.nw > 0) {
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1150,12 +1165,10 @@ __device__ unsigned long long g_stamps[64];
 // nact: the block's ACTIVE rows -- below them it is the identity padding of the system (the last block of every factorisation; the only
 // block of the reference's own problem sizes: 3 cameras are 13 rows of 128).  Only the leaves that hold active rows are factored; the
 // rest of the block is its own factor and inverse, and is written as such.
-__global__ __launch_bounds__(64 * CDW) void k_chol_diag(double *S, int ld, int kb, double *Linv, int *flag, int store_L, Gate g, int nact = NB, int tl = 0)
+// (the body: k_chol_diag = one block per launch on the chain's stream; k_chol_diag_server = every block of a factorisation in ONE
+//  resident workgroup -- round 5, below.  false: a pivot broke down, flag 1 is raised)
+__device__ __forceinline__ bool chol_diag_body(double *S, int ld, int kb, double *Linv, int *flag, int store_L, int nact, [[maybe_unused]] int tl)
 {
-    __builtin_amdgcn_s_setprio(3);
-    TL_MARK(tl, 0);
-    gate_enter(g);
-    TL_MARK(tl, 1);
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     double *L = reinterpret_cast<double *>(smem_raw);  // [128][DL]
     if (threadIdx.x >= 64) __builtin_amdgcn_s_setprio(2);   // wave 0 carries the serial chain: its few MFMAs go before its SIMD neighbour's
@@ -1288,7 +1301,7 @@ __global__ __launch_bounds__(64 * CDW) void k_chol_diag(double *S, int ld, int k
     for (int c0 = 0; c0 < NA; c0 += LB) {
         if (misc[0] != 0.0) {
             if (t == 0) flag_raise(flag, 1);
-            return;
+            return false;
         }
         const int r0 = c0 + LB, kk = c0 / LB;
         if (r0 >= NA) break;
@@ -1430,6 +1443,49 @@ __global__ __launch_bounds__(64 * CDW) void k_chol_diag(double *S, int ld, int k
     STAMP(16);
     STAMP(17);
     TL_MARK(tl, 2);
+    return true;
+}
+__global__ __launch_bounds__(64 * CDW) void k_chol_diag(double *S, int ld, int kb, double *Linv, int *flag, int store_L, Gate g, int nact = NB, int tl = 0)
+{
+    __builtin_amdgcn_s_setprio(3);
+    TL_MARK(tl, 0);
+    gate_enter(g);
+    TL_MARK(tl, 1);
+    (void)chol_diag_body(S, ld, kb, Linv, flag, store_L, nact, tl);
+}
+// The diagonal blocks of a whole factorisation in ONE workgroup that stays resident (round 5).  As a launch per block the 512-thread,
+// 132-KB workgroup had to find a CU every step -- and where the panel stream's latency kernels, unmasked since this round, fill the
+// CUs that are kept free of bulk work, it waited ~50 us for one at every second step of the right-looking regime (device timeline).
+// Here the workgroup keeps its CU: per block it waits for the counters the plan names (thread 0 polls, one agent-scope acquire,
+// workgroup barrier -- the consumer recipe), factors the block exactly as k_chol_diag does, drains its stores, and publishes its
+// ticket with an agent-scope release (a kernel boundary did that before).  A raised flag (breakdown: 1, a wait that timed out: 3)
+// ends the loop; the host then does what it always did.
+struct DiagItem { int kb, store_L, ticket, tl, nw, ctr[6], val[6]; };
+__global__ __launch_bounds__(64 * CDW) void k_chol_diag_server(double *S, int ld, double *Linv, int *flag, const DiagItem *__restrict__ items, int n_items, int *ctr_base, int own_ctr,
+                                                                int n_active)
+{
+    __builtin_amdgcn_s_setprio(3);
+    __shared__ int s_stop;
+    for (int it = 0; it < n_items; ++it) {
+        const DiagItem item = items[it];
+        TL_MARK(item.tl, 0);
+        if (threadIdx.x == 0) {
+            for (int i = 0; i < 6; ++i)
+                if (i < item.nw) ring_wait(ctr_base + item.ctr[i], item.val[i], flag);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            s_stop = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+        }
+        __syncthreads();
+        if (s_stop) return;
+        TL_MARK(item.tl, 1);
+        const int nact = min(NB, n_active - item.kb * NB);
+        const bool ok = chol_diag_body(S, ld, item.kb, Linv, flag, item.store_L, nact, item.tl);
+        if (!ok) return;                        // (uniform: every thread read the same LDS word behind a barrier)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_store(ctr_base + own_ctr, item.ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 // Dense blocked Cholesky, GEMM side.  S holds the reduced system and its trailing updates; the
@@ -1868,7 +1924,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt_pipe_tail(double *S, double 
         const unsigned e = map2[blockIdx.x - split];
         if (e == ~0u) return;
         if (threadIdx.x == 0) {
-            for (int i = 0; i < 5; ++i)
+            for (int i = 0; i < 6; ++i)
                 if (i < g2.nw) ring_wait(g2.c[i], g2.n[i], g2.flag);
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -2220,10 +2276,10 @@ static int ensure_chol_plan(rcn_ctx *ctx, int nblk)
 {
     chol::Params prm;
     prm.nblk = nblk; prm.tl_g = ctx->chol_tl_g; prm.tl_min = ctx->chol_tl_min; prm.pair = ctx->chol_group >= 2 ? 1 : 0;
-    prm.pair_min = ctx->chol_pair_min; prm.pipe_min = ctx->chol_pipe_min; prm.pg_stream = ctx->chol_pg_stream; prm.fuse_tail = ctx->chol_fuse_tail; prm.head_small = ctx->chol_head_small; prm.tl_serial = ctx->chol_tl_serial; prm.window = ctx->chol_window;
+    prm.pair_min = ctx->chol_pair_min; prm.pipe_min = ctx->chol_pipe_min; prm.pg_stream = ctx->chol_pg_stream; prm.fuse_tail = ctx->chol_fuse_tail; prm.head_small = ctx->chol_head_small; prm.tl_serial = ctx->chol_tl_serial; prm.window = ctx->chol_window; prm.diag_server = ctx->chol_diag_server;
     const chol::Params &o = ctx->chol_plan.prm_asked;
     if (ctx->chol_plan_valid && o.nblk == prm.nblk && o.tl_g == prm.tl_g && o.tl_min == prm.tl_min && o.pair == prm.pair && o.pair_min == prm.pair_min &&
-        o.pipe_min == prm.pipe_min && o.pg_stream == prm.pg_stream && o.fuse_tail == prm.fuse_tail && o.head_small == prm.head_small && o.tl_serial == prm.tl_serial && o.window == prm.window) return RCN_OK;
+        o.pipe_min == prm.pipe_min && o.pg_stream == prm.pg_stream && o.fuse_tail == prm.fuse_tail && o.head_small == prm.head_small && o.tl_serial == prm.tl_serial && o.window == prm.window && o.diag_server == prm.diag_server) return RCN_OK;
     ctx->chol_plan_valid = false;
     ctx->chol_plan = chol::make_plan(prm);
     ctx->chol_plan.prm_asked = prm;
@@ -2231,6 +2287,26 @@ static int ensure_chol_plan(rcn_ctx *ctx, int nblk)
     const size_t nm = std::max<size_t>(ctx->chol_plan.maps.size(), 1);
     RCN_HIP(ctx->bulk_map.reserve(nm * sizeof(unsigned)));
     if (!ctx->chol_plan.maps.empty()) RCN_HIP(hipMemcpy(ctx->bulk_map.p, ctx->chol_plan.maps.data(), ctx->chol_plan.maps.size() * sizeof(unsigned), hipMemcpyHostToDevice));
+    if (prm.diag_server && !ctx->diag_stream) {      // (tools/ only: the product's plans have no resident workgroup)
+        int lo = 0, hi = 0;
+        if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { (void)hipGetLastError(); lo = hi = 0; }
+        const char *dsp = std::getenv("RCN_DIAG_STREAM_PRIO");
+        if (dsp && std::atoi(dsp) == 0) hi = 0;
+        RCN_HIP(hipStreamCreateWithPriority(&ctx->diag_stream, hipStreamNonBlocking, hi));
+    }
+    {   // the resident diagonal workgroup's list: block, whether the factor itself is stored (last block), ticket, waits
+        std::vector<DiagItem> items;
+        for (const chol::Op &op : ctx->chol_plan.ops) {
+            if (op.stream != chol::ST_E || op.kind != chol::DIAG) continue;
+            DiagItem it;
+            memset(&it, 0, sizeof(it));
+            it.kb = op.kb; it.store_L = op.kb == nblk - 1; it.ticket = op.ticket; it.tl = op.tl; it.nw = op.nw;
+            for (int i = 0; i < op.nw; ++i) { it.ctr[i] = op.w[i].ctr; it.val[i] = op.w[i].val; }
+            items.push_back(it);
+        }
+        RCN_HIP(ctx->diag_items.reserve(std::max<size_t>(items.size(), 1) * sizeof(DiagItem)));
+        if (!items.empty()) RCN_HIP(hipMemcpy(ctx->diag_items.p, items.data(), items.size() * sizeof(DiagItem), hipMemcpyHostToDevice));
+    }
     ctx->chol_plan_valid = true;
     return RCN_OK;
 }
@@ -2288,10 +2364,10 @@ int rcn_ba_factor_plan(int32_t n_blocks, const int32_t *params, int32_t *ops, in
     {
         rcn_ctx defaults;      // (never created on a device: only the schedule's parameters are read)
         prm.tl_g = defaults.chol_tl_g; prm.tl_min = defaults.chol_tl_min; prm.pair = defaults.chol_group >= 2; prm.pair_min = defaults.chol_pair_min; prm.pipe_min = defaults.chol_pipe_min;
-        prm.pg_stream = defaults.chol_pg_stream; prm.fuse_tail = defaults.chol_fuse_tail; prm.head_small = defaults.chol_head_small; prm.tl_serial = defaults.chol_tl_serial; prm.window = defaults.chol_window;
+        prm.pg_stream = defaults.chol_pg_stream; prm.fuse_tail = defaults.chol_fuse_tail; prm.head_small = defaults.chol_head_small; prm.tl_serial = defaults.chol_tl_serial; prm.window = defaults.chol_window; prm.diag_server = defaults.chol_diag_server;
     }
     prm.nblk = n_blocks;
-    if (params) { prm.tl_g = params[0]; prm.tl_min = params[1]; prm.pair = params[2]; prm.pair_min = params[3]; prm.pipe_min = params[4]; prm.pg_stream = params[5]; prm.fuse_tail = params[6]; prm.head_small = params[7]; prm.tl_serial = params[8]; prm.window = params[9]; }
+    if (params) { prm.tl_g = params[0]; prm.tl_min = params[1]; prm.pair = params[2]; prm.pair_min = params[3]; prm.pipe_min = params[4]; prm.pg_stream = params[5]; prm.fuse_tail = params[6]; prm.head_small = params[7]; prm.tl_serial = params[8]; prm.window = params[9]; prm.diag_server = params[10]; }
     if (prm.tl_g < 0 || prm.tl_g == 1 || prm.tl_g > 16 || prm.pipe_min < 1) return RCN_ERR_ARG;
     const chol::Plan pl = chol::make_plan(prm);
     *n_ops = (int64_t)pl.ops.size();
@@ -2301,7 +2377,8 @@ int rcn_ba_factor_plan(int32_t n_blocks, const int32_t *params, int32_t *ops, in
         const chol::Op &o = pl.ops[i];
         int32_t *w = ops + RCN_PLAN_OP_WORDS * i;
         const int32_t v[RCN_PLAN_OP_WORDS] = {o.kind, o.stream, o.ticket, o.kb, o.first, o.m, o.dj, o.nst, o.map_off, o.map_n, o.g, o.pos, o.nw,
-                                              o.w[0].ctr, o.w[0].val, o.w[1].ctr, o.w[1].val, o.w[2].ctr, o.w[2].val, o.w[3].ctr, o.w[3].val, o.w[4].ctr, o.w[4].val, o.tl, o.awaited, o.fuse_with, o.small};
+                                              o.w[0].ctr, o.w[0].val, o.w[1].ctr, o.w[1].val, o.w[2].ctr, o.w[2].val, o.w[3].ctr, o.w[3].val, o.w[4].ctr, o.w[4].val, o.w[5].ctr, o.w[5].val,
+                                              o.tl, o.awaited, o.fuse_with, o.small};
         memcpy(w, v, sizeof(v));
     }
     if (!pl.maps.empty()) memcpy(maps, pl.maps.data(), pl.maps.size() * sizeof(uint32_t));
@@ -2375,7 +2452,7 @@ int rcn_int_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_option
     d.poses = ws.get<double>(6 * (size_t)nc); d.intr = ws.get<double>(6 * (size_t)nc); d.pts = ws.get<double>(3 * (size_t)np);
     d.poses2 = ws.get<double>(6 * (size_t)nc); d.intr2 = ws.get<double>(6 * (size_t)nc); d.pts2 = ws.get<double>(3 * (size_t)np);
     double *uv = ws.get<double>(2 * (size_t)no);
-    int *ints = ws.get<int>((size_t)no * 3 + np + 1 + 2 * (nc + 1) + nc + 10 * (size_t)nc + 24);      // + flag words [0..7] and reduction tickets [8..11]
+    int *ints = ws.get<int>((size_t)no * 3 + np + 1 + 2 * (nc + 1) + nc + 10 * (size_t)nc + 24);      // + flag words [0..7], reduction tickets [8..11], the factorisation's counters [12..23]
     int *p_ocam = ints, *p_opt = p_ocam + no, *p_camobs = p_opt + no, *p_ptoff = p_camobs + no,
         *p_camobsoff = p_ptoff + np + 1, *p_camoff = p_camobsoff + nc + 1, *p_camdim = p_camoff + nc + 1,
         *p_cols = p_camdim + nc, *p_flag = p_cols + 10 * (size_t)nc;
@@ -2456,6 +2533,7 @@ int rcn_int_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_option
     RCN_HIP(hipMemsetAsync(d.Linv, 0, sizeof(double) * (size_t)nblk * NB * NB, st));   // upper triangles of the tile inverses stay zero
     if (nblk > 2) RCN_HIP(hipMemsetAsync(SI, 0, sizeof(double) * 2 * si_elems, st));   // blocks above a super-block inverse's diagonal stay zero (a column-0 pass reads 64 columns of one)
     RCN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_chol_diag), hipFuncAttributeMaxDynamicSharedMemorySize, NB * DL * 8));
+    RCN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_chol_diag_server), hipFuncAttributeMaxDynamicSharedMemorySize, NB * DL * 8));
     RCN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_nt_pipe<0, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, GST * GSTAGE_BYTES));
     RCN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_nt_pipe<0, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, GST * GSTAGE_BYTES));
     RCN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_nt_pipe<0, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, GST * GSTAGE_BYTES));
@@ -2621,6 +2699,7 @@ int rcn_int_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_option
         const bool chain = ctx->trsv_chain && 2 * nblk <= ctx->prop.multiProcessorCount;      // backward substitution as one launch
         if (!fused_finish) {
             RCN_HIP(hipMemsetAsync(d.flag, 0, 8 * sizeof(int), st));
+            RCN_HIP(hipMemsetAsync(d.flag + 12, 0, 12 * sizeof(int), st));
             if (!gather) RCN_HIP(hipMemsetAsync(Sb, 0, sizeof(double) * 100 * (size_t)nc * nc, st));
             if (npad > n) RCN_HIP(hipMemsetAsync(d.S + (size_t)n * npad, 0, sizeof(double) * (size_t)(npad - n) * npad, st));
             RCN_HIP(hipMemsetAsync(d.rhs, 0, sizeof(double) * npad, st));
@@ -2657,8 +2736,10 @@ int rcn_int_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_option
         // progress side by side) raises flag 3; the factorisation is then repeated on ONE stream in list order, and every later
         // one runs that way (ctx->chol_safe).  Same bits either way: no operation's arithmetic depends on where it runs.
         auto factorise = [&](bool safe) -> hipError_t {
-            hipStream_t str[chol::N_STREAMS] = {st, safe ? st : ctx->panel_stream, safe ? st : ctx->aux_stream, safe ? st : ctx->panel2_stream};
-            int *ctr[chol::N_CTR] = {d.flag + 2, d.flag + 3, d.flag + 4, d.flag + 5, d.flag + 6, d.flag + 7};
+            hipStream_t str[chol::N_STREAMS] = {st, safe ? st : ctx->panel_stream, safe ? st : ctx->aux_stream, safe ? st : ctx->panel2_stream, safe ? st : ctx->diag_stream};
+            int *const ctr_base = d.flag + 12;          // the streams' progress counters and the two head-tile counters (k_ba_S_finish clears them)
+            int *ctr[chol::N_CTR];
+            for (int c = 0; c < chol::N_CTR; ++c) ctr[c] = ctr_base + c;
             const chol::Plan &plan = ctx->chol_plan;
             if (!safe) {
                 hipError_t e = hipEventRecord(ctx->ba_ev[0], str[0]);
@@ -2684,9 +2765,16 @@ int rcn_int_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_option
                 if (with_pub) { g2.pub = ctr[o2.stream]; g2.pubval = o2.ticket - 1; }
                 return g2;
             };
+            // the diagonal blocks: ONE resident workgroup for all of them (k_chol_diag_server), started in front of everything else
+            const bool server = !safe && plan.n_ops[chol::ST_E] > 0;
+            if (server) {
+                const int n_active = rhs_row ? n + 1 : n;
+                k_chol_diag_server<<<1, 64 * CDW, NB * DL * 8, str[chol::ST_E]>>>(d.S, npad, d.Linv, d.flag, ctx->diag_items.as<DiagItem>(), plan.n_ops[chol::ST_E], ctr_base, chol::ST_E, n_active);
+            }
             for (size_t oi = 0; oi < plan.ops.size(); ++oi) {
                 const chol::Op &op = plan.ops[oi];
                 if (!safe && op.fuse_with >= 0) continue;      // its tiles went out with the bulk update in front of it
+                if (server && op.stream == chol::ST_E) continue;      // the resident workgroup's
                 hipStream_t sq = str[op.stream];
                 Gate g = gate_none(d.flag);
                 if (!safe) {
@@ -2703,7 +2791,7 @@ int rcn_int_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_option
                 // workgroups that spins while it holds its CU slots -- and polls one counter from every workgroup -- could keep the very
                 // kernel it waits for from becoming resident, and slows the chain's kernels beside it (measured: the critical-tile
                 // kernels took 11 us instead of 4 with the panel kernels spinning next to them).
-                const bool in_kernel = op.stream == chol::ST_A || ctx->chol_gate_in_kernel;
+                const bool in_kernel = (op.stream == chol::ST_A && ctx->chol_gate_in_kernel >= 0) || ctx->chol_gate_in_kernel > 0;      // (-1, tools/ only: a gate kernel in front on the chain too)
                 const bool pipe_kind = ((op.kind == chol::TRSM_PIPE || op.kind == chol::UPD_PIPE || op.kind == chol::PGEMM) && !op.small) || op.kind == chol::PUBLISH;
                 Gate gk = gate_none(d.flag);           // what the kernel itself gets
                 if (!safe) {

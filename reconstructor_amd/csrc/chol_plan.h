@@ -26,7 +26,7 @@
 namespace chol {
 
 enum Kind : int { DIAG = 0, TRSM_Q = 1, UPD_Q = 2, TRSM_PIPE = 3, UPD_PIPE = 4, SINV = 5, PGEMM = 6, PUBLISH = 7 };
-enum : int { ST_A = 0, ST_B = 1, ST_C = 2, ST_D = 3, N_STREAMS = 4, CTR_SIG1 = 4, CTR_SIG2 = 5, N_CTR = 6 };
+enum : int { ST_A = 0, ST_B = 1, ST_C = 2, ST_D = 3, ST_E = 4, N_STREAMS = 5, CTR_SIG1 = 5, CTR_SIG2 = 6, N_CTR = 7 };      // ST_E: the resident diagonal-block workgroup
 
 struct Wait { int ctr, val; };
 
@@ -39,7 +39,7 @@ struct Op {
     int map_off = 0, map_n = 0;   // pipe kernels: slice of Plan::maps (row << 16 | class << 14 | column; ~0 = no tile), a multiple of 8 long
     int g = 0, pos = 0;      // SINV: block row pos of the inverse of super-block [kb, kb + g); PGEMM: g
     int nw = 0;
-    Wait w[5] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}};
+    Wait w[6] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}};
     int tl = 0;              // slot of the diagnostic build's device timeline
     int small = 0;           // UPD_PIPE / PGEMM: a handful of chain-critical tiles -- the latency form (k_gemm_qm: 16 small workgroups per tile, no LDS) instead of the pipelined one
     int fuse_with = -1;      // PGEMM on the bulk stream: index of the bulk update whose launch carries this product's tiles as its tail (-1: a launch of its own)
@@ -53,6 +53,7 @@ struct Params {
     int pair = 1;         // right-looking regime: two panels per bulk update ...
     int pair_min = 24;    // ... while at least this many tile rows remain below the pair
     int pipe_min = 32;    // panel / column kernels go through the pipelined kernel from this many tiles on
+    int diag_server = 0;  // 1 (tools/, measured and not kept: EXPERIMENTS.md): the diagonal blocks of the whole factorisation in ONE resident workgroup (stream E) that publishes its own ticket when a block is done
     int window = 0;       // two-level regime, measured and NOT shipped: the head rows and the next super-diagonal block through the per-step latency kernels (a 2 g-row
                           // window of the chain).  The chain then reads tiles of the bulk update ONE super-step back instead of two, and waits for it: 8.9 against 8.45 ms
     int tl_serial = 0;    // two-level regime: below this many tile rows under the super-block the chain bounds a step, not the bulk update -- the
@@ -69,7 +70,7 @@ struct Plan {
     Params prm_asked;             // what the caller asked for (prm.fuse_tail is 0 when the fused form could not be used)
     std::vector<Op> ops;
     std::vector<uint32_t> maps;
-    int n_ops[N_STREAMS] = {0, 0, 0, 0};
+    int n_ops[N_STREAMS] = {0, 0, 0, 0, 0};
     int two_level_steps = 0;      // block steps covered by super-steps
 };
 
@@ -92,7 +93,7 @@ public:
         right_looking(p);
         // whoever is waited for must be followed by something that publishes its ticket
         for (int s = 0; s < N_STREAMS; ++s) {
-            if (plan.n_ops[s] == 0) continue;
+            if (plan.n_ops[s] == 0 || s == ST_E) continue;      // (the resident diagonal workgroup publishes a block's ticket when the block is done)
             bool need = false;
             for (const Op &o : plan.ops)
                 for (int i = 0; i < o.nw; ++i) need |= o.w[i].ctr == s && o.w[i].val == plan.n_ops[s];
@@ -154,7 +155,7 @@ private:
         // operations of the fourth stream were published when the host had enqueued the whole factorisation, 0.5 ms late).
         if (o.kind != PUBLISH)
             for (int c = 0; c < N_STREAMS; ++c)
-                if (c != o.stream && need[c] > have[o.stream][c] && need[c] == plan.n_ops[c]) {
+                if (c != o.stream && c != ST_E && need[c] > have[o.stream][c] && need[c] == plan.n_ops[c]) {
                     Op pb; pb.kind = PUBLISH; pb.stream = c;
                     add(pb, {}, {});
                 }
@@ -163,7 +164,7 @@ private:
         // (what an earlier operation of this stream has waited for, this one has too: streams run in order, counters only grow)
         o.nw = 0;
         for (int c = 0; c < N_CTR; ++c)
-            if (need[c] > have[o.stream][c]) { o.w[o.nw].ctr = c; o.w[o.nw].val = need[c]; ++o.nw; have[o.stream][c] = need[c]; }      // (at most 3 other streams + 2 head counters)
+            if (need[c] > have[o.stream][c]) { o.w[o.nw].ctr = c; o.w[o.nw].val = need[c]; ++o.nw; have[o.stream][c] = need[c]; }      // (at most 4 other streams + 2 head counters)
         int n1 = 0, n2 = 0;
         for (int t : reads) cells[(size_t)t].readers.push_back(idx);
         for (const Wr &w : writes) {
@@ -180,7 +181,7 @@ private:
     // ---- single operations
     void diag(int k)
     {
-        Op o; o.kind = DIAG; o.stream = ST_A; o.kb = k; o.tl = 8 * k + 0;
+        Op o; o.kind = DIAG; o.stream = prm.diag_server ? ST_E : ST_A; o.kb = k; o.tl = 8 * k + 0;
         add(o, {tS(k, k)}, {{tLinv(k), 0}, {tS(k, k), 0}});
     }
     void trsm_q(int stream, int kb, int first, int m, int tl)

@@ -1,5 +1,8 @@
 // ctx.hip -- context lifetime of the C ABI (include/rcn.h).
 #include "rcn_internal.h"
+#ifdef RCN_DIAG
+extern "C" int rcn_diag_set_poll(int mode, int sleeps);
+#endif
 #include <vector>
 
 #include <cstdlib>
@@ -91,6 +94,12 @@ int rcn_create(int device_id, rcn_ctx **out)
         delete ctx;
         return RCN_ERR_HIP;
     }
+#ifdef RCN_DIAG
+    {
+        const char *pm = std::getenv("RCN_POLL_MODE"), *ps = std::getenv("RCN_POLL_SLEEPS");
+        if (pm || ps) (void)rcn_diag_set_poll(pm ? std::atoi(pm) : 0, ps ? std::atoi(ps) : 1);
+    }
+#endif
     if (!ctx->panel2_stream && hipStreamCreateWithFlags(&ctx->panel2_stream, hipStreamNonBlocking) != hipSuccess) {
         delete ctx;
         return RCN_ERR_HIP;
@@ -137,6 +146,8 @@ int rcn_create(int device_id, rcn_ctx **out)
     if (ctm) ctx->chol_tl_min = std::atoi(ctm);
     const char *cps = std::getenv("RCN_CHOL_PGSTREAM");
     if (cps) ctx->chol_pg_stream = std::atoi(cps);
+    const char *cds = std::getenv("RCN_CHOL_DIAG_SERVER");
+    if (cds) ctx->chol_diag_server = std::atoi(cds);
     const char *cwn = std::getenv("RCN_CHOL_WINDOW");
     if (cwn) ctx->chol_window = std::atoi(cwn);
     const char *cts = std::getenv("RCN_CHOL_TL_SERIAL");
@@ -148,7 +159,7 @@ int rcn_create(int device_id, rcn_ctx **out)
     const char *cpp = std::getenv("RCN_CHOL_PG_PRIO");
     if (cpp) ctx->chol_pg_prio = cpp[0] != '0';
     const char *cgk = std::getenv("RCN_CHOL_GATE_IN_KERNEL");
-    ctx->chol_gate_in_kernel = cgk && cgk[0] == '1';
+    ctx->chol_gate_in_kernel = cgk ? std::atoi(cgk) : 0;
     const char *cht = std::getenv("RCN_CHOL_HOSTTIME");
     ctx->chol_host_time = cht && cht[0] == '1';
     const char *cpi = std::getenv("RCN_CHOL_PIPE_MIN");
@@ -170,7 +181,7 @@ void rcn_destroy(rcn_ctx *ctx)
     (void)hipStreamSynchronize(ctx->stream);
     rcn_match_release(ctx);
     DevBuf *bufs[] = {&ctx->img_table, &ctx->pairs_dev, &ctx->groups_dev, &ctx->cand, &ctx->owner,
-                      &ctx->fb_list, &ctx->sv_list, &ctx->counters, &ctx->out_tmp, &ctx->cnt_tmp, &ctx->scale_dev, &ctx->desc_bad, &ctx->bulk_map};
+                      &ctx->fb_list, &ctx->sv_list, &ctx->counters, &ctx->out_tmp, &ctx->cnt_tmp, &ctx->scale_dev, &ctx->desc_bad, &ctx->bulk_map, &ctx->diag_items};
     for (DevBuf *b : bufs) b->release();
     for (DevBuf &b : ctx->ba_ws) b.release();
     ctx->lm_ws.release();
@@ -198,6 +209,7 @@ void rcn_destroy(rcn_ctx *ctx)
     if (ctx->aux_stream) (void)hipStreamDestroy(ctx->aux_stream);
     if (ctx->panel_stream) (void)hipStreamDestroy(ctx->panel_stream);
     if (ctx->panel2_stream) (void)hipStreamDestroy(ctx->panel2_stream);
+    if (ctx->diag_stream) (void)hipStreamDestroy(ctx->diag_stream);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }

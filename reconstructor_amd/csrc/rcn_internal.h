@@ -188,20 +188,23 @@ struct rcn_ctx {
     uint64_t ba_pair_token = 0;         // whose pair lists the Schur-build workspace holds (0 = nobody's)
     std::vector<int> ba_pair_camdim;    // ... and the per-camera tangent dimensions they were built for (a camera without free parameters has no pairs)
     hipStream_t aux_stream = nullptr;   // lookahead stream of the Cholesky: bulk trailing updates (CU mask leaves one CU per XCD to the diagonal kernel)
+    hipStream_t diag_stream = nullptr;   // the resident workgroup that factors the diagonal blocks of a factorisation (k_chol_diag_server)
     hipStream_t panel2_stream = nullptr; // two-level regime of the Cholesky: the panel product for the rows below the head (same CU mask)
     hipStream_t panel_stream = nullptr; // second chain stream of the Cholesky: panels and first trailing columns behind the critical tile (same CU mask)
     // the factorisation's schedule (chol_plan.h: operations, streams, waits, tile maps) for the last shape solved; its maps in HBM
     DevBuf bulk_map;
     chol::Plan chol_plan;
+    DevBuf diag_items;                               // the resident diagonal workgroup's work list of that plan
     bool chol_plan_valid = false;
     int chol_tl_g = 4;                               // two-level regime: panels per super-step (K = 128 g per bulk update); 0 = right-looking steps only (diagnostic build: RCN_CHOL_TL)
+    int chol_diag_server = 0;                        // diagnostic build (RCN_CHOL_DIAG_SERVER=1): the diagonal blocks in one resident workgroup instead of a launch per block on the chain's stream
     int chol_window = 0;                             // two-level regime: 2 g-row window of the chain's latency kernels (RCN_CHOL_WINDOW)
     int chol_tl_serial = 0;                          // two-level regime: super-blocks with fewer tile rows below them run their small operations on the chain's stream (RCN_CHOL_TL_SERIAL)
     int chol_head_small = 1;                         // two-level regime: head rows' product + next super-diagonal block's update through k_gemm_qm (RCN_CHOL_HEAD_SMALL)
     int chol_fuse_tail = 1;                          // two-level regime: the panel product below the head rows as the tail of the previous bulk launch (RCN_CHOL_FUSE_TAIL)
     int chol_pg_stream = 1;                          // two-level regime: the panel product below the head rows on a stream of its own (RCN_CHOL_PGSTREAM)
     bool chol_pg_prio = true;                        // diagnostic build (RCN_CHOL_PG_PRIO=0): no raised wave priority for the panel product below the head rows
-    bool chol_gate_in_kernel = false;                // diagnostic build (RCN_CHOL_GATE_IN_KERNEL=1): waits of the small kernels off the chain inside them, not in a gate kernel in front
+    int chol_gate_in_kernel = 0;                     // diagnostic build (RCN_CHOL_GATE_IN_KERNEL=1): waits of the small kernels off the chain inside them, not in a gate kernel in front; -1: in front on the chain too
     bool chol_host_time = false;                     // diagnostic build (RCN_CHOL_HOSTTIME=1): print the host time of every factorisation's enqueue
     int chol_tl_min = 40;                            // ... while at least this many tile rows remain below the super-block (RCN_CHOL_TL_MIN)
     int chol_group = 2;                              // right-looking regime: panels per bulk update while many tile rows remain, 2 (K = 256) or 1

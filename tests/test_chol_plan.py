@@ -18,8 +18,8 @@ import pytest
 from reconstructor_amd import _lib
 
 DIAG, TRSM_Q, UPD_Q, TRSM_PIPE, UPD_PIPE, SINV, PGEMM, PUBLISH = range(8)
-OPW = 27
-N_STREAMS = 4          # counters 0 .. 3: progress of the streams; 4, 5: the two classes of leading tiles of the bulk updates
+OPW = 29
+N_STREAMS = 5          # counters 0 .. 4: progress of the streams (4: the resident workgroup of the diagonal blocks); 5, 6: the two classes of leading tiles of the bulk updates
 NONE = 0xFFFFFFFF
 
 
@@ -31,7 +31,7 @@ def get_plan(nblk, params=None):
     n_ops, n_maps = C.c_int64(0), C.c_int64(0)
     prm = None
     if params is not None:
-        prm = np.asarray(params, dtype=np.int32)
+        prm = np.asarray(tuple(params) + ((0,) if len(params) == 10 else ()), dtype=np.int32)      # (ten entries: the diagonal blocks as launches on the chain's stream, the product's way)
     pp = prm.ctypes.data if prm is not None else None
     fn(nblk, pp, None, 0, None, 0, C.byref(n_ops), C.byref(n_maps))
     ops = np.zeros((max(n_ops.value, 1), OPW), dtype=np.int32)
@@ -42,7 +42,7 @@ def get_plan(nblk, params=None):
     for r in ops[:n_ops.value]:
         o = dict(kind=int(r[0]), stream=int(r[1]), ticket=int(r[2]), kb=int(r[3]), first=int(r[4]), m=int(r[5]), dj=int(r[6]), nst=int(r[7]),
                  map_off=int(r[8]), map_n=int(r[9]), g=int(r[10]), pos=int(r[11]), waits=[(int(r[13 + 2 * i]), int(r[14 + 2 * i])) for i in range(int(r[12]))],
-                 awaited=int(r[24]), fuse_with=int(r[25]), small=int(r[26]))
+                 awaited=int(r[26]), fuse_with=int(r[27]), small=int(r[28]))
         o["tiles"] = [((int(e) >> 16), int(e) & 0x3FFF, (int(e) >> 14) & 3) for e in maps[o["map_off"]:o["map_off"] + o["map_n"]] if int(e) != NONE]
         out.append(o)
     return out
@@ -282,6 +282,7 @@ CASES = [
     (1, None), (2, None), (3, None), (6, None), (16, None),            # the reference's own sizes, cfg 4
     (40, None), (79, None),                                             # cfg 5: two-level super-steps, pairs, single steps
     (45, (8, 20, 1, 24, 32, 1, 1, 1, 30, 1)), (37, (4, 8, 0, 24, 6, 0, 1, 0, 0, 0)), (30, (2, 6, 1, 10, 4, 1, 0, 1, 99, 1)), (26, (0, 0, 1, 8, 4, 1, 1, 1, 0, 1)), (23, (0, 0, 0, 8, 64, 0, 0, 0, 0, 0)), (79, (4, 28, 1, 24, 32, 0, 0, 0, 0, 0)), (79, (4, 16, 1, 24, 32, 1, 1, 1, 44, 0)), (79, (4, 16, 1, 24, 32, 1, 1, 1, 0, 1)), (60, (4, 12, 1, 16, 8, 1, 1, 0, 30, 1)),
+    (79, (4, 40, 1, 24, 32, 1, 1, 1, 0, 0, 1)), (16, (4, 40, 1, 24, 32, 1, 1, 1, 0, 0, 1)), (37, (4, 8, 0, 24, 6, 0, 1, 0, 0, 0, 1)),      # the diagonal blocks in ONE resident workgroup (a fifth stream; tools/ only)
 ]
 
 
@@ -306,7 +307,7 @@ def test_waits_order_every_conflicting_pair(nblk, params):
     per_stream = {}
     for o in ops:
         per_stream.setdefault(o["stream"], []).append(o["ticket"])
-        assert len(o["waits"]) <= 5
+        assert len(o["waits"]) <= 6
         for ctr, val in o["waits"]:
             assert ctr != o["stream"]
     for s, tk in per_stream.items():
@@ -315,10 +316,12 @@ def test_waits_order_every_conflicting_pair(nblk, params):
     for o in ops:
         assert o["awaited"] == (1 if (o["stream"], o["ticket"] - 1) in waited else 0)
     for c, v in waited:
+        if c == 4:
+            continue          # the resident workgroup publishes each block's ticket itself, when the block is done
         assert v < len(per_stream[c]), "the last operation of a stream is waited for and nothing publishes it"
 
 
-@pytest.mark.parametrize("nblk,params", [(6, None), (16, None), (40, None), (79, None), (45, (8, 20, 1, 24, 32, 1, 1, 1, 30, 1)), (37, (4, 8, 0, 24, 6, 0, 1, 0, 0, 0)), (30, (2, 6, 1, 10, 4, 1, 0, 1, 99, 1))])
+@pytest.mark.parametrize("nblk,params", [(6, None), (16, None), (40, None), (79, None), (45, (8, 20, 1, 24, 32, 1, 1, 1, 30, 1)), (37, (4, 8, 0, 24, 6, 0, 1, 0, 0, 0)), (30, (2, 6, 1, 10, 4, 1, 0, 1, 99, 1)), (40, (4, 12, 1, 16, 8, 1, 1, 1, 0, 0, 1))])
 def test_any_order_the_waits_allow_gives_the_same_bits(nblk, params):
     ops = get_plan(nblk, params)
     T = 2 if nblk > 50 else 3
