@@ -359,7 +359,8 @@ int rcn_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *problem, const rcn_ba_optio
  * pipelined panel kernels, own stream for the two-level panel product (0/1), that product as the tail of the previous bulk launch (0/1), the head rows'
  * product and the next super-diagonal block's update through the latency kernel (0/1), rows below which a super-block's small operations
  * run on the chain's own stream, 2 g-row window of the chain's latency kernels (0/1), the diagonal
- * blocks in one resident workgroup (0/1)},
+ * blocks in one resident workgroup (0/1), bulk updates of the right-looking regime behind the next diagonal block (0/1), rows from which on the chain's next tiles are
+ * carved out of the right-looking regime's updates (0: never)},
  * NULL = what the library uses.  An operation is
  * RCN_PLAN_OP_WORDS int32: kind, stream, ticket, kb, first, m, dj, nst, map_off, map_n, g, pos, n_waits, 6 x (counter, value), timeline
  * slot, awaited, index of the bulk update whose launch carries this operation's tiles as its tail (-1: none), 1 = latency-kernel form.  Counters 0 .. 4 are the streams' progress counters (4: the resident workgroup that factors the diagonal blocks), 5 and 6 count the two

@@ -825,6 +825,7 @@ __device__ __forceinline__ f64x4 schur_mfma_chunk(const double *__restrict__ Wt,
 }
 
 // one wave per strictly-lower block (c, c2 < c), written straight into the dense reduced system
+template <int SMB>
 __global__ __launch_bounds__(256) void k_ba_schur_mfma(BaDev d, const int *off, const unsigned long long *list)
 {
     // (Round 4 tried dealing whole block rows to one XCD -- row c on XCD c % 8, so that camera c's Y rows are fetched into one
@@ -845,7 +846,7 @@ __global__ __launch_bounds__(256) void k_ba_schur_mfma(BaDev d, const int *off, 
     for (int base = e0; base < e1; base += 64) {
         const int cnt = min(64, e1 - base);
         const unsigned long long pr = lane < cnt ? list[base + lane] : 0ull;
-        acc = schur_mfma_chunk<false, 4>(d.WY, d.WY + WROW * (size_t)d.no, pr, cnt, lane, acc);
+        acc = schur_mfma_chunk<false, SMB>(d.WY, d.WY + WROW * (size_t)d.no, pr, cnt, lane, acc);
     }
     // C/D layout: column = lane & 15, row = (lane >> 4) + 4 * reg
     const int col = lane & 15, r0 = lane >> 4;
@@ -2276,10 +2277,10 @@ static int ensure_chol_plan(rcn_ctx *ctx, int nblk)
 {
     chol::Params prm;
     prm.nblk = nblk; prm.tl_g = ctx->chol_tl_g; prm.tl_min = ctx->chol_tl_min; prm.pair = ctx->chol_group >= 2 ? 1 : 0;
-    prm.pair_min = ctx->chol_pair_min; prm.pipe_min = ctx->chol_pipe_min; prm.pg_stream = ctx->chol_pg_stream; prm.fuse_tail = ctx->chol_fuse_tail; prm.head_small = ctx->chol_head_small; prm.tl_serial = ctx->chol_tl_serial; prm.window = ctx->chol_window; prm.diag_server = ctx->chol_diag_server;
+    prm.pair_min = ctx->chol_pair_min; prm.pipe_min = ctx->chol_pipe_min; prm.pg_stream = ctx->chol_pg_stream; prm.fuse_tail = ctx->chol_fuse_tail; prm.head_small = ctx->chol_head_small; prm.tl_serial = ctx->chol_tl_serial; prm.window = ctx->chol_window; prm.diag_server = ctx->chol_diag_server; prm.bulk_behind = ctx->chol_bulk_behind; prm.carve_rows = ctx->chol_carve_rows;
     const chol::Params &o = ctx->chol_plan.prm_asked;
     if (ctx->chol_plan_valid && o.nblk == prm.nblk && o.tl_g == prm.tl_g && o.tl_min == prm.tl_min && o.pair == prm.pair && o.pair_min == prm.pair_min &&
-        o.pipe_min == prm.pipe_min && o.pg_stream == prm.pg_stream && o.fuse_tail == prm.fuse_tail && o.head_small == prm.head_small && o.tl_serial == prm.tl_serial && o.window == prm.window && o.diag_server == prm.diag_server) return RCN_OK;
+        o.pipe_min == prm.pipe_min && o.pg_stream == prm.pg_stream && o.fuse_tail == prm.fuse_tail && o.head_small == prm.head_small && o.tl_serial == prm.tl_serial && o.window == prm.window && o.diag_server == prm.diag_server && o.bulk_behind == prm.bulk_behind && o.carve_rows == prm.carve_rows) return RCN_OK;
     ctx->chol_plan_valid = false;
     ctx->chol_plan = chol::make_plan(prm);
     ctx->chol_plan.prm_asked = prm;
@@ -2292,6 +2293,12 @@ static int ensure_chol_plan(rcn_ctx *ctx, int nblk)
         if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { (void)hipGetLastError(); lo = hi = 0; }
         const char *dsp = std::getenv("RCN_DIAG_STREAM_PRIO");
         if (dsp && std::atoi(dsp) == 0) hi = 0;
+        if (dsp && std::atoi(dsp) == 2) {      // a stream with a CU mask of all CUs: a hardware queue of its own?
+            const int ncu = ctx->prop.multiProcessorCount;
+            std::vector<uint32_t> full((ncu + 31) / 32, 0xFFFFFFFFu);
+            if (ncu % 32) full.back() = (1u << (ncu % 32)) - 1u;
+            RCN_HIP(hipExtStreamCreateWithCUMask(&ctx->diag_stream, (uint32_t)full.size(), full.data()));
+        } else
         RCN_HIP(hipStreamCreateWithPriority(&ctx->diag_stream, hipStreamNonBlocking, hi));
     }
     {   // the resident diagonal workgroup's list: block, whether the factor itself is stored (last block), ticket, waits
@@ -2364,10 +2371,10 @@ int rcn_ba_factor_plan(int32_t n_blocks, const int32_t *params, int32_t *ops, in
     {
         rcn_ctx defaults;      // (never created on a device: only the schedule's parameters are read)
         prm.tl_g = defaults.chol_tl_g; prm.tl_min = defaults.chol_tl_min; prm.pair = defaults.chol_group >= 2; prm.pair_min = defaults.chol_pair_min; prm.pipe_min = defaults.chol_pipe_min;
-        prm.pg_stream = defaults.chol_pg_stream; prm.fuse_tail = defaults.chol_fuse_tail; prm.head_small = defaults.chol_head_small; prm.tl_serial = defaults.chol_tl_serial; prm.window = defaults.chol_window; prm.diag_server = defaults.chol_diag_server;
+        prm.pg_stream = defaults.chol_pg_stream; prm.fuse_tail = defaults.chol_fuse_tail; prm.head_small = defaults.chol_head_small; prm.tl_serial = defaults.chol_tl_serial; prm.window = defaults.chol_window; prm.diag_server = defaults.chol_diag_server; prm.bulk_behind = defaults.chol_bulk_behind; prm.carve_rows = defaults.chol_carve_rows;
     }
     prm.nblk = n_blocks;
-    if (params) { prm.tl_g = params[0]; prm.tl_min = params[1]; prm.pair = params[2]; prm.pair_min = params[3]; prm.pipe_min = params[4]; prm.pg_stream = params[5]; prm.fuse_tail = params[6]; prm.head_small = params[7]; prm.tl_serial = params[8]; prm.window = params[9]; prm.diag_server = params[10]; }
+    if (params) { prm.tl_g = params[0]; prm.tl_min = params[1]; prm.pair = params[2]; prm.pair_min = params[3]; prm.pipe_min = params[4]; prm.pg_stream = params[5]; prm.fuse_tail = params[6]; prm.head_small = params[7]; prm.tl_serial = params[8]; prm.window = params[9]; prm.diag_server = params[10]; prm.bulk_behind = params[11]; prm.carve_rows = params[12]; }
     if (prm.tl_g < 0 || prm.tl_g == 1 || prm.tl_g > 16 || prm.pipe_min < 1) return RCN_ERR_ARG;
     const chol::Plan pl = chol::make_plan(prm);
     *n_ops = (int64_t)pl.ops.size();
@@ -2710,7 +2717,9 @@ int rcn_int_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_option
             if (nc > 1) {
                 const int nlow = nc * (nc - 1) / 2;
                 if (npairs_lower / (size_t)nlow > 128) k_ba_schur_mfma_wg<<<nlow, 512, 0, st>>>(d, pk_off, pk_list);   // long lists: a workgroup per block
-                else k_ba_schur_mfma<<<(nlow + 3) / 4, 256, 0, st>>>(d, pk_off, pk_list);
+                else if (ctx->schur_smb == 12) k_ba_schur_mfma<12><<<(nlow + 3) / 4, 256, 0, st>>>(d, pk_off, pk_list);
+                else if (ctx->schur_smb == 8) k_ba_schur_mfma<8><<<(nlow + 3) / 4, 256, 0, st>>>(d, pk_off, pk_list);
+                else k_ba_schur_mfma<4><<<(nlow + 3) / 4, 256, 0, st>>>(d, pk_off, pk_list);
             }
             if (nc < 128) k_ba_schur_diag_mfma<12><<<nc * csplit, 1024, 0, st>>>(d, pk_off, pk_list, ir, csplit);      // (few cameras: latency-bound, deep gathers)
             else k_ba_schur_diag_mfma<4><<<nc, 1024, 0, st>>>(d, pk_off, pk_list, ir, 1);
@@ -2736,15 +2745,24 @@ int rcn_int_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_option
         // progress side by side) raises flag 3; the factorisation is then repeated on ONE stream in list order, and every later
         // one runs that way (ctx->chol_safe).  Same bits either way: no operation's arithmetic depends on where it runs.
         auto factorise = [&](bool safe) -> hipError_t {
-            hipStream_t str[chol::N_STREAMS] = {st, safe ? st : ctx->panel_stream, safe ? st : ctx->aux_stream, safe ? st : ctx->panel2_stream, safe ? st : ctx->diag_stream};
+            // (the chain on a high-priority stream of the library's own, forked from and joined to the caller's: RCN_CHOL_CHAIN_STREAM, tools/)
+            const bool own_chain = !safe && ctx->chol_chain_stream && ctx->chain_stream;
+            hipStream_t str[chol::N_STREAMS] = {own_chain ? ctx->chain_stream : st, safe ? st : ctx->panel_stream, safe ? st : ctx->aux_stream, safe ? st : ctx->panel2_stream, safe ? st : ctx->diag_stream};
+#ifdef RCN_DIAG
+            const bool swap_ab = !safe && ctx->chol_chain_stream == 4;      // the chain on the panel stream's handle, the panels on the caller's stream
+            if (swap_ab) { str[0] = ctx->panel_stream; str[1] = st; }
+#else
+            const bool swap_ab = false;
+#endif
             int *const ctr_base = d.flag + 12;          // the streams' progress counters and the two head-tile counters (k_ba_S_finish clears them)
             int *ctr[chol::N_CTR];
             for (int c = 0; c < chol::N_CTR; ++c) ctr[c] = ctr_base + c;
             const chol::Plan &plan = ctx->chol_plan;
             if (!safe) {
-                hipError_t e = hipEventRecord(ctx->ba_ev[0], str[0]);
+                hipError_t e = hipEventRecord(ctx->ba_ev[0], st);
+                if ((own_chain || swap_ab) && e == hipSuccess) e = hipStreamWaitEvent(str[0], ctx->ba_ev[0], 0);
                 for (int s2 = 1; s2 < chol::N_STREAMS && e == hipSuccess; ++s2)
-                    if (plan.n_ops[s2]) e = hipStreamWaitEvent(str[s2], ctx->ba_ev[0], 0);     // the other streams start behind everything queued so far
+                    if (plan.n_ops[s2] && str[s2] != st) e = hipStreamWaitEvent(str[s2], ctx->ba_ev[0], 0);     // the other streams start behind everything queued so far
                 if (e != hipSuccess) return e;
             }
             const unsigned *maps = ctx->bulk_map.as<unsigned>();
@@ -2856,8 +2874,13 @@ int rcn_int_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_option
             // the chain continues (triangular solves) behind the last kernels of the other streams
             for (int s2 = 1; s2 < chol::N_STREAMS && e == hipSuccess; ++s2) {
                 if (!plan.n_ops[s2]) continue;
+                if (str[s2] == st) continue;
                 e = hipEventRecord(ctx->ba_ev[s2], str[s2]);
                 if (e == hipSuccess) e = hipStreamWaitEvent(str[0], ctx->ba_ev[s2], 0);
+            }
+            if ((own_chain || swap_ab) && e == hipSuccess) {
+                e = hipEventRecord(ctx->ba_ev[5], str[0]);
+                if (e == hipSuccess) e = hipStreamWaitEvent(st, ctx->ba_ev[5], 0);
             }
             return e;
         };

@@ -61,6 +61,15 @@ struct Params {
     int head_small = 1;   // two-level regime: the head rows' panel product and the update of the next super-diagonal block through the latency kernel
     int fuse_tail = 1;    // two-level regime: the panel product for the rows below the head rides as the TAIL of the previous bulk update's launch
                           // (it fills that launch's drain; as a launch of its own beside the bulk update both ran 15 % and more slower)
+    int bulk_behind = 0;  // right-looking regime, measured and NOT shipped: a bulk update listed BEHIND the next diagonal block, starting when that block's kernel has
+                          // started (its first thread publishes the chain's progress).  Workgroups are dispatched launch by launch, and a one-workgroup diagonal
+                          // kernel that arrives just behind a bulk launch waits 25-45 us for its several hundred workgroups to be placed (device timeline,
+                          // round 5); with the order turned round that wait is gone -- and the critical tile's update waits as much longer for the bulk
+                          // update's leading tiles, which now start later: 8.41-8.49 against 8.39-8.47 ms
+    int carve_rows = 0;   // right-looking regime, measured and NOT shipped (8.41-8.60 against 8.41 ms; the diagonal kernel shares its CUs with more small kernels and
+                          // the carved tiles wait for the WHOLE previous bulk update): from this many tile rows below the step on (0: never) the tiles the CHAIN reads next -- the next group's
+                          // diagonal window out of the bulk update, row kb + 2 out of a step's column updates -- go through the latency kernel as
+                          // operations of their own, so that the chain waits for a handful of small workgroups, not for a bulk launch's leading tiles
     int pg_stream = 1;    // two-level regime (first super-step, or fuse_tail = 0): the product for the rows below the head runs on a stream of its own (D) -- on B it would hold up the
                           // next super-step's in-block work, which the chain waits for
 };
@@ -122,6 +131,7 @@ private:
     std::vector<int> cum1, cum2;      // per operation: head tiles of class 1 / 2 counted out by the bulk stream up to and including it
     int sig_total[2] = {0, 0};
     int have[N_STREAMS][N_CTR] = {};
+    int extra_need[N_CTR] = {-1, -1, -1, -1, -1, -1, -1};      // consumed by the next add()
     bool fuse_bad = false;
     int sib = 0;                      // which of the two super-block inverse buffers the current super-step uses
     int last_bulk = -1;               // the last bulk update of the two-level regime: the next super-step's panel product may ride in its launch
@@ -143,6 +153,7 @@ private:
             if (cls > 0) { int &v = need[CTR_SIG1 + cls - 1]; v = std::max(v, cls == 1 ? cum1[(size_t)y] : cum2[(size_t)y]); }
             else { int &v = need[oy.stream]; v = std::max(v, oy.ticket); }
         };
+        for (int c = 0; c < N_CTR; ++c) { need[c] = std::max(need[c], extra_need[c]); extra_need[c] = -1; }      // (an ordering asked for on top of the tiles': bulk_behind)
         for (int t : reads) dep(cells[(size_t)t].wop, cells[(size_t)t].wcls);
         for (const Wr &w : writes) {
             Cell &c = cells[(size_t)w.tile];
@@ -179,10 +190,10 @@ private:
     }
 
     // ---- single operations
-    void diag(int k)
+    int diag(int k)
     {
         Op o; o.kind = DIAG; o.stream = prm.diag_server ? ST_E : ST_A; o.kb = k; o.tl = 8 * k + 0;
-        add(o, {tS(k, k)}, {{tLinv(k), 0}, {tS(k, k), 0}});
+        return add(o, {tS(k, k)}, {{tLinv(k), 0}, {tS(k, k), 0}});
     }
     void trsm_q(int stream, int kb, int first, int m, int tl)
     {
@@ -405,37 +416,61 @@ private:
     // ---- right-looking steps from block p on (rounds 3 / 4: critical tile first, pairs of panels per bulk update)
     void right_looking(int p)
     {
-        int g_size = 1, g_pos = 0;
+        int g_size = 1, g_pos = 0, diag_listed = -1;
         for (int kb = p; kb < nblk; ++kb) {
             const int m = nblk - kb - 1;
             if (g_pos == 0) g_size = (prm.pair && m - 2 >= prm.pair_min && m >= 4) ? 2 : 1;
             const int ncols = g_size - g_pos;
             const bool last_of_group = g_pos == g_size - 1;
-            diag(kb);
+            if (diag_listed != kb) diag(kb);
             if (m <= 0) break;
             trsm_q(ST_A, kb, 0, 1, 8 * kb + 1);
             upd_q(ST_A, kb, 0, 1, 1, 8 * kb + 2);
             if (m <= 1) continue;
             const bool piped = m - 1 >= prm.pipe_min;
+            const bool carve = prm.carve_rows > 0 && m <= prm.carve_rows;
             if (piped) trsm_pipe(ST_B, kb, kb + 2, nblk, 8 * kb + 3);
             else trsm_q(ST_B, kb, 1, m - 1, 8 * kb + 3);
+            if (carve) {
+                // row kb + 2 of the column updates first and by itself: what the next steps of the chain read
+                std::vector<uint32_t> crit;
+                for (int c = 1; c <= ncols && kb + c <= kb + 2; ++c) crit.push_back(map_entry(kb + 2, kb + c));
+                upd_pipe_list(ST_B, kb, 1, crit, 8 * kb + 4, 1);
+            }
+            const int r_first = carve ? kb + 3 : kb + 2;
             if (piped) {
                 std::vector<uint32_t> tiles;
-                for (int r = kb + 2; r < nblk; ++r)
+                for (int r = r_first; r < nblk; ++r)
                     for (int c = 1; c <= ncols && kb + c <= r; ++c) tiles.push_back(map_entry(r, kb + c));
-                upd_pipe_list(ST_B, kb, 1, tiles, 8 * kb + 4);
+                if (!tiles.empty()) upd_pipe_list(ST_B, kb, 1, tiles, 8 * kb + 4);
             } else {
-                for (int c = 1; c <= ncols; ++c) upd_q(ST_B, kb, 1, m - 1, c, 8 * kb + 3 + c);
+                for (int c = 1; c <= ncols; ++c) upd_q(ST_B, kb, r_first - kb - 1, nblk - r_first, c, 8 * kb + 3 + c);
             }
             if (!last_of_group) { ++g_pos; continue; }
             g_pos = 0;
             const int c0 = kb + 2, kfirst = kb - (g_size - 1);
+            // (carve: the next group's diagonal window -- what its chain steps read of this update -- as an operation of its own)
+            const int xw = carve ? std::min(nblk, c0 + g_size) : c0;
+            if (carve) {
+                std::vector<uint32_t> xt;
+                for (int i = c0; i < xw; ++i)
+                    for (int j = c0; j <= i; ++j) xt.push_back(map_entry(i, j));
+                upd_pipe_list(ST_B, kfirst, g_size, xt, 8 * kb + 5, 1);
+            }
             std::vector<uint32_t> lead;
             for (int i = c0; i < nblk; ++i)
-                for (int j = c0; j < c0 + g_size && j <= i; ++j) lead.push_back(map_entry(i, j, 1));
+                for (int j = c0; j < c0 + g_size && j <= i; ++j)
+                    if (i >= xw) lead.push_back(map_entry(i, j, 1));
             std::vector<uint32_t> per[8];
             region_map(c0, lead, [&](int, int j) { return j < c0 + g_size; }, per);
+            if (prm.bulk_behind && !prm.diag_server) {
+                // the next diagonal block first (it needs the critical tile's update only), and the bulk update not before its kernel runs
+                const Op &dn = plan.ops[(size_t)diag(kb + 1)];
+                diag_listed = kb + 1;
+                extra_need[dn.stream] = dn.ticket - 1;
+            }
             upd_pipe(ST_C, kfirst, g_size, per, 8 * kb + 6);
+            for (int &v : extra_need) v = -1;
         }
     }
 };

@@ -130,6 +130,8 @@ int rcn_create(int device_id, rcn_ctx **out)
     ctx->ba_atomics = bat && bat[0] == '1';
     const char *btf = getenv("RCN_BA_TRSV_FWD");
     ctx->ba_trsv_fwd = btf && btf[0] == '1';
+    const char *ssm = std::getenv("RCN_SCHUR_SMB");
+    if (ssm) ctx->schur_smb = std::atoi(ssm);
     const char *cs = std::getenv("RCN_CHOL_SAFE");
     ctx->chol_safe = cs && cs[0] == '1';
     const char *tch = std::getenv("RCN_TRSV_CHAIN");
@@ -146,6 +148,24 @@ int rcn_create(int device_id, rcn_ctx **out)
     if (ctm) ctx->chol_tl_min = std::atoi(ctm);
     const char *cps = std::getenv("RCN_CHOL_PGSTREAM");
     if (cps) ctx->chol_pg_stream = std::atoi(cps);
+    const char *ccs = std::getenv("RCN_CHOL_CHAIN_STREAM");
+    if (ccs) ctx->chol_chain_stream = std::atoi(ccs);
+    if (std::getenv("RCN_NO_PANEL2") && ctx->panel2_stream) { (void)hipStreamDestroy(ctx->panel2_stream); ctx->panel2_stream = nullptr; }      // (with RCN_CHOL_PGSTREAM=0 only)
+    if (ctx->chol_chain_stream && ctx->chol_chain_stream != 4 && !ctx->chain_stream) {
+        int lo = 0, hi = 0;
+        if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { (void)hipGetLastError(); lo = hi = 0; }
+        if (ctx->chol_chain_stream == 3) {      // a stream with a CU mask of all CUs: a hardware queue of its own?
+            const int ncu = ctx->prop.multiProcessorCount;
+            std::vector<uint32_t> full((ncu + 31) / 32, 0xFFFFFFFFu);
+            if (ncu % 32) full.back() = (1u << (ncu % 32)) - 1u;
+            if (hipExtStreamCreateWithCUMask(&ctx->chain_stream, (uint32_t)full.size(), full.data()) != hipSuccess) { (void)hipGetLastError(); ctx->chain_stream = nullptr; }
+        } else
+        if (hipStreamCreateWithPriority(&ctx->chain_stream, hipStreamNonBlocking, ctx->chol_chain_stream == 2 ? 0 : hi) != hipSuccess) { (void)hipGetLastError(); ctx->chain_stream = nullptr; }
+    }
+    const char *cbb = std::getenv("RCN_CHOL_BULK_BEHIND");
+    if (cbb) ctx->chol_bulk_behind = std::atoi(cbb);
+    const char *ccv = std::getenv("RCN_CHOL_CARVE");
+    if (ccv) ctx->chol_carve_rows = std::atoi(ccv);
     const char *cds = std::getenv("RCN_CHOL_DIAG_SERVER");
     if (cds) ctx->chol_diag_server = std::atoi(cds);
     const char *cwn = std::getenv("RCN_CHOL_WINDOW");
@@ -210,6 +230,7 @@ void rcn_destroy(rcn_ctx *ctx)
     if (ctx->panel_stream) (void)hipStreamDestroy(ctx->panel_stream);
     if (ctx->panel2_stream) (void)hipStreamDestroy(ctx->panel2_stream);
     if (ctx->diag_stream) (void)hipStreamDestroy(ctx->diag_stream);
+    if (ctx->chain_stream) (void)hipStreamDestroy(ctx->chain_stream);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }

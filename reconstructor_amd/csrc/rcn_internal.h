@@ -168,7 +168,9 @@ struct rcn_ctx {
     bool no_item_order = false;   // RCN_MATCH_NO_ORDER=1: work items in pair order instead of heaviest-first per XCD
     bool ba_atomics = false;   // RCN_BA_SCHUR_ATOMICS=1: atomic Schur accumulation instead of the gather form
     bool ba_trsv_fwd = false;  // RCN_BA_TRSV_FWD=1: separate forward substitution instead of the rhs row inside the factorisation
+    int schur_smb = 4;         // RCN_SCHUR_SMB=4/8/12: MFMA steps' worth of gathers in flight per wave of k_ba_schur_mfma
 #else
+    static constexpr int schur_smb = 4;
     static constexpr bool coarse_w4 = false;
     static constexpr int coarse_shape = -1;
     static constexpr int ablate = 0;
@@ -188,6 +190,8 @@ struct rcn_ctx {
     uint64_t ba_pair_token = 0;         // whose pair lists the Schur-build workspace holds (0 = nobody's)
     std::vector<int> ba_pair_camdim;    // ... and the per-camera tangent dimensions they were built for (a camera without free parameters has no pairs)
     hipStream_t aux_stream = nullptr;   // lookahead stream of the Cholesky: bulk trailing updates (CU mask leaves one CU per XCD to the diagonal kernel)
+    hipStream_t chain_stream = nullptr;  // diagnostic build (RCN_CHOL_CHAIN_STREAM=1): the factorisation's chain on a highest-priority stream of the library's own
+    int chol_chain_stream = 0;
     hipStream_t diag_stream = nullptr;   // the resident workgroup that factors the diagonal blocks of a factorisation (k_chol_diag_server)
     hipStream_t panel2_stream = nullptr; // two-level regime of the Cholesky: the panel product for the rows below the head (same CU mask)
     hipStream_t panel_stream = nullptr; // second chain stream of the Cholesky: panels and first trailing columns behind the critical tile (same CU mask)
@@ -198,6 +202,8 @@ struct rcn_ctx {
     bool chol_plan_valid = false;
     int chol_tl_g = 4;                               // two-level regime: panels per super-step (K = 128 g per bulk update); 0 = right-looking steps only (diagnostic build: RCN_CHOL_TL)
     int chol_diag_server = 0;                        // diagnostic build (RCN_CHOL_DIAG_SERVER=1): the diagonal blocks in one resident workgroup instead of a launch per block on the chain's stream
+    int chol_bulk_behind = 0;                        // right-looking regime: a bulk update starts when the next diagonal block's kernel has started (chol_plan.h; RCN_CHOL_BULK_BEHIND=1 in the diagnostic build: measured, not shipped)
+    int chol_carve_rows = 0;                         // right-looking regime: the chain's next tiles as latency-kernel operations of their own from this many rows on (chol_plan.h; RCN_CHOL_CARVE)
     int chol_window = 0;                             // two-level regime: 2 g-row window of the chain's latency kernels (RCN_CHOL_WINDOW)
     int chol_tl_serial = 0;                          // two-level regime: super-blocks with fewer tile rows below them run their small operations on the chain's stream (RCN_CHOL_TL_SERIAL)
     int chol_head_small = 1;                         // two-level regime: head rows' product + next super-diagonal block's update through k_gemm_qm (RCN_CHOL_HEAD_SMALL)
@@ -213,7 +219,7 @@ struct rcn_ctx {
     int chol_break = 0;                              // diagnostic build: 1 = break one cross-stream hand-off (forces the one-stream fallback); 2 = and put a NaN pivot behind it
     int chol_pair_min = 24;                          // two-panel bulk updates while at least this many tile rows remain below the pair
     bool chol_safe = false;             // a device-counter hand-off timed out once: factorise on one stream, in plain order, from then on
-    hipEvent_t ba_ev[9];             // [0]: fork of the factorisation's streams, [1..3]: their joins, [7]: pair lists
+    hipEvent_t ba_ev[9];             // [0]: fork of the factorisation's streams, [1..4]: their joins, [5]: the chain's own stream back to the caller's, [7]: pair lists
     hipEvent_t ba_tev[6];            // phase timing of rcn_ba_solve ([4], [5]: around k_ba_eval<true>)
     bool ba_ev_made = false;
 

@@ -31,7 +31,10 @@ def get_plan(nblk, params=None):
     n_ops, n_maps = C.c_int64(0), C.c_int64(0)
     prm = None
     if params is not None:
-        prm = np.asarray(tuple(params) + ((0,) if len(params) == 10 else ()), dtype=np.int32)      # (ten entries: the diagonal blocks as launches on the chain's stream, the product's way)
+        params = tuple(params) + ((0,) if len(params) == 10 else ())
+        params = params + ((0,) if len(params) == 11 else ())      # (eleven entries: bulk updates in front of the next diagonal block, the product's way)
+        params = params + ((0,) if len(params) == 12 else ())      # (twelve entries: nothing carved out of the right-looking regime's updates)
+        prm = np.asarray(params, dtype=np.int32)      # (ten entries: the diagonal blocks as launches on the chain's stream, the product's way)
     pp = prm.ctypes.data if prm is not None else None
     fn(nblk, pp, None, 0, None, 0, C.byref(n_ops), C.byref(n_maps))
     ops = np.zeros((max(n_ops.value, 1), OPW), dtype=np.int32)
@@ -281,7 +284,7 @@ def run_random_order(ops, nblk, T, A, seed):
 CASES = [
     (1, None), (2, None), (3, None), (6, None), (16, None),            # the reference's own sizes, cfg 4
     (40, None), (79, None),                                             # cfg 5: two-level super-steps, pairs, single steps
-    (45, (8, 20, 1, 24, 32, 1, 1, 1, 30, 1)), (37, (4, 8, 0, 24, 6, 0, 1, 0, 0, 0)), (30, (2, 6, 1, 10, 4, 1, 0, 1, 99, 1)), (26, (0, 0, 1, 8, 4, 1, 1, 1, 0, 1)), (23, (0, 0, 0, 8, 64, 0, 0, 0, 0, 0)), (79, (4, 28, 1, 24, 32, 0, 0, 0, 0, 0)), (79, (4, 16, 1, 24, 32, 1, 1, 1, 44, 0)), (79, (4, 16, 1, 24, 32, 1, 1, 1, 0, 1)), (60, (4, 12, 1, 16, 8, 1, 1, 0, 30, 1)),
+    (45, (8, 20, 1, 24, 32, 1, 1, 1, 30, 1)), (37, (4, 8, 0, 24, 6, 0, 1, 0, 0, 0)), (30, (2, 6, 1, 10, 4, 1, 0, 1, 99, 1)), (26, (0, 0, 1, 8, 4, 1, 1, 1, 0, 1)), (23, (0, 0, 0, 8, 64, 0, 0, 0, 0, 0)), (79, (4, 28, 1, 24, 32, 0, 0, 0, 0, 0)), (79, (4, 16, 1, 24, 32, 1, 1, 1, 44, 0)), (79, (4, 16, 1, 24, 32, 1, 1, 1, 0, 1)), (60, (4, 12, 1, 16, 8, 1, 1, 0, 30, 1)), (79, (4, 40, 1, 24, 32, 1, 1, 1, 0, 0, 0, 1)), (33, (0, 0, 1, 8, 4, 1, 1, 1, 0, 0, 0, 1)), (79, (4, 40, 1, 24, 32, 1, 1, 1, 0, 0, 0, 1, 34)), (41, (0, 0, 1, 8, 12, 1, 1, 1, 0, 0, 0, 1, 99)), (30, (0, 0, 1, 24, 64, 1, 1, 1, 0, 0, 0, 0, 99)), (7, (0, 0, 1, 2, 2, 1, 1, 1, 0, 0, 0, 1, 99)),      # (the last two: bulk updates listed in front of the next diagonal block, as in round 4)
     (79, (4, 40, 1, 24, 32, 1, 1, 1, 0, 0, 1)), (16, (4, 40, 1, 24, 32, 1, 1, 1, 0, 0, 1)), (37, (4, 8, 0, 24, 6, 0, 1, 0, 0, 0, 1)),      # the diagonal blocks in ONE resident workgroup (a fifth stream; tools/ only)
 ]
 
@@ -321,7 +324,7 @@ def test_waits_order_every_conflicting_pair(nblk, params):
         assert v < len(per_stream[c]), "the last operation of a stream is waited for and nothing publishes it"
 
 
-@pytest.mark.parametrize("nblk,params", [(6, None), (16, None), (40, None), (79, None), (45, (8, 20, 1, 24, 32, 1, 1, 1, 30, 1)), (37, (4, 8, 0, 24, 6, 0, 1, 0, 0, 0)), (30, (2, 6, 1, 10, 4, 1, 0, 1, 99, 1)), (40, (4, 12, 1, 16, 8, 1, 1, 1, 0, 0, 1))])
+@pytest.mark.parametrize("nblk,params", [(6, None), (16, None), (40, None), (79, None), (45, (8, 20, 1, 24, 32, 1, 1, 1, 30, 1)), (37, (4, 8, 0, 24, 6, 0, 1, 0, 0, 0)), (30, (2, 6, 1, 10, 4, 1, 0, 1, 99, 1)), (40, (4, 12, 1, 16, 8, 1, 1, 1, 0, 0, 1)), (40, (4, 24, 1, 8, 12, 1, 1, 1, 0, 0, 0, 1, 99))])
 def test_any_order_the_waits_allow_gives_the_same_bits(nblk, params):
     ops = get_plan(nblk, params)
     T = 2 if nblk > 50 else 3
@@ -369,3 +372,16 @@ def test_the_shipping_schedule_at_cfg5_is_two_level():
             in_window = i < group_end[p] + ((group_end[p] - p) if (window and group_end[p] - p > 1) else 0)
             want = j if in_window else p
             assert cnt[i, j] == want, (i, j, cnt[i, j], want)
+
+
+def test_bulk_updates_behind_the_next_diagonal_block():
+    """The plan option bulk_behind (measured, not shipped): a bulk update of the right-looking regime is listed behind the next diagonal
+    block and waits for the chain's counter to say that block's kernel has started (the value the block publishes with its first thread)."""
+    ops = get_plan(79, (4, 40, 1, 24, 32, 1, 1, 1, 0, 0, 0, 1))
+    rl = [i for i, o in enumerate(ops) if o["kind"] == UPD_PIPE and o["stream"] == 2 and o["nst"] < 64]
+    assert len(rl) >= 20
+    for i in rl:
+        prev_diag = max(j for j in range(i) if ops[j]["kind"] == DIAG)
+        assert ops[prev_diag]["kb"] == ops[i]["kb"] + ops[i]["nst"] // 16, "the next diagonal block is listed in front of the bulk update"
+        assert not any(ops[j]["stream"] == 0 for j in range(prev_diag + 1, i))
+        assert any(c == 0 and v >= ops[prev_diag]["ticket"] - 1 for c, v in ops[i]["waits"])
