@@ -824,6 +824,10 @@ __device__ __forceinline__ f64x4 schur_mfma_chunk(const double *__restrict__ Wt,
     return acc;
 }
 
+// (Round 5, measured and not kept -- profiles/r05_experiments/stream_kernels_schur_*.txt, 515-541 us per cfg-5 launch as it stands: more
+//  gathers in flight per block, SMB = 8 / 12: 557 / 675 us, the extra trips are predicated-off instructions; the operands fetched as
+//  whole 240-byte rows, 16 bytes per lane, through LDS: 674 us, same bits; two / three / four blocks per wave with all their gathers in
+//  flight at once: 689 / 819 / 883 us.  Neither latency nor the number of load instructions is what bounds it.)
 // one wave per strictly-lower block (c, c2 < c), written straight into the dense reduced system
 template <int SMB>
 __global__ __launch_bounds__(256) void k_ba_schur_mfma(BaDev d, const int *off, const unsigned long long *list)
@@ -2288,6 +2292,12 @@ static int ensure_chol_plan(rcn_ctx *ctx, int nblk)
     const size_t nm = std::max<size_t>(ctx->chol_plan.maps.size(), 1);
     RCN_HIP(ctx->bulk_map.reserve(nm * sizeof(unsigned)));
     if (!ctx->chol_plan.maps.empty()) RCN_HIP(hipMemcpy(ctx->bulk_map.p, ctx->chol_plan.maps.data(), ctx->chol_plan.maps.size() * sizeof(unsigned), hipMemcpyHostToDevice));
+    if (prm.pg_stream && !ctx->panel2_stream) {      // a fourth stream for the first super-step's panel product (the shipping plan has none)
+        if (ctx->bulk_cu_mask.empty() || hipExtStreamCreateWithCUMask(&ctx->panel2_stream, (uint32_t)ctx->bulk_cu_mask.size(), ctx->bulk_cu_mask.data()) != hipSuccess) {
+            (void)hipGetLastError();
+            RCN_HIP(hipStreamCreateWithFlags(&ctx->panel2_stream, hipStreamNonBlocking));
+        }
+    }
     if (prm.diag_server && !ctx->diag_stream) {      // (tools/ only: the product's plans have no resident workgroup)
         int lo = 0, hi = 0;
         if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { (void)hipGetLastError(); lo = hi = 0; }
@@ -2717,8 +2727,6 @@ int rcn_int_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_option
             if (nc > 1) {
                 const int nlow = nc * (nc - 1) / 2;
                 if (npairs_lower / (size_t)nlow > 128) k_ba_schur_mfma_wg<<<nlow, 512, 0, st>>>(d, pk_off, pk_list);   // long lists: a workgroup per block
-                else if (ctx->schur_smb == 12) k_ba_schur_mfma<12><<<(nlow + 3) / 4, 256, 0, st>>>(d, pk_off, pk_list);
-                else if (ctx->schur_smb == 8) k_ba_schur_mfma<8><<<(nlow + 3) / 4, 256, 0, st>>>(d, pk_off, pk_list);
                 else k_ba_schur_mfma<4><<<(nlow + 3) / 4, 256, 0, st>>>(d, pk_off, pk_list);
             }
             if (nc < 128) k_ba_schur_diag_mfma<12><<<nc * csplit, 1024, 0, st>>>(d, pk_off, pk_list, ir, csplit);      // (few cameras: latency-bound, deep gathers)

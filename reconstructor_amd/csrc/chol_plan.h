@@ -70,8 +70,10 @@ struct Params {
                           // the carved tiles wait for the WHOLE previous bulk update): from this many tile rows below the step on (0: never) the tiles the CHAIN reads next -- the next group's
                           // diagonal window out of the bulk update, row kb + 2 out of a step's column updates -- go through the latency kernel as
                           // operations of their own, so that the chain waits for a handful of small workgroups, not for a bulk launch's leading tiles
-    int pg_stream = 1;    // two-level regime (first super-step, or fuse_tail = 0): the product for the rows below the head runs on a stream of its own (D) -- on B it would hold up the
-                          // next super-step's in-block work, which the chain waits for
+    int pg_stream = 0;    // two-level regime (first super-step, or fuse_tail = 0), 1: the product for the rows below the head runs on a stream of its own (D) -- on B it holds up the
+                          // next super-step's in-block work, which the chain waits for.  With the products riding in the bulk launches only the first super-step is
+                          // left, and that measures the same either way (8.42-8.51 against 8.36-8.48 ms): the shipping plan keeps to three streams -- a process's
+                          // sixth stream is a slow one on this pool (EXPERIMENTS.md), and the library should not be the one that uses the fifth up
 };
 
 struct Plan {

@@ -71,10 +71,7 @@ int rcn_create(int device_id, rcn_ctx **out)
             (void)hipGetLastError();
             ctx->aux_stream = nullptr;
         }
-        if (hipExtStreamCreateWithCUMask(&ctx->panel2_stream, (uint32_t)mask.size(), mask.data()) != hipSuccess) {
-            (void)hipGetLastError();
-            ctx->panel2_stream = nullptr;
-        }
+        ctx->bulk_cu_mask = mask;      // (a second stream under the same mask is made when a plan asks for it: ensure_chol_plan)
         if (panel_mode != 1) {
             const std::vector<uint32_t> &pm = panel_mode == 2 ? mask8 : mask;
             if (hipExtStreamCreateWithCUMask(&ctx->panel_stream, (uint32_t)pm.size(), pm.data()) != hipSuccess) {
@@ -100,10 +97,6 @@ int rcn_create(int device_id, rcn_ctx **out)
         if (pm || ps) (void)rcn_diag_set_poll(pm ? std::atoi(pm) : 0, ps ? std::atoi(ps) : 1);
     }
 #endif
-    if (!ctx->panel2_stream && hipStreamCreateWithFlags(&ctx->panel2_stream, hipStreamNonBlocking) != hipSuccess) {
-        delete ctx;
-        return RCN_ERR_HIP;
-    }
     if (!ctx->aux_stream && hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking) != hipSuccess) {
         delete ctx;
         return RCN_ERR_HIP;
@@ -130,8 +123,6 @@ int rcn_create(int device_id, rcn_ctx **out)
     ctx->ba_atomics = bat && bat[0] == '1';
     const char *btf = getenv("RCN_BA_TRSV_FWD");
     ctx->ba_trsv_fwd = btf && btf[0] == '1';
-    const char *ssm = std::getenv("RCN_SCHUR_SMB");
-    if (ssm) ctx->schur_smb = std::atoi(ssm);
     const char *cs = std::getenv("RCN_CHOL_SAFE");
     ctx->chol_safe = cs && cs[0] == '1';
     const char *tch = std::getenv("RCN_TRSV_CHAIN");
@@ -150,7 +141,6 @@ int rcn_create(int device_id, rcn_ctx **out)
     if (cps) ctx->chol_pg_stream = std::atoi(cps);
     const char *ccs = std::getenv("RCN_CHOL_CHAIN_STREAM");
     if (ccs) ctx->chol_chain_stream = std::atoi(ccs);
-    if (std::getenv("RCN_NO_PANEL2") && ctx->panel2_stream) { (void)hipStreamDestroy(ctx->panel2_stream); ctx->panel2_stream = nullptr; }      // (with RCN_CHOL_PGSTREAM=0 only)
     if (ctx->chol_chain_stream && ctx->chol_chain_stream != 4 && !ctx->chain_stream) {
         int lo = 0, hi = 0;
         if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { (void)hipGetLastError(); lo = hi = 0; }

@@ -168,9 +168,7 @@ struct rcn_ctx {
     bool no_item_order = false;   // RCN_MATCH_NO_ORDER=1: work items in pair order instead of heaviest-first per XCD
     bool ba_atomics = false;   // RCN_BA_SCHUR_ATOMICS=1: atomic Schur accumulation instead of the gather form
     bool ba_trsv_fwd = false;  // RCN_BA_TRSV_FWD=1: separate forward substitution instead of the rhs row inside the factorisation
-    int schur_smb = 4;         // RCN_SCHUR_SMB=4/8/12: MFMA steps' worth of gathers in flight per wave of k_ba_schur_mfma
 #else
-    static constexpr int schur_smb = 4;
     static constexpr bool coarse_w4 = false;
     static constexpr int coarse_shape = -1;
     static constexpr int ablate = 0;
@@ -193,7 +191,8 @@ struct rcn_ctx {
     hipStream_t chain_stream = nullptr;  // diagnostic build (RCN_CHOL_CHAIN_STREAM=1): the factorisation's chain on a highest-priority stream of the library's own
     int chol_chain_stream = 0;
     hipStream_t diag_stream = nullptr;   // the resident workgroup that factors the diagonal blocks of a factorisation (k_chol_diag_server)
-    hipStream_t panel2_stream = nullptr; // two-level regime of the Cholesky: the panel product for the rows below the head (same CU mask)
+    hipStream_t panel2_stream = nullptr; // two-level regime of the Cholesky, plans with pg_stream only (not what ships): the panel product for the rows below the head (same CU mask); made on demand
+    std::vector<uint32_t> bulk_cu_mask;  // the bulk stream's CU mask
     hipStream_t panel_stream = nullptr; // second chain stream of the Cholesky: panels and first trailing columns behind the critical tile (same CU mask)
     // the factorisation's schedule (chol_plan.h: operations, streams, waits, tile maps) for the last shape solved; its maps in HBM
     DevBuf bulk_map;
@@ -208,7 +207,7 @@ struct rcn_ctx {
     int chol_tl_serial = 0;                          // two-level regime: super-blocks with fewer tile rows below them run their small operations on the chain's stream (RCN_CHOL_TL_SERIAL)
     int chol_head_small = 1;                         // two-level regime: head rows' product + next super-diagonal block's update through k_gemm_qm (RCN_CHOL_HEAD_SMALL)
     int chol_fuse_tail = 1;                          // two-level regime: the panel product below the head rows as the tail of the previous bulk launch (RCN_CHOL_FUSE_TAIL)
-    int chol_pg_stream = 1;                          // two-level regime: the panel product below the head rows on a stream of its own (RCN_CHOL_PGSTREAM)
+    int chol_pg_stream = 0;                          // two-level regime: the panel product below the head rows on a stream of its own (RCN_CHOL_PGSTREAM)
     bool chol_pg_prio = true;                        // diagnostic build (RCN_CHOL_PG_PRIO=0): no raised wave priority for the panel product below the head rows
     int chol_gate_in_kernel = 0;                     // diagnostic build (RCN_CHOL_GATE_IN_KERNEL=1): waits of the small kernels off the chain inside them, not in a gate kernel in front; -1: in front on the chain too
     bool chol_host_time = false;                     // diagnostic build (RCN_CHOL_HOSTTIME=1): print the host time of every factorisation's enqueue
