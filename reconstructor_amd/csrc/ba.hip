@@ -227,6 +227,12 @@ struct Fin {
     double *flag_out;
     double *zero;           // optional: a cell to clear (where the next gradient maximum is collected)
     double scale;
+    // optional (round 5): the step's scalars straight into the host's pinned mirror -- scal[0 .. 14) as they stand when this, the
+    // step's last reduction, is done, then the sequence number the host spins on.  A copy command plus a stream synchronisation took
+    // ~27 us of a small problem's ~110-us iteration; a store over the fabric and a poll take a few.
+    double *host;
+    const double *scal;
+    unsigned long long seq;
 };
 template <int NS>
 __device__ __forceinline__ void finish_sums(const double (&mine)[NS], double *partial, int stride, const Fin &f, double *sh)
@@ -254,6 +260,11 @@ __device__ __forceinline__ void finish_sums(const double (&mine)[NS], double *pa
         __hip_atomic_store(f.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (f.flag) *f.flag_out = (double)__hip_atomic_load(f.flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (f.zero) *f.zero = 0.0;
+        if (f.host) {
+            // (the other cells were written by earlier kernels of the stream, and by this thread just above)
+            for (int i = 0; i < 14; ++i) __hip_atomic_store(f.host + i, f.scal[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(reinterpret_cast<unsigned long long *>(f.host + 15), f.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
 }
 
@@ -717,6 +728,45 @@ __global__ __launch_bounds__(256) void k_pair_fill(BaDev d, const int *off, int 
         const int o = o0 + pr / k, o2 = o0 + pr % k;
         int key;
         if (pair_key(d, o, o2, key)) list[off[key] + atomicAdd(fill + key, 1)] = ((unsigned long long)o << 32) | (unsigned)o2;
+    }
+}
+
+// Count, scan and fill in ONE workgroup for the reference's own problem sizes (up to 32 cameras: nc^2 <= 1024 keys; round 5): the six
+// launches above (clear, count, three scan passes, fill) were ~25 us of a solve that is ~400 us long, and the host spent as long again
+// enqueueing them.  Per-key counters and fill cursors live in LDS; a thread walks the pairs of its landmarks.  The order inside a key
+// is whatever the atomics gave -- as in k_pair_fill -- and the two sort kernels behind make it ascending.
+__global__ __launch_bounds__(1024) void k_pair_small(BaDev d, int *off, unsigned long long *list, int nkeys)
+{
+    __shared__ int cnt[1024], cur[1024], sh[16];
+    const int t = threadIdx.x;
+    cnt[t] = 0; cur[t] = 0;
+    __syncthreads();
+    // tp threads per landmark (a power of two): they share out its pairs
+    int tp = 1;
+    while (2 * tp * d.np <= 1024 && tp < 64) tp *= 2;
+    const int sub = t & (tp - 1), jstep = 1024 / tp;
+    for (int j = t / tp; j < d.np; j += jstep) {
+        const int o0 = d.pt_off[j], k = d.pt_off[j + 1] - o0;
+        for (int pr = sub; pr < k * k; pr += tp) {
+            int key;
+            if (pair_key(d, o0 + pr / k, o0 + pr % k, key)) atomicAdd(&cnt[key], 1);
+        }
+    }
+    __syncthreads();
+    const int v = t < nkeys ? cnt[t] : 0;
+    const int inc = block_scan_1024(v, sh);
+    if (t < nkeys) off[t] = inc - v;
+    if (t == 1023) off[nkeys] = inc;
+    __syncthreads();
+    cnt[t] = inc - v;
+    __syncthreads();
+    for (int j = t / tp; j < d.np; j += jstep) {
+        const int o0 = d.pt_off[j], k = d.pt_off[j + 1] - o0;
+        for (int pr = sub; pr < k * k; pr += tp) {
+            const int o = o0 + pr / k, o2 = o0 + pr % k;
+            int key;
+            if (pair_key(d, o, o2, key)) list[cnt[key] + atomicAdd(&cur[key], 1)] = ((unsigned long long)o << 32) | (unsigned)o2;
+        }
     }
 }
 
@@ -2585,21 +2635,27 @@ int rcn_int_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_option
     // The lists are built on the panel stream, BESIDE the first evaluation (which needs nothing of them; both are eight launches or so, and
     // on the reference's problem sizes a solve is a few hundred launch-bound microseconds): the ctx stream waits for them in front of the loop.
     const bool pairs_build = gather && np > 0 && !pairs_cached;
-    if (pairs_build) {
+    // (queued BEHIND the first evaluation's launches, below: on these sizes the host's enqueue rate is what the device waits for, and the
+    //  evaluation is what the host waits for first)
+    auto build_pairs = [&]() -> int {
         hipStream_t sp = ctx->panel_stream;          // idle: the stream was synchronised above and every factorisation joins its streams
-        RCN_HIP(hipMemsetAsync(pk, 0, sizeof(int) * (3 * (size_t)nkeys + 4 + (nkeys + 1023) / 1024), sp));
-        const int thr = std::min(256, std::max(64, (kmax * kmax + 63) / 64 * 64));
-        k_pair_count<<<np, thr, 0, sp>>>(d, pk_cnt);
-        const int nchunks = (nkeys + 1023) / 1024;
-        k_scan_sums<<<nchunks, 1024, 0, sp>>>(pk_cnt, pk_sums, nkeys);
-        k_scan_top<<<1, 1024, 0, sp>>>(pk_sums, nchunks, pk_off + nkeys);
-        k_scan_apply<<<nchunks, 1024, 0, sp>>>(pk_cnt, pk_sums, pk_off, nkeys);
-        k_pair_fill<<<np, thr, 0, sp>>>(d, pk_off, pk_fill, pk_list);
+        if (nkeys <= 1024 && npairs_lower <= 16384) k_pair_small<<<1, 1024, 0, sp>>>(d, pk_off, pk_list, nkeys);      // (the smallest of the reference's own sizes: one launch for six; beyond, one workgroup walks the pairs slower than six launches)
+        else {
+            RCN_HIP(hipMemsetAsync(pk, 0, sizeof(int) * (3 * (size_t)nkeys + 4 + (nkeys + 1023) / 1024), sp));
+            const int thr = std::min(256, std::max(64, (kmax * kmax + 63) / 64 * 64));
+            k_pair_count<<<np, thr, 0, sp>>>(d, pk_cnt);
+            const int nchunks = (nkeys + 1023) / 1024;
+            k_scan_sums<<<nchunks, 1024, 0, sp>>>(pk_cnt, pk_sums, nkeys);
+            k_scan_top<<<1, 1024, 0, sp>>>(pk_sums, nchunks, pk_off + nkeys);
+            k_scan_apply<<<nchunks, 1024, 0, sp>>>(pk_cnt, pk_sums, pk_off, nkeys);
+            k_pair_fill<<<np, thr, 0, sp>>>(d, pk_off, pk_fill, pk_list);
+        }
         k_pair_sort<<<(nkeys + 127) / 128, 128, 0, sp>>>(pk_off, pk_list, nkeys);
         k_pair_sort_long<<<nkeys, 256, 0, sp>>>(pk_off, pk_list);
         RCN_HIP(hipGetLastError());
         RCN_HIP(hipEventRecord(ctx->ba_ev[7], sp));
-    }
+        return RCN_OK;
+    };
     ctx->ba_pair_token = (gather && np > 0) ? pair_token : 0;
     if (!pairs_cached) ctx->ba_pair_camdim = cam_dim;
     sum->pair_lists_reused = pairs_cached ? 1 : 0;
@@ -2615,10 +2671,32 @@ int rcn_int_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_option
     double cost = 0.0;
     bool cost_pending = false;
     int cost_iter = 0;
-    auto read_scal = [&](int cnt) -> hipError_t {
-        hipError_t e = hipMemcpyAsync(hs, d.scal, sizeof(double) * cnt, hipMemcpyDeviceToHost, st);
-        if (e != hipSuccess) return e;
-        e = hipStreamSynchronize(st);
+    // (the pinned mirror serves the small problems, where the round trip is a quarter of an iteration; the large ones time their phases
+    //  with events, which want the stream synchronised)
+    double *const mirror = (!phase_times && no > 0) ? ctx->ba_host_scal : nullptr;
+    auto read_scal = [&](int cnt, bool mirrored = false) -> hipError_t {
+        hipError_t e = hipSuccess;
+        if (mirrored && mirror) {
+            const unsigned long long want = ctx->ba_host_seq;
+            const unsigned long long *seqp = reinterpret_cast<const unsigned long long *>(mirror + 15);
+            const double t0 = now_s();
+            unsigned spins = 0;
+            while (__atomic_load_n(seqp, __ATOMIC_ACQUIRE) != want) {
+                if ((++spins & 0x3FFu) == 0) {
+                    if (hipStreamQuery(st) == hipSuccess) break;                 // the stream has drained: the store is there or will never come
+                    if (now_s() - t0 > 10.0) break;
+                }
+            }
+            if (__atomic_load_n(seqp, __ATOMIC_ACQUIRE) == want) for (int i = 0; i < cnt; ++i) hs[i] = mirror[i];
+            else {      // not expected: the ordinary way, which also reports what went wrong
+                e = hipMemcpyAsync(hs, d.scal, sizeof(double) * cnt, hipMemcpyDeviceToHost, st);
+                if (e == hipSuccess) e = hipStreamSynchronize(st);
+            }
+        } else {
+            e = hipMemcpyAsync(hs, d.scal, sizeof(double) * cnt, hipMemcpyDeviceToHost, st);
+            if (e != hipSuccess) return e;
+            e = hipStreamSynchronize(st);
+        }
         if (e == hipSuccess && cost_pending) {
             cost = hs[0];
             if (cost_iter < 160) sum->cost_trace[cost_iter] = cost;
@@ -2629,10 +2707,12 @@ int rcn_int_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_option
     // cost at (poses,intr,pts) -> scal[slot]; JAC also refreshes the observation rows and the raw blocks
     bool jac_pending = false;
     // tickets of the in-kernel reductions (finish_sums): d.flag + 8 .. 11, zero at rest
-    auto fin = [&](double *out, double scale, int which, bool with_flag, double *zero, double *out2 = nullptr) {
-        return Fin{out, out2, reinterpret_cast<unsigned *>(d.flag + 8 + which), with_flag ? d.flag : nullptr, d.scal + 13, zero, scale};
+    auto fin = [&](double *out, double scale, int which, bool with_flag, double *zero, double *out2 = nullptr, bool home = false) {
+        Fin f{out, out2, reinterpret_cast<unsigned *>(d.flag + 8 + which), with_flag ? d.flag : nullptr, d.scal + 13, zero, scale, nullptr, d.scal, 0ull};
+        if ((with_flag || home) && mirror) { f.host = mirror; f.seq = ++ctx->ba_host_seq; }      // the step's last reduction (the candidate's cost), the start's cost: the scalars go home by themselves
+        return f;
     };
-    auto eval = [&](bool jac, const double *ps, const double *in, const double *x, int slot, bool with_flag = false, bool rot_ready = false) -> hipError_t {
+    auto eval = [&](bool jac, const double *ps, const double *in, const double *x, int slot, bool with_flag = false, bool rot_ready = false, bool home = false) -> hipError_t {
         if (no > 0) {
             if (jac) {
                 // the streaming kernel of the solve, timed on its own (summary.jacobian_seconds): 224 B written per observation
@@ -2643,7 +2723,7 @@ int rcn_int_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_option
                 }
                 if (!rot_ready) k_ba_cam_rot<<<(nc + 127) / 128, 128, 0, st>>>(ps, nc, d.crot);      // (an accepted candidate brings its table: k_ba_plus)
                 if (phase_times) (void)hipEventRecord(ctx->ba_tev[4], st);
-                k_ba_eval<true><<<ebj, 128, 0, st>>>(d, ps, in, x, d.partial, fin(d.scal + slot, 0.5, 0, false, d.scal + 12));
+                k_ba_eval<true><<<ebj, 128, 0, st>>>(d, ps, in, x, d.partial, fin(d.scal + slot, 0.5, 0, false, d.scal + 12, nullptr, home));
                 if (phase_times) (void)hipEventRecord(ctx->ba_tev[5], st);
                 jac_pending = true;
             } else k_ba_eval<false><<<eb, 256, 0, st>>>(d, ps, in, x, d.partial, fin(d.scal + slot, 0.5, 0, with_flag, nullptr));
@@ -2658,11 +2738,12 @@ int rcn_int_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_option
         return hipGetLastError();
     };
 
-    RCN_HIP(eval(true, d.poses, d.intr, d.pts, 0));
+    RCN_HIP(eval(true, d.poses, d.intr, d.pts, 0, false, false, true));      // (its cost goes home by itself)
     const int dgrid = (std::max(n, 3 * np) + 255) / 256;
     k_ba_diag<<<std::max(dgrid, 1), 256, 0, st>>>(d, 0, 0.0, 0.0, opt->jacobi_scaling);
     RCN_HIP(hipGetLastError());
-    RCN_HIP(read_scal(1));
+    if (pairs_build) { const int rcp = build_pairs(); if (rcp) return rcp; }
+    RCN_HIP(read_scal(1, true));
     cost = hs[0];
     sum->initial_cost = cost;
     sum->initial_rms_px = std::sqrt(2.0 * cost / std::max(no, 1));
@@ -2921,7 +3002,7 @@ int rcn_int_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_option
         RCN_HIP(hipGetLastError());
         RCN_HIP(eval(false, d.poses2, d.intr2, d.pts2, 1, true));       // + the factorisation's flag word into scal[13]
         if (phase_times) RCN_HIP(hipEventRecord(ctx->ba_tev[3], st));
-        RCN_HIP(read_scal(14));
+        RCN_HIP(read_scal(14, true));
         const int hflag = (int)hs[13];
         if (grad_pending) {
             grad_pending = false;

@@ -106,6 +106,8 @@ int rcn_create(int device_id, rcn_ctx **out)
     for (auto &e : ctx->ba_tev)
         if (hipEventCreate(&e) != hipSuccess) { delete ctx; return RCN_ERR_HIP; }
     ctx->ba_ev_made = true;
+    if (hipHostMalloc(reinterpret_cast<void **>(&ctx->ba_host_scal), 16 * sizeof(double), hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); ctx->ba_host_scal = nullptr; }
+    else memset(ctx->ba_host_scal, 0, 16 * sizeof(double));
 #ifdef RCN_DIAG
     // Diagnostic build only (tools/librcn_diag.so, -DRCN_DIAG): ablations and alternative device paths.
     // The shipping library reads no environment variable.
@@ -152,6 +154,7 @@ int rcn_create(int device_id, rcn_ctx **out)
         } else
         if (hipStreamCreateWithPriority(&ctx->chain_stream, hipStreamNonBlocking, ctx->chol_chain_stream == 2 ? 0 : hi) != hipSuccess) { (void)hipGetLastError(); ctx->chain_stream = nullptr; }
     }
+    if (const char *bm = std::getenv("RCN_BA_MIRROR")) if (bm[0] == '0' && ctx->ba_host_scal) { (void)hipHostFree(ctx->ba_host_scal); ctx->ba_host_scal = nullptr; }      // the scalars by copy + synchronisation, as before round 5
     const char *cbb = std::getenv("RCN_CHOL_BULK_BEHIND");
     if (cbb) ctx->chol_bulk_behind = std::atoi(cbb);
     const char *ccv = std::getenv("RCN_CHOL_CARVE");
@@ -219,6 +222,7 @@ void rcn_destroy(rcn_ctx *ctx)
     if (ctx->aux_stream) (void)hipStreamDestroy(ctx->aux_stream);
     if (ctx->panel_stream) (void)hipStreamDestroy(ctx->panel_stream);
     if (ctx->panel2_stream) (void)hipStreamDestroy(ctx->panel2_stream);
+    if (ctx->ba_host_scal) (void)hipHostFree(ctx->ba_host_scal);
     if (ctx->diag_stream) (void)hipStreamDestroy(ctx->diag_stream);
     if (ctx->chain_stream) (void)hipStreamDestroy(ctx->chain_stream);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);

@@ -218,6 +218,8 @@ struct rcn_ctx {
     int chol_break = 0;                              // diagnostic build: 1 = break one cross-stream hand-off (forces the one-stream fallback); 2 = and put a NaN pivot behind it
     int chol_pair_min = 24;                          // two-panel bulk updates while at least this many tile rows remain below the pair
     bool chol_safe = false;             // a device-counter hand-off timed out once: factorise on one stream, in plain order, from then on
+    double *ba_host_scal = nullptr;   // pinned mirror of the LM step's scalars (16 doubles; [15]: sequence number), written by the step's last kernel
+    unsigned long long ba_host_seq = 0;
     hipEvent_t ba_ev[9];             // [0]: fork of the factorisation's streams, [1..4]: their joins, [5]: the chain's own stream back to the caller's, [7]: pair lists
     hipEvent_t ba_tev[6];            // phase timing of rcn_ba_solve ([4], [5]: around k_ba_eval<true>)
     bool ba_ev_made = false;
