@@ -77,12 +77,12 @@ def source_hash():
 def measured_traffic(kernel_key):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes -- only if that
     profile was taken on THIS source (else None: a stale file is not a measurement of this run)."""
-    path = os.path.join(ROOT, "profiles", "r04_match_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r05_match_traffic.json")
     if not os.path.exists(path):
         return None, "no PMC profile committed for this round"
     d = json.load(open(path))
     if d.get("source_hash") != source_hash():
-        return None, "profiles/r04_match_traffic.json was taken at source %s, this binary is %s: not quoted" % (d.get("source_hash"), source_hash())
+        return None, "profiles/r05_match_traffic.json was taken at source %s, this binary is %s: not quoted" % (d.get("source_hash"), source_hash())
     e = d.get(kernel_key)
     if not e:
         return None, "no entry for " + kernel_key
@@ -682,7 +682,7 @@ def grid_line(K, n_img, n_pairs_total, dt, steps, st, world, my_pairs):
     traffic, tnote = measured_traffic("k_coarse_top2<256>@%dx%d" % (n_img, K)) if world == 1 else (None, "PMC passes are single-GPU")
     roof = {"bound": "mfma", "kernel": "k_coarse_top2<256, 0, 1> (v_mfma_f32_16x16x32_f16)", "achieved": achieved, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": achieved / MFMA_F16_PEAK_TFLOPS, "traffic": traffic,
-            "traffic_note": "HBM bytes per launch from rocprofv3 --pmc passes on this exact source (profiles/r04_match_traffic.json); " + str(tnote),
+            "traffic_note": "HBM bytes per launch from rocprofv3 --pmc passes on this exact source (profiles/r05_match_traffic.json); " + str(tnote),
             # per LAUNCH like `traffic`: every resident fp16 image once (a pipeline chunk's pairs meet nearly all of them as train images)
             # + 8 B of candidate pair per query row of the launch's pairs
             "algorithmic_hbm_bytes_per_launch": float(n_img) * K * D * 2 + 8.0 * float(st["rows_total"]) * calls / launches,
