@@ -2351,7 +2351,10 @@ static int ensure_chol_plan(rcn_ctx *ctx, int nblk)
     if (prm.diag_server && !ctx->diag_stream) {      // (tools/ only: the product's plans have no resident workgroup)
         int lo = 0, hi = 0;
         if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { (void)hipGetLastError(); lo = hi = 0; }
-        const char *dsp = std::getenv("RCN_DIAG_STREAM_PRIO");
+        const char *dsp = nullptr;
+#ifdef RCN_DIAG
+        dsp = std::getenv("RCN_DIAG_STREAM_PRIO");      // 0: normal priority, 2: a CU mask of all CUs
+#endif
         if (dsp && std::atoi(dsp) == 0) hi = 0;
         if (dsp && std::atoi(dsp) == 2) {      // a stream with a CU mask of all CUs: a hardware queue of its own?
             const int ncu = ctx->prop.multiProcessorCount;

@@ -69,6 +69,9 @@ def test_shipping_library_reads_no_environment_switch(lib):
     for name in (b"RCN_COARSE_ABL", b"RCN_BA_SCHUR_ATOMICS", b"RCN_BA_TRSV_FWD", b"RCN_MATCH_CHUNKS", b"RCN_FORCE_EXACT",
                  b"RCN_MATCH_NO_ORDER", b"RCN_NO_CU_MASK"):
         assert name not in blob, name
+    import re
+    names = set(re.findall(rb"RCN_[A-Z][A-Z0-9_]{3,}", blob)) - {b"RCN_COUNTER_BYTES", b"RCN_HIST_BINS"}      # (two constants quoted in error messages)
+    assert not names, "the shipping binary names an environment switch: %r" % names
     assert b"DIAGNOSTIC" not in lib.rcn_version()
 
 
