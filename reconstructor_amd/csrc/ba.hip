@@ -2642,7 +2642,7 @@ int rcn_int_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_option
     //  evaluation is what the host waits for first)
     auto build_pairs = [&]() -> int {
         hipStream_t sp = ctx->panel_stream;          // idle: the stream was synchronised above and every factorisation joins its streams
-        if (nkeys <= 1024 && npairs_lower <= 16384) k_pair_small<<<1, 1024, 0, sp>>>(d, pk_off, pk_list, nkeys);      // (the smallest of the reference's own sizes: one launch for six; beyond, one workgroup walks the pairs slower than six launches)
+        if (ctx->ba_pair_small && nkeys <= 1024 && npairs_lower <= 16384) k_pair_small<<<1, 1024, 0, sp>>>(d, pk_off, pk_list, nkeys);      // (the smallest of the reference's own sizes: one launch for six; beyond, one workgroup walks the pairs slower than six launches)
         else {
             RCN_HIP(hipMemsetAsync(pk, 0, sizeof(int) * (3 * (size_t)nkeys + 4 + (nkeys + 1023) / 1024), sp));
             const int thr = std::min(256, std::max(64, (kmax * kmax + 63) / 64 * 64));

@@ -123,6 +123,8 @@ int rcn_create(int device_id, rcn_ctx **out)
     ctx->ablate = ab ? std::atoi(ab) : 0;
     const char *bat = std::getenv("RCN_BA_SCHUR_ATOMICS");
     ctx->ba_atomics = bat && bat[0] == '1';
+    const char *bps = getenv("RCN_PAIR_SMALL");
+    if (bps) ctx->ba_pair_small = bps[0] != '0';
     const char *btf = getenv("RCN_BA_TRSV_FWD");
     ctx->ba_trsv_fwd = btf && btf[0] == '1';
     const char *cs = std::getenv("RCN_CHOL_SAFE");

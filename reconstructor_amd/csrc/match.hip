@@ -2267,7 +2267,9 @@ int rcn_int_match_grid(rcn_ctx *ctx, const int32_t *pairs_host, int32_t n_pairs,
         if (g1 <= g0) continue;
         const int p0 = groups[g0].x, p1 = g1 < n_groups ? groups[g1].x : n_pairs, np_c = p1 - p0;
         // the chunk's candidates sit at the START of the buffer; the kernels index by grid-wide pair number
-        uint2 *cand_c = ctx->cand.as<uint2>() - (size_t)p0 * kq_stride;
+        // (indexed by grid-wide pair number: the chunk's table starts at pair p0.  The bias is applied to the ADDRESS -- a pointer in front
+        //  of its allocation is not something C++ pointer arithmetic may form; the kernels only ever index pairs p0 .. p1 - 1 of it)
+        uint2 *cand_c = reinterpret_cast<uint2 *>(reinterpret_cast<uintptr_t>(ctx->cand.as<uint2>()) - (uintptr_t)((size_t)p0 * kq_stride * sizeof(uint2)));
         const bool tm = prof && c < RCN_EV_CHUNKS;
         if (tm) { RCN_HIP(hipEventRecord(ctx->ev_c[evi][c][0], st)); ctx->ev_chunks[evi] = c + 1; }
         if (mfma) {

@@ -168,11 +168,12 @@ struct rcn_ctx {
     bool no_item_order = false;   // RCN_MATCH_NO_ORDER=1: work items in pair order instead of heaviest-first per XCD
     bool ba_atomics = false;   // RCN_BA_SCHUR_ATOMICS=1: atomic Schur accumulation instead of the gather form
     bool ba_trsv_fwd = false;  // RCN_BA_TRSV_FWD=1: separate forward substitution instead of the rhs row inside the factorisation
+    bool ba_pair_small = true; // RCN_PAIR_SMALL=0: the pair lists of the smallest graphs by the six general launches too
 #else
     static constexpr bool coarse_w4 = false;
     static constexpr int coarse_shape = -1;
     static constexpr int ablate = 0;
-    static constexpr bool force_exact = false, no_item_order = false, ba_atomics = false, ba_trsv_fwd = false;
+    static constexpr bool force_exact = false, no_item_order = false, ba_atomics = false, ba_trsv_fwd = false, ba_pair_small = true;
 #endif
 
     // ---- BA state (ba.hip)

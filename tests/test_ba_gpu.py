@@ -425,3 +425,39 @@ def test_a_broken_stream_hand_off_falls_back_to_one_stream_with_the_same_bits(gp
     assert r.returncode == 0, r.stderr[-2000:]
     d = json.loads(r.stdout.strip().splitlines()[-1])
     assert d["sched"] == 0 and d["invalid"] == 0 and d["h"] == hashlib.sha256(P1.tobytes() + I1.tobytes() + X1.tobytes()).hexdigest()
+
+
+_SMALL = """
+import sys, hashlib
+sys.path.insert(0, %r)
+import numpy as np
+import torch
+from reconstructor_amd import _lib, ba, synth_ba
+ctx = _lib.Context(0)
+h = hashlib.sha256()
+for nc, npts, k in ((3, 40, 3), (6, 300, 5), (9, 150, 6), (12, 700, 8), (25, 1500, 8)):
+    sc = synth_ba.make_scene(nc, npts, obs_per_point=k, seed=61)
+    P, I, X, s = ba.solve_scene(ctx, sc)
+    h.update(P.tobytes() + I.tobytes() + X.tobytes() + repr((s["iterations"], s["termination"], s["final_cost"])).encode())
+print(h.hexdigest())
+"""
+
+
+def test_small_solve_shortcuts_change_no_bit(gpu_ctx):
+    """Round 5: the LM step's scalars reach the host through a pinned mirror written by the step's last kernel, and the smallest graphs'
+    pair lists are counted, scanned and filled by one workgroup.  Both are shortcuts around the same arithmetic: with either switched
+    off (diagnostic build, child process) five small solves give the product's bits."""
+    import hashlib, os, subprocess, sys
+    from reconstructor_amd import ba
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    diag = os.path.join(root, "tools", "librcn_diag.so")
+    assert os.path.exists(diag), "tools/librcn_diag.so missing: run __graft_entry__.build()"
+    h = hashlib.sha256()
+    for nc, npts, k in ((3, 40, 3), (6, 300, 5), (9, 150, 6), (12, 700, 8), (25, 1500, 8)):
+        sc = synth_ba.make_scene(nc, npts, obs_per_point=k, seed=61)
+        P, I, X, s = ba.solve_scene(gpu_ctx, sc)
+        h.update(P.tobytes() + I.tobytes() + X.tobytes() + repr((s["iterations"], s["termination"], s["final_cost"])).encode())
+    for env in ({"RCN_BA_MIRROR": "0"}, {"RCN_PAIR_SMALL": "0"}):
+        r = subprocess.run([sys.executable, "-c", _SMALL % root], env=dict(os.environ, RCN_LIB=diag, **env), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert r.stdout.strip().splitlines()[-1] == h.hexdigest(), env
