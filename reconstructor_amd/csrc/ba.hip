@@ -735,11 +735,12 @@ __global__ __launch_bounds__(256) void k_pair_fill(BaDev d, const int *off, int 
 // launches above (clear, count, three scan passes, fill) were ~25 us of a solve that is ~400 us long, and the host spent as long again
 // enqueueing them.  Per-key counters and fill cursors live in LDS; a thread walks the pairs of its landmarks.  The order inside a key
 // is whatever the atomics gave -- as in k_pair_fill -- and the two sort kernels behind make it ascending.
-__global__ __launch_bounds__(1024) void k_pair_small(BaDev d, int *off, unsigned long long *list, int nkeys)
+__global__ __launch_bounds__(1024) void k_pair_small(BaDev d, int *off, unsigned long long *list, int nkeys, int *long_count)
 {
     __shared__ int cnt[1024], cur[1024], sh[16];
     const int t = threadIdx.x;
     cnt[t] = 0; cur[t] = 0;
+    if (t == 0) *long_count = 0;          // (the general path's clear covers this word)
     __syncthreads();
     // tp threads per landmark (a power of two): they share out its pairs
     int tp = 1;
@@ -772,13 +773,16 @@ __global__ __launch_bounds__(1024) void k_pair_small(BaDev d, int *off, unsigned
 
 // fixed order inside every block: ascending (o, o2); segments are short except the diagonal blocks
 #define PAIR_SORT_SHORT 32
-__global__ void k_pair_sort(const int *off, unsigned long long *list, int nkeys)
+// (long_keys / long_count: the keys whose segments are too long for a thread, listed for k_pair_sort_long -- round 5: that kernel was
+//  launched with a workgroup per KEY, a million workgroups at cfg 5 of which none had anything to do: 0.41 ms of every solve that
+//  builds its lists)
+__global__ void k_pair_sort(const int *off, unsigned long long *list, int nkeys, int *long_keys, int *long_count)
 {
     const int key = blockIdx.x * blockDim.x + threadIdx.x;
     if (key >= nkeys) return;
     unsigned long long *a = list + off[key];
     const int n = off[key + 1] - off[key];
-    if (n > PAIR_SORT_SHORT) return;           // long segments: k_pair_sort_long
+    if (n > PAIR_SORT_SHORT) { long_keys[atomicAdd(long_count, 1)] = key; return; }           // long segments: k_pair_sort_long
     for (int i = 1; i < n; ++i) {
         const unsigned long long v = a[i];
         int p = i - 1;
@@ -789,12 +793,14 @@ __global__ void k_pair_sort(const int *off, unsigned long long *list, int nkeys)
 
 // Long segments (few cameras sharing thousands of landmarks: the reference's own regime, 3..25 views):
 // one workgroup per segment, bitonic sort -- in LDS up to 4096 entries, in global memory beyond.
-__global__ __launch_bounds__(256) void k_pair_sort_long(const int *off, unsigned long long *list)
+__global__ __launch_bounds__(256) void k_pair_sort_long(const int *off, unsigned long long *list, const int *long_keys, const int *long_count)
 {
     __shared__ unsigned long long sh[4096];
-    const int key = blockIdx.x, t = threadIdx.x;
+    const int t = threadIdx.x, nlong = *long_count;
+    for (int idx = blockIdx.x; idx < nlong; idx += gridDim.x) {      // (uniform over the workgroup)
+    const int key = long_keys[idx];
     const int n = off[key + 1] - off[key];
-    if (n <= PAIR_SORT_SHORT) return;
+    __syncthreads();                                               // the staging of the last key is free
     unsigned long long *g = list + off[key];
     int P = 64;
     while (P < n) P <<= 1;
@@ -818,6 +824,7 @@ __global__ __launch_bounds__(256) void k_pair_sort_long(const int *off, unsigned
             __syncthreads();
         }
     if (in_lds) for (int i = t; i < n; i += 256) g[i] = sh[i];
+    }
 }
 
 // ---- MFMA form of the gather (default).  k_ba_wy tabulates, per observation, the scaled
@@ -2642,7 +2649,8 @@ int rcn_int_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_option
     //  evaluation is what the host waits for first)
     auto build_pairs = [&]() -> int {
         hipStream_t sp = ctx->panel_stream;          // idle: the stream was synchronised above and every factorisation joins its streams
-        if (ctx->ba_pair_small && nkeys <= 1024 && npairs_lower <= 16384) k_pair_small<<<1, 1024, 0, sp>>>(d, pk_off, pk_list, nkeys);      // (the smallest of the reference's own sizes: one launch for six; beyond, one workgroup walks the pairs slower than six launches)
+        int *const long_keys = pk_cnt, *const long_count = pk_fill + nkeys;      // (the counts are dead once the lists are filled; a spare word behind the fill cursors)
+        if (ctx->ba_pair_small && nkeys <= 1024 && npairs_lower <= 16384) k_pair_small<<<1, 1024, 0, sp>>>(d, pk_off, pk_list, nkeys, long_count);      // (the smallest of the reference's own sizes: one launch for six; beyond, one workgroup walks the pairs slower than six launches)
         else {
             RCN_HIP(hipMemsetAsync(pk, 0, sizeof(int) * (3 * (size_t)nkeys + 4 + (nkeys + 1023) / 1024), sp));
             const int thr = std::min(256, std::max(64, (kmax * kmax + 63) / 64 * 64));
@@ -2653,8 +2661,8 @@ int rcn_int_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_option
             k_scan_apply<<<nchunks, 1024, 0, sp>>>(pk_cnt, pk_sums, pk_off, nkeys);
             k_pair_fill<<<np, thr, 0, sp>>>(d, pk_off, pk_fill, pk_list);
         }
-        k_pair_sort<<<(nkeys + 127) / 128, 128, 0, sp>>>(pk_off, pk_list, nkeys);
-        k_pair_sort_long<<<nkeys, 256, 0, sp>>>(pk_off, pk_list);
+        k_pair_sort<<<(nkeys + 127) / 128, 128, 0, sp>>>(pk_off, pk_list, nkeys, long_keys, long_count);
+        k_pair_sort_long<<<std::min(nkeys, 2048), 256, 0, sp>>>(pk_off, pk_list, long_keys, long_count);
         RCN_HIP(hipGetLastError());
         RCN_HIP(hipEventRecord(ctx->ba_ev[7], sp));
         return RCN_OK;
