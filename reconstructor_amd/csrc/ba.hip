@@ -1507,13 +1507,37 @@ __device__ __forceinline__ bool chol_diag_body(double *S, int ld, int kb, double
     TL_MARK(tl, 2);
     return true;
 }
-__global__ __launch_bounds__(64 * CDW) void k_chol_diag(double *S, int ld, int kb, double *Linv, int *flag, int store_L, Gate g, int nact = NB, int tl = 0)
+// (x_out != nullptr, systems of ONE block -- the reference's own sizes up to a dozen cameras; round 5: the backward substitution of the
+//  block rides in this launch, x = Linv' y with y = row `yrow` of the factor just stored.  The arithmetic is k_trsv_bwd_chain's for its
+//  last block row -- four partial sums of 32, combined pairwise -- so the bits are the same; one launch less per LM iteration.)
+__global__ __launch_bounds__(64 * CDW) void k_chol_diag(double *S, int ld, int kb, double *Linv, int *flag, int store_L, Gate g, int nact = NB, int tl = 0,
+                                                        double *x_out = nullptr, int yrow = 0)
 {
     __builtin_amdgcn_s_setprio(3);
     TL_MARK(tl, 0);
     gate_enter(g);
     TL_MARK(tl, 1);
-    (void)chol_diag_body(S, ld, kb, Linv, flag, store_L, nact, tl);
+    const bool ok = chol_diag_body(S, ld, kb, Linv, flag, store_L, nact, tl);
+    if (!x_out || !ok) return;              // (uniform)
+    static_assert(64 * CDW == 512, "the substitution's four groups of 128 threads");
+    __shared__ double xk[NB], part[4][NB];
+    __syncthreads();                         // the block's inverse and its last row are in memory for every thread of the workgroup
+    const int t = threadIdx.x & 127, gq = threadIdx.x >> 7;
+    const double *Lk = Linv + (size_t)kb * NB * NB;
+    double li[32];
+#pragma unroll
+    for (int m = 0; m < 32; ++m) li[m] = Lk[(size_t)(32 * gq + m) * NB + t];
+    if (gq == 0) {
+        const int idx = kb * NB + t;
+        xk[t] = idx < yrow ? S[(size_t)yrow * ld + idx] : 0.0;
+    }
+    __syncthreads();
+    double sum = 0.0;
+#pragma unroll
+    for (int m = 0; m < 32; ++m) sum += li[m] * xk[32 * gq + m];      // zeros above the diagonal
+    part[gq][t] = sum;
+    __syncthreads();
+    if (gq == 0) x_out[(size_t)kb * NB + t] = (part[0][t] + part[1][t]) + (part[2][t] + part[3][t]);
 }
 // The diagonal blocks of a whole factorisation in ONE workgroup that stays resident (round 5).  As a launch per block the 512-thread,
 // 132-KB workgroup had to find a CU every step -- and where the panel stream's latency kernels, unmasked since this round, fill the
@@ -2844,6 +2868,8 @@ int rcn_int_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_option
         // by one (two classes, flag[5], flag[6]).  A wait that times out (2 s: a runtime that does not let the three streams
         // progress side by side) raises flag 3; the factorisation is then repeated on ONE stream in list order, and every later
         // one runs that way (ctx->chol_safe).  Same bits either way: no operation's arithmetic depends on where it runs.
+        // (one block: the backward substitution rides in the diagonal kernel's launch)
+        const bool trsv_in_diag = nblk == 1 && rhs_row && chain && fused_finish && ctx->trsv_chain;
         auto factorise = [&](bool safe) -> hipError_t {
             // (the chain on a high-priority stream of the library's own, forked from and joined to the caller's: RCN_CHOL_CHAIN_STREAM, tools/)
             const bool own_chain = !safe && ctx->chol_chain_stream && ctx->chain_stream;
@@ -2927,7 +2953,8 @@ int rcn_int_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_option
                 case chol::DIAG: {
                     // (active rows of the block: the system's n rows, and the right-hand-side row behind them when it rides along)
                     const int nact = std::min(NB, (rhs_row ? n + 1 : n) - op.kb * NB);
-                    k_chol_diag<<<1, 64 * CDW, NB * DL * 8, sq>>>(d.S, npad, op.kb, d.Linv, d.flag, op.kb == nblk - 1, gk, nact, op.tl);
+                    k_chol_diag<<<1, 64 * CDW, NB * DL * 8, sq>>>(d.S, npad, op.kb, d.Linv, d.flag, op.kb == nblk - 1, gk, nact, op.tl,
+                                                                   trsv_in_diag ? d.rhs : nullptr, n);
                     break;
                 }
                 case chol::TRSM_Q:
@@ -2994,7 +3021,8 @@ int rcn_int_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_option
         else if (!rhs_row) for (int kb = 0; kb < nblk; ++kb) k_trsv_fwd<<<nblk - kb, 128, 0, st>>>(d.L, npad, kb, d.Linv, d.rhs, d.yc);
         if (chain) {
             if (!rhs_row) RCN_HIP(hipMemsetAsync(d.rhs, 0xFF, sizeof(double) * npad, st));      // the sentinel
-            if (y_in_row) k_trsv_bwd_chain<<<nblk, 512, 0, st>>>(d.L, npad, nblk, d.Linv, nullptr, d.rhs, d.flag, d.S, n);
+            if (trsv_in_diag) {}      // done by k_chol_diag
+            else if (y_in_row) k_trsv_bwd_chain<<<nblk, 512, 0, st>>>(d.L, npad, nblk, d.Linv, nullptr, d.rhs, d.flag, d.S, n);
             else k_trsv_bwd_chain<<<nblk, 512, 0, st>>>(d.L, npad, nblk, d.Linv, d.yc, d.rhs, d.flag);
         }
         else for (int kb = nblk - 1; kb >= 0; --kb) k_trsv_bwd<<<kb + 1, 512, 0, st>>>(d.L, npad, kb, d.Linv, d.yc, d.rhs);
