@@ -950,11 +950,14 @@ __global__ __launch_bounds__(512) void k_ba_schur_mfma_wg(BaDev d, const int *of
     }
 }
 
+#define RCN_RHS_BETA 1.0e200
 // diagonal blocks: one 16-wave workgroup per camera; wave w takes the observations w, w+16, ... of
 // the camera (a pair (o, o)) and the listed pairs of the key (c, c); the 16 partial blocks are
 // summed in wave order and  scaled U + D/radius  is added before the store into S; column 10 of
 // the same product is the camera's reduced right-hand side.
-__device__ __forceinline__ void schur_diag_finish(const BaDev &d, int c, int idx, double v, double inv_radius)
+// (fin: -1 the right-hand side stays in d.rhs; 0 / 1 it goes straight into row n of the padded system -- what k_ba_S_finish did in a
+//  launch of its own until round 5 -- and with 1 the cell in d.rhs takes k_trsv_bwd_chain's "not there yet" pattern)
+__device__ __forceinline__ void schur_diag_finish(const BaDev &d, int c, int idx, double v, double inv_radius, int fin = -1)
 {
     const int a = idx >> 4, b = idx & 15, dc = d.cam_dim[c], offc = d.cam_off[c];
     if (a < dc && b < dc) {
@@ -962,15 +965,34 @@ __device__ __forceinline__ void schur_diag_finish(const BaDev &d, int c, int idx
         if (a == b) v += d.dgc[offc + a] * inv_radius;
         d.S[(size_t)(offc + a) * d.npad + offc + b] = v;
     } else if (a < dc && b == 10) {   // reduced right-hand side: scaled gc - sum_o Y_o gp
-        d.rhs[offc + a] = d.gcraw[10 * (size_t)c + a] * d.sc[offc + a] + v;
+        const double r = d.gcraw[10 * (size_t)c + a] * d.sc[offc + a] + v;
+        if (fin < 0) d.rhs[offc + a] = r;
+        else {
+            d.S[(size_t)d.n * d.npad + offc + a] = r;
+            if (fin == 1) reinterpret_cast<unsigned long long *>(d.rhs)[offc + a] = 0xFFFFFFFFFFFFFFFFull;
+            else d.rhs[offc + a] = r;
+        }
     }
 }
 // (`split` > 1: a camera's observations are spread over that many workgroups, see k_ba_cam_raw; SMB: gather
 // depth, 12 in that latency-bound regime, 4 when a thousand cameras keep the chip full anyway)
+// (fin >= 0, round 5: the launch also does what k_ba_S_finish did between the Schur build and the factorisation -- the cameras'
+//  workgroups put their right-hand sides into row n themselves (schur_diag_finish), the workgroups BEHIND them write the rest of the
+//  padded rows and the factorisation's flag word and stream counters: one launch less per LM iteration)
 template <int SMB>
-__global__ __launch_bounds__(1024) void k_ba_schur_diag_mfma(BaDev d, const int *off, const unsigned long long *list, double inv_radius, int split)
+__global__ __launch_bounds__(1024) void k_ba_schur_diag_mfma(BaDev d, const int *off, const unsigned long long *list, double inv_radius, int split, int fin = -1)
 {
     __shared__ double part[16][256];
+    if ((int)blockIdx.x >= d.nc * split) {      // (uniform over the workgroup)
+        const size_t idx = (size_t)((int)blockIdx.x - d.nc * split) * 1024 + threadIdx.x, cnt = (size_t)(d.npad - d.n) * d.npad;
+        if (idx == 0) { const int ps = d.flag[1]; d.flag[1] = 0; d.flag[0] = ps ? 1 : 0; }
+        else if ((idx >= 2 && idx < 8) || (idx >= 12 && idx < 24)) d.flag[idx] = 0;
+        if (idx >= cnt) return;
+        const int i = d.n + (int)(idx / d.npad), j = (int)(idx % d.npad);
+        if (i == d.n && j < d.n) return;        // the cameras' workgroups'
+        d.S[(size_t)i * d.npad + j] = i == j ? (i == d.n ? RCN_RHS_BETA : 1.0) : 0.0;
+        return;
+    }
     const int c = blockIdx.x / split, sidx = blockIdx.x - c * split, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int dc = d.cam_dim[c], key = c * d.nc + c;
     if (dc == 0) return;
@@ -995,7 +1017,7 @@ __global__ __launch_bounds__(1024) void k_ba_schur_diag_mfma(BaDev d, const int 
         double v = 0.0;
         for (int k = 0; k < 16; ++k) v += part[k][threadIdx.x];
         if (split > 1) __hip_atomic_store(d.csplit + ((size_t)c * split + sidx) * 256 + threadIdx.x, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        else schur_diag_finish(d, c, threadIdx.x, v, inv_radius);
+        else schur_diag_finish(d, c, threadIdx.x, v, inv_radius, fin);
     }
     if (split > 1) {      // as in k_ba_cam_raw: the last of the camera's workgroups adds the partial blocks, in index order (k_ba_schur_diag_fin before)
         __shared__ int s_last;
@@ -1006,12 +1028,11 @@ __global__ __launch_bounds__(1024) void k_ba_schur_diag_mfma(BaDev d, const int 
         if (s_last && threadIdx.x < 256) {
             double v = 0.0;
             for (int k = 0; k < split; ++k) v += __hip_atomic_load(d.csplit + ((size_t)c * split + k) * 256 + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            schur_diag_finish(d, c, threadIdx.x, v, inv_radius);
+            schur_diag_finish(d, c, threadIdx.x, v, inv_radius, fin);
             if (threadIdx.x == 0) __hip_atomic_store(d.tickets + d.nc + c, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 }
-#define RCN_RHS_BETA 1.0e200
 // Everything between the Schur build and the factorisation in ONE launch (round 4; three clears and two small kernels before):
 // the padded rows of the dense system -- zero, identity on the diagonal, the right-hand side in row n under its huge diagonal
 // entry (k_ba_S_rhs_row) -- and the factorisation's flag word and stream counters.
@@ -2845,10 +2866,12 @@ int rcn_int_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_option
                 if (npairs_lower / (size_t)nlow > 128) k_ba_schur_mfma_wg<<<nlow, 512, 0, st>>>(d, pk_off, pk_list);   // long lists: a workgroup per block
                 else k_ba_schur_mfma<4><<<(nlow + 3) / 4, 256, 0, st>>>(d, pk_off, pk_list);
             }
-            if (nc < 128) k_ba_schur_diag_mfma<12><<<nc * csplit, 1024, 0, st>>>(d, pk_off, pk_list, ir, csplit);      // (few cameras: latency-bound, deep gathers)
-            else k_ba_schur_diag_mfma<4><<<nc, 1024, 0, st>>>(d, pk_off, pk_list, ir, 1);
-            if (fused_finish) k_ba_S_finish<<<(unsigned)(((size_t)(npad - n) * npad + 255) / 256), 256, 0, st>>>(d, chain ? 1 : 0);
-            else if (npad > n) k_ba_S_pad<<<(npad - n + 127) / 128, 128, 0, st>>>(d);
+            // (fused_finish: the padded rows, the right-hand-side row and the flag words ride in the same launch)
+            const int fin = fused_finish ? (chain ? 1 : 0) : -1;
+            const int fin_blocks = fused_finish ? (int)(((size_t)(npad - n) * npad + 1023) / 1024) : 0;
+            if (nc < 128) k_ba_schur_diag_mfma<12><<<nc * csplit + fin_blocks, 1024, 0, st>>>(d, pk_off, pk_list, ir, csplit, fin);      // (few cameras: latency-bound, deep gathers)
+            else k_ba_schur_diag_mfma<4><<<nc + fin_blocks, 1024, 0, st>>>(d, pk_off, pk_list, ir, 1, fin);
+            if (!fused_finish && npad > n) k_ba_S_pad<<<(npad - n + 127) / 128, 128, 0, st>>>(d);
         } else {
             if (np > 0) k_ba_schur<<<np, std::min(256, std::max(64, 64 * ((kmax * kmax + 7) / 8))), 0, st>>>(d, Sb);
             k_ba_S_assemble<<<nc + 1, 256, 0, st>>>(d, Sb, ir);
