@@ -569,10 +569,8 @@ __global__ void k_ba_diag(BaDev d, int what, double lo, double hi, int jacobi)
 }
 
 // per point: V = scaled Vraw + dgp/radius, V^-1, scaled g_p
-__global__ void k_ba_point_solve(BaDev d, double inv_radius)
+__device__ __forceinline__ void point_solve_body(const BaDev &d, int j, double inv_radius)
 {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= d.np) return;
     double V[9];
     const double *s = d.sp + 3 * (size_t)j;
     for (int a = 0; a < 3; ++a)
@@ -594,6 +592,11 @@ __global__ void k_ba_point_solve(BaDev d, double inv_radius)
     }
     for (int i = 0; i < 9; ++i) d.Vinv[9 * (size_t)j + i] = Vi[i];
     for (int i = 0; i < 3; ++i) d.gps[3 * (size_t)j + i] = d.gpraw[3 * (size_t)j + i] * s[i];
+}
+__global__ void k_ba_point_solve(BaDev d, double inv_radius)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < d.np) point_solve_body(d, j, inv_radius);
 }
 
 // scaled W_o = (Jc' Jp) (10 x 3) of one observation
@@ -2346,11 +2349,24 @@ __device__ __forceinline__ void ba_lm_diag_entry(const BaDev &d, int i, double l
         d.dgp[i] = fmin(fmax(v * d.sp[i] * d.sp[i], lo), hi);
     }
 }
-__global__ __launch_bounds__(256) void k_ba_gradmax(BaDev d, double *out, int with_diag = 0, double lo = 0.0, double hi = 0.0)
+// (with_diag = 2, round 5: and the damped 3 x 3 blocks of k_ba_point_solve at trust-region radius 1 / inv_radius -- a landmark's three
+//  diagonal entries and its block by ONE thread, so nothing crosses threads: the step that follows an accepted one loses a launch)
+__global__ __launch_bounds__(256) void k_ba_gradmax(BaDev d, double *out, int with_diag = 0, double lo = 0.0, double hi = 0.0, double inv_radius = 0.0)
 {
     __shared__ double sh[4];
     const int t0 = blockIdx.x * 256 + threadIdx.x, stride = gridDim.x * 256;
-    if (with_diag)
+    if (with_diag == 2) {
+        for (int i = t0; i < d.n; i += stride) ba_lm_diag_entry(d, i, lo, hi);          // (i < n <= 3 np is not given: the camera part on its own)
+        for (int j = t0; j < d.np; j += stride) {
+            for (int a = 0; a < 3; ++a) {
+                const int i = 3 * j + a;
+                const double v = d.Vraw[9 * (size_t)j + 4 * a];
+                d.dgp[i] = fmin(fmax(v * d.sp[i] * d.sp[i], lo), hi);
+            }
+            point_solve_body(d, j, inv_radius);
+        }
+    }
+    else if (with_diag)
         for (int i = t0; i < d.n || i < 3 * d.np; i += stride) ba_lm_diag_entry(d, i, lo, hi);
     double m = 0.0;
     for (int i = t0; i < d.nc; i += stride)
@@ -2807,7 +2823,7 @@ int rcn_int_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_option
 
     if (pairs_build) RCN_HIP(hipStreamWaitEvent(st, ctx->ba_ev[7], 0));      // the Schur build of the first iteration reads the lists
     double radius = opt->initial_trust_region_radius, decrease = 2.0;
-    bool reuse_diag = false, need_gradient = true, grad_pending = false, diag_fresh = false;
+    bool reuse_diag = false, need_gradient = true, grad_pending = false, diag_fresh = false, points_fresh = false;
     int invalid_run = 0, termination = 0, iter = 0;
     for (;;) {
         if (need_gradient) {
@@ -2818,10 +2834,12 @@ int rcn_int_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_option
             // (its cell, scal[12], was cleared by the evaluation at this point: k_ba_eval<true>, finish_sums)
             // (whenever the gradient is due, so is the LM diagonal -- an accepted step, or the start -- and both come from the raw blocks
             //  of the evaluation just queued: one launch; a loop that ends below has written a diagonal nobody reads)
-            k_ba_gradmax<<<std::max(1, std::min(1024, (std::max(std::max(nc, n), 3 * np) + 255) / 256)), 256, 0, st>>>(d, d.scal + 12, reuse_diag ? 0 : 1,
-                                                                                                                     opt->min_lm_diagonal, opt->max_lm_diagonal);
+            // (... and with the diagonal the landmarks' damped blocks at the radius the next step will use: k_ba_point_solve's launch)
+            k_ba_gradmax<<<std::max(1, std::min(1024, (std::max(std::max(nc, n), 3 * np) + 255) / 256)), 256, 0, st>>>(d, d.scal + 12, reuse_diag ? 0 : 2,
+                                                                                                                     opt->min_lm_diagonal, opt->max_lm_diagonal, 1.0 / radius);
             RCN_HIP(hipGetLastError());
             diag_fresh = !reuse_diag;
+            points_fresh = !reuse_diag;
             need_gradient = false;
             grad_pending = true;
         }
@@ -2858,7 +2876,8 @@ int rcn_int_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_option
             if (npad > n) RCN_HIP(hipMemsetAsync(d.S + (size_t)n * npad, 0, sizeof(double) * (size_t)(npad - n) * npad, st));
             RCN_HIP(hipMemsetAsync(d.rhs, 0, sizeof(double) * npad, st));
         }
-        if (np > 0) k_ba_point_solve<<<(np + 127) / 128, 128, 0, st>>>(d, ir);
+        if (np > 0 && !points_fresh) k_ba_point_solve<<<(np + 127) / 128, 128, 0, st>>>(d, ir);      // (a step behind an accepted one: done in k_ba_gradmax's launch)
+        points_fresh = false;
         if (no > 0) k_ba_wy<<<(unsigned)((10 * (size_t)no + 255) / 256), 256, 0, st>>>(d);
         if (gather) {
             if (nc > 1) {
