@@ -24,6 +24,7 @@ def main():
     ctx = _lib.Context(0)
     rng = np.random.default_rng(seed)
     t0, n, checked, blocks = time.time(), 0, 0, set()
+    t_said = t0
     while time.time() - t0 < budget:
         nc = int(rng.integers(lo, hi))
         npts = int(rng.integers(8, 30)) * nc
@@ -44,6 +45,9 @@ def main():
                 sys.exit(1)
             checked += 1
         n += 1
+        if time.time() - t_said > 60.0:      # (a run that says nothing for minutes is taken for hung)
+            t_said = time.time()
+            print("  ... %d problems so far, %.0f s" % (n, time.time() - t0), flush=True)
     print("soak ok: %d problems solved twice, bit-equal; %d of them equal to the oracle; factorisations of %d .. %d blocks; %.0f s, seed %d"
           % (n, checked, min(blocks), max(blocks), time.time() - t0, seed))
 

@@ -22,7 +22,11 @@ def main():
     rng = np.random.default_rng(seed)
     m = HipL2Matcher(device=0)
     t0, cases, rows = time.time(), 0, 0
+    t_said = time.time()
     while time.time() - t0 < budget:
+        if time.time() - t_said > 60.0:      # (a run that says nothing for minutes is taken for hung)
+            t_said = time.time()
+            print("  ... %.0f s" % (time.time() - t0), flush=True)
         kind = rng.choice(["superpoint", "superpoint", "superpoint", "sift", "orb"])
         n = int(rng.integers(2, 7))
         big = rng.random() < 0.05
