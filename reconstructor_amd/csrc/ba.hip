@@ -582,7 +582,7 @@ __device__ __forceinline__ void point_solve_body(const BaDev &d, int j, double i
     double Vi[9];
     if (!(det > 0.0) || !isfinite(det)) {
         d.flag[0] = 1;
-        d.flag[1] = 1;      // (k_ba_S_finish clears the flag words BEHIND this kernel: it restores [0] from this word)
+        d.flag[1] = 1;      // (the trailing workgroups of the Schur diagonal launch clear the flag words BEHIND this kernel: they restore [0] from this word)
         for (int i = 0; i < 9; ++i) Vi[i] = 0.0;
     } else {
         const double id = 1.0 / det;
@@ -958,8 +958,8 @@ __global__ __launch_bounds__(512) void k_ba_schur_mfma_wg(BaDev d, const int *of
 // the camera (a pair (o, o)) and the listed pairs of the key (c, c); the 16 partial blocks are
 // summed in wave order and  scaled U + D/radius  is added before the store into S; column 10 of
 // the same product is the camera's reduced right-hand side.
-// (fin: -1 the right-hand side stays in d.rhs; 0 / 1 it goes straight into row n of the padded system -- what k_ba_S_finish did in a
-//  launch of its own until round 5 -- and with 1 the cell in d.rhs takes k_trsv_bwd_chain's "not there yet" pattern)
+// (fin: -1 the right-hand side stays in d.rhs; 0 / 1 it goes straight into row n of the padded system -- a launch of its own, k_ba_S_finish,
+//  did that until round 5 -- and with 1 the cell in d.rhs takes k_trsv_bwd_chain's "not there yet" pattern)
 __device__ __forceinline__ void schur_diag_finish(const BaDev &d, int c, int idx, double v, double inv_radius, int fin = -1)
 {
     const int a = idx >> 4, b = idx & 15, dc = d.cam_dim[c], offc = d.cam_off[c];
@@ -979,7 +979,7 @@ __device__ __forceinline__ void schur_diag_finish(const BaDev &d, int c, int idx
 }
 // (`split` > 1: a camera's observations are spread over that many workgroups, see k_ba_cam_raw; SMB: gather
 // depth, 12 in that latency-bound regime, 4 when a thousand cameras keep the chip full anyway)
-// (fin >= 0, round 5: the launch also does what k_ba_S_finish did between the Schur build and the factorisation -- the cameras'
+// (fin >= 0, round 5: the launch also does everything that lies between the Schur build and the factorisation (round 4's k_ba_S_finish) -- the cameras'
 //  workgroups put their right-hand sides into row n themselves (schur_diag_finish), the workgroups BEHIND them write the rest of the
 //  padded rows and the factorisation's flag word and stream counters: one launch less per LM iteration)
 template <int SMB>
@@ -1035,27 +1035,6 @@ __global__ __launch_bounds__(1024) void k_ba_schur_diag_mfma(BaDev d, const int 
             if (threadIdx.x == 0) __hip_atomic_store(d.tickets + d.nc + c, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
-}
-// Everything between the Schur build and the factorisation in ONE launch (round 4; three clears and two small kernels before):
-// the padded rows of the dense system -- zero, identity on the diagonal, the right-hand side in row n under its huge diagonal
-// entry (k_ba_S_rhs_row) -- and the factorisation's flag word and stream counters.
-// (sentinel: the one-launch backward substitution follows -- the thread that has just moved rhs[j] into the system's last row leaves
-//  k_trsv_bwd_chain's "not there yet" pattern in its place: the solution will appear there)
-__global__ __launch_bounds__(256) void k_ba_S_finish(BaDev d, int sentinel)
-{
-    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x, cnt = (size_t)(d.npad - d.n) * d.npad;
-    // ([1]: k_ba_point_solve met a block that is singular in floating point in THIS iteration -- the step is invalid, as in the oracle;
-    //  the other words belong to the factorisation that follows)
-    if (idx == 0) { const int ps = d.flag[1]; d.flag[1] = 0; d.flag[0] = ps ? 1 : 0; }
-    else if ((idx >= 2 && idx < 8) || (idx >= 12 && idx < 24)) d.flag[idx] = 0;      // ([12 ..): the factorisation's stream counters)
-    if (idx >= cnt) return;
-    const int i = d.n + (int)(idx / d.npad), j = (int)(idx % d.npad);
-    double v = i == j ? 1.0 : 0.0;
-    if (i == d.n) {
-        v = j < d.n ? d.rhs[j] : (j == d.n ? RCN_RHS_BETA : 0.0);
-        if (sentinel) reinterpret_cast<unsigned long long *>(d.rhs)[j] = 0xFFFFFFFFFFFFFFFFull;
-    }
-    d.S[(size_t)i * d.npad + j] = v;
 }
 // padded rows of the dense system: identity (the gather form writes every other lower block itself)
 __global__ void k_ba_S_pad(BaDev d)
@@ -2865,7 +2844,7 @@ int rcn_int_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_option
         if (phase_times) RCN_HIP(hipEventRecord(ctx->ba_tev[0], st));
         // [0] breakdown / gate flag, [2..7] progress counters of the factorisation's streams.  In the default form (gather Schur build, the
         // right-hand side as row n of the padded system) the flag words, the padded rows and the right-hand-side row are all written by
-        // k_ba_S_finish behind the Schur kernels, and nothing has to be cleared up front: the Schur kernels write every entry of rhs below n.
+        // the Schur diagonal launch (its cameras' workgroups and the workgroups behind them), and nothing has to be cleared up front: the Schur kernels write every entry of rhs below n.
         const bool rhs_row = npad > n && !ctx->ba_trsv_fwd;
         const bool fused_finish = gather && rhs_row;
         const bool chain = ctx->trsv_chain && 2 * nblk <= ctx->prop.multiProcessorCount;      // backward substitution as one launch
@@ -2922,7 +2901,7 @@ int rcn_int_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_option
 #else
             const bool swap_ab = false;
 #endif
-            int *const ctr_base = d.flag + 12;          // the streams' progress counters and the two head-tile counters (k_ba_S_finish clears them)
+            int *const ctr_base = d.flag + 12;          // the streams' progress counters and the two head-tile counters (the Schur diagonal launch's trailing workgroups clear them)
             int *ctr[chol::N_CTR];
             for (int c = 0; c < chol::N_CTR; ++c) ctr[c] = ctr_base + c;
             const chol::Plan &plan = ctx->chol_plan;
@@ -3056,7 +3035,7 @@ int rcn_int_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_option
         // (up to two blocks there is no panel rest, no column rest and no bulk update: nothing for the other two streams to do)
         RCN_HIP(factorise(ctx->chol_safe || nblk <= 2));
         if (phase_times) RCN_HIP(hipEventRecord(ctx->ba_tev[2], st));
-        // (rhs_row + chain, the default: the sentinel was left by k_ba_S_finish and the chain kernel reads y out of the factor's last row
+        // (rhs_row + chain, the default: the sentinel was left by the Schur diagonal launch and the chain kernel reads y out of the factor's last row
         //  itself -- no launch in between; k_ba_y_from_row remains for the per-step kernels and the other ways to build the system)
         const bool y_in_row = chain && fused_finish;
         if (rhs_row && !y_in_row) k_ba_y_from_row<<<(npad + 255) / 256, 256, 0, st>>>(d, chain ? 1 : 0);

@@ -461,3 +461,31 @@ def test_small_solve_shortcuts_change_no_bit(gpu_ctx):
         r = subprocess.run([sys.executable, "-c", _SMALL % root], env=dict(os.environ, RCN_LIB=diag, **env), capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stdout + r.stderr
         assert r.stdout.strip().splitlines()[-1] == h.hexdigest(), env
+
+
+@pytest.mark.parametrize("env", [{"RCN_CHOL_DIAG_SERVER": "1"}, {"RCN_CHOL_BULK_BEHIND": "1"}, {"RCN_CHOL_GATE_IN_KERNEL": "1"},
+                                 {"RCN_CHOL_GATE_IN_KERNEL": "-1"}, {"RCN_CHOL_DIAG_SERVER": "1", "RCN_POLL_MODE": "1"}])
+def test_where_and_when_an_operation_runs_changes_no_bit(gpu_ctx, env):
+    """The factorisation's schedule is data (csrc/chol_plan.h), and no operation's arithmetic depends on where or when it runs: the plan
+    options that only move operations between streams or reorder the list -- the diagonal blocks in one resident workgroup, bulk updates
+    behind the next diagonal block, waits inside the kernels or in gate kernels in front -- give the shipping schedule's bits
+    (diagnostic build, child process).  (Options that hand tiles to ANOTHER kernel -- the two-level regime's thresholds, the carved
+    tiles -- give their own, equally repeatable bits: tools/soak_ba_large.py solves every problem twice under them.)"""
+    import hashlib, json, os, subprocess, sys
+    from reconstructor_amd import ba
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    diag = os.path.join(root, "tools", "librcn_diag.so")
+    assert os.path.exists(diag), "tools/librcn_diag.so missing: run __graft_entry__.build()"
+    sc = synth_ba.make_scene(260, 5200, obs_per_point=6, seed=78)         # 18 blocks of 128
+    P1, I1, X1, s1 = ba.solve_scene(gpu_ctx, sc)
+    assert s1["factor_schedule"] == 0 and s1["invalid_steps"] == 0
+    code = ("import sys, json, hashlib; sys.path.insert(0, %r)\n"
+            "from reconstructor_amd import _lib, ba, synth_ba\n"
+            "sc = synth_ba.make_scene(260, 5200, obs_per_point=6, seed=78)\n"
+            "P, I, X, s = ba.solve_scene(_lib.Context(0), sc)\n"
+            "print(json.dumps({'h': hashlib.sha256(P.tobytes() + I.tobytes() + X.tobytes()).hexdigest(), 'sched': s['factor_schedule'], 'it': s['iterations']}))\n" % root)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=dict(os.environ, RCN_LIB=diag, **env))
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["sched"] == 0 and d["it"] == s1["iterations"]
+    assert d["h"] == hashlib.sha256(P1.tobytes() + I1.tobytes() + X1.tobytes()).hexdigest()
