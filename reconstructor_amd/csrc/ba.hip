@@ -2800,7 +2800,7 @@ int rcn_int_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_option
     sum->initial_rms_px = std::sqrt(2.0 * cost / std::max(no, 1));
     sum->cost_trace[0] = cost;
 
-    if (pairs_build) RCN_HIP(hipStreamWaitEvent(st, ctx->ba_ev[7], 0));      // the Schur build of the first iteration reads the lists
+    bool pairs_awaited = !pairs_build;      // (the first Schur build waits for the lists -- not the gradient, the landmark blocks and W / Y in front of it)
     double radius = opt->initial_trust_region_radius, decrease = 2.0;
     bool reuse_diag = false, need_gradient = true, grad_pending = false, diag_fresh = false, points_fresh = false;
     int invalid_run = 0, termination = 0, iter = 0;
@@ -2859,6 +2859,7 @@ int rcn_int_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_option
         points_fresh = false;
         if (no > 0) k_ba_wy<<<(unsigned)((10 * (size_t)no + 255) / 256), 256, 0, st>>>(d);
         if (gather) {
+            if (!pairs_awaited) { RCN_HIP(hipStreamWaitEvent(st, ctx->ba_ev[7], 0)); pairs_awaited = true; }
             if (nc > 1) {
                 const int nlow = nc * (nc - 1) / 2;
                 if (npairs_lower / (size_t)nlow > 128) k_ba_schur_mfma_wg<<<nlow, 512, 0, st>>>(d, pk_off, pk_list);   // long lists: a workgroup per block
@@ -3182,6 +3183,7 @@ int rcn_int_ba_solve(rcn_ctx *ctx, const rcn_ba_problem *pb, const rcn_ba_option
         if (iter < 160 && !cost_pending) sum->cost_trace[iter] = cost;
     }
     if (cost_pending) RCN_HIP(read_scal(1));       // (every exit of the loop has read the scalars since the last accepted step: not reached)
+    if (!pairs_awaited) RCN_HIP(hipStreamWaitEvent(st, ctx->ba_ev[7], 0));      // (a solve that ended before its first step: the lists it queued are kept for the next one)
     RCN_HIP(hipStreamSynchronize(st));
     sum->solve_seconds = now_s() - t_start;
     if (jac_pending && phase_times) {
